@@ -1,0 +1,163 @@
+/*
+ * spyhip.h - C ABI of the MI355X (gfx950) spectral-estimation / cross-spectral
+ * connectivity hot path.
+ *
+ * This is the drop-in boundary underneath Syncopy's `computeFunction` plug-in
+ * surface (reference: syncopy/shared/computational_routine.py:51-1108 and the
+ * cF contract in doc/source/developer/compute_kernels.rst:63-88).  The
+ * reference has no native code; every entry point below names the reference
+ * *Python* function whose arithmetic it replaces.  Python binds this header
+ * through ctypes (syncopy_amd/backend.py); INTEGRATION.md shows the stub a
+ * Syncopy maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; spyhip_last_error()
+ *    returns a thread-local message for the last failure;
+ *  - pointers suffixed `_d` are DEVICE pointers (HBM), all others are host
+ *    pointers that are consumed before the call returns;
+ *  - all work is enqueued on the context's HIP stream (spyhip_ctx_set_stream),
+ *    nothing synchronises unless stated; caller owns every buffer;
+ *  - complex64 = interleaved (re, im) float pairs, complex128 = double pairs;
+ *  - trial data live in ONE (rows x ld) float32 matrix, channel fastest, as
+ *    AnalogData does (syncopy/datatype/continuous_data.py:405); a "segment" is
+ *    `nsig` consecutive rows starting at `seg_start[b]` of which only rows in
+ *    [seg_lo[b], seg_hi[b]) are read (others count as 0.0f - this is the zero
+ *    extension of stft.py:101-117); a trial is the segment
+ *    start=lo=sampleinfo[t,0], hi=sampleinfo[t,1].
+ */
+#ifndef SPYHIP_H
+#define SPYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spyhip_ctx spyhip_ctx;
+typedef struct spyhip_fft_plan spyhip_fft_plan;
+typedef struct spyhip_cwt_plan spyhip_cwt_plan;
+
+/* output conversions = syncopy/shared/const_def.py:25-37 `spectralConversions` */
+enum spyhip_output {
+    SPYHIP_OUT_POW = 0,
+    SPYHIP_OUT_ABS = 1,
+    SPYHIP_OUT_FOURIER = 2, /* complex64 ("fourier" / "complex") */
+    SPYHIP_OUT_REAL = 3,
+    SPYHIP_OUT_IMAG = 4,
+    SPYHIP_OUT_ANGLE = 5,
+    SPYHIP_OUT_ABSREAL = 6,
+    SPYHIP_OUT_ABSIMAG = 7
+};
+
+/* polynomial removal before tapering = scipy.signal.detrend call sites
+ * specest/compRoutines.py:169-172, connectivity/ST_compRoutines.py:405-409,
+ * per segment in specest/stft.py:131-132 */
+enum spyhip_detrend { SPYHIP_DETREND_NONE = -1, SPYHIP_DETREND_CONSTANT = 0, SPYHIP_DETREND_LINEAR = 1 };
+
+/* ---- context ------------------------------------------------------------ */
+int spyhip_version(void);
+const char* spyhip_last_error(void);
+int spyhip_ctx_create(int device, spyhip_ctx** ctx);
+int spyhip_ctx_destroy(spyhip_ctx* ctx);
+/* `stream` is a hipStream_t (NULL = the null stream) */
+int spyhip_ctx_set_stream(spyhip_ctx* ctx, void* stream);
+int spyhip_ctx_synchronize(spyhip_ctx* ctx);
+
+/* ---- K1/K2: (multi-)tapered FFT of segments ------------------------------
+ * Replaces mtmfft (specest/mtmfft.py:16-129) + the tail of mtmfft_cF
+ * (specest/compRoutines.py:169-189), and, with nsig == nfft == nperseg and
+ * one segment per frame, stft/mtmconvol (specest/stft.py:16-159,
+ * specest/mtmconvol.py:136-150).
+ *
+ *   X[b,k,f,c] = scale * sum_{n<nsig} w[k,n] * x_b[n,c] * exp(-2 pi i f n / nfft)
+ *
+ * tapers : K x nsig float64, already normalised as _norm_taper
+ *          (specest/_norm_spec.py:27-46); scale as _norm_spec (:10-24).
+ * detrend: enum spyhip_detrend, applied per segment to the (zero-extended)
+ *          nsig samples; demean_taper: subtract the per-channel mean again
+ *          after tapering (mtmfft.py:115-116).
+ * freq_idx: nfsel indices into the nfft/2+1 rfft bins (NULL = all bins);
+ *          duplicates must already be squashed (shared/tools.py:334-336).
+ * output  : enum spyhip_output; keeptapers=0 averages the converted values
+ *          over tapers (compRoutines.py:188-189).
+ * Result  : (B, Kout, nfsel, nchan) float32 or complex64, Kout = keeptapers ? K : 1.
+ */
+int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int nchan, int ntaper,
+                           const double* tapers, double scale, int detrend, int demean_taper,
+                           const int32_t* freq_idx, int nfsel, int output, int keeptapers,
+                           spyhip_fft_plan** plan);
+int spyhip_fft_plan_destroy(spyhip_fft_plan* plan);
+/* data_d: float32 (rows x ld); chan_idx_d: nchan column indices or NULL
+ * (=0..nchan-1); seg_*_d: B int64 each; out_d: see above. */
+int spyhip_fft_exec(spyhip_fft_plan* plan, const float* data_d, int64_t ld,
+                    const int32_t* chan_idx_d, const int64_t* seg_start_d, const int64_t* seg_lo_d,
+                    const int64_t* seg_hi_d, int nseg, void* out_d);
+/* name of the dominant kernel a plan launches (for rocprof matching) */
+const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* plan);
+
+/* ---- K4: cross-spectral density accumulation (MFMA) -----------------------
+ * Replaces the outer product + taper mean of csd (connectivity/csd.py:94-115),
+ * spectral_dyadic_product_cF (connectivity/ST_compRoutines.py:30-117) and the
+ * trial sum of ComputationalRoutine.compute_sequential
+ * (shared/computational_routine.py:1022-1032):
+ *
+ *   acc[f,i,j] += sum_{r<nrows} X[r,f,i] * conj(X[r,f,j])        (i >= j)
+ *
+ * spec_d: complex64 (nrows, nfreq, nchan), nrows = trials x tapers (the
+ * layout spyhip_fft_exec writes with output=FOURIER, keeptapers=1);
+ * acc_d: complex64 (nfreq, nchan, nchan); only the lower triangle (incl.
+ * diagonal, 32x32 tile granularity) is maintained until spyhip_csd_finalize. */
+int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                          void* acc_d);
+/* acc[f,i,j] *= scale on the lower triangle and acc[f,j,i] = conj(acc[f,i,j]):
+ * scale = 1/(ntaper*ntrials) turns the sum into the taper- and trial-mean. */
+int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, double scale);
+
+/* ---- K5: coherence normalisation ------------------------------------------
+ * Replaces normalize_csd (connectivity/csd.py:118-172):
+ *   out[f,i,j] = conv( csd[f,i,j] / sqrt(csd[f,i,i]*csd[f,j,j]) )
+ * output: POW/ABS/FOURIER/REAL/IMAG/ANGLE; out_d float32 or complex64
+ * (nfreq, nchan, nchan); csd_d must be a full Hermitian array. */
+int spyhip_coh_normalize(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, int output,
+                         void* out_d);
+
+/* ---- K3: Morlet continuous wavelet transform ------------------------------
+ * Replaces cwt_time (specest/wavelets/transform.py:88-108) with Morlet.time
+ * (specest/wavelets/wavelets.py:27-86) and the tail of wavelet_cF
+ * (specest/compRoutines.py:582-595): detrend, full linear convolution with
+ * the sampled complete Morlet kernel of every scale, cropped like
+ * scipy.signal.fftconvolve(mode="same"), converted with `output`.
+ * Result per segment: (ntime_out, 1, nscales, nchan), where the ntime_out
+ * kept samples are post_start + i*post_step of the nsig input samples. */
+int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
+                           double dt, double w0, int detrend, int output, int post_start,
+                           int post_step, int ntime_out, spyhip_cwt_plan** plan);
+int spyhip_cwt_plan_destroy(spyhip_cwt_plan* plan);
+int spyhip_cwt_exec(spyhip_cwt_plan* plan, const float* data_d, int64_t ld,
+                    const int32_t* chan_idx_d, const int64_t* seg_start_d, int nseg, void* out_d,
+                    int accumulate);
+
+/* ---- K6: Wilson spectral factorisation + Granger-Geweke causality ---------
+ * Replaces regularize_csd / wilson_sf (connectivity/wilson_sf.py:16-254) and
+ * granger (connectivity/granger.py:10-79) as called from granger_cF
+ * (connectivity/AV_compRoutines.py:293-412).  csd_d: complex64 (nfreq, C, C)
+ * trial-averaged CSD.  granger_d: float32 (nfreq, C, C).  info (host, 4
+ * doubles): converged, max rel. err, reg. factor, initial cond. num.
+ * H_d / Sigma_d (complex128 (nfreq,C,C) / float64 (C,C)) may be NULL. */
+int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, double rtol, int niter,
+                   double cond_max, double eps_max, void* granger_d, void* H_d, void* Sigma_d,
+                   double* info);
+
+/* ---- utilities on the in-HBM trial queue ----------------------------------
+ * y[i] = (y[i] + x[i]) elementwise float32 sum used by keeptrials=False
+ * accumulation of real spectra (computational_routine.py:1022-1032). */
+int spyhip_axpy_f32(spyhip_ctx* ctx, const float* x_d, float* y_d, int64_t n, float alpha);
+/* out[r, :] = alpha * sum_t in[t, r, :]  (trial mean of (T, n) float32) */
+int spyhip_trial_mean_f32(spyhip_ctx* ctx, const float* in_d, float* out_d, int64_t ntrials, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPYHIP_H */

@@ -1,0 +1,193 @@
+# -*- coding: utf-8 -*-
+"""
+Golden-vector generator: runs the REAL reference (esi-neuroscience/syncopy,
+mounted read-only at /root/reference) in the build container and writes small
+input/output fixtures to tests/golden/*.npz.
+
+Run through ``oracle/make_golden.sh`` (it sets up the interpreter, SPYDIR and
+the two empty stand-in modules for the optional cluster / curve-fitting
+imports ``dask_jobqueue`` and ``fooof`` that the reference imports at module
+load but never touches on this path).  The reference never ships: only the
+arrays written here do.
+
+TEST INFRASTRUCTURE ONLY - see oracle/spy_oracle.py header.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+import syncopy as spy
+from syncopy import synthdata
+from syncopy.connectivity.wilson_sf import wilson_sf, regularize_csd
+from syncopy.connectivity.granger import granger
+from syncopy.connectivity.csd import csd as ref_csd
+from syncopy.specest.mtmfft import mtmfft as ref_mtmfft
+from syncopy.specest.mtmconvol import mtmconvol as ref_mtmconvol
+from syncopy.specest.wavelet import wavelet as ref_wavelet
+from syncopy.specest.wavelets import Morlet
+
+OUT = sys.argv[1] if len(sys.argv) > 1 else "tests/golden"
+os.makedirs(OUT, exist_ok=True)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def trials_of(d):
+    return [np.array(t) for t in d.trials]
+
+
+def ca(data, sl=slice(None), **opts):
+    r = spy.connectivityanalysis(data, **opts)  # keep the object alive while reading its HDF5 file
+    return np.array(r.data[sl])
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+# ---------------------------------------------------------------- c1 (BASELINE config 1)
+c1 = synthdata.ar2_network(nTrials=20, nSamples=2000, AdjMat=np.zeros((16, 16)), seed=42)
+s = spy.freqanalysis(c1, method="mtmfft", tapsmofrq=2)
+coh = spy.connectivityanalysis(c1, method="coh", tapsmofrq=2)
+csd_lim = spy.connectivityanalysis(c1, method="csd", tapsmofrq=2, foilim=[0, 60])
+save(
+    "c1",
+    data_sha256=sha(c1.data[()]),
+    trial0=np.array(c1.trials[0]),
+    trial19_tail=np.array(c1.trials[19])[-4:],
+    sampleinfo=c1.sampleinfo,
+    samplerate=c1.samplerate,
+    pow=s.data[()],
+    freq=s.freq,
+    taper=np.array([str(t) for t in s.taper]),
+    coh_abs=coh.data[()],
+    csd_foilim_0_60=csd_lim.data[()],
+    csd_freq=csd_lim.freq,
+)
+
+# ---------------------------------------------------------------- small coupled network: csd / coh / granger
+adj = np.zeros((5, 5))
+adj[0, 1] = 0.25
+adj[3, 2] = 0.2
+adj[1, 4] = 0.15
+n5 = synthdata.ar2_network(nTrials=60, nSamples=1000, AdjMat=adj, seed=7, samplerate=200)
+kw = {}
+for outp in ["abs", "pow", "complex", "angle", "imag", "real"]:
+    kw["coh_" + outp] = ca(n5, method="coh", tapsmofrq=3, output=outp)
+kw["csd"] = ca(n5, method="csd", tapsmofrq=3)
+kw["csd_keeptrials_first3"] = ca(n5, slice(0, 3), method="csd", tapsmofrq=3, keeptrials=True)
+kw["coh_hann_pad"] = ca(n5, method="coh", taper="hann", pad="nextpow2")
+kw["coh_foi"] = ca(n5, method="coh", tapsmofrq=3, foi=[10, 20.2, 40, 40.1, 77])
+g = spy.connectivityanalysis(n5, method="granger", tapsmofrq=3)
+kw["granger"] = g.data[()]
+kw["granger_info"] = np.array(
+    [float(g.info["converged"]), g.info["max rel. err"], g.info["reg. factor"], g.info["initial cond. num"]]
+)
+kw["freq"] = g.freq
+save("conn5", adj=adj, data=np.stack(trials_of(n5)), samplerate=n5.samplerate, **kw)
+
+# ---------------------------------------------------------------- mtmfft option sweep (incl. unequal trial lengths + selections)
+rng = np.random.default_rng(2024)
+lens = [1500, 2000, 1800, 2000]
+trl = []
+tt = np.arange(2000) / 1000.0
+for n in lens:
+    x = rng.normal(size=(n, 4)).astype("f4")
+    x[:, 0] += 3 * np.cos(2 * np.pi * 30 * tt[:n]).astype("f4")
+    x[:, 2] += (2 * np.cos(2 * np.pi * 111 * tt[:n]) + 5 + 0.002 * np.arange(n)).astype("f4")
+    trl.append(x)
+# trials live in one (time x channel) block; the third one overlaps the second by 100 samples
+# and every trial starts 250 samples before its trigger (offset -250)
+block = np.concatenate(trl, axis=0)
+starts = np.array([0, 1500, 3400, 5300])
+trldef = np.stack([starts, starts + np.array(lens), np.full(4, -250)], axis=1)
+uneq = spy.AnalogData(data=block, samplerate=1000, trialdefinition=trldef)
+trl = [np.array(t) for t in uneq.trials]
+kw = {"block": block, "trialdefinition": uneq.trialdefinition, "samplerate": uneq.samplerate}
+
+
+def fa(name, data=uneq, **opts):
+    r = spy.freqanalysis(data, method="mtmfft", **opts)
+    kw[name] = r.data[()]
+    kw[name + "_freq"] = r.freq
+    kw[name + "_trialdef"] = r.trialdefinition
+
+
+fa("v_fourier_keeptapers", tapsmofrq=3, keeptapers=True, output="fourier")
+fa("v_hann_nextpow2", taper="hann", pad="nextpow2", output="pow")
+fa("v_foilim_linear_abs", taper="hann", foilim=[10, 100], polyremoval=1, output="abs")
+fa("v_foi_boxcar_avg", taper=None, foi=[5, 30.3, 30.4, 111, 250], keeptrials=False, polyremoval=0)
+fa("v_pad3s_dpss", tapsmofrq=2, pad=3.0, output="pow")
+fa("v_ftcompat", taper="hann", ft_compat=True, pad="nextpow2")
+fa("v_demean_taper", tapsmofrq=4, demean_taper=True, keeptapers=True, output="fourier", polyremoval=None)
+fa("v_kaiser", taper="kaiser", taper_opt={"beta": 4.5}, output="real")
+fa("v_ntaper3", tapsmofrq=4, nTaper=3, output="pow")
+fa("v_select", tapsmofrq=2, select={"trials": [2, 0, 3], "channel": [3, 1], "latency": [0.1, 1.2]})
+for outp in ["imag", "angle", "absreal", "absimag"]:
+    fa("v_out_" + outp, taper="hann", output=outp, select={"trials": [1]})
+save("mtmfft_variants", **kw)
+
+# ---------------------------------------------------------------- time-frequency: mtmconvol + wavelet
+tf = synthdata.ar2_network(nTrials=3, nSamples=2000, AdjMat=np.zeros((4, 4)), seed=11)
+kw = {"data": np.stack(trials_of(tf)), "samplerate": tf.samplerate, "trialdefinition": tf.trialdefinition}
+
+
+def tfa(name, **opts):
+    r = spy.freqanalysis(tf, **opts)
+    kw[name] = r.data[()]
+    kw[name + "_freq"] = r.freq
+    kw[name + "_trialdef"] = r.trialdefinition
+    kw[name + "_time0"] = np.array(r.time[0])
+
+
+tfa("conv_hann_half", method="mtmconvol", taper="hann", t_ftimwin=0.5, toi=0.5)
+tfa("conv_hann_pow2", method="mtmconvol", taper="hann", t_ftimwin=0.256, toi=0.75, foilim=[0, 200])
+tfa("conv_dpss_keep", method="mtmconvol", tapsmofrq=2, t_ftimwin=0.4, toi=0.5, keeptapers=True, output="fourier",
+    foilim=[0, 120])
+tfa("conv_all", method="mtmconvol", taper="hann", t_ftimwin=0.1, toi="all", foi=[20, 40, 60], polyremoval=1)
+tfa("conv_toi_equi", method="mtmconvol", taper="hann", t_ftimwin=0.05, toi=np.arange(-0.5, 0.5, 0.01))
+tfa("conv_toi_irreg", method="mtmconvol", taper="hann", t_ftimwin=0.3, toi=np.array([-0.6, -0.45, 0.0, 0.31]))
+tfa("wav_all", method="wavelet", wavelet="Morlet", width=6, foi=np.arange(10, 110, 10), toi="all")
+tfa("wav_toi", method="wavelet", wavelet="Morlet", width=4, foi=np.array([8.0, 33.0, 150.0]),
+    toi=np.arange(-0.8, 0.8, 0.05), output="fourier")
+tfa("wav_auto_scales", method="wavelet", wavelet="Morlet", toi="all", output="abs", keeptrials=False)
+save("tf_variants", **kw)
+
+# ---------------------------------------------------------------- backend-level vectors
+kw = {}
+# harmonic known-answer signal (tests/backend/test_timefreq.py:351-404)
+fs = 1000
+t = np.arange(1000) / fs
+sig = (5 * np.cos(2 * np.pi * 40 * t) + 3 * np.cos(2 * np.pi * 100 * t)).astype("f4")[:, None] * np.ones((1, 2), "f4")
+kw["harm_sig"] = sig
+ftr, fr = ref_mtmfft(sig, fs, taper=None)
+kw["harm_boxcar"] = ftr
+ftr, fr = ref_mtmfft(sig, fs, nSamples=1500, taper="dpss", taper_opt={"Kmax": 5, "NW": 3})
+kw["harm_dpss_pad1500"] = ftr
+ftr, fr = ref_mtmconvol(sig, fs, nperseg=200, noverlap=150, taper="hann")
+kw["harm_stft"] = ftr
+kw["harm_cwt"] = ref_wavelet(sig, fs, np.array([0.05, 0.02, 0.008]), Morlet(w0=6))
+# single-trial csd incl. its norm=True branch (tests/backend/test_conn.py:88-158)
+x5 = np.array(n5.trials[0])
+kw["st_csd"], _ = ref_csd(x5, 200, taper="dpss", taper_opt={"Kmax": 5, "NW": 3}, norm=False)
+kw["st_csd_norm"], _ = ref_csd(x5, 200, taper="dpss", taper_opt={"Kmax": 5, "NW": 3}, norm=True)
+# Wilson / Granger on the trial-averaged CSD of the 5-channel network
+CSD = ca(n5, method="csd", tapsmofrq=3)[0].astype(np.complex128)
+H, Sigma, conv, err = wilson_sf(CSD, nIter=100, rtol=5e-6)
+kw.update(w_csd=CSD, w_H=H, w_Sigma=Sigma, w_conv=np.array(conv), w_err=np.array(err))
+kw["w_granger"] = granger(CSD, H, Sigma)
+# regularisation of an ill-conditioned CSD (tests/backend/test_conn.py:215-242)
+bad = CSD.copy()
+bad[:, 4, :] = bad[:, 3, :] * (1 + 1e-7)
+bad[:, :, 4] = bad[:, :, 3] * (1 + 1e-7)
+reg, eps, cn0 = regularize_csd(bad, cond_max=1e4, eps_max=1e-1)
+kw.update(r_in=bad, r_out=reg, r_eps=np.array(eps), r_cn0=np.array(cn0))
+save("backend", **kw)
+
+print("numpy", np.__version__, "scipy", __import__("scipy").__version__, "python", sys.version.split()[0])

@@ -1,0 +1,76 @@
+"""ctypes binding of libspyhip.so (declarations follow include/spyhip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or cannot be
+loaded, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libspyhip.so")
+
+_lib = None
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/spyhip.h
+SIGNATURES = {
+    "spyhip_version": (C.c_int, []),
+    "spyhip_last_error": (C.c_char_p, []),
+    "spyhip_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "spyhip_ctx_destroy": (C.c_int, [vp]),
+    "spyhip_ctx_set_stream": (C.c_int, [vp, vp]),
+    "spyhip_ctx_synchronize": (C.c_int, [vp]),
+    "spyhip_fft_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, C.c_double, C.c_int,
+                                         C.c_int, c_i32p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "spyhip_fft_plan_destroy": (C.c_int, [vp]),
+    "spyhip_fft_exec": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp]),
+    "spyhip_fft_plan_kernel_name": (C.c_char_p, [vp]),
+    "spyhip_csd_accumulate": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    "spyhip_csd_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double]),
+    "spyhip_coh_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "spyhip_cwt_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_f64p, C.c_double, C.c_double, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "spyhip_cwt_plan_destroy": (C.c_int, [vp]),
+    "spyhip_cwt_exec": (C.c_int, [vp, vp, C.c_int64, vp, vp, C.c_int, vp, C.c_int]),
+    "spyhip_granger": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, vp, vp, vp,
+                                 c_f64p]),
+    "spyhip_axpy_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float]),
+    "spyhip_trial_mean_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64]),
+}
+
+
+class SpyHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libspyhip.so (once).  Import torch first so that both share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpyHipError(
+            f"{LIB_PATH} is missing: build it with `python -m syncopy_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64.so.7 first; ours then binds to the same runtime)
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().spyhip_last_error().decode("utf-8", "replace")
+        raise SpyHipError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,177 @@
+"""Thin Python layer over the C ABI of libspyhip.so (include/spyhip.h).
+
+PyTorch is used for device memory and streams only: tensors are allocated by
+torch, their raw device pointers are handed to the HIP library, and all kernels
+are enqueued on torch's current stream.  There is no CPU code path here.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SpyHipError, check
+
+OUTPUT_KIND = {"pow": 0, "abs": 1, "fourier": 2, "complex": 2, "real": 3, "imag": 4, "angle": 5,
+               "absreal": 6, "absimag": 7}
+DETREND = {None: -1, False: -1, 0: 0, 1: 1}
+
+_contexts = {}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise SpyHipError("no HIP device visible: syncopy_amd has no CPU fallback (torch.cuda.is_available() is False)")
+
+
+class Context:
+    """One spyhip_ctx per device, bound to torch's current stream at every call."""
+
+    def __init__(self, device):
+        require_gpu()
+        self.lib = _lib.load()
+        self.device = int(device)
+        h = C.c_void_p()
+        check(self.lib.spyhip_ctx_create(self.device, C.byref(h)), "spyhip_ctx_create")
+        self.handle = h
+
+    def bind_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.spyhip_ctx_set_stream(self.handle, C.c_void_p(s)), "spyhip_ctx_set_stream")
+
+    def synchronize(self):
+        check(self.lib.spyhip_ctx_synchronize(self.handle), "spyhip_ctx_synchronize")
+
+
+def context(device=None):
+    require_gpu()
+    if device is None:
+        device = torch.cuda.current_device()
+    device = torch.device(device).index if not isinstance(device, int) else device
+    if device is None:
+        device = torch.cuda.current_device()
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+class FFTPlan:
+    """spyhip_fft_plan: tapered FFT of segments of a (rows x ld) float32 matrix."""
+
+    def __init__(self, nsig, nfft, nchan, tapers, scale, detrend=None, demean_taper=False, freq_idx=None,
+                 output="pow", keeptapers=True, device=None):
+        self.ctx = context(device)
+        tapers = np.ascontiguousarray(np.atleast_2d(tapers), dtype=np.float64)
+        assert tapers.shape[1] == nsig, (tapers.shape, nsig)
+        self.nsig, self.nfft, self.nchan, self.ntaper = int(nsig), int(nfft), int(nchan), tapers.shape[0]
+        self.output = output
+        self.kind = OUTPUT_KIND[output]
+        self.keeptapers = bool(keeptapers)
+        nf = self.nfft // 2 + 1
+        if freq_idx is None:
+            fi_p, self.nfsel = None, nf
+        else:
+            fi = np.ascontiguousarray(freq_idx, dtype=np.int32)
+            fi_p, self.nfsel = fi.ctypes.data_as(_lib.c_i32p), int(fi.size)
+        h = C.c_void_p()
+        self.ctx.bind_stream()
+        check(self.ctx.lib.spyhip_fft_plan_create(
+            self.ctx.handle, self.nsig, self.nfft, self.nchan, self.ntaper,
+            tapers.ctypes.data_as(_lib.c_f64p), float(scale), DETREND[detrend], int(bool(demean_taper)),
+            fi_p, self.nfsel, self.kind, int(self.keeptapers), C.byref(h)), "spyhip_fft_plan_create")
+        self.handle = h
+        self.kout = self.ntaper if self.keeptapers else 1
+        self.out_dtype = torch.complex64 if self.kind == 2 else torch.float32
+
+    @property
+    def kernel_name(self):
+        return self.ctx.lib.spyhip_fft_plan_kernel_name(self.handle).decode()
+
+    def out_shape(self, nseg):
+        return (nseg, self.kout, self.nfsel, self.nchan)
+
+    def execute(self, data, seg_start, seg_lo=None, seg_hi=None, chan_idx=None, out=None):
+        """data: (rows, ld) float32 cuda tensor; seg_*: int64 cuda tensors of equal length."""
+        assert data.is_cuda and data.dtype == torch.float32 and data.dim() == 2 and data.is_contiguous()
+        dev = data.device
+        nseg = int(seg_start.numel())
+        if seg_lo is None:
+            seg_lo = seg_start
+        if seg_hi is None:
+            seg_hi = seg_start + self.nsig
+        for t in (seg_start, seg_lo, seg_hi):
+            assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == nseg
+        if chan_idx is not None:
+            assert chan_idx.is_cuda and chan_idx.dtype == torch.int32 and chan_idx.numel() == self.nchan
+        else:
+            assert data.shape[1] >= self.nchan
+        if out is None:
+            out = torch.empty(self.out_shape(nseg), dtype=self.out_dtype, device=dev)
+        else:
+            assert out.is_cuda and out.is_contiguous() and out.dtype == self.out_dtype
+            assert tuple(out.shape) == self.out_shape(nseg), (tuple(out.shape), self.out_shape(nseg))
+        self.ctx.bind_stream()
+        check(self.ctx.lib.spyhip_fft_exec(self.handle, _ptr(data), int(data.shape[1]), _ptr(chan_idx),
+                                           _ptr(seg_start), _ptr(seg_lo), _ptr(seg_hi), nseg, _ptr(out)),
+              "spyhip_fft_exec")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.ctx.lib.spyhip_fft_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def csd_accumulate(spec, acc):
+    """acc[f,i,j] += sum_r spec[r,f,i] conj(spec[r,f,j]) on the lower triangle (MFMA).
+    spec: (..., F, C) complex64 (leading dims flattened to rows); acc: (F, C, C) complex64."""
+    assert spec.is_cuda and spec.dtype == torch.complex64 and spec.is_contiguous()
+    assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous()
+    F, Cn = spec.shape[-2], spec.shape[-1]
+    assert tuple(acc.shape) == (F, Cn, Cn), (tuple(acc.shape), (F, Cn, Cn))
+    nrows = spec.numel() // (F * Cn)
+    ctx = context(spec.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_csd_accumulate(ctx.handle, _ptr(spec), nrows, F, Cn, _ptr(acc)), "spyhip_csd_accumulate")
+    return acc
+
+
+def csd_finalize(acc, scale):
+    """Scale the accumulated lower triangle and mirror it: acc becomes the full Hermitian CSD."""
+    assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and acc.dim() == 3
+    F, Cn, _ = acc.shape
+    ctx = context(acc.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_csd_finalize(ctx.handle, _ptr(acc), F, Cn, float(scale)), "spyhip_csd_finalize")
+    return acc
+
+
+def coh_normalize(csd, output="abs"):
+    """Coherency csd_ij / sqrt(csd_ii csd_jj) + output conversion; csd: (F, C, C) complex64, full Hermitian."""
+    assert csd.is_cuda and csd.dtype == torch.complex64 and csd.is_contiguous() and csd.dim() == 3
+    F, Cn, _ = csd.shape
+    kind = OUTPUT_KIND[output]
+    out = torch.empty((F, Cn, Cn), dtype=torch.complex64 if kind == 2 else torch.float32, device=csd.device)
+    ctx = context(csd.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_coh_normalize(ctx.handle, _ptr(csd), F, Cn, kind, _ptr(out)), "spyhip_coh_normalize")
+    return out
+
+
+def trial_mean(x):
+    """Sequential float32 sum over axis 0 followed by one division (trial averaging order of the reference)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    T = x.shape[0]
+    n = x.numel() // T
+    out = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
+    ctx = context(x.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_trial_mean_f32(ctx.handle, _ptr(x), _ptr(out), T, n), "spyhip_trial_mean_f32")
+    return out

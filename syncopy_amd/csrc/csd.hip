@@ -1,0 +1,95 @@
+// Host side of K4/K5: cross-spectral accumulation, finalisation and coherence
+// normalisation (spyhip_csd_accumulate / spyhip_csd_finalize / spyhip_coh_normalize).
+#include "spy_common.h"
+#include "csd_kernel.h"
+
+using spycsd::CsdArgs;
+
+namespace {
+
+template <int TPW>
+int launch_accum(spyhip_ctx* ctx, const CsdArgs& a, size_t lds) {
+    auto kern = spycsd::csd_accum_kernel<TPW>;
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long per = 4LL * TPW;
+    const long long grid = (a.nitems + per - 1) / per;
+    if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(spycsd::CSD_THREADS), lds, ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                                     void* acc_d) {
+    if (!ctx || !spec_d || !acc_d) { spy::set_error("csd_accumulate: null argument"); return -1; }
+    if (nrows < 0 || nfreq < 1 || nchan < 1) { spy::set_error("csd_accumulate: bad shape"); return -1; }
+    if (nrows == 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    CsdArgs a{};
+    a.spec = reinterpret_cast<const float2*>(spec_d);
+    a.nrows = nrows; a.F = nfreq; a.C = nchan;
+    a.acc = reinterpret_cast<float2*>(acc_d);
+    a.nt = (nchan + 31) / 32;
+    a.ntiles = a.nt * (a.nt + 1) / 2;
+    a.nitems = (long long)nfreq * a.ntiles;
+    a.cpad = a.nt * 32;
+    // tiles per wave: 9 packs the 36 tiles of C=256 into one workgroup per frequency
+    int tpw = 1;
+    if (a.ntiles % 36 == 0) tpw = 9;
+    else if (a.ntiles >= 10) tpw = 5;
+    else if (a.ntiles >= 3) tpw = 3;
+    // frequencies a workgroup can touch: items [i0, i0+4*tpw) span at most this many f
+    const int per = 4 * tpw;
+    int nfb = (per + a.ntiles - 1) / a.ntiles;
+    if (per % a.ntiles != 0 && a.ntiles > 1) nfb += 1;
+    if (nfb > nfreq) nfb = nfreq;
+    const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
+    int kb = 32;
+    while (kb > 2 && (size_t)kb * rowbytes > ctx->lds_per_block) kb -= 2;
+    if ((size_t)kb * rowbytes > ctx->lds_per_block) {
+        spy::set_error("csd_accumulate: %d channels do not fit the LDS staging buffer", nchan);
+        return -3;
+    }
+    if (kb > nrows) kb = (int)((nrows + 1) & ~1LL);
+    a.kb = kb;
+    const size_t lds = (size_t)kb * rowbytes;
+    switch (tpw) {
+        case 9: return launch_accum<9>(ctx, a, lds);
+        case 5: return launch_accum<5>(ctx, a, lds);
+        case 3: return launch_accum<3>(ctx, a, lds);
+        default: return launch_accum<1>(ctx, a, lds);
+    }
+}
+
+extern "C" int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, double scale) {
+    if (!ctx || !acc_d) { spy::set_error("csd_finalize: null argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long n = (long long)nfreq * nchan * nchan;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(spycsd::csd_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<float2*>(acc_d), nfreq, nchan, (float)scale);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int spyhip_coh_normalize(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, int output,
+                                    void* out_d) {
+    if (!ctx || !csd_d || !out_d) { spy::set_error("coh_normalize: null argument"); return -1; }
+    if (output < SPYHIP_OUT_POW || output > SPYHIP_OUT_ABSIMAG) { spy::set_error("coh_normalize: bad output %d", output); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long n = (long long)nfreq * nchan * nchan;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (output == SPYHIP_OUT_FOURIER)
+        hipLaunchKernelGGL(spycsd::coh_normalize_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float2*>(csd_d), nfreq, nchan, output, out_d);
+    else
+        hipLaunchKernelGGL(spycsd::coh_normalize_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float2*>(csd_d), nfreq, nchan, output, out_d);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}

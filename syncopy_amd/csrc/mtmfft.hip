@@ -1,0 +1,312 @@
+// Host side of K1/K2: plan construction and kernel dispatch for the tapered-FFT
+// kernels (spyhip_fft_plan_create / spyhip_fft_exec of include/spyhip.h).
+#include <cmath>
+#include <cstdlib>
+#include <string>
+
+#include "spy_common.h"
+#include "mtmfft_kernel.h"
+#include "mtmfft_generic.h"
+
+using spyfft::GenPlan;
+using spyfft::MtmArgs;
+
+struct spyhip_fft_plan {
+    spyhip_ctx* ctx = nullptr;
+    int nsig = 0, nfft = 0, nchan = 0, ntaper = 0, nfsel = 0, output = 0, keeptapers = 1;
+    int detrend = -1, demean_taper = 0;
+    float scale = 1.f;
+    bool pow2 = false;
+    int log2n = 0, G = 1;
+    GenPlan gen{};
+    size_t lds_bytes = 0;
+    spy::DevBuf<float> tapers;
+    spy::DevBuf<float2> tw, chirp, bhat;
+    spy::DevBuf<int> fpos;
+    bool identity_freq = true;
+    std::string kernel_name;
+};
+
+namespace {
+
+const double PI = 3.14159265358979323846264338327950288;
+
+std::vector<float2> twiddle_table(int n) {
+    std::vector<float2> t(n);
+    for (int m = 0; m < n; ++m) {
+        const double ang = -2.0 * PI * (double)m / (double)n;
+        t[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    return t;
+}
+
+// radix schedule of the generic Stockham passes; false if n has a prime factor > 13
+bool factorize(int n, int* radix, int* nfac) {
+    static const int cand[] = {16, 8, 4, 2, 3, 5, 7, 11, 13};
+    int k = 0;
+    for (int c : cand) {
+        while (n % c == 0 && n > 1) {
+            if (k >= spyfft::GEN_MAXFAC) return false;
+            radix[k++] = c;
+            n /= c;
+        }
+    }
+    *nfac = k;
+    return n == 1;
+}
+
+// host reference FFT (double, recursive radix-2) used once per plan for the Bluestein filter
+void fft_host(std::vector<double>& re, std::vector<double>& im) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * PI / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = std::cos(ang * k), wi = std::sin(ang * k);
+                const size_t a = i + k, b = i + k + len / 2;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr;
+                im[b] = im[a] - ti;
+                re[a] += tr;
+                im[a] += ti;
+            }
+    }
+}
+
+template <int LOG2N, int G, int OUTK, bool MEAN>
+int launch_pow2(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
+    using C = spyfft::Cfg<LOG2N, G>;
+    auto kern = spyfft::mtmfft_pow2_kernel<LOG2N, G, OUTK, MEAN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int LOG2N, int G>
+int launch_pow2_mode(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
+    const bool mean = !p->keeptapers;
+    const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+    switch (outk * 2 + (mean ? 1 : 0)) {
+        case 0: return launch_pow2<LOG2N, G, 0, false>(p, a, grid);
+        case 1: return launch_pow2<LOG2N, G, 0, true>(p, a, grid);
+        case 2: return launch_pow2<LOG2N, G, 1, false>(p, a, grid);
+        case 3: return launch_pow2<LOG2N, G, 1, true>(p, a, grid);
+        case 4: return launch_pow2<LOG2N, G, 2, false>(p, a, grid);
+        default: return launch_pow2<LOG2N, G, 2, true>(p, a, grid);
+    }
+}
+
+template <int OUTK, bool MEAN>
+int launch_generic(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
+    auto kern = spyfft::mtmfft_generic_kernel<OUTK, MEAN>;
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(spyfft::GEN_THREADS), p->lds_bytes, p->ctx->stream, a, p->gen);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// preferred pair-interleave G per power-of-two length (workgroup = N/16*G threads)
+int default_G(int log2n, int nchan) {
+    int g;
+    switch (log2n) {
+        case 8: g = 16; break;
+        case 9: g = 8; break;
+        case 10: g = 4; break;
+        case 11: g = 4; break;
+        case 12: g = 4; break;
+        case 13: g = 2; break;
+        default: g = 1; break;
+    }
+    if (log2n == 12) {
+        const char* e = std::getenv("SPYHIP_FFT_G");
+        if (e) {
+            const int v = std::atoi(e);
+            if (v == 1 || v == 2 || v == 4) g = v;
+        }
+        const int npairs = (nchan + 1) / 2;
+        while (g > 1 && g > npairs) g >>= 1;
+    }
+    return g;
+}
+
+}  // namespace
+
+extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int nchan, int ntaper,
+                                      const double* tapers, double scale, int detrend, int demean_taper,
+                                      const int32_t* freq_idx, int nfsel, int output, int keeptapers,
+                                      spyhip_fft_plan** out) {
+    if (!ctx || !out || !tapers) { spy::set_error("fft_plan_create: null argument"); return -1; }
+    if (nsig < 1 || nfft < nsig || nchan < 1 || ntaper < 1) {
+        spy::set_error("fft_plan_create: need 1 <= nsig <= nfft, nchan >= 1, ntaper >= 1 (got %d %d %d %d)",
+                       nsig, nfft, nchan, ntaper);
+        return -1;
+    }
+    if (output < SPYHIP_OUT_POW || output > SPYHIP_OUT_ABSIMAG) { spy::set_error("bad output kind %d", output); return -1; }
+    if (detrend < -1 || detrend > 1) { spy::set_error("bad detrend %d", detrend); return -1; }
+    const int nf = nfft / 2 + 1;
+    auto* p = new spyhip_fft_plan();
+    p->ctx = ctx;
+    p->nsig = nsig; p->nfft = nfft; p->nchan = nchan; p->ntaper = ntaper;
+    p->output = output; p->keeptapers = keeptapers ? 1 : 0;
+    p->detrend = detrend; p->demean_taper = demean_taper ? 1 : 0;
+    p->scale = (float)scale;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+
+    std::vector<float> tf((size_t)ntaper * nsig);
+    for (size_t i = 0; i < tf.size(); ++i) tf[i] = (float)tapers[i];
+    if (p->tapers.upload(tf, ctx->stream)) { delete p; return -2; }
+
+    // frequency selection -> inverse map bin -> output slot
+    p->identity_freq = (freq_idx == nullptr);
+    p->nfsel = freq_idx ? nfsel : nf;
+    if (freq_idx) {
+        std::vector<int> fpos(nf, -1);
+        bool ident = (nfsel == nf);
+        for (int i = 0; i < nfsel; ++i) {
+            const int f = freq_idx[i];
+            if (f < 0 || f >= nf) { spy::set_error("freq_idx[%d]=%d outside [0,%d)", i, f, nf); delete p; return -1; }
+            if (fpos[f] >= 0) { spy::set_error("freq_idx holds duplicate bin %d", f); delete p; return -1; }
+            fpos[f] = i;
+            ident = ident && (f == i);
+        }
+        p->identity_freq = ident;
+        if (!ident && p->fpos.upload(fpos, ctx->stream)) { delete p; return -2; }
+    }
+
+    const int outk = output == SPYHIP_OUT_FOURIER ? 2 : (output == SPYHIP_OUT_POW ? 0 : 1);
+    char mode[32];
+    std::snprintf(mode, sizeof mode, "%d, %s", outk, p->keeptapers ? "false" : "true");
+    p->pow2 = spy::is_pow2((unsigned)nfft) && nfft >= 256 && nfft <= 16384 && !std::getenv("SPYHIP_FORCE_GENERIC");
+    if (p->pow2) {
+        p->log2n = spy::ilog2((unsigned)nfft);
+        p->G = default_G(p->log2n, nchan);
+        if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "mtmfft_pow2_kernel<%d, %d, %s>", p->log2n, p->G, mode);
+        p->kernel_name = buf;
+    } else {
+        GenPlan& g = p->gen;
+        g.nfft = nfft;
+        g.bluestein = 0;
+        g.n = nfft;
+        if (nfft < 16) { spy::set_error("nfft=%d too short (need >= 16)", nfft); delete p; return -1; }
+        if (!factorize(nfft, g.radix, &g.nfac)) {
+            // Bluestein: circular convolution of length M = pow2 >= 2*nfft-1
+            int M = 16;
+            while (M < 2 * nfft - 1) M <<= 1;
+            g.bluestein = 1;
+            g.n = M;
+            factorize(M, g.radix, &g.nfac);
+            std::vector<float2> chirp(nfft);
+            std::vector<double> br(M, 0.0), bi(M, 0.0);
+            for (long long n = 0; n < nfft; ++n) {
+                const long long m = (n * n) % (2LL * nfft);  // exact phase reduction
+                const double ang = PI * (double)m / (double)nfft;
+                chirp[n] = make_float2((float)std::cos(ang), (float)-std::sin(ang));
+                br[n] = std::cos(ang);
+                bi[n] = std::sin(ang);
+                if (n > 0) { br[M - n] = br[n]; bi[M - n] = bi[n]; }
+            }
+            fft_host(br, bi);
+            std::vector<float2> bhat(M);
+            for (int i = 0; i < M; ++i) bhat[i] = make_float2((float)(br[i] / M), (float)(bi[i] / M));
+            if (p->chirp.upload(chirp, ctx->stream) || p->bhat.upload(bhat, ctx->stream)) { delete p; return -2; }
+            g.chirp = p->chirp.p;
+            g.bhat = p->bhat.p;
+        }
+        if (p->tw.upload(twiddle_table(g.n), ctx->stream)) { delete p; return -2; }
+        const size_t work = (size_t)2 * g.n * sizeof(float2);
+        const size_t staged = work + (size_t)nsig * sizeof(float2);
+        g.stage_x = staged <= ctx->lds_per_block ? 1 : 0;
+        p->lds_bytes = g.stage_x ? staged : work;
+        if (p->lds_bytes > ctx->lds_per_block) {
+            spy::set_error("nfft=%d needs %zu bytes of LDS (> %zu): unsupported length", nfft, p->lds_bytes, ctx->lds_per_block);
+            delete p;
+            return -3;
+        }
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "mtmfft_generic_kernel<%s>", mode);
+        p->kernel_name = buf;
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int spyhip_fft_plan_destroy(spyhip_fft_plan* p) {
+    delete p;
+    return 0;
+}
+
+extern "C" const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* p) {
+    return p ? p->kernel_name.c_str() : "";
+}
+
+extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t ld, const int32_t* chan_idx_d,
+                               const int64_t* seg_start_d, const int64_t* seg_lo_d, const int64_t* seg_hi_d,
+                               int nseg, void* out_d) {
+    if (!p || !data_d || !seg_start_d || !seg_lo_d || !seg_hi_d || !out_d) { spy::set_error("fft_exec: null argument"); return -1; }
+    if (nseg <= 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(p->ctx->device));
+    MtmArgs a{};
+    a.data = data_d; a.ld = ld; a.chan_idx = chan_idx_d;
+    a.seg_start = reinterpret_cast<const long long*>(seg_start_d);
+    a.seg_lo = reinterpret_cast<const long long*>(seg_lo_d);
+    a.seg_hi = reinterpret_cast<const long long*>(seg_hi_d);
+    a.nseg = nseg; a.nsig = p->nsig; a.nchan = p->nchan; a.ntaper = p->ntaper;
+    a.tapers = p->tapers.p; a.tw = p->tw.p; a.scale = p->scale;
+    a.detrend = p->detrend; a.demean_taper = p->demean_taper;
+    a.fpos = p->identity_freq ? nullptr : p->fpos.p;
+    a.nfsel = p->nfsel; a.out_kind = p->output; a.out = out_d;
+    const int npairs = (p->nchan + 1) / 2;
+    if (p->pow2) {
+        const int G = p->G;
+        a.npg = (npairs + G - 1) / G;
+        int S = 16 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+        a.S = S;
+        a.ncl = (a.npg + S - 1) / S;
+        const long long nclusters = (long long)nseg * a.ncl;
+        const long long grid = ((nclusters + 7) / 8) * S * 8;
+        if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
+        const unsigned g = (unsigned)grid;
+        switch (p->log2n * 100 + G) {
+            case 816: return launch_pow2_mode<8, 16>(p, a, g);
+            case 908: return launch_pow2_mode<9, 8>(p, a, g);
+            case 1004: return launch_pow2_mode<10, 4>(p, a, g);
+            case 1104: return launch_pow2_mode<11, 4>(p, a, g);
+            case 1201: return launch_pow2_mode<12, 1>(p, a, g);
+            case 1202: return launch_pow2_mode<12, 2>(p, a, g);
+            case 1204: return launch_pow2_mode<12, 4>(p, a, g);
+            case 1302: return launch_pow2_mode<13, 2>(p, a, g);
+            case 1401: return launch_pow2_mode<14, 1>(p, a, g);
+            default: spy::set_error("no kernel for log2n=%d G=%d", p->log2n, G); return -1;
+        }
+    }
+    const long long grid = (long long)nseg * npairs;
+    if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
+    const bool mean = !p->keeptapers;
+    const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+    switch (outk * 2 + (mean ? 1 : 0)) {
+        case 0: return launch_generic<0, false>(p, a, (unsigned)grid);
+        case 1: return launch_generic<0, true>(p, a, (unsigned)grid);
+        case 2: return launch_generic<1, false>(p, a, (unsigned)grid);
+        case 3: return launch_generic<1, true>(p, a, (unsigned)grid);
+        case 4: return launch_generic<2, false>(p, a, (unsigned)grid);
+        default: return launch_generic<2, true>(p, a, (unsigned)grid);
+    }
+}

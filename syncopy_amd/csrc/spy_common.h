@@ -1,0 +1,75 @@
+// Shared host-side plumbing of libspyhip: context, error reporting, launch checks.
+#pragma once
+#ifndef SPY_HOST_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spyhip.h"
+
+#ifndef SPY_HOST_EMU
+#define SPY_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) char name##_raw[]; \
+    type* name = reinterpret_cast<type*>(name##_raw)
+#endif
+
+struct spyhip_ctx {
+    int device = 0;
+#ifndef SPY_HOST_EMU
+    hipStream_t stream = nullptr;
+#endif
+    int num_cu = 256;
+    size_t lds_per_block = 160 * 1024;
+};
+
+namespace spy {
+
+void set_error(const char* fmt, ...);
+
+#ifndef SPY_HOST_EMU
+#define SPY_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            spy::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                           __LINE__);                                                        \
+            return -2;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+// device buffer owned by a plan
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        n = count;
+        if (count == 0) return 0;
+        SPY_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        return 0;
+    }
+    int upload(const std::vector<T>& h, hipStream_t s) {
+        if (alloc(h.size())) return -2;
+        if (h.empty()) return 0;
+        SPY_HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        SPY_HIP_CHECK(hipStreamSynchronize(s));
+        return 0;
+    }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+#endif
+
+static inline int ilog2(unsigned v) {
+    int l = 0;
+    while ((1u << l) < v) ++l;
+    return l;
+}
+static inline bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
+
+}  // namespace spy

@@ -1,0 +1,113 @@
+"""ctypes front end of the CPU emulation of the HIP kernels (TEST INFRASTRUCTURE ONLY).
+
+Mirrors the plan construction of syncopy_amd/csrc/mtmfft.hip in NumPy so that a
+test can run one kernel configuration on host arrays and compare it with the
+oracle.  Never imported by the package.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_emu  # noqa: E402
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_emu.build())
+    return _lib
+
+
+def _p(a, typ):
+    return None if a is None else a.ctypes.data_as(C.POINTER(typ))
+
+
+def twiddles(n):
+    m = np.arange(n, dtype=np.float64)
+    ang = -2.0 * np.pi * m / n
+    return np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32).copy()
+
+
+def factorize(n):
+    rad = []
+    for c in (16, 8, 4, 2, 3, 5, 7, 11, 13):
+        while n % c == 0 and n > 1:
+            rad.append(c)
+            n //= c
+    return rad, n == 1
+
+
+OUT_KINDS = {"pow": 0, "abs": 1, "fourier": 2, "complex": 2, "real": 3, "imag": 4, "angle": 5,
+             "absreal": 6, "absimag": 7}
+
+
+def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
+             freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False):
+    """Emulated spyhip_fft_exec.  data: (rows, ld) float32; tapers: (K, nsig) float64."""
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    ld = data.shape[1]
+    nchan = ld if chan_idx is None else len(chan_idx)
+    ci = None if chan_idx is None else np.ascontiguousarray(chan_idx, dtype=np.int32)
+    ss = np.ascontiguousarray(seg_start, dtype=np.int64)
+    sl = np.ascontiguousarray(seg_lo, dtype=np.int64)
+    sh = np.ascontiguousarray(seg_hi, dtype=np.int64)
+    nseg = len(ss)
+    K = tapers.shape[0]
+    tp = np.ascontiguousarray(tapers, dtype=np.float32)
+    nf = nfft // 2 + 1
+    if freq_idx is None:
+        fpos, nfsel = None, nf
+    else:
+        fi = np.asarray(freq_idx, dtype=np.int64)
+        nfsel = len(fi)
+        fpos = np.full(nf, -1, dtype=np.int32)
+        fpos[fi] = np.arange(nfsel, dtype=np.int32)
+    kind = OUT_KINDS[output]
+    kout = K if keeptapers else 1
+    out = np.full((nseg, kout, nfsel, nchan), np.nan, dtype=np.complex64 if kind == 2 else np.float32)
+    pow2 = (nfft & (nfft - 1)) == 0 and 256 <= nfft <= 16384 and not force_generic
+    if pow2:
+        log2n = int(np.log2(nfft))
+        if G is None:
+            G = {8: 16, 9: 8, 10: 4, 11: 4, 12: 2, 13: 2, 14: 1}[log2n]
+        tw = twiddles(nfft)
+        rc = lib().emu_mtmfft_pow2(
+            C.c_int(log2n), C.c_int(G), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
+            _p(ss, C.c_longlong), _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg),
+            C.c_int(nsig), C.c_int(nchan), C.c_int(K), _p(tp, C.c_float), _p(tw, C.c_float),
+            C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), _p(fpos, C.c_int),
+            C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0, f"no emulated kernel for log2n={log2n} G={G}"
+        return out
+    rad, ok = factorize(nfft)
+    n, blu, chirp, bhat = nfft, 0, None, None
+    if not ok:
+        M = 16
+        while M < 2 * nfft - 1:
+            M *= 2
+        k = np.arange(nfft, dtype=np.int64)
+        ang = np.pi * ((k * k) % (2 * nfft)) / nfft
+        chirp = np.stack([np.cos(ang), -np.sin(ang)], axis=1).astype(np.float32).copy()
+        b = np.zeros(M, dtype=np.complex128)
+        b[:nfft] = np.exp(1j * ang)
+        b[M - nfft + 1:] = b[1:nfft][::-1]
+        bh = np.fft.fft(b) / M
+        bhat = np.stack([bh.real, bh.imag], axis=1).astype(np.float32).copy()
+        n, blu = M, 1
+        rad, _ = factorize(M)
+    tw = twiddles(n)
+    radix = np.asarray(rad, dtype=np.int32)
+    stage_x = 1 if (2 * n + nsig) * 8 <= 160 * 1024 else 0
+    lib().emu_mtmfft_generic(
+        C.c_int(n), C.c_int(len(rad)), _p(radix, C.c_int), C.c_int(nfft), C.c_int(blu), _p(chirp, C.c_float),
+        _p(bhat, C.c_float), C.c_int(stage_x), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
+        _p(ss, C.c_longlong), _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg), C.c_int(nsig),
+        C.c_int(nchan), C.c_int(K), _p(tp, C.c_float), _p(tw, C.c_float), C.c_float(scale), C.c_int(detrend),
+        C.c_int(int(demean_taper)), _p(fpos, C.c_int), C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)),
+        out.ctypes.data_as(C.c_void_p))
+    return out

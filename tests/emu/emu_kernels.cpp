@@ -1,0 +1,123 @@
+// CPU emulation driver for the HIP kernels (TEST INFRASTRUCTURE ONLY, see hip_emu.h).
+// Compiles the kernel headers of syncopy_amd/csrc unchanged and runs them
+// workgroup by workgroup on OS threads.  Built by tests/emu/build_emu.py into
+// tests/emu/_build/libspyemu.so; only tests/ load it.
+#include "hip_emu.h"
+#include <algorithm>
+using std::max;
+using std::min;
+
+namespace emu {
+thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+thread_local BlockCtx* t_ctx = nullptr;
+}  // namespace emu
+
+#include "../../syncopy_amd/csrc/spy_common.h"
+#include "../../syncopy_amd/csrc/mtmfft_kernel.h"
+#include "../../syncopy_amd/csrc/mtmfft_generic.h"
+
+namespace spy {
+void set_error(const char*, ...) {}
+}  // namespace spy
+
+using spyfft::GenPlan;
+using spyfft::MtmArgs;
+
+namespace {
+
+template <int LOG2N, int G, int OUTK, bool MEAN>
+void run_pow2(const MtmArgs& a, unsigned grid, long only_block) {
+    using C = spyfft::Cfg<LOG2N, G>;
+    emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES,
+                [&] { spyfft::mtmfft_pow2_kernel<LOG2N, G, OUTK, MEAN>(a); }, only_block);
+}
+
+template <int LOG2N, int G>
+void run_pow2_mode(const MtmArgs& a, unsigned grid, int outk, int mean, long only_block) {
+    switch (outk * 2 + mean) {
+        case 0: run_pow2<LOG2N, G, 0, false>(a, grid, only_block); break;
+        case 1: run_pow2<LOG2N, G, 0, true>(a, grid, only_block); break;
+        case 2: run_pow2<LOG2N, G, 1, false>(a, grid, only_block); break;
+        case 3: run_pow2<LOG2N, G, 1, true>(a, grid, only_block); break;
+        case 4: run_pow2<LOG2N, G, 2, false>(a, grid, only_block); break;
+        default: run_pow2<LOG2N, G, 2, true>(a, grid, only_block); break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Mirrors the argument marshalling of spyhip_fft_exec for the power-of-two kernel.
+// All pointers are host pointers.  Returns 0, or -1 for an unsupported (log2n, G).
+int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int* chan_idx,
+                    const long long* seg_start, const long long* seg_lo, const long long* seg_hi, int nseg,
+                    int nsig, int nchan, int ntaper, const float* tapers, const float* tw, float scale,
+                    int detrend, int demean_taper, const int* fpos, int nfsel, int out_kind, int keeptapers,
+                    void* out) {
+    MtmArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
+    a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
+    a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
+    a.out_kind = out_kind; a.out = out;
+    const int npairs = (nchan + 1) / 2;
+    a.npg = (npairs + G - 1) / G;
+    int S = 16 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+    a.S = S;
+    a.ncl = (a.npg + S - 1) / S;
+    const long long nclusters = (long long)nseg * a.ncl;
+    const unsigned grid = (unsigned)(((nclusters + 7) / 8) * S * 8);
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    const int mean = keeptapers ? 0 : 1;
+    switch (log2n * 100 + G) {
+        case 816: run_pow2_mode<8, 16>(a, grid, outk, mean, -1); break;
+        case 908: run_pow2_mode<9, 8>(a, grid, outk, mean, -1); break;
+        case 1004: run_pow2_mode<10, 4>(a, grid, outk, mean, -1); break;
+        case 1104: run_pow2_mode<11, 4>(a, grid, outk, mean, -1); break;
+        case 1201: run_pow2_mode<12, 1>(a, grid, outk, mean, -1); break;
+        case 1202: run_pow2_mode<12, 2>(a, grid, outk, mean, -1); break;
+        case 1204: run_pow2_mode<12, 4>(a, grid, outk, mean, -1); break;
+        case 1302: run_pow2_mode<13, 2>(a, grid, outk, mean, -1); break;
+        case 1401: run_pow2_mode<14, 1>(a, grid, outk, mean, -1); break;
+        default: return -1;
+    }
+    return 0;
+}
+
+int emu_mtmfft_generic(int n, int nfac, const int* radix, int nfft, int bluestein, const float* chirp,
+                       const float* bhat, int stage_x, const float* data, long long ld, const int* chan_idx,
+                       const long long* seg_start, const long long* seg_lo, const long long* seg_hi, int nseg,
+                       int nsig, int nchan, int ntaper, const float* tapers, const float* tw, float scale,
+                       int detrend, int demean_taper, const int* fpos, int nfsel, int out_kind, int keeptapers,
+                       void* out) {
+    MtmArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
+    a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
+    a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
+    a.out_kind = out_kind; a.out = out;
+    GenPlan g{};
+    g.n = n; g.nfac = nfac; g.nfft = nfft; g.bluestein = bluestein; g.stage_x = stage_x;
+    for (int i = 0; i < nfac; ++i) g.radix[i] = radix[i];
+    g.chirp = reinterpret_cast<const float2*>(chirp);
+    g.bhat = reinterpret_cast<const float2*>(bhat);
+    const size_t lds = ((size_t)2 * n + (stage_x ? nsig : 0)) * sizeof(float2);
+    const unsigned grid = (unsigned)nseg * (unsigned)((nchan + 1) / 2);
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    const bool mean = !keeptapers;
+    auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(spyfft::GEN_THREADS), lds, fn); };
+    switch (outk * 2 + (mean ? 1 : 0)) {
+        case 0: go([&] { spyfft::mtmfft_generic_kernel<0, false>(a, g); }); break;
+        case 1: go([&] { spyfft::mtmfft_generic_kernel<0, true>(a, g); }); break;
+        case 2: go([&] { spyfft::mtmfft_generic_kernel<1, false>(a, g); }); break;
+        case 3: go([&] { spyfft::mtmfft_generic_kernel<1, true>(a, g); }); break;
+        case 4: go([&] { spyfft::mtmfft_generic_kernel<2, false>(a, g); }); break;
+        default: go([&] { spyfft::mtmfft_generic_kernel<2, true>(a, g); }); break;
+    }
+    return 0;
+}
+
+}  // extern "C"
