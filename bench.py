@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Headline benchmark: trials/s for mtmfft + coherence (BASELINE.json configs[2] data shape:
+256 channels x 4096 samples x 1000 trials per GPU, 7 DPSS tapers, full 256x256 CSD).
+
+One "step" = one complete pass of the hot path over the rank's in-HBM trial queue:
+    for every batch of trials:  detrend -> taper -> FFT (complex spectra, all tapers)   [K1]
+                                 acc += X X^H on the fp32 matrix cores                     [K4]
+    (N > 1) RCCL all-reduce of the CSD accumulator over xGMI                               [C1]
+    scale + Hermitian mirror, coherence normalisation -> (F, C, C) float32                 [K5]
+Trials shard across ranks with no other exchange (weak scaling: 1000 trials per GPU).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--trials", type=int, default=1000, help="trials per GPU")
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=125, help="trials per FFT/CSD launch pair")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(nchan, nsamp, budget_s=30.0):
+    """Reference-faithful CPU path (oracle = port of the reference's NumPy/SciPy calls) timed on
+    the host: single-trial cross spectra exactly as csd.py:94-102 does them (incl. the
+    (K,F,C,C) temporary), the per-trial cost of the reference's compute_sequential loop."""
+    from oracle import spy_oracle as O
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(nsamp, nchan)).astype(np.float32)
+    topt = {"NW": 1.0 * nsamp / 1000.0, "Kmax": 7}
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        O.cross_spectra_cF(x.copy(), samplerate=1000.0, nSamples=nsamp, foi=None, taper="dpss", taper_opt=topt,
+                           polyremoval=0, faithful=True)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s / 2 or n >= 8:
+            break
+    return {"value": n / el, "unit": "trials/s", "cores": 1, "kind": "port",
+            "sample": f"{n} trial(s) of {nchan} ch x {nsamp} samples, cross_spectra_cF (mtmfft + (K,F,C,C) outer "
+                      f"product + taper mean, as csd.py:94-102), {el:.1f} s on one host core"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: syncopy_amd has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from scipy.signal import windows
+    from syncopy_amd import backend as be
+    from syncopy_amd import synthdata
+
+    C, N, T, K = args.channels, args.samples, args.trials, 7
+    F = N // 2 + 1
+    fs = 1000.0
+    NW = 1.0 * N / fs                      # tapsmofrq = 1 Hz -> NW = 4.096, Kmax = 7
+    tapers = windows.dpss(N, NW, K) * np.sqrt(N)
+    scale = np.sqrt(2) / N
+    data = synthdata.ar2_uncoupled_fast(C, N, T, seed=1234 + rank)          # (T*N, C) float32 in HBM
+    starts_all = torch.arange(T, device="cuda", dtype=torch.int64) * N
+    plan = be.FFTPlan(N, N, C, tapers, scale, detrend=0, demean_taper=False, freq_idx=None, output="fourier",
+                      keeptapers=True)
+    B = min(args.batch, T)
+    spec = torch.empty(plan.out_shape(B), dtype=torch.complex64, device="cuda")
+    acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    ev_csd, ev_fft = [], []
+
+    def step(timed):
+        acc.zero_()
+        for b0 in range(0, T, B):
+            nb = min(B, T - b0)
+            sp = spec[:nb]
+            if timed:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+            plan.execute(data, starts_all[b0:b0 + nb], out=sp)
+            if timed:
+                e1.record()
+            be.csd_accumulate(sp, acc)
+            if timed:
+                e2.record()
+                ev_fft.append((e0, e1, nb))
+                ev_csd.append((e1, e2, nb))
+        if world > 1:
+            dist.all_reduce(torch.view_as_real(acc))
+        be.csd_finalize(acc, 1.0 / (K * T * world))
+        return be.coh_normalize(acc, "abs")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        coh = step(True)
+    fence()
+    el = time.perf_counter() - t0
+    tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+
+    if rank == 0:
+        assert bool(torch.isfinite(coh).all()), "non-finite coherence"
+        diag = coh[:, torch.arange(C), torch.arange(C)]
+        assert float((diag - 1).abs().max()) < 1e-5, "coherence diagonal must be 1"
+        csd_ms = [a.elapsed_time(b) for a, b, _ in ev_csd]
+        fft_ms = [a.elapsed_time(b) for a, b, _ in ev_fft]
+        rows = [nb * K for _, _, nb in ev_csd]
+        flops = [8.0 * r * F * C * (C + 1) / 2 for r in rows]                 # Hermitian-minimal, SURVEY 8d
+        achieved = sum(flops) / (sum(csd_ms) * 1e-3) / 1e12
+        fft_bytes = sum(nb * (N * C * 4 + K * F * C * 8) for _, _, nb in ev_fft)
+        value = world * T * args.steps / el
+        line = {
+            "metric": "trials/sec for mtmfft+coherence (256 ch x 4096 samples, 7 DPSS tapers, full CSD)",
+            "value": value,
+            "unit": "trials/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: connectivityanalysis method='coh' on AR(2) AnalogData, "
+                            f"{C} ch x {N} samp x {T} trials per GPU, tapsmofrq=1 Hz (NW={NW:.3f}, 7 tapers), "
+                            "polyremoval=0, output='abs', inputs resident in HBM",
+                "trials_per_gpu": T, "channels": C, "samples": N, "tapers": K, "freqs": F, "batch": B,
+                "channel_samples_per_s": value * N * C,
+                "fft_kernel": plan.kernel_name,
+                "fft_ms_per_trial": sum(fft_ms) / (T * args.steps),
+                "fft_stream_GBps": fft_bytes / (sum(fft_ms) * 1e-3) / 1e9,
+                "csd_ms_per_trial": sum(csd_ms) / (T * args.steps),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "spycsd::csd_accum_kernel<9>",
+                "achieved": achieved,
+                "peak": PEAK_MFMA_F32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_MFMA_F32_TFLOPS,
+                "flop_per_launch": flops[0],
+                "avg_launch_ms": float(np.mean(csd_ms)),
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(C, N)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""Compute functions on trial averages (signatures of syncopy/connectivity/AV_compRoutines.py:
+normalize_csd_cF:36 / NormalizeCrossSpectra:115, granger_cF:293 / GrangerCausality:415)."""
+import numpy as np
+import torch
+
+from .. import backend
+from ..shared.computational_routine import ComputationalRoutine
+from ..shared.const_def import spectralDTypes
+from ..shared.errors import SPYValueError
+
+
+def normalize_csd_cF(csd_av_dat, output="abs", chunkShape=None, noCompute=False):
+    """Coherency C_ij = S_ij / sqrt(S_ii S_jj) of the trial-averaged CSD (nTime, nFreq, N, N)."""
+    outShape = csd_av_dat.shape
+    fmt = spectralDTypes["fourier"] if output in ("complex", "fourier") else spectralDTypes["abs"]
+    if noCompute:
+        return outShape, fmt
+    backend.require_gpu()
+    dev = torch.from_numpy(np.ascontiguousarray(csd_av_dat, dtype=np.complex64)).cuda()
+    res = [backend.coh_normalize(dev[t], output) for t in range(dev.shape[0])]
+    return torch.stack(res, dim=0).cpu().numpy()
+
+
+class _AverageRoutine(ComputationalRoutine):
+    dimord = ["time", "freq", "channel_i", "channel_j"]
+
+    def pre_check(self):
+        if self.numTrials is None:
+            raise SPYValueError("Initialize the computational Routine first!", varname=self.__class__.__name__,
+                                actual="ComputationalRoutine not initialized!")
+        if self.numTrials != 1:
+            raise SPYValueError("1 trial: normalizations can only be done on averaged quantities!", varname="data",
+                                actual=f"DataSet contains {self.numTrials} trials")
+
+    def _device_input(self, data):
+        dev = getattr(data, "_dev", None)
+        if dev is None:
+            dev = torch.from_numpy(np.ascontiguousarray(data.data, dtype=np.complex64)).cuda()
+        return dev
+
+    def process_metadata(self, data, out):
+        out.channel_i = np.array(data.channel_i)
+        out.channel_j = np.array(data.channel_j)
+        out.freq = data.freq
+        out.trialdefinition = data.trialdefinition.copy()
+        out.samplerate = data.samplerate
+
+
+class NormalizeCrossSpectra(_AverageRoutine):
+    computeFunction = staticmethod(normalize_csd_cF)
+    method = ""
+    valid_kws = ["output"]
+
+    def compute_hip(self, data, out):
+        dev = self._device_input(data)
+        res = torch.stack([backend.coh_normalize(dev[t].contiguous(), self.cfg["output"])
+                           for t in range(dev.shape[0])], dim=0)
+        out._dev = res
+        out.data = res.cpu().numpy()

@@ -1,0 +1,103 @@
+"""Single-trial cross-spectra on MI355X (signatures of syncopy/connectivity/ST_compRoutines.py:
+cross_spectra_cF:269 / CrossSpectra:427, spectral_dyadic_product_cF:30)."""
+from hashlib import blake2b
+
+import numpy as np
+import torch
+
+from .. import backend
+from ..datatype import selected_channels, trial_rows
+from ..shared.computational_routine import ComputationalRoutine, propagate_properties
+from ..shared.const_def import spectralDTypes
+from ..shared.tools import best_match
+from ..specest import hip_spectral as hs
+
+
+def _freqs_hash(freqs):
+    return np.array(blake2b(freqs).hexdigest().encode("utf-8"))
+
+
+def _freq_selection(nSamples, samplerate, foi):
+    freqs = np.fft.rfftfreq(nSamples, 1 / samplerate)
+    if foi is not None:
+        _, freq_idx = best_match(freqs, foi, squash_duplicates=True)
+    else:
+        freq_idx = np.arange(freqs.size)
+    return freqs, freq_idx
+
+
+def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, polyremoval, freq_idx, acc_of_trial):
+    """Accumulate sum_k X_k X_k^H of every trial in `rows` into `acc_of_trial(i)` (device (F,C,C) c64)."""
+    ntaper = 1
+    for sel, spec in hs.run_mtmfft_batches(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, False,
+                                           polyremoval, freq_idx, "fourier", True):
+        ntaper = spec.shape[1]
+        groups = {}
+        for k, i in enumerate(sel):
+            groups.setdefault(id(acc_of_trial(i)), (acc_of_trial(i), []))[1].append(k)
+        for acc, ks in groups.values():
+            if len(ks) == spec.shape[0]:
+                backend.csd_accumulate(spec, acc)
+            else:
+                for k in ks:
+                    backend.csd_accumulate(spec[k], acc)
+    return ntaper
+
+
+def cross_spectra_cF(trl_dat, samplerate=1, nSamples=None, foi=None, taper="hann", taper_opt=None,
+                     demean_taper=False, polyremoval=False, timeAxis=0, chunkShape=None, noCompute=False):
+    """Single-trial cross spectra between all channels; returns (1, nFreq, N, N) complex64."""
+    dat = trl_dat.T if timeAxis != 0 else trl_dat
+    if nSamples is None:
+        nSamples = dat.shape[0]
+    nChannels = dat.shape[1]
+    freqs, freq_idx = _freq_selection(nSamples, samplerate, foi)
+    outShape = (1, freq_idx.size, nChannels, nChannels)
+    if noCompute:
+        return outShape, spectralDTypes["fourier"]
+    backend.require_gpu()
+    dev = torch.from_numpy(np.ascontiguousarray(dat, dtype=np.float32)).cuda()
+    acc = torch.zeros(outShape[1:], dtype=torch.complex64, device=dev.device)
+    pr = polyremoval if polyremoval in (0, 1) and polyremoval is not False else None
+    K = _csd_of_rows(dev, [(0, dev.shape[0])], None, nSamples, taper, taper_opt, demean_taper, pr, freq_idx,
+                     lambda i: acc)
+    backend.csd_finalize(acc, 1.0 / K)
+    return acc.cpu().numpy()[np.newaxis], {"freqs_hash": _freqs_hash(freqs)}
+
+
+class CrossSpectra(ComputationalRoutine):
+    dimord = ["time", "freq", "channel_i", "channel_j"]
+    computeFunction = staticmethod(cross_spectra_cF)
+    valid_kws = ["samplerate", "nSamples", "foi", "taper", "taper_opt", "demean_taper", "polyremoval", "timeAxis",
+                 "tapsmofrq", "nTaper", "pad", "output"]
+
+    def compute_hip(self, data, out):
+        """Trial-accumulated CSD straight from the in-HBM trial queue (MFMA rank-K updates)."""
+        cfg = self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
+        freqs, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
+        pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
+        F, C = self.targetShapes[0][1], self.targetShapes[0][2]
+        T = self.numTrials
+        if self.keeptrials:
+            acc = torch.zeros((T, F, C, C), dtype=torch.complex64, device=dev.device)
+            getter = lambda i: acc[i]                      # noqa: E731
+        else:
+            acc = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
+            getter = lambda i: acc                         # noqa: E731
+        K = _csd_of_rows(dev, rows, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"], cfg["demean_taper"], pr,
+                         freq_idx, getter)
+        if self.keeptrials:
+            for t in range(T):
+                backend.csd_finalize(acc[t], 1.0 / K)
+        else:
+            backend.csd_finalize(acc, 1.0 / (K * T))
+        self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T
+        out._dev = acc.reshape(self.outputShape)
+        out.data = out._dev.cpu().numpy()
+
+    def process_metadata(self, data, out):
+        propagate_properties(data, out, self.keeptrials)
+        out.freq = self.cfg["foi"]

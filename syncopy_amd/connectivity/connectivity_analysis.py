@@ -1,0 +1,110 @@
+"""`connectivityanalysis` metafunction for method = 'csd' | 'coh' | 'granger' on AnalogData.
+
+Two-stage pipeline of syncopy/connectivity/connectivity_analysis.py: single-trial
+cross-spectra accumulated over trials (ST stage, :587-599), then one evaluation on the
+trial average (AV stage, :677-679).  Parameter handling follows :286-473 and the
+`cross_spectra` helper (:775-872).
+"""
+import numbers
+
+import numpy as np
+
+from ..datatype import AnalogData, CrossSpectralData, selected_channels, selected_trialdefinition
+from ..shared.const_def import connectivity_outputs, connectivityMethods
+from ..shared.errors import SPYTypeError, SPYValueError, SPYWarning
+from ..shared.input_processors import process_foi, process_padding, process_taper
+from ..shared.tools import best_match
+from .AV_compRoutines import NormalizeCrossSpectra
+from .ST_compRoutines import CrossSpectra
+
+
+def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi=None, foilim=None, pad="maxperlen",
+                         polyremoval=0, tapsmofrq=None, nTaper=None, taper="hann", taper_opt=None, jackknife=False,
+                         select=None, compute_method=None, routine_classes=None, **kwargs):
+    """Cross-spectral connectivity of AnalogData on MI355X (arguments as spy.connectivityanalysis,
+    connectivity_analysis.py:51-67)."""
+    if not isinstance(data, AnalogData) or data.data is None:
+        raise SPYValueError("either AnalogData or SpectralData as input", "data", data.__class__.__name__)
+    if method not in connectivityMethods:
+        raise SPYValueError("one of " + ", ".join(connectivityMethods), varname="method", actual=method)
+    if not isinstance(jackknife, bool):
+        raise SPYTypeError(jackknife, "jackknife", "boolean")
+    if jackknife:
+        raise NotImplementedError("jackknife replicates are listed as 'next' in SURVEY.md section 8f")
+    if polyremoval is not None:
+        if not isinstance(polyremoval, numbers.Number) or polyremoval not in (0, 1):
+            raise SPYValueError("0, 1 or None", varname="polyremoval", actual=polyremoval)
+    classes = {"csd": CrossSpectra, "coh": NormalizeCrossSpectra}
+    try:
+        from .AV_compRoutines import GrangerCausality
+        classes["granger"] = GrangerCausality
+    except ImportError:
+        pass
+    classes.update(routine_classes or {})
+    data.selectdata(select)
+    try:
+        return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
+                             nTaper, taper, taper_opt, compute_method)
+    finally:
+        data.selection = None
+
+
+def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq, nTaper, taper,
+                  taper_opt, compute_method):
+    fs = data.samplerate
+    timeAxis = data.dimord.index("time")
+    trl = selected_trialdefinition(data)
+    lenTrials = np.diff(trl[:, :2]).squeeze(axis=1)
+    nTrials = lenTrials.size
+    if nTrials == 1:
+        raise SPYValueError("multi-trial input data, spectral connectivity measures critically depend on trial "
+                            "averaging!", "data", "only one trial")
+    if keeptrials is not False and method in ("coh", "granger"):
+        raise SPYValueError(f"False, trial averaging needed for method {method}!", varname="keeptrials",
+                            actual=keeptrials)
+    nSamples = process_padding(pad, lenTrials, fs)
+    foi, foilim = process_foi(foi, foilim, fs)
+    if method == "granger":
+        if foi is not None or foilim is not None:
+            raise SPYValueError("no foi specification for Granger analysis", "foi/foilim",
+                                "foi or foilim specification")
+        chans = selected_channels(data)
+        nChannels = len(data.channel) if chans is None else len(chans)
+        if nChannels / nTrials > 0.1:
+            SPYWarning("Multi-channel Granger analysis can be numerically unstable, it is recommended to have at "
+                       "least 10 times the number of trials compared to the number of channels.")
+    freqs = np.fft.rfftfreq(nSamples, 1 / fs)
+    if foi is not None:
+        foi, _ = best_match(freqs, foi, squash_duplicates=True)
+    elif foilim is not None:
+        foi, _ = best_match(freqs, foilim, span=True, squash_duplicates=True)
+    else:
+        foi = freqs
+    taper, taper_opt = process_taper(taper, taper_opt, tapsmofrq, nTaper, keeptapers=False, foimax=foi.max(),
+                                     samplerate=fs, nSamples=lenTrials.mean(), output="pow")
+    log_dict = {"method": method, "output": output, "keeptrials": keeptrials, "polyremoval": polyremoval,
+                "pad": pad, "foi": foi, "taper": taper, "taper_opt": taper_opt}
+
+    st = classes["csd"](samplerate=fs, nSamples=nSamples, taper=taper, taper_opt=taper_opt,
+                        demean_taper=(method == "granger"), polyremoval=polyremoval, timeAxis=timeAxis, foi=foi)
+    if method == "coh":
+        if output not in connectivity_outputs:
+            raise SPYValueError(f"one of {sorted(connectivity_outputs)}", varname="output", actual=output)
+        av = classes["coh"](output=output)
+    elif method == "granger":
+        if "granger" not in classes:
+            raise NotImplementedError("Wilson/Granger kernels are not part of this build")
+        av = classes["granger"](rtol=5e-6, nIter=100, cond_max=1e4)
+    else:
+        av = None
+
+    st_out = CrossSpectralData(dimord=CrossSpectra.dimord)
+    st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=bool(keeptrials))
+    st.compute(data, st_out, parallel=False, log_dict=log_dict, method=compute_method)
+    if av is None:
+        return st_out
+    out = CrossSpectralData(dimord=st_out.dimord)
+    av.initialize(st_out, out._stackingDim, chan_per_worker=None, keeptrials=False)
+    av.pre_check()
+    av.compute(st_out, out, parallel=False, log_dict=log_dict, method=compute_method)
+    return out

@@ -1,0 +1,240 @@
+"""Compute functions / compute classes of spectral estimation on MI355X.
+
+Signatures, dry-run behaviour and return conventions follow
+syncopy/specest/compRoutines.py (mtmfft_cF:60, mtmconvol_cF:245, wavelet_cF:483;
+MultiTaperFFT:194, MultiTaperFFTConvol:417, WaveletTransform:598) so the classes can
+be bound under spy.freqanalysis unchanged; all arithmetic runs in libspyhip.
+"""
+from hashlib import blake2b
+
+import numpy as np
+import torch
+
+from ..datatype import selected_channels, trial_rows
+from ..shared.computational_routine import ComputationalRoutine, propagate_properties
+from ..shared.const_def import spectralDTypes
+from ..shared.tools import best_match
+from . import hip_spectral as hs
+
+
+def _freqs_hash(freqs):
+    return np.array(blake2b(freqs).hexdigest().encode("utf-8"))
+
+
+def _as_device_trial(trl_dat, timeAxis):
+    """One host trial -> (time x channel) float32 matrix in HBM."""
+    backend = hs.backend
+    backend.require_gpu()
+    dat = trl_dat.T if timeAxis != 0 else trl_dat
+    return torch.from_numpy(np.ascontiguousarray(dat, dtype=np.float32)).cuda()
+
+
+# --------------------------------------------------------------------------- mtmfft
+def mtmfft_cF(trl_dat, foi=None, timeAxis=0, keeptapers=True, polyremoval=None, output="pow", noCompute=False,
+              chunkShape=None, method_kwargs=None):
+    """(Multi-)tapered Fourier transform of one trial; returns (1, nTaper|1, nFreq, nChannel)."""
+    dat = trl_dat.T if timeAxis != 0 else trl_dat
+    nSamples = dat.shape[0] if method_kwargs["nSamples"] is None else method_kwargs["nSamples"]
+    nChannels = dat.shape[1]
+    freqs = np.fft.rfftfreq(nSamples, 1 / method_kwargs["samplerate"])
+    _, freq_idx = best_match(freqs, foi, squash_duplicates=True)
+    nTaper = method_kwargs["taper_opt"].get("Kmax", 1)
+    outShape = (1, max(1, nTaper * keeptapers), freq_idx.size, nChannels)
+    if noCompute:
+        return outShape, spectralDTypes[output]
+
+    dev = _as_device_trial(trl_dat, timeAxis)
+    res = hs.run_mtmfft(dev, [(0, dev.shape[0])], None, nSamples, method_kwargs["taper"], method_kwargs["taper_opt"],
+                        method_kwargs.get("demean_taper", False), method_kwargs.get("ft_compat", False), polyremoval,
+                        freq_idx, output, keeptapers)[0]
+    spec = res.cpu().numpy()[np.newaxis]
+    return spec, {"freqs_hash": _freqs_hash(freqs)}
+
+
+class MultiTaperFFT(ComputationalRoutine):
+    computeFunction = staticmethod(mtmfft_cF)
+    valid_kws = ["samplerate", "nSamples", "taper", "taper_opt", "demean_taper", "ft_compat", "foi", "timeAxis",
+                 "keeptapers", "polyremoval", "output", "method_kwargs", "tapsmofrq", "nTaper", "pad"]
+
+    def compute_hip(self, data, out):
+        """All trials from the in-HBM queue; trial mean (keeptrials=False) in the reference's order."""
+        mk, cfg = self.cfg["method_kwargs"], self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        lengths = [b - a for a, b in rows]
+        freqs = np.fft.rfftfreq(mk["nSamples"] if mk["nSamples"] is not None else lengths[0], 1 / mk["samplerate"])
+        _, freq_idx = best_match(freqs, cfg["foi"], squash_duplicates=True)
+        res = hs.run_mtmfft(dev, rows, chans, mk["nSamples"], mk["taper"], mk["taper_opt"],
+                            mk.get("demean_taper", False), mk.get("ft_compat", False), cfg["polyremoval"], freq_idx,
+                            cfg["output"], cfg["keeptapers"])
+        stacked = torch.stack(res, dim=0)           # (nTrials, Kout, F, C)
+        self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * self.numTrials
+        if self.keeptrials:
+            out.data = stacked.cpu().numpy().reshape(self.outputShape)
+        else:
+            if stacked.dtype == torch.float32:
+                mean = hs.backend.trial_mean(stacked.contiguous())
+            else:
+                mean = torch.view_as_complex(
+                    hs.backend.trial_mean(torch.view_as_real(stacked.contiguous()).contiguous()))
+            out.data = mean.cpu().numpy().reshape(self.outputShape)
+
+    def process_metadata(self, data, out):
+        hashes = {bytes(m["freqs_hash"]) for m in self.metadata if m}
+        if len(hashes) > 1:
+            raise ValueError("frequency axes of the trials differ")
+        propagate_properties(data, out, self.keeptrials)
+        taper_kw = self.cfg["method_kwargs"]["taper"]
+        if taper_kw is None:
+            out.taper = np.array(["None"])
+        elif taper_kw == "dpss":
+            nTaper = self.outputShape[out.dimord.index("taper")]
+            out.taper = np.array([taper_kw + str(i) for i in range(nTaper)])
+        else:
+            out.taper = np.array([taper_kw])
+        out.freq = self.cfg["foi"]
+
+
+# --------------------------------------------------------------------------- mtmconvol
+def _frame_ids(n_frames, postselect):
+    return np.arange(n_frames)[postselect]
+
+
+def _stft_geometry(nsamp, nperseg, noverlap, toi_is_array):
+    """(nTime, boundary) of mtmconvol for a trial of nsamp samples (mtmconvol.py:120-126)."""
+    step = nperseg - noverlap
+    nTime = int(np.ceil(nsamp / step))
+    if toi_is_array:
+        return nTime - nperseg, False
+    return nTime, True
+
+
+def _mtmconvol_device(dev, row0, nsamp, soi, postselect, equidistant, toi, foi, keeptapers, polyremoval, output,
+                      method_kwargs, chans):
+    """Time-frequency spectrum of one trial (rows [row0, row0+nsamp) of `dev`) -> device tensor."""
+    nperseg, noverlap = method_kwargs["nperseg"], method_kwargs["noverlap"]
+    taper, taper_opt = method_kwargs["taper"], method_kwargs["taper_opt"]
+    fs = method_kwargs["samplerate"]
+    if equidistant:
+        s0, s1, _ = soi.indices(nsamp)
+        nTime, boundary = _stft_geometry(s1 - s0, nperseg, noverlap, isinstance(toi, np.ndarray))
+        freqs = np.fft.rfftfreq(nperseg, 1 / fs)
+        _, fidx = best_match(freqs, foi, squash_duplicates=True)
+        frames = _frame_ids(max(nTime, 0), postselect)
+        return hs.run_stft(dev, row0, s0, s1, frames, nperseg, nperseg - noverlap, boundary, chans, taper,
+                           taper_opt, polyremoval, fidx, output, keeptapers)
+    # one window per soi entry: plain (un-detrended, un-padded) mtmfft per window (compRoutines.py:392-408)
+    rows = []
+    for sl in soi:
+        a, b, _ = sl.indices(nsamp)
+        rows.append((row0 + a, row0 + max(a, b)))
+    lens = {b - a for a, b in rows}
+    fidx = {}
+    for n in lens:
+        _, fidx[n] = best_match(np.fft.rfftfreq(n, 1 / fs), foi, squash_duplicates=True)
+    if len({v.size for v in fidx.values()}) != 1:
+        raise ValueError("analysis windows of different lengths select different numbers of frequencies")
+    res = [None] * len(rows)
+    for n in lens:
+        which = [i for i, (a, b) in enumerate(rows) if b - a == n]
+        part = hs.run_mtmfft(dev, [rows[i] for i in which], chans, None, taper, taper_opt, False, False, None,
+                             fidx[n], output, keeptapers)
+        for i, r in zip(which, part):
+            res[i] = r
+    return torch.stack(res, dim=0)
+
+
+def mtmconvol_cF(trl_dat, soi, postselect, equidistant=True, toi=None, foi=None, nTaper=1, tapsmofrq=None,
+                 timeAxis=0, keeptapers=True, polyremoval=0, output="pow", noCompute=False, chunkShape=None,
+                 method_kwargs=None):
+    """Sliding-window (multi-)tapered FFT of one trial; returns (nTime, nTaper|1, nFreq, nChannel)."""
+    dat = trl_dat.T if timeAxis != 0 else trl_dat
+    nChannels = dat.shape[1]
+    if isinstance(toi, np.ndarray):
+        nTime = toi.size
+    else:
+        nTime = int(np.ceil(dat.shape[0] / (method_kwargs["nperseg"] - method_kwargs["noverlap"])))
+    taper_opt = method_kwargs["taper_opt"]
+    if taper_opt:
+        nTaper = taper_opt.get("Kmax", 1)
+    outShape = (nTime, max(1, nTaper * keeptapers), foi.size, nChannels)
+    if noCompute:
+        return outShape, spectralDTypes[output]
+    dev = _as_device_trial(trl_dat, timeAxis)
+    res = _mtmconvol_device(dev, 0, dev.shape[0], soi, postselect, equidistant, toi, foi, keeptapers, polyremoval,
+                            output, method_kwargs, None)
+    return res.cpu().numpy()
+
+
+class MultiTaperFFTConvol(ComputationalRoutine):
+    computeFunction = staticmethod(mtmconvol_cF)
+    valid_kws = ["soi", "postselect", "equidistant", "toi", "foi", "nTaper", "tapsmofrq", "timeAxis", "keeptapers",
+                 "polyremoval", "output", "method_kwargs", "samplerate", "nperseg", "noverlap", "taper", "taper_opt",
+                 "t_ftimwin", "pad"]
+
+    def compute_hip(self, data, out):
+        cfg = self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        parts = []
+        for k, (a, b) in enumerate(rows):
+            soi, postselect = self._argv(k)
+            parts.append(_mtmconvol_device(dev, a, b - a, soi, postselect, cfg["equidistant"], cfg["toi"], cfg["foi"],
+                                           cfg["keeptapers"], cfg["polyremoval"], cfg["output"],
+                                           cfg["method_kwargs"], chans))
+        _store_trials(self, out, parts)
+
+    def process_metadata(self, data, out):
+        propagate_properties(data, out, self.keeptrials, time_axis=True)
+        trl, fs = _make_trialdef(self.cfg, out.trialdefinition.copy(), data.samplerate)
+        out.trialdefinition, out.samplerate = trl, fs
+        nTaper = self.outputShape[out.dimord.index("taper")]
+        out.taper = np.array([str(self.cfg["method_kwargs"]["taper"])] * nTaper)
+        out.freq = self.cfg["foi"]
+
+
+def _store_trials(cr, out, parts):
+    """Stack per-trial device results along time (keeptrials) or average them sequentially."""
+    for k, p in enumerate(parts):
+        if tuple(p.shape) != tuple(cr.targetShapes[k]):
+            raise ValueError(f"trial {k}: result shape {tuple(p.shape)} != dry-run shape {cr.targetShapes[k]}")
+    if cr.keeptrials:
+        out.data = torch.cat(parts, dim=0).cpu().numpy().reshape(cr.outputShape)
+        return
+    stacked = torch.stack(parts, dim=0).contiguous()
+    if stacked.dtype == torch.float32:
+        mean = hs.backend.trial_mean(stacked)
+    else:
+        mean = torch.view_as_complex(hs.backend.trial_mean(torch.view_as_real(stacked).contiguous()))
+    out.data = mean.cpu().numpy().reshape(cr.outputShape)
+
+
+def _make_trialdef(cfg, trialdefinition, samplerate):
+    """Timing of time-frequency outputs (rules of specest/compRoutines.py:813-900)."""
+    toi = cfg["toi"]
+    if isinstance(toi, np.ndarray):
+        nToi = toi.size
+        time = np.cumsum([nToi] * trialdefinition.shape[0])
+        trialdefinition[:, 0] = time - nToi
+        trialdefinition[:, 1] = time
+        tSteps = np.diff(toi)
+        if tSteps.size and np.allclose(tSteps, [tSteps[0]] * tSteps.size):
+            samplerate = 1 / (toi[1] - toi[0])
+        else:
+            samplerate = 1.0
+            trialdefinition[:, 2] = 0
+        trialdefinition[:, 2] = toi[0] * samplerate
+    elif np.issubdtype(type(toi), np.number):
+        mKw = cfg["method_kwargs"]
+        winSize = mKw["nperseg"] - mKw["noverlap"]
+        lens = np.ceil(np.diff(trialdefinition[:, :2]) / winSize)
+        sumLens = np.cumsum(lens).reshape(lens.shape)
+        trialdefinition[:, 0] = np.ravel(sumLens - lens)
+        trialdefinition[:, 1] = sumLens.ravel()
+        trialdefinition[:, 2] = trialdefinition[:, 2] / winSize
+        samplerate = np.round(samplerate / winSize, 2)
+    else:
+        bounds = np.cumsum(np.diff(trialdefinition[:, :2]))
+        trialdefinition[1:, 0] = bounds[:-1]
+        trialdefinition[:, 1] = bounds
+    return trialdefinition, samplerate

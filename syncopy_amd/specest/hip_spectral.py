@@ -1,0 +1,128 @@
+"""Device-side execution of the (multi-)tapered FFT family: host bookkeeping only
+(taper tables, plan cache, segment lists); every number is produced by libspyhip.
+
+Used by the compute functions in compRoutines.py both for one trial at a time
+(the reference's cF contract) and for all trials at once (in-HBM trial queue).
+"""
+import numpy as np
+import torch
+from scipy.signal import windows
+
+from .. import backend
+
+_plan_cache = {}
+_taper_cache = {}
+
+
+def taper_table(taper, nsig, nnorm, taper_opt=None):
+    """(K, nsig) float64 window rows, normalised for spectral power
+    (semantics of specest/_norm_spec.py:27-46; window length = actual signal
+    length, normalisation length = padded length, mtmfft.py:96-101)."""
+    taper = "boxcar" if taper is None else taper
+    opt = {} if not taper_opt else dict(taper_opt)
+    key = (taper, int(nsig), int(nnorm), tuple(sorted(opt.items())))
+    if key not in _taper_cache:
+        w = np.atleast_2d(getattr(windows, taper)(int(nsig), **opt)).astype(np.float64)
+        if taper == "dpss":
+            w = w * np.sqrt(nnorm)
+        elif taper == "boxcar":
+            w = w * np.sqrt(nnorm / w.sum())
+        else:
+            w = w * (np.sqrt(4 / 3) * np.sqrt(nnorm / w.sum()))
+        _taper_cache[key] = w
+    return _taper_cache[key]
+
+
+def spec_scale(nsig, nfft, ft_compat=False):
+    """sqrt(2)/N normalisation of every rfft bin (specest/_norm_spec.py:10-24, mtmfft.py:119-127)."""
+    if ft_compat:
+        return np.sqrt(2) / nfft
+    return np.sqrt(2) / (nsig * np.sqrt(nfft / nsig))
+
+
+def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_taper, freq_idx, output, keeptapers,
+             device):
+    fkey = None if freq_idx is None else np.asarray(freq_idx, dtype=np.int32).tobytes()
+    key = (int(nsig), int(nfft), int(nchan), taper, tuple(sorted((taper_opt or {}).items())), int(nnorm),
+           float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device))
+    if key not in _plan_cache:
+        tp = taper_table(taper, nsig, nnorm, taper_opt)
+        _plan_cache[key] = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
+                                           keeptapers, device=device)
+    return _plan_cache[key]
+
+
+def full_freq_idx(freq_idx, nfft):
+    """None if the selection is the identity (saves the index lookup in the kernel)."""
+    if freq_idx is None:
+        return None
+    freq_idx = np.asarray(freq_idx)
+    nf = nfft // 2 + 1
+    if freq_idx.size == nf and np.array_equal(freq_idx, np.arange(nf)):
+        return None
+    return freq_idx.astype(np.int32)
+
+
+def run_mtmfft(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_taper, ft_compat, polyremoval, freq_idx,
+               output, keeptapers):
+    """Tapered FFT of the trials `rows` = [(start, stop)] of the device matrix.
+    Returns a list of (Kout, F, C) device tensors views into per-length batches, one per trial."""
+    device = dev_data.device
+    nchan = dev_data.shape[1] if chan_idx is None else len(chan_idx)
+    ci = None if chan_idx is None else torch.tensor(np.asarray(chan_idx), dtype=torch.int32, device=device)
+    lengths = np.array([b - a for a, b in rows])
+    results = [None] * len(rows)
+    for n in np.unique(lengths):
+        which = np.nonzero(lengths == n)[0]
+        n = int(n)
+        N = n if nfft is None else int(nfft)
+        plan = get_plan(n, N, nchan, taper, taper_opt, N, spec_scale(n, N, ft_compat), polyremoval, demean_taper,
+                        full_freq_idx(freq_idx, N), output, keeptapers, device)
+        starts = torch.tensor([rows[i][0] for i in which], dtype=torch.int64, device=device)
+        out = plan.execute(dev_data, starts, chan_idx=ci)
+        for k, i in enumerate(which):
+            results[i] = out[k]
+    return results
+
+
+def run_stft(dev_data, row0, soi_start, soi_stop, frames, nperseg, step, boundary, chan_idx, taper, taper_opt,
+             polyremoval, freq_idx, output, keeptapers):
+    """Sliding-window tapered FFT (stft.py:16-159 / mtmconvol.py:136-150) of one trial.
+    frames: indices of the STFT frames to evaluate; frame s starts at
+    soi_start + s*step - (nperseg//2 if boundary), samples outside [soi_start, soi_stop) are zero."""
+    device = dev_data.device
+    nchan = dev_data.shape[1] if chan_idx is None else len(chan_idx)
+    ci = None if chan_idx is None else torch.tensor(np.asarray(chan_idx), dtype=torch.int32, device=device)
+    opt = dict(taper_opt or {})
+    if taper == "dpss":
+        opt["sym"] = False          # mtmconvol.py:110-111
+    plan = get_plan(nperseg, nperseg, nchan, taper, opt, nperseg, np.sqrt(2) / nperseg, polyremoval, False,
+                    full_freq_idx(freq_idx, nperseg), output, keeptapers, device)
+    frames = np.asarray(frames, dtype=np.int64)
+    lead = nperseg // 2 if boundary else 0
+    starts = torch.from_numpy(row0 + soi_start + frames * step - lead).to(device)
+    lo = torch.full_like(starts, row0 + soi_start)
+    hi = torch.full_like(starts, row0 + soi_stop)
+    return plan.execute(dev_data, starts, lo, hi, chan_idx=ci)
+
+
+def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_taper, ft_compat, polyremoval,
+                       freq_idx, output, keeptapers, max_bytes=8 << 30):
+    """Generator over (trial indices, (B, Kout, F, C) device tensor) batches: trials of equal length share a
+    plan; a batch is bounded by `max_bytes` of spectra so the intermediate stays a small part of HBM."""
+    device = dev_data.device
+    nchan = dev_data.shape[1] if chan_idx is None else len(chan_idx)
+    ci = None if chan_idx is None else torch.tensor(np.asarray(chan_idx), dtype=torch.int32, device=device)
+    lengths = np.array([b - a for a, b in rows])
+    for n in np.unique(lengths):
+        which = np.nonzero(lengths == n)[0]
+        n = int(n)
+        N = n if nfft is None else int(nfft)
+        plan = get_plan(n, N, nchan, taper, taper_opt, N, spec_scale(n, N, ft_compat), polyremoval, demean_taper,
+                        full_freq_idx(freq_idx, N), output, keeptapers, device)
+        per_trial = int(np.prod(plan.out_shape(1))) * (8 if plan.kind == 2 else 4)
+        bmax = max(1, int(max_bytes // per_trial))
+        for i in range(0, which.size, bmax):
+            sel = which[i:i + bmax]
+            starts = torch.tensor([rows[j][0] for j in sel], dtype=torch.int64, device=device)
+            yield sel, plan.execute(dev_data, starts, chan_idx=ci)

@@ -1,0 +1,71 @@
+"""Compute classes bound to the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+They reuse the product's front ends / engine (host logic) but replace every
+computeFunction by its NumPy restatement in oracle/spy_oracle.py, so that
+(a) the oracle can be pinned against the golden vectors through the same parameter
+mapping, and (b) GPU tests can compare product vs oracle on arbitrary inputs."""
+import numpy as np
+
+from oracle import spy_oracle as O
+from syncopy_amd.connectivity.AV_compRoutines import NormalizeCrossSpectra, _AverageRoutine
+from syncopy_amd.connectivity.ST_compRoutines import CrossSpectra
+from syncopy_amd.specest.compRoutines import MultiTaperFFT, MultiTaperFFTConvol, _make_trialdef
+from syncopy_amd.shared.computational_routine import ComputationalRoutine, propagate_properties
+
+
+class OracleMultiTaperFFT(MultiTaperFFT):
+    computeFunction = staticmethod(O.mtmfft_cF)
+
+
+class OracleMultiTaperFFTConvol(MultiTaperFFTConvol):
+    computeFunction = staticmethod(O.mtmconvol_cF)
+
+
+def _wavelet_cF(trl, preselect, postselect, toi=None, timeAxis=0, polyremoval=None, output="pow", noCompute=False,
+                chunkShape=None, method_kwargs=None):
+    return O.wavelet_cF(trl, preselect, postselect, toi, timeAxis, polyremoval, output, noCompute, chunkShape,
+                        method_kwargs)
+
+
+class OracleWaveletTransform(ComputationalRoutine):
+    computeFunction = staticmethod(_wavelet_cF)
+
+    def process_metadata(self, data, out):
+        propagate_properties(data, out, self.keeptrials, time_axis=True)
+        out.trialdefinition, out.samplerate = _make_trialdef(self.cfg, out.trialdefinition.copy(), data.samplerate)
+        out.freq = getattr(self, "_foi", None)
+
+
+def _cross_spectra_cF(trl, samplerate=1, nSamples=None, foi=None, taper="hann", taper_opt=None, demean_taper=False,
+                      polyremoval=False, timeAxis=0, chunkShape=None, noCompute=False):
+    return O.cross_spectra_cF(trl, samplerate, nSamples, foi, taper, taper_opt, demean_taper, polyremoval, timeAxis,
+                              chunkShape, noCompute, faithful=True)
+
+
+class OracleCrossSpectra(CrossSpectra):
+    computeFunction = staticmethod(_cross_spectra_cF)
+
+
+def _normalize_cF(csd_av_dat, output="abs", chunkShape=None, noCompute=False):
+    if noCompute:
+        return csd_av_dat.shape, np.complex64 if output in ("complex", "fourier") else np.float32
+    return O.normalize_csd(csd_av_dat, output)
+
+
+class OracleNormalizeCrossSpectra(NormalizeCrossSpectra):
+    computeFunction = staticmethod(_normalize_cF)
+
+
+class OracleGrangerCausality(_AverageRoutine):
+    computeFunction = staticmethod(O.granger_cF)
+
+    def process_metadata(self, data, out):
+        super().process_metadata(data, out)
+        for key, value in (self.metadata[0] or {}).items():
+            label, cast = key.split("--")
+            out.info[label] = bool(value) if cast == "bool" else float(value)
+
+
+ORACLE_FREQ = {"mtmfft": OracleMultiTaperFFT, "mtmconvol": OracleMultiTaperFFTConvol,
+               "wavelet": OracleWaveletTransform}
+ORACLE_CONN = {"csd": OracleCrossSpectra, "coh": OracleNormalizeCrossSpectra, "granger": OracleGrangerCausality}
