@@ -5,7 +5,7 @@ from hashlib import blake2b
 import numpy as np
 import torch
 
-from .. import backend
+from .. import backend, parallel
 from ..datatype import selected_channels, trial_rows
 from ..shared.computational_routine import ComputationalRoutine, propagate_properties
 from ..shared.const_def import spectralDTypes
@@ -81,22 +81,28 @@ class CrossSpectra(ComputationalRoutine):
         pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
         F, C = self.targetShapes[0][1], self.targetShapes[0][2]
         T = self.numTrials
+        mine = self.my_trials()                            # this rank's contiguous trial shard
+        rows = [rows[k] for k in mine]
         if self.keeptrials:
-            acc = torch.zeros((T, F, C, C), dtype=torch.complex64, device=dev.device)
+            acc = torch.zeros((len(rows), F, C, C), dtype=torch.complex64, device=dev.device)
             getter = lambda i: acc[i]                      # noqa: E731
         else:
             acc = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
             getter = lambda i: acc                         # noqa: E731
         K = _csd_of_rows(dev, rows, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"], cfg["demean_taper"], pr,
-                         freq_idx, getter)
-        if self.keeptrials:
-            for t in range(T):
-                backend.csd_finalize(acc[t], 1.0 / K)
-        else:
-            backend.csd_finalize(acc, 1.0 / (K * T))
+                         freq_idx, getter) if rows else 1
+        K = int(cfg["taper_opt"].get("Kmax", K)) if cfg["taper_opt"] else K
         self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T
-        out._dev = acc.reshape(self.outputShape)
-        out.data = out._dev.cpu().numpy()
+        if self.keeptrials:
+            for t in range(len(rows)):
+                backend.csd_finalize(acc[t], 1.0 / K)
+            out._dev = None
+            out.data = parallel.gather_trials(acc.cpu().numpy()).reshape(self.outputShape)
+        else:
+            parallel.allreduce_sum_(acc)                   # the ONE collective of the path (RCCL over xGMI)
+            backend.csd_finalize(acc, 1.0 / (K * T))
+            out._dev = acc.reshape(self.outputShape)
+            out.data = out._dev.cpu().numpy()
 
     def process_metadata(self, data, out):
         propagate_properties(data, out, self.keeptrials)

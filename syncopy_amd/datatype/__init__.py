@@ -106,6 +106,8 @@ class AnalogData(_Base):
     def device_data(self, device=None):
         """The (time x channel) float32 matrix in HBM (uploaded once, C-order, channel fastest)."""
         import torch
+        from ..backend import require_gpu
+        require_gpu()                      # loud failure: there is no CPU path
         dev = torch.device("cuda" if device is None else device)
         if self._device is None or self._device.device != dev and self._device.device.index != dev.index:
             host = self.data if self.dimord.index("time") == 0 else self.data.T

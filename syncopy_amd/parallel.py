@@ -1,0 +1,66 @@
+"""Trial sharding across GPUs: one process per GPU, `torch.distributed` (backend "nccl" =
+RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Semantics of the reference's trial-parallel map (computational_routine.py:806-942): trials are
+independent; outputs with keeptrials=True are concatenated, outputs with keeptrials=False are
+one sum-reduction (the reference's mutex-guarded `+=`, kwarg_decorators.py:723-735) followed by a
+single division by the global trial count.  Here: contiguous trial ranges per rank (remainder
+to the low ranks), ONE all-reduce of the accumulator, no other data-path collective.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    """(rank, world_size); (0, 1) without an initialised process group."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n, size):
+    """Contiguous ranges [lo, hi) of n trials for `size` ranks, remainder to the low ranks."""
+    base, rem = divmod(n, size)
+    bounds, lo = [], 0
+    for r in range(size):
+        hi = lo + base + (1 if r < rem else 0)
+        bounds.append((lo, hi))
+        lo = hi
+    return bounds
+
+
+def my_shard(n):
+    rank, size = world()
+    return shard_bounds(n, size)[rank]
+
+
+def allreduce_sum_(t):
+    """In-place sum over ranks of a torch tensor (complex tensors go as interleaved floats);
+    fixed reduction algorithm of the backend => identical result on every rank."""
+    _, size = world()
+    if size > 1:
+        dist.all_reduce(torch.view_as_real(t) if t.is_complex() else t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def allreduce_sum_numpy(a):
+    """Sum over ranks of a host array (used by the sequential / oracle-bound engine path)."""
+    _, size = world()
+    if size == 1:
+        return a
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    allreduce_sum_(t)
+    return t.cpu().numpy()
+
+
+def gather_trials(local):
+    """Concatenate per-rank host arrays along axis 0 in rank order (keeptrials=True outputs)."""
+    _, size = world()
+    if size == 1:
+        return local
+    parts = [None] * size
+    dist.all_gather_object(parts, local)
+    return np.concatenate([p for p in parts if p is not None and p.shape[0] > 0], axis=0)

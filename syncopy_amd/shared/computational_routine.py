@@ -14,6 +14,7 @@ from inspect import signature
 
 import numpy as np
 
+from .. import parallel
 from ..datatype import FauxTrial, selected_channels, trial_rows
 from .errors import SPYValueError
 
@@ -109,18 +110,32 @@ class ComputationalRoutine(ABC):
             arr = arr[:, chans] if tax == 0 else arr[chans, :]
         return np.array(arr)   # fresh copy, as the reference hands the cF (computational_routine.py:1001)
 
+    def my_trials(self):
+        """Trial indices of this rank (all trials without a process group; parallel.py)."""
+        lo, hi = parallel.my_shard(self.numTrials)
+        return range(lo, hi)
+
     def compute_sequential(self, data, out):
-        """Trial loop of the reference: call the cF per trial, stack or accumulate in the output dtype."""
+        """Trial loop of the reference: call the cF per trial, stack or accumulate in the output dtype.
+        With a process group each rank loops over its contiguous trial shard; partial sums are
+        all-reduced once, stacked results are concatenated in rank order."""
         rows = trial_rows(data)
         chans = selected_channels(data)
-        target = np.zeros(self.outputShape, dtype=self.dtype)
+        mine = self.my_trials()
+        if self.keeptrials:
+            shp = list(self.outputShape)
+            shp[self.stackingDim] = sum(self.targetShapes[k][self.stackingDim] for k in mine)
+            target = np.zeros(shp, dtype=self.dtype)
+        else:
+            target = np.zeros(self.outputShape, dtype=self.dtype)
+        self.metadata = [None] * self.numTrials
         pos = 0
-        for k in range(self.numTrials):
+        for k in mine:
             arr = self._host_trial(data, k, rows, chans)
             res, details = parse_cF_returns(self.computeFunction(arr, *self._argv(k), chunkShape=self.chunkShape,
                                                                  noCompute=False, **self.cfg))
             res = np.asarray(res).reshape(self.targetShapes[k])
-            self.metadata.append(details)
+            self.metadata[k] = details
             if self.keeptrials:
                 n = res.shape[self.stackingDim]
                 idx = [slice(None)] * res.ndim
@@ -130,7 +145,10 @@ class ComputationalRoutine(ABC):
             else:
                 target += res
         if not self.keeptrials:
+            target = parallel.allreduce_sum_numpy(target)
             target /= self.numTrials
+        elif self.stackingDim == 0:
+            target = parallel.gather_trials(target)
         out.data = target
 
     @abstractmethod

@@ -10,6 +10,7 @@ from hashlib import blake2b
 import numpy as np
 import torch
 
+from .. import parallel
 from ..datatype import selected_channels, trial_rows
 from ..shared.computational_routine import ComputationalRoutine, propagate_properties
 from ..shared.const_def import spectralDTypes
@@ -64,20 +65,12 @@ class MultiTaperFFT(ComputationalRoutine):
         lengths = [b - a for a, b in rows]
         freqs = np.fft.rfftfreq(mk["nSamples"] if mk["nSamples"] is not None else lengths[0], 1 / mk["samplerate"])
         _, freq_idx = best_match(freqs, cfg["foi"], squash_duplicates=True)
+        rows = [rows[k] for k in self.my_trials()]          # this rank's trial shard
         res = hs.run_mtmfft(dev, rows, chans, mk["nSamples"], mk["taper"], mk["taper_opt"],
                             mk.get("demean_taper", False), mk.get("ft_compat", False), cfg["polyremoval"], freq_idx,
                             cfg["output"], cfg["keeptapers"])
-        stacked = torch.stack(res, dim=0)           # (nTrials, Kout, F, C)
         self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * self.numTrials
-        if self.keeptrials:
-            out.data = stacked.cpu().numpy().reshape(self.outputShape)
-        else:
-            if stacked.dtype == torch.float32:
-                mean = hs.backend.trial_mean(stacked.contiguous())
-            else:
-                mean = torch.view_as_complex(
-                    hs.backend.trial_mean(torch.view_as_real(stacked.contiguous()).contiguous()))
-            out.data = mean.cpu().numpy().reshape(self.outputShape)
+        _store_trials(self, out, res, stack=True)
 
     def process_metadata(self, data, out):
         hashes = {bytes(m["freqs_hash"]) for m in self.metadata if m}
@@ -177,7 +170,8 @@ class MultiTaperFFTConvol(ComputationalRoutine):
         dev = data.device_data()
         rows, chans = trial_rows(data), selected_channels(data)
         parts = []
-        for k, (a, b) in enumerate(rows):
+        for k in self.my_trials():
+            a, b = rows[k]
             soi, postselect = self._argv(k)
             parts.append(_mtmconvol_device(dev, a, b - a, soi, postselect, cfg["equidistant"], cfg["toi"], cfg["foi"],
                                            cfg["keeptapers"], cfg["polyremoval"], cfg["output"],
@@ -193,20 +187,34 @@ class MultiTaperFFTConvol(ComputationalRoutine):
         out.freq = self.cfg["foi"]
 
 
-def _store_trials(cr, out, parts):
-    """Stack per-trial device results along time (keeptrials) or average them sequentially."""
-    for k, p in enumerate(parts):
+def _store_trials(cr, out, parts, stack=False):
+    """Results of this rank's trials -> `out.data`: concatenated along the stacking axis in rank order
+    (keeptrials) or summed sequentially in the output dtype, all-reduced once and divided by the global
+    trial count (computational_routine.py:1022-1032 / kwarg_decorators.py:723-735)."""
+    mine = list(cr.my_trials())
+    if stack:
+        parts = [p.unsqueeze(0) for p in parts]
+    for k, p in zip(mine, parts):
         if tuple(p.shape) != tuple(cr.targetShapes[k]):
             raise ValueError(f"trial {k}: result shape {tuple(p.shape)} != dry-run shape {cr.targetShapes[k]}")
+    dev = torch.device("cuda")
+    dtype = torch.complex64 if np.issubdtype(cr.dtype, np.complexfloating) else torch.float32
     if cr.keeptrials:
-        out.data = torch.cat(parts, dim=0).cpu().numpy().reshape(cr.outputShape)
+        tail = tuple(cr.outputShape[1:])
+        local = torch.cat(parts, dim=0).cpu().numpy() if parts else np.zeros((0,) + tail, dtype=cr.dtype)
+        out.data = parallel.gather_trials(local).reshape(cr.outputShape)
         return
-    stacked = torch.stack(parts, dim=0).contiguous()
-    if stacked.dtype == torch.float32:
-        mean = hs.backend.trial_mean(stacked)
+    if parts:
+        stacked = torch.stack(parts, dim=0).contiguous()
+        n = stacked.shape[0]
+        if stacked.dtype == torch.float32:
+            total = hs.backend.trial_mean(stacked) * n
+        else:
+            total = torch.view_as_complex(hs.backend.trial_mean(torch.view_as_real(stacked).contiguous())) * n
     else:
-        mean = torch.view_as_complex(hs.backend.trial_mean(torch.view_as_real(stacked).contiguous()))
-    out.data = mean.cpu().numpy().reshape(cr.outputShape)
+        total = torch.zeros(cr.outputShape, dtype=dtype, device=dev)
+    parallel.allreduce_sum_(total)
+    out.data = (total / cr.numTrials).cpu().numpy().reshape(cr.outputShape)
 
 
 def _make_trialdef(cfg, trialdefinition, samplerate):

@@ -111,3 +111,26 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
         C.c_int(int(demean_taper)), _p(fpos, C.c_int), C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)),
         out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def csd_accumulate(spec, acc, force_tpw=0):
+    """Emulated spyhip_csd_accumulate: spec (R, F, C) complex64, acc (F, C, C) complex64 (in place)."""
+    spec = np.ascontiguousarray(spec, dtype=np.complex64)
+    assert acc.dtype == np.complex64 and acc.flags.c_contiguous
+    R, F, Cn = spec.shape
+    return lib().emu_csd_accumulate(spec.ctypes.data_as(C.c_void_p), C.c_longlong(R), C.c_int(F), C.c_int(Cn),
+                                    acc.ctypes.data_as(C.c_void_p), C.c_int(force_tpw))
+
+
+def csd_finalize(acc, scale):
+    F, Cn, _ = acc.shape
+    lib().emu_csd_finalize(acc.ctypes.data_as(C.c_void_p), C.c_int(F), C.c_int(Cn), C.c_float(scale))
+
+
+def coh_normalize(csd, output="abs"):
+    F, Cn, _ = csd.shape
+    kind = OUT_KINDS[output]
+    out = np.empty((F, Cn, Cn), dtype=np.complex64 if kind == 2 else np.float32)
+    lib().emu_coh_normalize(csd.ctypes.data_as(C.c_void_p), C.c_int(F), C.c_int(Cn), C.c_int(kind),
+                            out.ctypes.data_as(C.c_void_p))
+    return out

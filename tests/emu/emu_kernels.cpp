@@ -15,6 +15,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/spy_common.h"
 #include "../../syncopy_amd/csrc/mtmfft_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
+#include "../../syncopy_amd/csrc/csd_kernel.h"
 
 namespace spy {
 void set_error(const char*, ...) {}
@@ -118,6 +119,52 @@ int emu_mtmfft_generic(int n, int nfac, const int* radix, int nfft, int bluestei
         default: go([&] { spyfft::mtmfft_generic_kernel<2, true>(a, g); }); break;
     }
     return 0;
+}
+
+// Mirrors spyhip_csd_accumulate (host logic of csd.hip) for the emulated MFMA kernel.
+int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* acc, int force_tpw) {
+    spycsd::CsdArgs a{};
+    a.spec = reinterpret_cast<const float2*>(spec);
+    a.nrows = nrows; a.F = F; a.C = C;
+    a.acc = reinterpret_cast<float2*>(acc);
+    a.nt = (C + 31) / 32;
+    a.ntiles = a.nt * (a.nt + 1) / 2;
+    a.nitems = (long long)F * a.ntiles;
+    a.cpad = a.nt * 32;
+    int tpw = 1;
+    if (a.ntiles % 36 == 0) tpw = 9;
+    else if (a.ntiles >= 10) tpw = 5;
+    else if (a.ntiles >= 3) tpw = 3;
+    if (force_tpw > 0) tpw = force_tpw;
+    const int per = 4 * tpw;
+    int nfb = (per + a.ntiles - 1) / a.ntiles;
+    if (per % a.ntiles != 0 && a.ntiles > 1) nfb += 1;
+    if (nfb > F) nfb = F;
+    const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
+    int kb = 32;
+    while (kb > 2 && (size_t)kb * rowbytes > 160 * 1024) kb -= 2;
+    if (kb > nrows) kb = (int)((nrows + 1) & ~1LL);
+    a.kb = kb;
+    const size_t lds = (size_t)kb * rowbytes;
+    const unsigned grid = (unsigned)((a.nitems + per - 1) / per);
+    switch (tpw) {
+        case 9: emu::launch(dim3(grid), dim3(256), lds, [&] { spycsd::csd_accum_kernel<9>(a); }); break;
+        case 5: emu::launch(dim3(grid), dim3(256), lds, [&] { spycsd::csd_accum_kernel<5>(a); }); break;
+        case 3: emu::launch(dim3(grid), dim3(256), lds, [&] { spycsd::csd_accum_kernel<3>(a); }); break;
+        default: emu::launch(dim3(grid), dim3(256), lds, [&] { spycsd::csd_accum_kernel<1>(a); }); break;
+    }
+    return tpw;
+}
+
+void emu_csd_finalize(float* acc, int F, int C, float scale) {
+    emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::csd_finalize_kernel(reinterpret_cast<float2*>(acc), F, C, scale); });
+}
+
+void emu_coh_normalize(const float* csd, int F, int C, int kind, void* out) {
+    if (kind == SPYHIP_OUT_FOURIER)
+        emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::coh_normalize_kernel<true>(reinterpret_cast<const float2*>(csd), F, C, kind, out); });
+    else
+        emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::coh_normalize_kernel<false>(reinterpret_cast<const float2*>(csd), F, C, kind, out); });
 }
 
 }  // extern "C"

@@ -1,0 +1,105 @@
+"""The HIP kernel sources, compiled unchanged for the host and run workgroup-by-workgroup on OS
+threads (tests/emu/hip_emu.h), against the oracle.  This checks index arithmetic, LDS layouts,
+the packed-real-FFT separation and the MFMA lane maps without a GPU; the `-m gpu` tests are the
+parity tests proper."""
+import numpy as np
+import pytest
+
+import emu_driver as E
+from oracle import spy_oracle as O
+from parity import assert_parity, excess
+
+
+def _fft_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=False, G=None, generic=False,
+              freq_idx=None, chan_idx=None, nseg=2, seed=1):
+    rng = np.random.default_rng(seed)
+    data = rng.normal(size=(nsig * nseg + 9, nchan)).astype("f4")
+    ss = np.array([4 + i * nsig for i in range(nseg)])
+    taper, topt = ("dpss", {"NW": (K + 1) / 2, "Kmax": K}) if K > 1 else ("hann", {})
+    tapers = O.taper_table(taper, nsig, nfft, topt)
+    out = E.fft_exec(data, ss, ss, ss + nsig, nsig, nfft, tapers, O.spec_scale(nsig, nfft), detrend, demean_taper,
+                     freq_idx, output, keeptapers, chan_idx=chan_idx, G=G, force_generic=generic)
+    freqs = np.fft.rfftfreq(nfft, 1e-3)
+    foi = freqs if freq_idx is None else freqs[freq_idx]
+    for b in range(nseg):
+        x = data[ss[b]:ss[b] + nsig]
+        if chan_idx is not None:
+            x = x[:, chan_idx]
+        ref, _ = O.mtmfft_cF(np.array(x), foi=foi, keeptapers=keeptapers, polyremoval=None if detrend < 0 else detrend,
+                             output=output, method_kwargs=dict(samplerate=1000.0, taper=taper, taper_opt=topt,
+                                                               nSamples=nfft, demean_taper=demean_taper))
+        assert_parity(out[b], ref[0], what=f"segment {b}")
+
+
+@pytest.mark.parametrize("log2n,G", [(8, 16), (9, 8), (10, 4), (11, 4), (12, 1), (12, 2), (12, 4), (13, 2), (14, 1)])
+def test_pow2_kernel_every_length(log2n, G):
+    n = 1 << log2n
+    nchan = 2 * G + 1 if n <= 4096 else 3          # odd channel count: dummy partner in the last pair
+    _fft_case(n, n, nchan, 2, "pow", False, 0, G=G, nseg=1)
+
+
+def test_pow2_kernel_modes():
+    _fft_case(1000, 1024, 5, 3, "fourier", True, 1, demean_taper=True)
+    _fft_case(1024, 1024, 5, 3, "fourier", False, 0)
+    _fft_case(700, 1024, 4, 1, "abs", True, -1)
+    _fft_case(512, 512, 6, 2, "real", False, 0, freq_idx=np.array([5, 0, 256, 100]), chan_idx=[5, 5, 0, 3, 1])
+
+
+@pytest.mark.parametrize("nsig,nfft", [(2000, 2000), (500, 1000), (360, 360), (77, 154), (101, 202), (64, 64)])
+def test_generic_kernel_lengths(nsig, nfft):
+    # 2000 = 16*5^3 (BASELINE config 1), 154 = 2*7*11, 202 = 2*101 -> Bluestein
+    _fft_case(nsig, nfft, 3, 2, "pow", False, 0)
+    _fft_case(nsig, nfft, 2, 1, "fourier", True, 1, demean_taper=True, nseg=1)
+
+
+def test_generic_kernel_matches_pow2_kernel():
+    _fft_case(1024, 1024, 4, 2, "pow", True, 0, generic=True)
+
+
+def test_zero_extended_segments():
+    rng = np.random.default_rng(2)
+    nsig = nfft = 256
+    data = rng.normal(size=(1000, 4)).astype("f4")
+    starts = np.array([-128, 0, 872, 300])
+    lo = np.array([0, 0, 100, 350])
+    hi = np.array([1000, 1000, 1000, 420])
+    tapers = O.taper_table("hann", nsig, nfft)
+    out = E.fft_exec(data, starts, lo, hi, nsig, nfft, tapers, np.sqrt(2) / nsig, 0, False, None, "fourier", True)
+    for b in range(4):
+        seg = np.zeros((nsig, 4), "f4")
+        for n in range(nsig):
+            r = starts[b] + n
+            if lo[b] <= r < hi[b]:
+                seg[n] = data[r]
+        seg -= seg.mean(axis=0)
+        ref = (np.fft.rfft(tapers[0][:, None] * seg, axis=0) * (np.sqrt(2) / nsig)).astype(np.complex64)
+        assert_parity(out[b, 0], ref, what=f"segment {b}")
+
+
+def test_fp32_fft_error_level():
+    """Documents the accuracy the float32 kernel delivers: ~1e-7 of the rms bin amplitude."""
+    rng = np.random.default_rng(1)
+    n = 4096
+    data = rng.normal(size=(n, 4)).astype("f4")
+    z = np.array([0])
+    out = E.fft_exec(data, z, z, z + n, n, n, np.ones((1, n)), 1.0, -1, False, None, "fourier", True, G=2)[0, 0]
+    ref = np.fft.rfft(data.astype("f8"), axis=0)
+    rms = np.sqrt((np.abs(ref) ** 2).mean())
+    assert np.abs(out - ref).max() / rms < 1e-6
+    assert np.sqrt((np.abs(out - ref) ** 2).mean()) / rms < 3e-7
+
+
+@pytest.mark.parametrize("C,F,R,tpw", [(5, 9, 6, 0), (40, 5, 7, 0), (70, 3, 10, 0), (130, 2, 4, 0), (33, 4, 5, 1),
+                                       (256, 1, 4, 0)])
+def test_csd_mfma_kernel(C, F, R, tpw):
+    rng = np.random.default_rng(C)
+    spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)
+    acc = np.zeros((F, C, C), np.complex64)
+    E.csd_accumulate(spec[:R // 2], acc, tpw)
+    E.csd_accumulate(spec[R // 2:], acc, tpw)
+    E.csd_finalize(acc, 1.0 / R)
+    ref = (np.einsum("rfi,rfj->fij", spec.astype(np.complex128), spec.conj().astype(np.complex128)) / R)
+    assert_parity(acc, ref.astype(np.complex64), what="csd")
+    assert np.array_equal(acc, acc.conj().transpose(0, 2, 1)) and np.all(acc.imag[:, range(C), range(C)] == 0)
+    for output in ("abs", "pow", "complex", "imag"):
+        assert_parity(E.coh_normalize(acc, output), O.normalize_csd(acc, output), what=output)
