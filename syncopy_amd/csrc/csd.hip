@@ -7,12 +7,12 @@ using spycsd::CsdArgs;
 
 namespace {
 
-template <int TPW>
+template <int TA, int TB>
 int launch_accum(spyhip_ctx* ctx, const CsdArgs& a, size_t lds) {
-    auto kern = spycsd::csd_accum_kernel<TPW>;
+    auto kern = spycsd::csd_accum_kernel<TA, TB>;
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long long per = 4LL * TPW;
+    const long long per = 4LL * (TA + TB);
     const long long grid = (a.nitems + per - 1) / per;
     if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(spycsd::CSD_THREADS), lds, ctx->stream, a);
@@ -36,32 +36,30 @@ extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_
     a.ntiles = a.nt * (a.nt + 1) / 2;
     a.nitems = (long long)nfreq * a.ntiles;
     a.cpad = a.nt * 32;
-    // tiles per wave: 9 packs the 36 tiles of C=256 into one workgroup per frequency
-    int tpw = 1;
-    if (a.ntiles % 36 == 0) tpw = 9;
-    else if (a.ntiles >= 10) tpw = 5;
-    else if (a.ntiles >= 3) tpw = 3;
-    // frequencies a workgroup can touch: items [i0, i0+4*tpw) span at most this many f
-    const int per = 4 * tpw;
+    // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
+    int ta = 1, tb = 1;
+    if (a.ntiles >= 21) { ta = 5; tb = 4; }
+    else if (a.ntiles >= 6) { ta = 3; tb = 2; }
+    // frequencies a workgroup can touch: items [i0, i0+per) span at most this many f
+    const int per = 4 * (ta + tb);
     int nfb = (per + a.ntiles - 1) / a.ntiles;
     if (per % a.ntiles != 0 && a.ntiles > 1) nfb += 1;
     if (nfb > nfreq) nfb = nfreq;
     const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
+    // a chunk holds at most 256 threads x CSD_PF staged elements (64 KiB)
+    const size_t chunk_max = (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2);
     int kb = 32;
-    while (kb > 2 && (size_t)kb * rowbytes > ctx->lds_per_block) kb -= 2;
-    if ((size_t)kb * rowbytes > ctx->lds_per_block) {
+    while (kb > 2 && (size_t)kb * rowbytes > chunk_max) kb -= 2;
+    if ((size_t)kb * rowbytes > chunk_max || (size_t)kb * rowbytes > ctx->lds_per_block) {
         spy::set_error("csd_accumulate: %d channels do not fit the LDS staging buffer", nchan);
         return -3;
     }
     if (kb > nrows) kb = (int)((nrows + 1) & ~1LL);
     a.kb = kb;
     const size_t lds = (size_t)kb * rowbytes;
-    switch (tpw) {
-        case 9: return launch_accum<9>(ctx, a, lds);
-        case 5: return launch_accum<5>(ctx, a, lds);
-        case 3: return launch_accum<3>(ctx, a, lds);
-        default: return launch_accum<1>(ctx, a, lds);
-    }
+    if (ta == 5) return launch_accum<5, 4>(ctx, a, lds);
+    if (ta == 3) return launch_accum<3, 2>(ctx, a, lds);
+    return launch_accum<1, 1>(ctx, a, lds);
 }
 
 extern "C" int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, double scale) {

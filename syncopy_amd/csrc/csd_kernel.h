@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace spycsd {
 
-constexpr int CSD_THREADS = 256;
+constexpr int CSD_THREADS = 512;   // 8 waves = 2 per SIMD: one wave's LDS waits hide behind the other's MFMAs
 
 struct CsdArgs {
     const float2* spec;   // (nrows, F, C) complex64
@@ -45,36 +45,50 @@ __device__ __forceinline__ void tile_of(int tt, int& ti, int& tj) {
     tj = tt - i * (i + 1) / 2;
 }
 
-template <int TPW>
+__device__ __forceinline__ int opaque_i(int v) {
+#ifndef SPY_HOST_EMU
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chunk <= 32 KiB of LDS)
+
+// Waves 0-3 own TA tiles each, waves 4-7 TB tiles each (TA >= TB): with (5,4) a workgroup
+// covers the 36 lower-triangle tiles of one frequency at C=256 and every SIMD (waves w and
+// w+4) carries 9 tiles.  5 x 32 accumulator registers per wave fit the AGPR file, so the
+// MFMA chain never leaves it (9 tiles on ONE wave need 288 and made hipcc rotate accumulators
+// through VGPRs inside the loop).
+// One chunk of kb rows is fetched into registers (all loads in flight together) while the
+// previous chunk is being multiplied, then written to LDS.
+template <int TA, int TB>
 __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     SPY_DYN_SMEM(float2, X);   // [kb][rowlen]
+    constexpr int PER = 4 * (TA + TB);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
+    const int ntile_w = wave < 4 ? TA : TB;                                  // wave-uniform
+    const int first_w = wave < 4 ? wave * TA : 4 * TA + (wave - 4) * TB;
 
-    const long long item0 = (long long)blockIdx.x * (4 * TPW);
-    long long last = item0 + 4 * TPW;
+    const long long item0 = (long long)blockIdx.x * PER;
+    long long last = item0 + PER;
     if (last > a.nitems) last = a.nitems;
     if (item0 >= a.nitems) return;
     const int f_lo = (int)(item0 / a.ntiles);
     const int nfb = (int)((last - 1) / a.ntiles) - f_lo + 1;
     const int rowlen = nfb * a.cpad;
 
-    int aoff[TPW], boff[TPW], tf[TPW], tti[TPW], ttj[TPW];
-    bool valid[TPW];
-    f32x16 accr[TPW], acci[TPW];
+    int aoff[TA], boff[TA];
+    f32x16 accr[TA], acci[TA];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const long long item = item0 + (long long)wave * TPW + t;
-        valid[t] = item < a.nitems;
+    for (int t = 0; t < TA; ++t) {
+        const long long item = item0 + first_w + t;
         int f = f_lo, ti = 0, tj = 0;
-        if (valid[t]) {
+        if (t < ntile_w && item < a.nitems) {
             f = (int)(item / a.ntiles);
             tile_of((int)(item % a.ntiles), ti, tj);
         }
-        tf[t] = f;
-        tti[t] = ti;
-        ttj[t] = tj;
         aoff[t] = (f - f_lo) * a.cpad + ti * 32 + l31;
         boff[t] = (f - f_lo) * a.cpad + tj * 32 + l31;
 #pragma unroll
@@ -84,23 +98,56 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         }
     }
 
-    const int total = a.kb * rowlen;
-    for (long long r0 = 0; r0 < a.nrows; r0 += a.kb) {
-        // ---- stage kb rows of the nfb frequencies (zero fill: padding channels, rows past the end)
-        for (int u = tid; u < total; u += CSD_THREADS) {
-            const int kr = u / rowlen, cc = u - kr * rowlen;
-            const int fb = cc / a.cpad, c = cc - fb * a.cpad;
-            const long long row = r0 + kr;
-            float2 val = make_float2(0.f, 0.f);
-            if (row < a.nrows && c < a.C) val = a.spec[((size_t)row * a.F + (f_lo + fb)) * a.C + c];
-            X[u] = val;
+    // element i of this thread = LDS slot u = tid + 512*i = (row kr, column cc) of the chunk
+    const int total = a.kb * rowlen;                       // <= 512 * CSD_PF
+    const int step_q = CSD_THREADS / rowlen, step_r = CSD_THREADS % rowlen;
+    const int kr0 = tid / rowlen, cc0 = tid % rowlen;
+    const size_t rowstride = (size_t)a.F * a.C;            // float2 elements between rows r and r+1
+    const unsigned rowbytes = (unsigned)rowstride * 8u;    // a chunk spans < 4 GiB: 32-bit lane offsets
+    const float2* fbase = a.spec + (size_t)f_lo * a.C;
+
+    float2 pf[CSD_PF];
+    auto fetch = [&](long long r0) {
+        // opaque: the (row, column) walk is recomputed per chunk instead of being hoisted out of the
+        // row loop into ~100 long-lived VGPRs (offsets + predicates of all CSD_PF elements)
+        int kr = opaque_i(kr0), cc = opaque_i(cc0);
+        const char* base = reinterpret_cast<const char*>(fbase + (size_t)r0 * rowstride);   // wave-uniform
+        const long long rleft = a.nrows - r0;
+#pragma unroll
+        for (int i = 0; i < CSD_PF; ++i) {
+            float2 v = make_float2(0.f, 0.f);
+            if (tid + CSD_THREADS * i < total) {
+                int fb = 0, c = cc;
+                if (nfb > 1) {
+                    fb = cc / a.cpad;
+                    c = cc - fb * a.cpad;
+                }
+                if (kr < rleft && c < a.C)
+                    v = *reinterpret_cast<const float2*>(base + ((unsigned)kr * rowbytes + (unsigned)(fb * a.C + c) * 8u));
+            }
+            pf[i] = v;
+            cc += step_r;
+            kr += step_q;
+            if (cc >= rowlen) {
+                cc -= rowlen;
+                kr += 1;
+            }
         }
+    };
+
+    fetch(0);
+    for (long long r0 = 0; r0 < a.nrows; r0 += a.kb) {
+#pragma unroll
+        for (int i = 0; i < CSD_PF; ++i)
+            if (tid + CSD_THREADS * i < total) X[tid + CSD_THREADS * i] = pf[i];
         __syncthreads();
+        if (r0 + a.kb < a.nrows) fetch(r0 + a.kb);          // in flight during the MFMA phase
         // ---- rank-2 updates
         for (int ks = 0; ks < a.kb; ks += 2) {
             const float2* xr = X + (ks + lhi) * rowlen;
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
+            for (int t = 0; t < TA; ++t) {
+                if (t >= TB && t >= ntile_w) break;           // waves 4-7 own TB tiles
                 const float2 av = xr[aoff[t]];
                 const float2 bv = xr[boff[t]];
                 accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accr[t], 0, 0, 0);
@@ -114,15 +161,19 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
 
     // ---- acc += tile (each (f, tile) is owned by exactly one wave: plain read-modify-write)
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        if (!valid[t]) continue;
-        const int j = ttj[t] * 32 + l31;
+    for (int t = 0; t < TA; ++t) {
+        const long long item = item0 + first_w + t;
+        if (t >= ntile_w || item >= a.nitems) continue;
+        const int f = (int)(item / a.ntiles);
+        int ti, tj;
+        tile_of((int)(item % a.ntiles), ti, tj);
+        const int j = tj * 32 + l31;
         if (j >= a.C) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = tti[t] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             if (i < a.C) {
-                float2* p = a.acc + ((size_t)tf[t] * a.C + i) * a.C + j;
+                float2* p = a.acc + ((size_t)f * a.C + i) * a.C + j;
                 float2 v = *p;
                 v.x += accr[t][r];
                 v.y += acci[t][r];

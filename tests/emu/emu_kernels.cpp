@@ -131,29 +131,28 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     a.ntiles = a.nt * (a.nt + 1) / 2;
     a.nitems = (long long)F * a.ntiles;
     a.cpad = a.nt * 32;
-    int tpw = 1;
-    if (a.ntiles % 36 == 0) tpw = 9;
-    else if (a.ntiles >= 10) tpw = 5;
-    else if (a.ntiles >= 3) tpw = 3;
-    if (force_tpw > 0) tpw = force_tpw;
-    const int per = 4 * tpw;
+    int ta = 1, tb = 1;
+    if (a.ntiles >= 21) { ta = 5; tb = 4; }
+    else if (a.ntiles >= 6) { ta = 3; tb = 2; }
+    if (force_tpw == 1) { ta = 1; tb = 1; }
+    if (force_tpw == 3) { ta = 3; tb = 2; }
+    if (force_tpw == 5) { ta = 5; tb = 4; }
+    const int per = 4 * (ta + tb);
     int nfb = (per + a.ntiles - 1) / a.ntiles;
     if (per % a.ntiles != 0 && a.ntiles > 1) nfb += 1;
     if (nfb > F) nfb = F;
     const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
     int kb = 32;
-    while (kb > 2 && (size_t)kb * rowbytes > 160 * 1024) kb -= 2;
+    while (kb > 2 && (size_t)kb * rowbytes > (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2)) kb -= 2;
     if (kb > nrows) kb = (int)((nrows + 1) & ~1LL);
     a.kb = kb;
     const size_t lds = (size_t)kb * rowbytes;
     const unsigned grid = (unsigned)((a.nitems + per - 1) / per);
-    switch (tpw) {
-        case 9: emu::launch(dim3(grid), dim3(256), lds, [&] { spycsd::csd_accum_kernel<9>(a); }); break;
-        case 5: emu::launch(dim3(grid), dim3(256), lds, [&] { spycsd::csd_accum_kernel<5>(a); }); break;
-        case 3: emu::launch(dim3(grid), dim3(256), lds, [&] { spycsd::csd_accum_kernel<3>(a); }); break;
-        default: emu::launch(dim3(grid), dim3(256), lds, [&] { spycsd::csd_accum_kernel<1>(a); }); break;
-    }
-    return tpw;
+    const unsigned T = spycsd::CSD_THREADS;
+    if (ta == 5) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4>(a); });
+    else if (ta == 3) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<3, 2>(a); });
+    else emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<1, 1>(a); });
+    return ta;
 }
 
 void emu_csd_finalize(float* acc, int F, int C, float scale) {

@@ -89,8 +89,8 @@ def test_fp32_fft_error_level():
     assert np.sqrt((np.abs(out - ref) ** 2).mean()) / rms < 3e-7
 
 
-@pytest.mark.parametrize("C,F,R,tpw", [(5, 9, 6, 0), (40, 5, 7, 0), (70, 3, 10, 0), (130, 2, 4, 0), (33, 4, 5, 1),
-                                       (256, 1, 4, 0)])
+@pytest.mark.parametrize("C,F,R,tpw", [(5, 9, 6, 0), (40, 5, 7, 0), (70, 3, 10, 5), (130, 2, 4, 0), (33, 4, 5, 1),
+                                       (100, 3, 5, 0), (256, 2, 4, 0)])
 def test_csd_mfma_kernel(C, F, R, tpw):
     rng = np.random.default_rng(C)
     spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)
