@@ -56,7 +56,7 @@ extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_
     }
     if (kb > nrows) kb = (int)((nrows + 1) & ~1LL);
     a.kb = kb;
-    const size_t lds = (size_t)kb * rowbytes;
+    const size_t lds = 2 * (size_t)kb * rowbytes;     // double buffered
     if (ta == 5) return launch_accum<5, 4>(ctx, a, lds);
     if (ta == 3) return launch_accum<3, 2>(ctx, a, lds);
     return launch_accum<1, 1>(ctx, a, lds);

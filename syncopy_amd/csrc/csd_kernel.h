@@ -52,6 +52,12 @@ __device__ __forceinline__ int opaque_i(int v) {
     return v;
 }
 
+__device__ __forceinline__ void sched_fence_csd() {
+#ifndef SPY_HOST_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chunk <= 32 KiB of LDS)
 
 // Waves 0-3 own TA tiles each, waves 4-7 TB tiles each (TA >= TB): with (5,4) a workgroup
@@ -63,7 +69,7 @@ constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chu
 // previous chunk is being multiplied, then written to LDS.
 template <int TA, int TB>
 __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
-    SPY_DYN_SMEM(float2, X);   // [kb][rowlen]
+    SPY_DYN_SMEM(float2, X);   // 2 x [kb][rowlen]
     constexpr int PER = 4 * (TA + TB);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -107,7 +113,9 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     const float2* fbase = a.spec + (size_t)f_lo * a.C;
 
     float2 pf[CSD_PF];
+    unsigned okmask = 0;
     auto fetch = [&](long long r0) {
+        okmask = 0;
         // opaque: the (row, column) walk is recomputed per chunk instead of being hoisted out of the
         // row loop into ~100 long-lived VGPRs (offsets + predicates of all CSD_PF elements)
         int kr = opaque_i(kr0), cc = opaque_i(cc0);
@@ -115,17 +123,20 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         const long long rleft = a.nrows - r0;
 #pragma unroll
         for (int i = 0; i < CSD_PF; ++i) {
-            float2 v = make_float2(0.f, 0.f);
-            if (tid + CSD_THREADS * i < total) {
-                int fb = 0, c = cc;
-                if (nfb > 1) {
-                    fb = cc / a.cpad;
-                    c = cc - fb * a.cpad;
-                }
-                if (kr < rleft && c < a.C)
-                    v = *reinterpret_cast<const float2*>(base + ((unsigned)kr * rowbytes + (unsigned)(fb * a.C + c) * 8u));
+            // branch-free: clamp to a valid element, load unconditionally, select afterwards - a load
+            // inside a conditional block gets its own s_waitcnt vmcnt(0) and the CSD_PF round trips to
+            // HBM would run back to back instead of together
+            int fb = 0, c = cc;
+            if (nfb > 1) {
+                fb = cc / a.cpad;
+                c = cc - fb * a.cpad;
             }
-            pf[i] = v;
+            const bool ok = (tid + CSD_THREADS * i < total) && (kr < rleft) && (c < a.C);
+            const int krc = (int)(kr < rleft ? kr : rleft - 1);
+            const int fbc = fb < nfb ? fb : nfb - 1;
+            const int cc_c = c < a.C ? c : a.C - 1;
+            pf[i] = *reinterpret_cast<const float2*>(base + ((unsigned)krc * rowbytes + (unsigned)(fbc * a.C + cc_c) * 8u));
+            okmask |= ok ? (1u << i) : 0u;      // the zero-fill select happens at LDS-write time: no early wait
             cc += step_r;
             kr += step_q;
             if (cc >= rowlen) {
@@ -135,28 +146,54 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         }
     };
 
+    // LDS is double buffered: chunk i+1 is written into the other half while chunk i is being
+    // multiplied, so there is ONE barrier per chunk and no wave waits for the stage.
+    // (buffers addressed as X[buf*total + ...]: a pointer array would decay to flat addressing)
     fetch(0);
-    for (long long r0 = 0; r0 < a.nrows; r0 += a.kb) {
 #pragma unroll
-        for (int i = 0; i < CSD_PF; ++i)
-            if (tid + CSD_THREADS * i < total) X[tid + CSD_THREADS * i] = pf[i];
-        __syncthreads();
-        if (r0 + a.kb < a.nrows) fetch(r0 + a.kb);          // in flight during the MFMA phase
-        // ---- rank-2 updates
+    for (int i = 0; i < CSD_PF; ++i)
+        if (tid + CSD_THREADS * i < total)
+            X[tid + CSD_THREADS * i] = ((okmask >> i) & 1u) ? pf[i] : make_float2(0.f, 0.f);
+    if (a.kb < a.nrows) fetch(a.kb);
+    __syncthreads();
+    int buf = 0;
+    for (long long r0 = 0; r0 < a.nrows; r0 += a.kb, buf ^= 1) {
+        bool more = r0 + a.kb < a.nrows;
+#ifdef CSD_DBG_NOSTAGE
+        more = false;
+#endif
+        if (more) {
+            // chunk r0+kb (fetched during the previous iteration) -> other buffer; then start fetching r0+2kb
+            const int nxt = (buf ^ 1) * total;
+#pragma unroll
+            for (int i = 0; i < CSD_PF; ++i)
+                if (tid + CSD_THREADS * i < total)
+                    X[nxt + tid + CSD_THREADS * i] = ((okmask >> i) & 1u) ? pf[i] : make_float2(0.f, 0.f);
+            if (r0 + 2 * a.kb < a.nrows) fetch(r0 + 2 * a.kb);
+        }
+        // ---- rank-2 updates: all operand reads of a row pair are issued before its first MFMA
+        const int cur = buf * total;
         for (int ks = 0; ks < a.kb; ks += 2) {
-            const float2* xr = X + (ks + lhi) * rowlen;
+            const float2* xr = X + (cur + (ks + lhi) * rowlen);
+            float2 av[TA], bv[TA];
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                av[t] = xr[aoff[t]];
+                bv[t] = xr[boff[t]];
+            }
+            sched_fence_csd();      // keep the reads ahead of the MFMA chain (hipcc otherwise re-sinks them)
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
                 if (t >= TB && t >= ntile_w) break;           // waves 4-7 own TB tiles
-                const float2 av = xr[aoff[t]];
-                const float2 bv = xr[boff[t]];
-                accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accr[t], 0, 0, 0);
-                accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, accr[t], 0, 0, 0);
-                acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acci[t], 0, 0, 0);
-                acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av.x, bv.y, acci[t], 0, 0, 0);
+                accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv[t].x, accr[t], 0, 0, 0);
+                acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[t].x, acci[t], 0, 0, 0);
+                accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[t].y, accr[t], 0, 0, 0);
+                acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[t].x, bv[t].y, acci[t], 0, 0, 0);
             }
         }
+#ifndef CSD_DBG_NOBARRIER
         __syncthreads();
+#endif
     }
 
     // ---- acc += tile (each (f, tile) is owned by exactly one wave: plain read-modify-write)
@@ -168,17 +205,19 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         int ti, tj;
         tile_of((int)(item % a.ntiles), ti, tj);
         const int j = tj * 32 + l31;
-        if (j >= a.C) continue;
+        // read-modify-write of the 16 rows this lane holds: all loads first (clamped, branch-free), then stores
+        const int jc = j < a.C ? j : a.C - 1;
+        float2* const pbase = a.acc + (size_t)f * a.C * a.C + jc;
+        float2 old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (i < a.C) {
-                float2* p = a.acc + ((size_t)f * a.C + i) * a.C + j;
-                float2 v = *p;
-                v.x += accr[t][r];
-                v.y += acci[t][r];
-                *p = v;
-            }
+            old[r] = pbase[(size_t)(i < a.C ? i : a.C - 1) * a.C];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (i < a.C && j < a.C) pbase[(size_t)i * a.C] = make_float2(old[r].x + accr[t][r], old[r].y + acci[t][r]);
         }
     }
 }
