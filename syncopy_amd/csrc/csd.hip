@@ -8,12 +8,31 @@ using spycsd::CsdArgs;
 namespace {
 
 template <int TA, int TB>
-int launch_accum(spyhip_ctx* ctx, const CsdArgs& a, size_t lds) {
+int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item_end) {
     auto kern = spycsd::csd_accum_kernel<TA, TB>;
+    const int per = 4 * (TA + TB);
+    // frequencies a workgroup can touch: items [i0, i0+per) span at most this many f
+    int nfb = (per + a.ntiles - 1) / a.ntiles;
+    if (per % a.ntiles != 0 && a.ntiles > 1) nfb += 1;
+    if (nfb > a.F) nfb = a.F;
+    const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
+    // a chunk holds at most 512 threads x CSD_PF staged elements; LDS is double buffered
+    const size_t chunk_max = (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2);
+    int kb = 32;
+    while (kb > 2 && (size_t)kb * rowbytes > chunk_max) kb -= 2;
+    if ((size_t)kb * rowbytes > chunk_max || 2 * (size_t)kb * rowbytes > ctx->lds_per_block) {
+        spy::set_error("csd_accumulate: %d channels do not fit the LDS staging buffer", a.C);
+        return -3;
+    }
+    if (kb > a.nrows) kb = (int)((a.nrows + 1) & ~1LL);
+    a.kb = kb;
+    a.item_base = item_base;
+    a.item_end = item_end;
+    const size_t lds = 2 * (size_t)kb * rowbytes;
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long long per = 4LL * (TA + TB);
-    const long long grid = (a.nitems + per - 1) / per;
+    const long long grid = (item_end - item_base + per - 1) / per;
+    if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(spycsd::CSD_THREADS), lds, ctx->stream, a);
     SPY_HIP_CHECK(hipGetLastError());
@@ -37,29 +56,21 @@ extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_
     a.nitems = (long long)nfreq * a.ntiles;
     a.cpad = a.nt * 32;
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
-    int ta = 1, tb = 1;
-    if (a.ntiles >= 21) { ta = 5; tb = 4; }
-    else if (a.ntiles >= 6) { ta = 3; tb = 2; }
-    // frequencies a workgroup can touch: items [i0, i0+per) span at most this many f
-    const int per = 4 * (ta + tb);
-    int nfb = (per + a.ntiles - 1) / a.ntiles;
-    if (per % a.ntiles != 0 && a.ntiles > 1) nfb += 1;
-    if (nfb > nfreq) nfb = nfreq;
-    const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
-    // a chunk holds at most 256 threads x CSD_PF staged elements (64 KiB)
-    const size_t chunk_max = (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2);
-    int kb = 32;
-    while (kb > 2 && (size_t)kb * rowbytes > chunk_max) kb -= 2;
-    if ((size_t)kb * rowbytes > chunk_max || (size_t)kb * rowbytes > ctx->lds_per_block) {
-        spy::set_error("csd_accumulate: %d channels do not fit the LDS staging buffer", nchan);
-        return -3;
+    if (a.ntiles >= 21) {
+        // One workgroup per CU: F = 2049 frequencies on 256 CUs would leave a 9th, almost empty round.
+        // The workgroups beyond the last full round are re-cut into 1-tile-per-wave workgroups
+        // (4.5x more, each 5x shorter), so the tail costs ~1/5 of a round and stays deterministic.
+        const long long per = 36, nwg = (a.nitems + per - 1) / per;
+        const long long full = (nwg / ctx->num_cu) * ctx->num_cu, rem = nwg - full;
+        if (full > 0 && rem > 0 && rem * 4 <= ctx->num_cu) {
+            const int rc = launch_accum<5, 4>(ctx, a, 0, full * per);
+            if (rc) return rc;
+            return launch_accum<1, 1>(ctx, a, full * per, a.nitems);
+        }
+        return launch_accum<5, 4>(ctx, a, 0, a.nitems);
     }
-    if (kb > nrows) kb = (int)((nrows + 1) & ~1LL);
-    a.kb = kb;
-    const size_t lds = 2 * (size_t)kb * rowbytes;     // double buffered
-    if (ta == 5) return launch_accum<5, 4>(ctx, a, lds);
-    if (ta == 3) return launch_accum<3, 2>(ctx, a, lds);
-    return launch_accum<1, 1>(ctx, a, lds);
+    if (a.ntiles >= 6) return launch_accum<3, 2>(ctx, a, 0, a.nitems);
+    return launch_accum<1, 1>(ctx, a, 0, a.nitems);
 }
 
 extern "C" int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, double scale) {

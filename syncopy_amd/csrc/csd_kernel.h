@@ -32,6 +32,8 @@ struct CsdArgs {
     int nt;               // channel tiles = ceil(C/32)
     int ntiles;           // nt*(nt+1)/2
     long long nitems;     // F*ntiles
+    long long item_base;  // this launch covers items [item_base, item_end)
+    long long item_end;
     int cpad;             // nt*32
     int kb;               // rows per LDS chunk (even)
 };
@@ -77,10 +79,10 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     const int ntile_w = wave < 4 ? TA : TB;                                  // wave-uniform
     const int first_w = wave < 4 ? wave * TA : 4 * TA + (wave - 4) * TB;
 
-    const long long item0 = (long long)blockIdx.x * PER;
+    const long long item0 = a.item_base + (long long)blockIdx.x * PER;
     long long last = item0 + PER;
-    if (last > a.nitems) last = a.nitems;
-    if (item0 >= a.nitems) return;
+    if (last > a.item_end) last = a.item_end;
+    if (item0 >= a.item_end) return;
     const int f_lo = (int)(item0 / a.ntiles);
     const int nfb = (int)((last - 1) / a.ntiles) - f_lo + 1;
     const int rowlen = nfb * a.cpad;
@@ -91,7 +93,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     for (int t = 0; t < TA; ++t) {
         const long long item = item0 + first_w + t;
         int f = f_lo, ti = 0, tj = 0;
-        if (t < ntile_w && item < a.nitems) {
+        if (t < ntile_w && item < a.item_end) {
             f = (int)(item / a.ntiles);
             tile_of((int)(item % a.ntiles), ti, tj);
         }
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
         const long long item = item0 + first_w + t;
-        if (t >= ntile_w || item >= a.nitems) continue;
+        if (t >= ntile_w || item >= a.item_end) continue;
         const int f = (int)(item / a.ntiles);
         int ti, tj;
         tile_of((int)(item % a.ntiles), ti, tj);

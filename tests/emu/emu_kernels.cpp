@@ -146,6 +146,7 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     while (kb > 2 && (size_t)kb * rowbytes > (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2)) kb -= 2;
     if (kb > nrows) kb = (int)((nrows + 1) & ~1LL);
     a.kb = kb;
+    a.item_base = 0; a.item_end = a.nitems;
     const size_t lds = 2 * (size_t)kb * rowbytes;
     const unsigned grid = (unsigned)((a.nitems + per - 1) / per);
     const unsigned T = spycsd::CSD_THREADS;

@@ -119,7 +119,8 @@ def test_fft_zero_extended_segments(be):
         assert_parity(out[b, 0], ref, what=f"segment {b}")
 
 
-@pytest.mark.parametrize("C,F,R", [(5, 33, 14), (16, 101, 140), (40, 17, 35), (70, 9, 64), (256, 5, 70)])
+@pytest.mark.parametrize("C,F,R", [(5, 33, 14), (16, 101, 140), (40, 17, 35), (70, 9, 64), (256, 5, 70),
+                                   (256, 259, 10)])    # 259 workgroups on 256 CUs: exercises the re-cut tail
 def test_csd_accumulate_vs_oracle(be, C, F, R):
     rng = np.random.default_rng(C + F)
     spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)
