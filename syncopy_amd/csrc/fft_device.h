@@ -153,15 +153,23 @@ __device__ __forceinline__ void fft_forward(float2 (&v)[16], float2* lds, int j,
         const int Ns = 1 << (4 * p);
         const int k = j & (Ns - 1);
         if (p > 0) {
+            // twiddles w^r, r = 1..15, w = tw[k*stride]: six table loads (w^1,w^2,w^3,w^4,w^8,w^12) issued
+            // together, the other nine as w^(4a) * w^b - one extra fp32 rounding (~6e-8) instead of nine
+            // more dependent L2 round trips per pass
             const unsigned kb = (unsigned)(k * (C::N / (Ns * 16))) * 8u;   // byte offset of tw[k*stride]
-            // twiddles in two batches: bounds the registers in flight (the scheduler
-            // would otherwise issue all 15 table loads up front)
+            float2 wb[4], wa[4];
+            wb[1] = ldg<float2>(tw, kb);
+            wb[2] = ldg<float2>(tw, kb * 2u);
+            wb[3] = ldg<float2>(tw, kb * 3u);
+            wa[1] = ldg<float2>(tw, kb * 4u);
+            wa[2] = ldg<float2>(tw, kb * 8u);
+            wa[3] = ldg<float2>(tw, kb * 12u);
 #pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], ldg<float2>(tw, kb * (unsigned)r));
-            sched_fence();
-#pragma unroll
-            for (int r = 8; r < 16; ++r) v[r] = cmul(v[r], ldg<float2>(tw, kb * (unsigned)r));
-            sched_fence();
+            for (int r = 1; r < 16; ++r) {
+                const int hi = r >> 2, lo = r & 3;
+                const float2 w = (hi == 0) ? wb[lo] : (lo == 0 ? wa[hi] : cmul(wa[hi], wb[lo]));
+                v[r] = cmul(v[r], w);
+            }
         }
         dft<16>(v);
         const bool last = (p == C::NP16 - 1) && (C::RLAST == 1);

@@ -129,7 +129,7 @@ int default_G(int log2n, int nchan) {
         case 9: g = 8; break;
         case 10: g = 4; break;
         case 11: g = 4; break;
-        case 12: g = 4; break;
+        case 12: g = 2; break;
         case 13: g = 2; break;
         default: g = 1; break;
     }

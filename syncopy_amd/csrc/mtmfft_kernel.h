@@ -186,6 +186,8 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) mtmfft_pow2_kernel(
     const float hs = 0.5f * a.scale;
     const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
     constexpr unsigned OSZ = CPLX ? 8u : 4u;   // bytes per output element
+    // complex outputs of a channel pair are 16 contiguous bytes: aligned when nchan is even
+    const bool pair16 = ((a.nchan & 1) == 0) && ((reinterpret_cast<size_t>(a.out) & 15) == 0);
 
     for (int k = 0; k < a.ntaper; ++k) {
         const int j = opaque(j0);
@@ -259,8 +261,12 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) mtmfft_pow2_kernel(
                 if (fi >= 0) {
                     const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
                     if (CPLX) {
-                        if (has0) stg<float2>(slab, o, xa);
-                        if (has1) stg<float2>(slab, o + OSZ, xb);
+                        if (has1 && pair16) {
+                            stg<float4>(slab, o, make_float4(xa.x, xa.y, xb.x, xb.y));   // one 16-byte store per bin
+                        } else {
+                            if (has0) stg<float2>(slab, o, xa);
+                            if (has1) stg<float2>(slab, o + OSZ, xb);
+                        }
                     } else {
                         if (has0) stg<float>(slab, o, convert_real<OUTK>(xa, a.out_kind));
                         if (has1) stg<float>(slab, o + OSZ, convert_real<OUTK>(xb, a.out_kind));
