@@ -126,18 +126,21 @@ int spyhip_coh_normalize(spyhip_ctx* ctx, const void* csd_d, int nfreq, int ncha
 /* ---- K3: Morlet continuous wavelet transform ------------------------------
  * Replaces cwt_time (specest/wavelets/transform.py:88-108) with Morlet.time
  * (specest/wavelets/wavelets.py:27-86) and the tail of wavelet_cF
- * (specest/compRoutines.py:582-595): detrend, full linear convolution with
- * the sampled complete Morlet kernel of every scale, cropped like
- * scipy.signal.fftconvolve(mode="same"), converted with `output`.
- * Result per segment: (ntime_out, 1, nscales, nchan), where the ntime_out
- * kept samples are post_start + i*post_step of the nsig input samples. */
+ * (specest/compRoutines.py:582-595): detrend the whole trial, full linear
+ * convolution of the nsig pre-selected samples with the sampled complete Morlet
+ * kernel of every scale (M = 10*s/dt taps, amplitude sqrt(dt)/(8 pi s)), cropped
+ * like scipy.signal.fftconvolve(mode="same"), converted with `output`.
+ * tpos (host, nsig entries or NULL): output slot of sample n or -1 (post-selection).
+ * Result per segment: (ntime_out, 1, nscales, nchan) float32 / complex64. */
 int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
-                           double dt, double w0, int detrend, int output, int post_start,
-                           int post_step, int ntime_out, spyhip_cwt_plan** plan);
+                           double dt, double w0, int detrend, int output, const int32_t* tpos,
+                           int ntime_out, spyhip_cwt_plan** plan);
 int spyhip_cwt_plan_destroy(spyhip_cwt_plan* plan);
+/* seg_start_d: row of sample 0 of each pre-selected signal; trial_lo_d/trial_hi_d: rows of the
+ * whole trial (detrending range); accumulate != 0: out_d += result (trial averaging). */
 int spyhip_cwt_exec(spyhip_cwt_plan* plan, const float* data_d, int64_t ld,
-                    const int32_t* chan_idx_d, const int64_t* seg_start_d, int nseg, void* out_d,
-                    int accumulate);
+                    const int32_t* chan_idx_d, const int64_t* seg_start_d, const int64_t* trial_lo_d,
+                    const int64_t* trial_hi_d, int nseg, void* out_d, int accumulate);
 
 /* ---- K6: Wilson spectral factorisation + Granger-Geweke causality ---------
  * Replaces regularize_csd / wilson_sf (connectivity/wilson_sf.py:16-254) and

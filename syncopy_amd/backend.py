@@ -129,6 +129,60 @@ class FFTPlan:
             pass
 
 
+class CWTPlan:
+    """spyhip_cwt_plan: Morlet CWT (overlap-save FFT convolution) of segments of the trial matrix."""
+
+    def __init__(self, nsig, nchan, scales, dt, w0=6.0, detrend=None, output="pow", tpos=None, ntime_out=None,
+                 device=None):
+        self.ctx = context(device)
+        scales = np.ascontiguousarray(scales, dtype=np.float64)
+        self.nsig, self.nchan, self.nscales = int(nsig), int(nchan), int(scales.size)
+        self.kind = OUTPUT_KIND[output]
+        if tpos is None:
+            tp, self.ntime_out = None, self.nsig
+        else:
+            tpa = np.ascontiguousarray(tpos, dtype=np.int32)
+            assert tpa.size == self.nsig
+            tp, self.ntime_out = tpa.ctypes.data_as(_lib.c_i32p), int(ntime_out)
+        h = C.c_void_p()
+        self.ctx.bind_stream()
+        check(self.ctx.lib.spyhip_cwt_plan_create(
+            self.ctx.handle, self.nsig, self.nchan, self.nscales, scales.ctypes.data_as(_lib.c_f64p), float(dt),
+            float(w0), DETREND[detrend], self.kind, tp, self.ntime_out, C.byref(h)), "spyhip_cwt_plan_create")
+        self.handle = h
+        self.out_dtype = torch.complex64 if self.kind == 2 else torch.float32
+
+    def out_shape(self, nseg):
+        return (nseg, self.ntime_out, self.nscales, self.nchan)
+
+    def execute(self, data, seg_start, trial_lo, trial_hi, chan_idx=None, out=None, accumulate=False):
+        assert data.is_cuda and data.dtype == torch.float32 and data.dim() == 2 and data.is_contiguous()
+        nseg = int(seg_start.numel())
+        for t in (seg_start, trial_lo, trial_hi):
+            assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == nseg
+        if chan_idx is not None:
+            assert chan_idx.is_cuda and chan_idx.dtype == torch.int32 and chan_idx.numel() == self.nchan
+        if out is None:
+            assert not accumulate
+            out = torch.zeros(self.out_shape(nseg), dtype=self.out_dtype, device=data.device)
+        else:
+            assert out.is_cuda and out.is_contiguous() and out.dtype == self.out_dtype
+            assert tuple(out.shape) == self.out_shape(nseg)
+        self.ctx.bind_stream()
+        check(self.ctx.lib.spyhip_cwt_exec(self.handle, _ptr(data), int(data.shape[1]), _ptr(chan_idx),
+                                           _ptr(seg_start), _ptr(trial_lo), _ptr(trial_hi), nseg, _ptr(out),
+                                           int(bool(accumulate))), "spyhip_cwt_exec")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.ctx.lib.spyhip_cwt_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 def csd_accumulate(spec, acc):
     """acc[f,i,j] += sum_r spec[r,f,i] conj(spec[r,f,j]) on the lower triangle (MFMA).
     spec: (..., F, C) complex64 (leading dims flattened to rows); acc: (F, C, C) complex64."""

@@ -1,0 +1,175 @@
+// Host side of K3: Morlet kernel spectra (fp64 on the host, once per plan) and launch of the
+// overlap-save CWT kernel (spyhip_cwt_plan_create / spyhip_cwt_exec).
+#include <cmath>
+#include <string>
+
+#include "spy_common.h"
+#include "host_fft.h"
+#include "cwt_kernel.h"
+
+using spyfft::CwtArgs;
+
+struct spyhip_cwt_plan {
+    spyhip_ctx* ctx = nullptr;
+    int nsig = 0, nchan = 0, nscales = 0, detrend = -1, output = 0, ntime_out = 0;
+    int log2n = 0, G = 1, V = 0, halo = 0, nblocks = 0;
+    bool identity_time = true;
+    spy::DevBuf<float2> tw, hspec;
+    spy::DevBuf<int> cshift, tpos;
+    spy::DevBuf<double> trend;
+    size_t trend_cap = 0;
+};
+
+namespace {
+const double PI = 3.14159265358979323846264338327950288;
+
+template <int LOG2N, int G, int OUTK>
+int launch_cwt(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
+    using C = spyfft::Cfg<LOG2N, G>;
+    auto kern = spyfft::cwt_kernel<LOG2N, G, OUTK>;
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int LOG2N, int G>
+int launch_cwt_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
+    if (p->output == SPYHIP_OUT_FOURIER) return launch_cwt<LOG2N, G, 2>(p, a, grid);
+    if (p->output == SPYHIP_OUT_POW) return launch_cwt<LOG2N, G, 0>(p, a, grid);
+    return launch_cwt<LOG2N, G, 1>(p, a, grid);
+}
+}  // namespace
+
+extern "C" int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
+                                      double dt, double w0, int detrend, int output, const int32_t* tpos,
+                                      int ntime_out, spyhip_cwt_plan** out) {
+    if (!ctx || !scales || !out) { spy::set_error("cwt_plan_create: null argument"); return -1; }
+    if (nsig < 1 || nchan < 1 || nscales < 1 || dt <= 0) { spy::set_error("cwt_plan_create: bad shape"); return -1; }
+    if (output < SPYHIP_OUT_POW || output > SPYHIP_OUT_ABSIMAG) { spy::set_error("bad output kind %d", output); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+
+    // ---- sampled kernels (transform.py:96-103), trimmed to the taps that can overlap the signal
+    struct Ker { std::vector<double> re, im; int c; };
+    std::vector<Ker> kers(nscales);
+    int lmax = 1, halo = 0, right = 0;
+    for (int s = 0; s < nscales; ++s) {
+        const double sc = scales[s];
+        const double M = 10.0 * sc / dt;
+        const double t0 = (-M + 1.0) / 2.0, t1 = (M + 1.0) / 2.0;
+        long long L = (long long)std::ceil(t1 - t0);               // len(np.arange(t0, t1))
+        if (L < 1) L = 1;
+        const long long c = (L - 1) / 2;                            // fftconvolve mode="same" offset
+        // y[n] = sum_m h[m] x[n + c - m], 0 <= n + c - m < nsig  =>  m in [c - (nsig-1), c + (nsig-1)]
+        const long long m0 = std::max<long long>(0, c - (nsig - 1));
+        const long long m1 = std::min<long long>(L, c + nsig);      // exclusive
+        Ker& k = kers[s];
+        k.c = (int)(c - m0);
+        const double norm = std::sqrt(dt) / (sc * 8.0 * PI) * std::pow(PI, -0.25);
+        const double corr = std::exp(-0.5 * w0 * w0);
+        k.re.resize(m1 - m0);
+        k.im.resize(m1 - m0);
+        for (long long m = m0; m < m1; ++m) {
+            const double x = (t0 + (double)m) * dt / sc;            // t / s
+            const double g = norm * std::exp(-0.5 * x * x);
+            k.re[m - m0] = g * (std::cos(w0 * x) - corr);
+            k.im[m - m0] = g * std::sin(w0 * x);
+        }
+        const int Lt = (int)(m1 - m0);
+        lmax = std::max(lmax, Lt);
+        halo = std::max(halo, Lt - 1 - k.c);                        // reach to the left: L-1-c
+        right = std::max(right, k.c);
+    }
+    // block length: power of two >= 2x the longest (trimmed) kernel, within what the LDS FFT supports
+    int NB = 1024;
+    while (NB < 2 * (halo + right + 1) && NB < 16384) NB <<= 1;
+    const int V = NB - halo - right;
+    if (V < 1) {
+        spy::set_error("cwt_plan_create: kernel support of %d taps exceeds the %d-point block FFT "
+                       "(scale too large for this signal length)", lmax, NB);
+        return -3;
+    }
+    auto* p = new spyhip_cwt_plan();
+    p->ctx = ctx; p->nsig = nsig; p->nchan = nchan; p->nscales = nscales;
+    p->detrend = detrend; p->output = output;
+    p->log2n = spy::ilog2((unsigned)NB);
+    p->G = (p->log2n <= 12) ? 2 : 1;
+    p->V = V; p->halo = halo; p->nblocks = (nsig + V - 1) / V;
+
+    std::vector<float2> tw(NB), hs((size_t)nscales * NB);
+    for (int m = 0; m < NB; ++m) {
+        const double ang = -2.0 * PI * m / NB;
+        tw[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    std::vector<int> cshift(nscales);
+    for (int s = 0; s < nscales; ++s) {
+        std::vector<double> re(NB, 0.0), im(NB, 0.0);
+        for (size_t m = 0; m < kers[s].re.size(); ++m) { re[m] = kers[s].re[m]; im[m] = kers[s].im[m]; }
+        spy::fft_host(re, im);
+        for (int k = 0; k < NB; ++k) hs[(size_t)s * NB + k] = make_float2((float)(re[k] / NB), (float)(im[k] / NB));
+        cshift[s] = halo + kers[s].c;
+    }
+    if (p->tw.upload(tw, ctx->stream) || p->hspec.upload(hs, ctx->stream) || p->cshift.upload(cshift, ctx->stream)) {
+        delete p;
+        return -2;
+    }
+    p->identity_time = (tpos == nullptr);
+    p->ntime_out = tpos ? ntime_out : nsig;
+    if (tpos) {
+        std::vector<int> tp(tpos, tpos + nsig);
+        for (int v : tp)
+            if (v >= ntime_out) { spy::set_error("cwt_plan_create: tpos entry %d >= ntime_out %d", v, ntime_out); delete p; return -1; }
+        if (p->tpos.upload(tp, ctx->stream)) { delete p; return -2; }
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int spyhip_cwt_plan_destroy(spyhip_cwt_plan* p) {
+    delete p;
+    return 0;
+}
+
+extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t ld, const int32_t* chan_idx_d,
+                               const int64_t* seg_start_d, const int64_t* trial_lo_d, const int64_t* trial_hi_d,
+                               int nseg, void* out_d, int accumulate) {
+    if (!p || !data_d || !seg_start_d || !trial_lo_d || !trial_hi_d || !out_d) { spy::set_error("cwt_exec: null argument"); return -1; }
+    if (nseg <= 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(p->ctx->device));
+    CwtArgs a{};
+    a.data = data_d; a.ld = ld; a.chan_idx = chan_idx_d;
+    a.seg_start = reinterpret_cast<const long long*>(seg_start_d);
+    a.trial_lo = reinterpret_cast<const long long*>(trial_lo_d);
+    a.trial_hi = reinterpret_cast<const long long*>(trial_hi_d);
+    a.nseg = nseg; a.nsig = p->nsig; a.nchan = p->nchan; a.nscales = p->nscales;
+    a.tw = p->tw.p; a.hspec = p->hspec.p; a.cshift = p->cshift.p;
+    a.V = p->V; a.halo = p->halo; a.nblocks = p->nblocks;
+    a.detrend = p->detrend; a.out_kind = p->output;
+    a.tpos = p->identity_time ? nullptr : p->tpos.p;
+    a.ntime_out = p->ntime_out; a.out = out_d; a.accumulate = accumulate;
+    if (p->detrend >= 0) {
+        const size_t need = (size_t)nseg * p->nchan * 2;
+        if (need > p->trend_cap) {
+            if (p->trend.p) { (void)hipFree(p->trend.p); p->trend.p = nullptr; }
+            if (p->trend.alloc(need)) return -2;
+            p->trend_cap = need;
+        }
+        a.trend = p->trend.p;
+        hipLaunchKernelGGL(spyfft::cwt_trend_kernel, dim3((p->nchan + 63) / 64, nseg), dim3(256), 0, p->ctx->stream,
+                           a, p->trend.p);
+        SPY_HIP_CHECK(hipGetLastError());
+    }
+    const long long ngrp = (p->nchan + p->G - 1) / p->G;
+    const long long grid = (long long)nseg * ngrp * p->nblocks;
+    if (grid > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
+    const unsigned g = (unsigned)grid;
+    switch (p->log2n) {
+        case 10: return launch_cwt_out<10, 2>(p, a, g);
+        case 11: return launch_cwt_out<11, 2>(p, a, g);
+        case 12: return launch_cwt_out<12, 2>(p, a, g);
+        case 13: return launch_cwt_out<13, 1>(p, a, g);
+        case 14: return launch_cwt_out<14, 1>(p, a, g);
+        default: spy::set_error("cwt_exec: unsupported block length 2^%d", p->log2n); return -1;
+    }
+}

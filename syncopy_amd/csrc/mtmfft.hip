@@ -5,6 +5,7 @@
 #include <string>
 
 #include "spy_common.h"
+#include "host_fft.h"
 #include "mtmfft_kernel.h"
 #include "mtmfft_generic.h"
 
@@ -53,33 +54,6 @@ bool factorize(int n, int* radix, int* nfac) {
     }
     *nfac = k;
     return n == 1;
-}
-
-// host reference FFT (double, recursive radix-2) used once per plan for the Bluestein filter
-void fft_host(std::vector<double>& re, std::vector<double>& im) {
-    const size_t n = re.size();
-    for (size_t i = 1, j = 0; i < n; ++i) {
-        size_t bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) {
-            std::swap(re[i], re[j]);
-            std::swap(im[i], im[j]);
-        }
-    }
-    for (size_t len = 2; len <= n; len <<= 1) {
-        const double ang = -2.0 * PI / (double)len;
-        for (size_t i = 0; i < n; i += len)
-            for (size_t k = 0; k < len / 2; ++k) {
-                const double wr = std::cos(ang * k), wi = std::sin(ang * k);
-                const size_t a = i + k, b = i + k + len / 2;
-                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
-                re[b] = re[a] - tr;
-                im[b] = im[a] - ti;
-                re[a] += tr;
-                im[a] += ti;
-            }
-    }
 }
 
 template <int LOG2N, int G, int OUTK, bool MEAN>
@@ -223,7 +197,7 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
                 bi[n] = std::sin(ang);
                 if (n > 0) { br[M - n] = br[n]; bi[M - n] = bi[n]; }
             }
-            fft_host(br, bi);
+            spy::fft_host(br, bi);
             std::vector<float2> bhat(M);
             for (int i = 0; i < M; ++i) bhat[i] = make_float2((float)(br[i] / M), (float)(bi[i] / M));
             if (p->chirp.upload(chirp, ctx->stream) || p->bhat.upload(bhat, ctx->stream)) { delete p; return -2; }

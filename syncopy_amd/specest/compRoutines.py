@@ -187,6 +187,102 @@ class MultiTaperFFTConvol(ComputationalRoutine):
         out.freq = self.cfg["foi"]
 
 
+# --------------------------------------------------------------------------- wavelet
+def _postselect_map(nsig, postselect):
+    """Sample -> output-slot map of a post-selection (slice or index list).  Returns (tpos or None,
+    n_unique, gather) where `gather` re-creates duplicates / order of an index list (or None)."""
+    if isinstance(postselect, slice):
+        idx = np.arange(nsig)[postselect]
+    else:
+        idx = np.asarray(postselect, dtype=np.int64)
+        idx = np.where(idx < 0, idx + nsig, idx)
+    if idx.size == nsig and np.array_equal(idx, np.arange(nsig)):
+        return None, nsig, None
+    uniq, inverse = np.unique(idx, return_inverse=True)
+    tpos = np.full(nsig, -1, dtype=np.int32)
+    tpos[uniq] = np.arange(uniq.size, dtype=np.int32)
+    gather = None if np.array_equal(inverse, np.arange(idx.size)) else inverse
+    return tpos, int(uniq.size), gather
+
+
+_cwt_plans = {}
+
+
+def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwargs):
+    """Wavelet spectra of trials `rows` (absolute [start, stop)) with per-trial pre/post-selections.
+    Returns a list of (nTime, 1, nScales, C) device tensors."""
+    device = dev.device
+    nchan = dev.shape[1] if chans is None else len(chans)
+    ci = None if chans is None else torch.tensor(np.asarray(chans), dtype=torch.int32, device=device)
+    scales = np.asarray(method_kwargs["scales"], dtype=np.float64)
+    dt = 1.0 / method_kwargs["samplerate"]
+    w0 = float(method_kwargs.get("w0", 6.0))
+    results = [None] * len(rows)
+    groups = {}
+    for k, ((a, b), ps, qs) in enumerate(zip(rows, pre, post)):
+        s0, s1, _ = ps.indices(b - a)
+        nsig = max(s1 - s0, 0)
+        tpos, nuniq, gather = _postselect_map(nsig, qs)
+        key = (nsig, None if tpos is None else tpos.tobytes(), None if gather is None else gather.tobytes())
+        groups.setdefault(key, (nsig, tpos, nuniq, gather, []))[4].append((k, a + s0, a, b))
+    for nsig, tpos, nuniq, gather, members in groups.values():
+        pkey = (nsig, nchan, scales.tobytes(), dt, w0, polyremoval, output, None if tpos is None else tpos.tobytes(),
+                str(device))
+        if pkey not in _cwt_plans:
+            _cwt_plans[pkey] = hs.backend.CWTPlan(nsig, nchan, scales, dt, w0, polyremoval, output, tpos, nuniq,
+                                                  device=device)
+        plan = _cwt_plans[pkey]
+        starts = torch.tensor([m[1] for m in members], dtype=torch.int64, device=device)
+        lo = torch.tensor([m[2] for m in members], dtype=torch.int64, device=device)
+        hi = torch.tensor([m[3] for m in members], dtype=torch.int64, device=device)
+        out = plan.execute(dev, starts, lo, hi, chan_idx=ci)
+        for i, m in enumerate(members):
+            r = out[i]
+            if gather is not None:
+                r = r.index_select(0, torch.from_numpy(gather).to(device))
+            results[m[0]] = r.unsqueeze(1)
+    return results
+
+
+def wavelet_cF(trl_dat, preselect, postselect, toi=None, timeAxis=0, polyremoval=None, output="pow", noCompute=False,
+               chunkShape=None, method_kwargs=None):
+    """Morlet wavelet transform of one trial; returns (nTime, 1, nScales, nChannel)."""
+    dat = trl_dat.T if timeAxis != 0 else trl_dat
+    nChannels = dat.shape[1]
+    nTime = toi.size if isinstance(toi, np.ndarray) else dat.shape[0]
+    nScales = method_kwargs["scales"].size
+    outShape = (nTime, 1, nScales, nChannels)
+    if noCompute:
+        return outShape, spectralDTypes[output]
+    dev = _as_device_trial(trl_dat, timeAxis)
+    res = _wavelet_device(dev, [(0, dev.shape[0])], [preselect], [postselect], None, polyremoval, output,
+                          method_kwargs)[0]
+    return res.cpu().numpy()
+
+
+class WaveletTransform(ComputationalRoutine):
+    computeFunction = staticmethod(wavelet_cF)
+    valid_kws = ["preselect", "postselect", "toi", "timeAxis", "polyremoval", "output", "method_kwargs", "samplerate",
+                 "scales", "wavelet", "width", "foi"]
+
+    def compute_hip(self, data, out):
+        cfg = self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        mine = list(self.my_trials())
+        pre = [self._argv(k)[0] for k in mine]
+        post = [self._argv(k)[1] for k in mine]
+        parts = _wavelet_device(dev, [rows[k] for k in mine], pre, post, chans, cfg["polyremoval"], cfg["output"],
+                                cfg["method_kwargs"])
+        _store_trials(self, out, parts)
+
+    def process_metadata(self, data, out):
+        propagate_properties(data, out, self.keeptrials, time_axis=True)
+        out.trialdefinition, out.samplerate = _make_trialdef(self.cfg, out.trialdefinition.copy(), data.samplerate)
+        out.taper = np.array(["None"])
+        out.freq = getattr(self, "_foi", None)
+
+
 def _store_trials(cr, out, parts, stack=False):
     """Results of this rank's trials -> `out.data`: concatenated along the stacking axis in rank order
     (keeptrials) or summed sequentially in the output dtype, all-reduced once and divided by the global

@@ -134,3 +134,59 @@ def coh_normalize(csd, output="abs"):
     lib().emu_coh_normalize(csd.ctypes.data_as(C.c_void_p), C.c_int(F), C.c_int(Cn), C.c_int(kind),
                             out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def cwt_plan_tables(nsig, scales, dt, w0):
+    """NumPy mirror of the plan construction in syncopy_amd/csrc/cwt.hip."""
+    kers, halo, right = [], 0, 0
+    for sc in scales:
+        M = 10.0 * sc / dt
+        t0, t1 = (-M + 1.0) / 2.0, (M + 1.0) / 2.0
+        L = max(int(np.ceil(t1 - t0)), 1)
+        c = (L - 1) // 2
+        m0, m1 = max(0, c - (nsig - 1)), min(L, c + nsig)
+        m = np.arange(m0, m1, dtype=np.float64)
+        x = (t0 + m) * dt / sc
+        norm = np.sqrt(dt) / (sc * 8.0 * np.pi) * np.pi ** (-0.25)
+        h = norm * np.exp(-0.5 * x * x) * (np.exp(1j * w0 * x) - np.exp(-0.5 * w0 * w0))
+        kers.append((h, c - m0))
+        halo = max(halo, h.size - 1 - (c - m0))
+        right = max(right, c - m0)
+    NB = 1024
+    while NB < 2 * (halo + right + 1) and NB < 16384:
+        NB *= 2
+    V = NB - halo - right
+    assert V >= 1
+    hs = np.zeros((len(scales), NB), dtype=np.complex128)
+    cshift = np.zeros(len(scales), dtype=np.int32)
+    for s, (h, c) in enumerate(kers):
+        hs[s, :h.size] = h
+        cshift[s] = halo + c
+    hs = np.fft.fft(hs, axis=1) / NB
+    hspec = np.stack([hs.real, hs.imag], axis=-1).astype(np.float32).copy()
+    return NB, V, halo, cshift, hspec
+
+
+def cwt_exec(data, seg_start, trial_lo, trial_hi, nsig, scales, dt, w0=6.0, detrend=-1, output="pow", tpos=None,
+             ntime_out=None, chan_idx=None):
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    ld = data.shape[1]
+    nchan = ld if chan_idx is None else len(chan_idx)
+    ci = None if chan_idx is None else np.ascontiguousarray(chan_idx, dtype=np.int32)
+    ss, tl, th = (np.ascontiguousarray(a, dtype=np.int64) for a in (seg_start, trial_lo, trial_hi))
+    NB, V, halo, cshift, hspec = cwt_plan_tables(nsig, scales, dt, w0)
+    log2n = int(np.log2(NB))
+    G = 2 if log2n <= 12 else 1
+    tw = twiddles(NB)
+    kind = OUT_KINDS[output]
+    tp = None if tpos is None else np.ascontiguousarray(tpos, dtype=np.int32)
+    nto = nsig if tpos is None else int(ntime_out)
+    out = np.zeros((len(ss), nto, len(scales), nchan), dtype=np.complex64 if kind == 2 else np.float32)
+    rc = lib().emu_cwt(C.c_int(log2n), C.c_int(G), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
+                       _p(ss, C.c_longlong), _p(tl, C.c_longlong), _p(th, C.c_longlong), C.c_int(len(ss)),
+                       C.c_int(nsig), C.c_int(nchan), C.c_int(len(scales)), _p(tw, C.c_float),
+                       hspec.ctypes.data_as(C.POINTER(C.c_float)), _p(cshift, C.c_int), C.c_int(V), C.c_int(halo),
+                       C.c_int((nsig + V - 1) // V), C.c_int(detrend), C.c_int(kind), _p(tp, C.c_int), C.c_int(nto),
+                       out.ctypes.data_as(C.c_void_p), C.c_int(0))
+    assert rc == 0
+    return out

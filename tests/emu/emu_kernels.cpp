@@ -16,6 +16,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
 #include "../../syncopy_amd/csrc/csd_kernel.h"
+#include "../../syncopy_amd/csrc/cwt_kernel.h"
 
 namespace spy {
 void set_error(const char*, ...) {}
@@ -165,6 +166,36 @@ void emu_coh_normalize(const float* csd, int F, int C, int kind, void* out) {
         emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::coh_normalize_kernel<true>(reinterpret_cast<const float2*>(csd), F, C, kind, out); });
     else
         emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::coh_normalize_kernel<false>(reinterpret_cast<const float2*>(csd), F, C, kind, out); });
+}
+
+// CWT: plan tables (kernel spectra, shifts) are built by the Python mirror of cwt.hip.
+int emu_cwt(int log2n, int G, const float* data, long long ld, const int* chan_idx, const long long* seg_start,
+            const long long* trial_lo, const long long* trial_hi, int nseg, int nsig, int nchan, int nscales,
+            const float* tw, const float* hspec, const int* cshift, int V, int halo, int nblocks, int detrend,
+            int out_kind, const int* tpos, int ntime_out, void* out, int accumulate) {
+    spyfft::CwtArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx; a.seg_start = seg_start; a.trial_lo = trial_lo; a.trial_hi = trial_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.nscales = nscales;
+    a.tw = reinterpret_cast<const float2*>(tw); a.hspec = reinterpret_cast<const float2*>(hspec); a.cshift = cshift;
+    a.V = V; a.halo = halo; a.nblocks = nblocks; a.detrend = detrend; a.out_kind = out_kind; a.tpos = tpos;
+    a.ntime_out = ntime_out; a.out = out; a.accumulate = accumulate;
+    std::vector<double> trend((size_t)nseg * nchan * 2, 0.0);
+    a.trend = trend.data();
+    if (detrend >= 0)
+        emu::launch(dim3((nchan + 63) / 64, nseg), dim3(256), 0, [&] { spyfft::cwt_trend_kernel(a, trend.data()); });
+    const unsigned grid = (unsigned)nseg * (unsigned)((nchan + G - 1) / G) * (unsigned)nblocks;
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+#define CWT_CASE(L, GG) \
+    if (log2n == L && G == GG) { \
+        using C = spyfft::Cfg<L, GG>; \
+        if (outk == 2) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt_kernel<L, GG, 2>(a); }); \
+        else if (outk == 0) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt_kernel<L, GG, 0>(a); }); \
+        else emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt_kernel<L, GG, 1>(a); }); \
+        return 0; \
+    }
+    CWT_CASE(10, 2) CWT_CASE(11, 2) CWT_CASE(12, 2) CWT_CASE(13, 1) CWT_CASE(14, 1)
+#undef CWT_CASE
+    return -1;
 }
 
 }  // extern "C"

@@ -103,3 +103,21 @@ def test_csd_mfma_kernel(C, F, R, tpw):
     assert np.array_equal(acc, acc.conj().transpose(0, 2, 1)) and np.all(acc.imag[:, range(C), range(C)] == 0)
     for output in ("abs", "pow", "complex", "imag"):
         assert_parity(E.coh_normalize(acc, output), O.normalize_csd(acc, output), what=output)
+
+
+@pytest.mark.parametrize("nsig,scales,detrend,output", [
+    (700, [0.05, 0.02, 0.004], 0, "pow"),            # kernels of 500/200/40 taps, one block
+    (3000, [0.03, 0.006], 1, "fourier"),             # several overlap-save blocks
+    (300, [0.2, 0.01], -1, "abs"),                   # kernel (2000 taps) much longer than the signal: trimmed
+])
+def test_cwt_kernel(nsig, scales, detrend, output):
+    rng = np.random.default_rng(nsig)
+    nchan = 3
+    data = rng.normal(size=(nsig + 40, nchan)).astype("f4") + 0.5
+    pre0 = 7                                          # pre-selection starts inside the trial
+    ss, lo, hi = np.array([pre0 + 5]), np.array([5]), np.array([5 + nsig + 20])
+    scales = np.asarray(scales)
+    out = E.cwt_exec(data, ss, lo, hi, nsig, scales, 1e-3, 6.0, detrend, output)[0]
+    trial = O.detrend(np.array(data[5:5 + nsig + 20]), None if detrend < 0 else detrend)
+    ref = O.convert_output(O.cwt(trial[pre0:pre0 + nsig], 1000.0, scales).transpose(1, 0, 2), output)
+    assert_parity(out, ref, what="cwt")

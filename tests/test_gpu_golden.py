@@ -104,8 +104,8 @@ def tf(golden_dir):
 
 
 @pytest.mark.parametrize("how", ["hip", "sequential"])
-@pytest.mark.parametrize("name", sorted(n for n in TF_VARIANTS if n.startswith("conv")))
-def test_mtmconvol_variants(tf, name, how):
+@pytest.mark.parametrize("name", sorted(TF_VARIANTS))
+def test_timefreq_variants(tf, name, how):
     z, data = tf
     out = spy.freqanalysis(data, compute_method=how, **TF_VARIANTS[name])
     ref = z[name]
