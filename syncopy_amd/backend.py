@@ -219,6 +219,28 @@ def coh_normalize(csd, output="abs"):
     return out
 
 
+def granger(csd, rtol=5e-6, niter=100, cond_max=1e4, eps_max=1e-1, want_factors=False):
+    """Wilson spectral factorisation + Granger causality of a trial-averaged CSD (F, C, C) complex64.
+    Returns (granger float32 (F,C,C), info dict[, H complex128 (F,C,C), Sigma complex128 (C,C)])."""
+    assert csd.is_cuda and csd.dtype == torch.complex64 and csd.is_contiguous() and csd.dim() == 3
+    F, Cn, _ = csd.shape
+    out = torch.empty((F, Cn, Cn), dtype=torch.float32, device=csd.device)
+    H = torch.empty((F, Cn, Cn), dtype=torch.complex128, device=csd.device) if want_factors else None
+    Sig = torch.empty((Cn, Cn), dtype=torch.complex128, device=csd.device) if want_factors else None
+    info = (C.c_double * 4)()
+    ctx = context(csd.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_granger(ctx.handle, _ptr(csd), F, Cn, float(rtol), int(niter), float(cond_max),
+                                 float(eps_max), _ptr(out), _ptr(H), _ptr(Sig), info), "spyhip_granger")
+    meta = {"converged": bool(info[0]), "max rel. err": float(info[1]), "reg. factor": float(info[2]),
+            "initial cond. num": float(info[3])}
+    if meta["reg. factor"] == 0.0:
+        meta["reg. factor"] = 0
+    elif meta["reg. factor"] == -1.0:
+        meta["reg. factor"] = -1
+    return (out, meta, H, Sig) if want_factors else (out, meta)
+
+
 def trial_mean(x):
     """Sequential float32 sum over axis 0 followed by one division (trial averaging order of the reference)."""
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()

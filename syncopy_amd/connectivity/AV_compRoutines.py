@@ -57,3 +57,46 @@ class NormalizeCrossSpectra(_AverageRoutine):
                            for t in range(dev.shape[0])], dim=0)
         out._dev = res
         out.data = res.cpu().numpy()
+
+
+def granger_cF(csd_av_dat, rtol=5e-6, nIter=100, cond_max=1e4, chunkShape=None, noCompute=False):
+    """Pairwise Granger-Geweke causality from the trial-averaged CSD (1, nFreq, N, N): regularisation,
+    Wilson factorisation and the Granger formula all run on the device.  Returns (1, nFreq, N, N) float32
+    and the reference's metadata keys (AV_compRoutines.py:404-409)."""
+    outShape = csd_av_dat.shape
+    if noCompute:
+        return outShape, spectralDTypes["abs"]
+    backend.require_gpu()
+    dev = torch.from_numpy(np.ascontiguousarray(csd_av_dat[0], dtype=np.complex64)).cuda()
+    G, meta = backend.granger(dev, rtol=rtol, niter=nIter, cond_max=cond_max, eps_max=1e-1)
+    return G.cpu().numpy()[None, ...], _granger_metadata(meta)
+
+
+def _granger_metadata(meta):
+    return {
+        "converged--bool": np.array(meta["converged"]),
+        "max rel. err--float": np.array(meta["max rel. err"]),
+        "reg. factor--float": np.array(meta["reg. factor"]),
+        "initial cond. num--float": np.array(meta["initial cond. num"]),
+    }
+
+
+class GrangerCausality(_AverageRoutine):
+    computeFunction = staticmethod(granger_cF)
+    method = ""
+    valid_kws = ["rtol", "nIter", "cond_max"]
+    metadata_keys = ("converged", "max rel. err", "reg. factor", "initial cond. num")
+
+    def compute_hip(self, data, out):
+        dev = self._device_input(data)
+        G, meta = backend.granger(dev[0].contiguous(), rtol=self.cfg["rtol"], niter=self.cfg["nIter"],
+                                  cond_max=self.cfg["cond_max"], eps_max=1e-1)
+        self.metadata = [_granger_metadata(meta)]
+        out._dev = G.unsqueeze(0)
+        out.data = out._dev.cpu().numpy()
+
+    def process_metadata(self, data, out):
+        super().process_metadata(data, out)
+        for key, value in (self.metadata[0] or {}).items():
+            label, cast = key.split("--")
+            out.info[label] = bool(value) if cast == "bool" else float(value)

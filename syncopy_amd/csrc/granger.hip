@@ -1,0 +1,209 @@
+// Host side of K6: regularisation, Wilson iteration and Granger causality on the device
+// (spyhip_granger of include/spyhip.h).  One scalar (the convergence error) is read back per
+// iteration, as is one vector of F eigenvalue estimates per condition-number evaluation.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "spy_common.h"
+#include "granger_kernels.h"
+
+using spywil::cd;
+
+namespace {
+const double PI = 3.14159265358979323846264338327950288;
+
+struct Dev {
+    std::vector<void*> ptrs;
+    ~Dev() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T> T* alloc(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+int gemm(spyhip_ctx* ctx, const cd* A, const cd* B, cd* C, int n, int batch, long long sA, long long sB, long long sC,
+         int opB, int addI) {
+    dim3 grid((n + spywil::GT - 1) / spywil::GT, (n + spywil::GT - 1) / spywil::GT, batch);
+    hipLaunchKernelGGL(spywil::zgemm_kernel, grid, dim3(256), 0, ctx->stream, A, B, C, n, sA, sB, sC, opB, addI);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int check_info(spyhip_ctx* ctx, int* info_d, int batch, const char* what) {
+    std::vector<int> h(batch);
+    SPY_HIP_CHECK(hipMemcpyAsync(h.data(), info_d, batch * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < batch; ++b)
+        if (h[b]) { spy::set_error("%s failed for matrix %d of %d", what, b, batch); return -6; }
+    return 0;
+}
+
+int invert(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d) {
+    const size_t lds = (size_t)n * (2 * sizeof(cd) + sizeof(int));
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::zinv_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(spywil::zinv_kernel, dim3(batch), dim3(256), lds, ctx->stream, M, n, info_d);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cholesky(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d) {
+    hipLaunchKernelGGL(spywil::zchol_kernel, dim3(batch), dim3(256), (size_t)n * sizeof(cd), ctx->stream, M, n, info_d);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// max_f cond_2(A_f) for Hermitian A_f: |lambda|_max(A) * |lambda|_max(A^-1) by power iteration
+int max_cond(spyhip_ctx* ctx, const cd* A, cd* work, int n, int F, double* lam_d, int* info_d, double* out) {
+    const size_t bytes = (size_t)F * n * n * sizeof(cd);
+    SPY_HIP_CHECK(hipMemcpyAsync(work, A, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (invert(ctx, work, n, F, info_d)) return -2;
+    const size_t lds = (size_t)2 * n * sizeof(cd);
+    const int iters = 400;
+    hipLaunchKernelGGL(spywil::power_kernel, dim3(F), dim3(256), lds, ctx->stream, A, n, iters, lam_d);
+    hipLaunchKernelGGL(spywil::power_kernel, dim3(F), dim3(256), lds, ctx->stream, work, n, iters, lam_d + F);
+    SPY_HIP_CHECK(hipGetLastError());
+    std::vector<double> h(2 * (size_t)F);
+    std::vector<int> hi(F);
+    SPY_HIP_CHECK(hipMemcpyAsync(h.data(), lam_d, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SPY_HIP_CHECK(hipMemcpyAsync(hi.data(), info_d, F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double m = 0.0;
+    for (int f = 0; f < F; ++f) {
+        double c = hi[f] ? INFINITY : h[f] * h[F + f];
+        if (!(c == c)) c = INFINITY;
+        m = std::max(m, c);
+    }
+    *out = m;
+    return 0;
+}
+
+bool plus_plan(int L, spywil::PlusPlan* pl) {
+    pl->L = L;
+    int k = 0, n = L;
+    static const int cand[] = {4, 2, 3, 5, 7, 11, 13};
+    for (int c : cand)
+        while (n % c == 0 && n > 1) { if (k >= spywil::PO_MAXFAC) return false; pl->radix[k++] = c; n /= c; }
+    for (int p = 17; n > 1; p += 2)
+        while (n % p == 0) { if (k >= spywil::PO_MAXFAC) return false; pl->radix[k++] = p; n /= p; }
+    pl->nfac = k;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, double rtol, int niter,
+                              double cond_max, double eps_max, void* granger_d, void* H_d, void* Sigma_d,
+                              double* info) {
+    if (!ctx || !csd_d || !granger_d || !info) { spy::set_error("granger: null argument"); return -1; }
+    if (nfreq < 3 || nchan < 1) { spy::set_error("granger: need nfreq >= 3 and nchan >= 1"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const int F = nfreq, n = nchan, L = 2 * (F - 1);
+    const size_t nn = (size_t)n * n, tot = (size_t)F * nn;
+    spywil::PlusPlan pl;
+    if (!plus_plan(L, &pl) || (size_t)2 * L * sizeof(cd) > ctx->lds_per_block) {
+        spy::set_error("granger: %d frequencies (lag-domain length %d) exceed the LDS FFT of the plus operator "
+                       "(the reference documents its defaults for up to 5000 samples)", F, L);
+        return -3;
+    }
+    Dev dev;
+    cd* A = dev.alloc<cd>(tot);
+    cd* U = dev.alloc<cd>(tot);
+    cd* psi = dev.alloc<cd>(tot);
+    cd* T1 = dev.alloc<cd>(tot);
+    cd* T2 = dev.alloc<cd>(tot);
+    cd* small = dev.alloc<cd>(6 * nn);        // g0, psi0, psi0 next, g0+S, Sigma, scratch
+    cd* tw = dev.alloc<cd>(L);
+    double* lam = dev.alloc<double>(2 * (size_t)F);
+    int* inf = dev.alloc<int>(F);
+    const int nred = 1024;
+    double* part = dev.alloc<double>(nred);
+    if (!A || !U || !psi || !T1 || !T2 || !small || !tw || !lam || !inf || !part) {
+        spy::set_error("granger: out of device memory (%zu bytes per work array)", tot * sizeof(cd));
+        return -2;
+    }
+    cd *g0 = small, *psi0 = small + nn, *psi0n = small + 2 * nn, *g0S = small + 3 * nn, *Sig = small + 4 * nn,
+       *scr = small + 5 * nn;
+    {
+        std::vector<cd> h(L);
+        for (int m = 0; m < L; ++m) { const double a = -2.0 * PI * m / L; h[m] = make_double2(std::cos(a), std::sin(a)); }
+        SPY_HIP_CHECK(hipMemcpyAsync(tw, h.data(), L * sizeof(cd), hipMemcpyHostToDevice, ctx->stream));
+        SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    const unsigned eb = (unsigned)std::min<size_t>((tot + 255) / 256, 8192);
+    const float2* csd = reinterpret_cast<const float2*>(csd_d);
+
+    // ---- regularize_csd (wilson_sf.py:197-254)
+    double cond0 = 0.0, factor = 0.0;
+    hipLaunchKernelGGL(spywil::widen_kernel, dim3(eb), dim3(256), 0, ctx->stream, csd, A, n, (long long)tot, 0.0);
+    if (max_cond(ctx, A, T1, n, F, lam, inf, &cond0)) return -2;
+    if (!(cond0 < cond_max)) {
+        factor = -1.0;
+        const int nsteps = 15;
+        for (int s = 0; s < nsteps; ++s) {
+            const double e10 = -10.0 + (std::log10(eps_max) + 10.0) * s / (nsteps - 1);
+            const double eps = std::pow(10.0, e10);
+            hipLaunchKernelGGL(spywil::widen_kernel, dim3(eb), dim3(256), 0, ctx->stream, csd, A, n, (long long)tot, eps);
+            double c = 0.0;
+            if (max_cond(ctx, A, T1, n, F, lam, inf, &c)) return -2;
+            if (c < cond_max) { factor = eps; break; }
+        }
+    }
+
+    // ---- Wilson factorisation (wilson_sf.py:16-120)
+    SPY_HIP_CHECK(hipMemcpyAsync(U, A, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    if (cholesky(ctx, U, n, F, inf)) return -2;
+    if (int rc = check_info(ctx, inf, F, "Cholesky factorisation of the CSD (not positive definite)")) return rc;
+    hipLaunchKernelGGL(spywil::gamma0_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, A, F, n, scr);
+    if (cholesky(ctx, scr, n, 1, inf)) return -2;
+    if (int rc = check_info(ctx, inf, 1, "Cholesky factorisation of gamma_0 (not positive definite)")) return rc;
+    hipLaunchKernelGGL(spywil::transpose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, scr, psi0, n);
+    hipLaunchKernelGGL(spywil::tile_kernel, dim3(eb), dim3(256), 0, ctx->stream, psi0, psi, F, n);
+    SPY_HIP_CHECK(hipGetLastError());
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::plus_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * L * sizeof(cd))));
+    bool converged = false;
+    double err = INFINITY;
+    for (int it = 0; it < niter; ++it) {
+        SPY_HIP_CHECK(hipMemcpyAsync(T1, psi, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+        if (invert(ctx, T1, n, F, inf)) return -2;                                        // psi^-1
+        if (gemm(ctx, T1, U, T2, n, F, nn, nn, nn, 0, 0)) return -2;                       // psi^-1 U
+        if (gemm(ctx, T2, T2, T1, n, F, nn, nn, nn, 1, 1)) return -2;                      // g + I
+        hipLaunchKernelGGL(spywil::plus_kernel, dim3((unsigned)nn), dim3(256), 2 * L * sizeof(cd), ctx->stream,
+                           T1, F, n, pl, tw, T2, g0);                                      // T2 = [g+I]^+
+        hipLaunchKernelGGL(spywil::add_S_kernel, dim3(eb), dim3(256), 0, ctx->stream, T2, g0, g0S, F, n);
+        SPY_HIP_CHECK(hipGetLastError());
+        if (gemm(ctx, psi, T2, T1, n, F, nn, nn, nn, 0, 0)) return -2;                     // psi (g+ + S)
+        std::swap(psi, T1);
+        if (gemm(ctx, psi0, g0S, psi0n, n, 1, nn, nn, nn, 0, 0)) return -2;                // psi0 (g+_0 + S)
+        std::swap(psi0, psi0n);
+        if (gemm(ctx, psi, psi, T1, n, F, nn, nn, nn, 1, 0)) return -2;                    // psi psi^H
+        hipLaunchKernelGGL(spywil::relerr_kernel, dim3(nred), dim3(256), 0, ctx->stream, A, T1, (long long)tot, part);
+        SPY_HIP_CHECK(hipGetLastError());
+        std::vector<double> hp(nred);
+        SPY_HIP_CHECK(hipMemcpyAsync(hp.data(), part, nred * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        err = 0.0;
+        for (double v : hp) if (v > err || v != v) err = v;
+        if (err < rtol) { converged = true; break; }
+    }
+    // ---- noise covariance, transfer function, Granger causality (wilson_sf.py:113-120, granger.py:53-77)
+    if (gemm(ctx, psi0, psi0, Sig, n, 1, nn, nn, nn, 1, 0)) return -2;                     // psi0 psi0^T (psi0 is real)
+    SPY_HIP_CHECK(hipMemcpyAsync(scr, psi0, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    if (invert(ctx, scr, n, 1, inf)) return -2;
+    if (gemm(ctx, psi, scr, T1, n, F, nn, 0, nn, 0, 0)) return -2;                         // H = psi psi0^-1
+    hipLaunchKernelGGL(spywil::granger_kernel, dim3(eb), dim3(256), 0, ctx->stream, A, T1, Sig, F, n,
+                       reinterpret_cast<float*>(granger_d));
+    SPY_HIP_CHECK(hipGetLastError());
+    if (H_d) SPY_HIP_CHECK(hipMemcpyAsync(H_d, T1, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    if (Sigma_d) SPY_HIP_CHECK(hipMemcpyAsync(Sigma_d, Sig, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    info[0] = converged ? 1.0 : 0.0;
+    info[1] = err;
+    info[2] = factor;
+    info[3] = cond0;
+    return 0;
+}

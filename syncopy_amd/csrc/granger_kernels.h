@@ -1,0 +1,391 @@
+// K6: Wilson spectral matrix factorisation + Granger-Geweke causality in complex128.
+//
+// Reference semantics: regularize_csd / wilson_sf / _plusOperator / _psi0_initial / max_rel_err
+// (connectivity/wilson_sf.py:16-254) and granger (connectivity/granger.py:10-79), driven by
+// granger_cF (connectivity/AV_compRoutines.py:293-412).
+//
+// The reference mirrors the CSD to negative frequencies (wilson_sf.py:63) and works on 2(F-1)
+// matrices; every matrix at -f is the complex conjugate of the one at +f and stays so through
+// inverse, products and the plus operator, so all batched linear algebra here runs on the F
+// non-negative frequencies only and the lag-domain step uses the conjugate-symmetric extension
+// (real(ifft(full)) == irfft(half) exactly).
+#pragma once
+
+namespace spywil {
+
+typedef double2 cd;
+
+__device__ __forceinline__ cd cmul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cd cmulc(cd a, cd b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+__device__ __forceinline__ cd cadd(cd a, cd b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cd csub(cd a, cd b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double cabs2(cd a) { return a.x * a.x + a.y * a.y; }
+
+// ---- complex64 (F,C,C) -> complex128, + eps on the diagonal (regularize_csd: CSD + eps*I)
+__global__ void __launch_bounds__(256) widen_kernel(const float2* in, cd* out, int C, long long n, double eps) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int j = (int)(e % C), i = (int)((e / C) % C);
+        const float2 v = in[e];
+        out[e] = make_double2((double)v.x + (i == j ? eps : 0.0), (double)v.y);
+    }
+}
+
+// ---- batched C[b] = A[b] * op(B[b]) (+ I), n x n, opB: 0 = B, 1 = B^H; strideB = 0 broadcasts B
+constexpr int GT = 32;   // output tile
+constexpr int GK = 8;    // k step
+__global__ void __launch_bounds__(256) zgemm_kernel(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB,
+                                                    long long sC, int opB, int addI) {
+    __shared__ cd As[GT][GK + 1];
+    __shared__ cd Bs[GK][GT + 1];
+    const int b = blockIdx.z, ti = blockIdx.y * GT, tj = blockIdx.x * GT;
+    const cd* Ab = A + (size_t)b * sA;
+    const cd* Bb = B + (size_t)b * sB;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // 16 x 16 threads, 2 x 2 outputs each
+    cd acc[2][2];
+    for (int u = 0; u < 2; ++u)
+        for (int w = 0; w < 2; ++w) acc[u][w] = make_double2(0.0, 0.0);
+    for (int k0 = 0; k0 < n; k0 += GK) {
+        {   // 256 threads stage 32x8 of A and 8x32 of op(B)
+            const int r = tid >> 3, kk = tid & 7;
+            const int gi = ti + r, gk = k0 + kk;
+            As[r][kk] = (gi < n && gk < n) ? Ab[(size_t)gi * n + gk] : make_double2(0.0, 0.0);
+            const int kk2 = tid >> 5, cc = tid & 31;
+            const int gk2 = k0 + kk2, gj = tj + cc;
+            cd v = make_double2(0.0, 0.0);
+            if (gk2 < n && gj < n) {
+                if (opB == 0) v = Bb[(size_t)gk2 * n + gj];
+                else { v = Bb[(size_t)gj * n + gk2]; v.y = -v.y; }
+            }
+            Bs[kk2][cc] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
+            const cd a0 = As[ty * 2][kk], a1 = As[ty * 2 + 1][kk];
+            const cd b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
+            acc[0][0] = cadd(acc[0][0], cmul(a0, b0));
+            acc[0][1] = cadd(acc[0][1], cmul(a0, b1));
+            acc[1][0] = cadd(acc[1][0], cmul(a1, b0));
+            acc[1][1] = cadd(acc[1][1], cmul(a1, b1));
+        }
+        __syncthreads();
+    }
+    cd* Cb = Cm + (size_t)b * sC;
+    for (int u = 0; u < 2; ++u)
+        for (int w = 0; w < 2; ++w) {
+            const int gi = ti + ty * 2 + u, gj = tj + tx * 2 + w;
+            if (gi < n && gj < n) {
+                cd v = acc[u][w];
+                if (addI && gi == gj) v.x += 1.0;
+                Cb[(size_t)gi * n + gj] = v;
+            }
+        }
+}
+
+// ---- batched in-place inverse: Gauss-Jordan with partial pivoting, one workgroup per matrix.
+// `info[b]` = 1 if a zero pivot was met.
+__global__ void __launch_bounds__(256) zinv_kernel(cd* M, int n, int* info) {
+    SPY_DYN_SMEM(char, raw);
+    cd* rowk = reinterpret_cast<cd*>(raw);            // n
+    cd* colk = rowk + n;                              // n
+    int* perm = reinterpret_cast<int*>(colk + n);     // n
+    __shared__ double redv[256];
+    __shared__ int redi[256];
+    cd* A = M + (size_t)blockIdx.x * n * n;
+    const int tid = threadIdx.x;
+    int bad = 0;
+    for (int k = 0; k < n; ++k) {
+        // pivot search in column k, rows k..n-1
+        double best = -1.0;
+        int bi = k;
+        for (int i = k + tid; i < n; i += 256) {
+            const double v = cabs2(A[(size_t)i * n + k]);
+            if (v > best) { best = v; bi = i; }
+        }
+        redv[tid] = best;
+        redi[tid] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                if (redv[tid + s] > redv[tid] || (redv[tid + s] == redv[tid] && redi[tid + s] < redi[tid])) {
+                    redv[tid] = redv[tid + s];
+                    redi[tid] = redi[tid + s];
+                }
+            }
+            __syncthreads();
+        }
+        const int p = redi[0];
+        if (redv[0] <= 0.0) bad = 1;
+        if (tid == 0) perm[k] = p;
+        // swap rows k and p, cache the (new) pivot row
+        for (int j = tid; j < n; j += 256) {
+            const cd a = A[(size_t)k * n + j], c = A[(size_t)p * n + j];
+            if (p != k) { A[(size_t)p * n + j] = a; }
+            rowk[j] = c;
+        }
+        __syncthreads();
+        const cd piv = rowk[k];
+        const double d = cabs2(piv);
+        const cd pinv = d > 0.0 ? make_double2(piv.x / d, -piv.y / d) : make_double2(0.0, 0.0);
+        for (int j = tid; j < n; j += 256) {
+            cd v = (j == k) ? pinv : cmul(rowk[j], pinv);
+            A[(size_t)k * n + j] = v;
+            // column k of the other rows (read before it is overwritten)
+            colk[j] = (j == k) ? make_double2(0.0, 0.0) : A[(size_t)j * n + k];
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += 256) rowk[j] = A[(size_t)k * n + j];
+        __syncthreads();
+        // eliminate: rows i != k
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, j = e - i * n;
+            if (i == k) continue;
+            const cd f = colk[i];
+            if (j == k) A[e] = make_double2(-(f.x * rowk[k].x - f.y * rowk[k].y), -(f.x * rowk[k].y + f.y * rowk[k].x));
+            else A[e] = csub(A[e], cmul(f, rowk[j]));
+        }
+        __syncthreads();
+    }
+    // undo the row permutation: swap columns in reverse order
+    for (int k = n - 1; k >= 0; --k) {
+        const int p = perm[k];
+        if (p != k) {
+            for (int i = tid; i < n; i += 256) {
+                const cd a = A[(size_t)i * n + k];
+                A[(size_t)i * n + k] = A[(size_t)i * n + p];
+                A[(size_t)i * n + p] = a;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && info) info[blockIdx.x] = bad;
+}
+
+// ---- batched Cholesky A = L L^H (lower, in place; the strict upper triangle is zeroed), one workgroup per matrix
+__global__ void __launch_bounds__(256) zchol_kernel(cd* M, int n, int* info) {
+    SPY_DYN_SMEM(char, raw);
+    cd* colk = reinterpret_cast<cd*>(raw);   // n
+    cd* A = M + (size_t)blockIdx.x * n * n;
+    const int tid = threadIdx.x;
+    int bad = 0;
+    for (int k = 0; k < n; ++k) {
+        const double dk = A[(size_t)k * n + k].x;
+        __syncthreads();                       // every thread has read the pivot before it is overwritten
+        if (!(dk > 0.0)) bad = 1;
+        const double l = sqrt(dk > 0.0 ? dk : 1.0);
+        for (int i = k + tid; i < n; i += 256) {
+            cd v = A[(size_t)i * n + k];
+            v = (i == k) ? make_double2(l, 0.0) : make_double2(v.x / l, v.y / l);
+            A[(size_t)i * n + k] = v;
+            colk[i] = v;
+        }
+        __syncthreads();
+        const int m = n - k - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = k + 1 + e / m, j = k + 1 + e % m;
+            if (j <= i) A[(size_t)i * n + j] = csub(A[(size_t)i * n + j], cmulc(colk[i], colk[j]));
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        if (j > i) A[e] = make_double2(0.0, 0.0);
+    }
+    if (tid == 0 && info) info[blockIdx.x] = bad;
+}
+
+// ---- gamma0 = sum over the full (mirrored) frequency axis = A[0] + A[F-1] + sum_{0<f<F-1} 2 Re-part...
+// (fft(CSD_full)[0], wilson_sf.py:135-140), then symmetrised real part: out[i,j] = Re((g[i,j] + conj(g[j,i]))/2)
+__global__ void __launch_bounds__(256) gamma0_kernel(const cd* A, int F, int n, cd* out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e / n, j = e - i * n;
+    double s = 0.0;
+    for (int f = 0; f < F; ++f) {
+        const double w = (f == 0 || f == F - 1) ? 1.0 : 2.0;   // +f and -f: a + conj(a) = 2 Re(a) ... per entry pair
+        // full-spectrum sum of entry (i,j): A[f][i][j] + conj(A[f][i][j]) for mirrored f
+        const cd a = A[((size_t)f * n + i) * n + j], b = A[((size_t)f * n + j) * n + i];
+        // Re( (g_ij + conj(g_ji)) / 2 ) with g = sum over full spectrum
+        s += 0.5 * w * (a.x + b.x);
+        (void)a;
+    }
+    out[e] = make_double2(s, 0.0);
+}
+
+// ---- plus operator along the frequency axis for every matrix entry (wilson_sf.py:154-184)
+// one workgroup per entry (i,j): half spectrum g[0..F-1] -> conjugate-symmetric sequence of length
+// L = 2(F-1) -> inverse DFT (real) -> halve lag 0 and lag L/2, zero negative lags -> forward DFT.
+// Generic length: Stockham passes with radices 2..16 and O(R^2) butterflies for other primes.
+constexpr int PO_MAXFAC = 24;
+struct PlusPlan {
+    int L, nfac;
+    int radix[PO_MAXFAC];
+};
+
+__device__ __forceinline__ void po_pass(const cd* in, cd* out, int L, int R, int Ns, const cd* tw, int sign, int tid) {
+    // tw[m] = exp(-2 pi i m / L); sign = -1 forward, +1 inverse (conjugated twiddles)
+    const int nb = L / R, tws = L / (Ns * R), wr = L / R;
+    for (int jb = tid; jb < nb; jb += 256) {
+        const int k = jb % Ns;
+        const int base = (jb / Ns) * Ns * R + k;
+        for (int q = 0; q < R; ++q) {
+            cd s = make_double2(0.0, 0.0);
+            for (int r = 0; r < R; ++r) {
+                cd x = in[jb + r * nb];
+                // twiddle exp(-+2 pi i r k / (Ns R)) and DFT kernel exp(-+2 pi i r q / R)
+                long long idx = ((long long)r * k * tws + (long long)((r * q) % R) * wr) % L;
+                cd w = tw[idx];
+                if (sign > 0) w.y = -w.y;
+                s = cadd(s, cmul(x, w));
+            }
+            out[base + q * Ns] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, int n, PlusPlan pl, const cd* tw, cd* gp, cd* g0) {
+    SPY_DYN_SMEM(cd, buf);          // 2 x L
+    const int L = pl.L, tid = threadIdx.x;
+    const int e = blockIdx.x;       // entry i*n + j
+    cd* a = buf;
+    cd* b = buf + L;
+    const size_t fs = (size_t)n * n;
+    for (int f = tid; f < F; f += 256) {
+        const cd v = g[(size_t)f * fs + e];
+        a[f] = v;
+        if (f > 0 && f < F - 1) a[L - f] = make_double2(v.x, -v.y);
+    }
+    __syncthreads();
+    int Ns = 1;
+    for (int p = 0; p < pl.nfac; ++p) {          // inverse DFT (unnormalised)
+        po_pass(a, b, L, pl.radix[p], Ns, tw, +1, tid);
+        __syncthreads();
+        Ns *= pl.radix[p];
+        cd* t = a; a = b; b = t;
+    }
+    const double invL = 1.0 / (double)L;
+    const int half = L / 2;
+    for (int t = tid; t < L; t += 256) {
+        double beta = a[t].x * invL;             // np.real(ifft(g))
+        if (t == 0 || t == half) beta *= 0.5;
+        if (t > half) beta = 0.0;
+        a[t] = make_double2(beta, 0.0);
+    }
+    __syncthreads();
+    if (tid == 0) g0[e] = a[0];
+    __syncthreads();
+    Ns = 1;
+    for (int p = 0; p < pl.nfac; ++p) {          // forward DFT
+        po_pass(a, b, L, pl.radix[p], Ns, tw, -1, tid);
+        __syncthreads();
+        Ns *= pl.radix[p];
+        cd* t = a; a = b; b = t;
+    }
+    for (int f = tid; f < F; f += 256) gp[(size_t)f * fs + e] = a[f];
+}
+
+// S = triu(g0) - triu(g0)^H ; out_b[f] = gp[f] + S (all f) ; out0 = g0 + S
+__global__ void __launch_bounds__(256) add_S_kernel(cd* gp, const cd* g0, cd* out0, int F, int n) {
+    const long long tot = (long long)F * n * n;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
+        const int j = (int)(e % n), i = (int)((e / n) % n);
+        cd S = make_double2(0.0, 0.0);
+        if (j > i) S = g0[(size_t)i * n + j];
+        else if (j < i) { const cd t = g0[(size_t)j * n + i]; S = make_double2(-t.x, t.y); }
+        else { const cd t = g0[(size_t)i * n + i]; S = make_double2(0.0, 2.0 * t.y); }   // t - conj(t)
+        gp[e] = cadd(gp[e], S);
+        if (e < (long long)n * n) out0[e] = cadd(g0[e], S);
+    }
+}
+
+// max over all entries of |A - B| / |A|  (max_rel_err, wilson_sf.py:190-194): per-block maxima
+__global__ void __launch_bounds__(256) relerr_kernel(const cd* A, const cd* B, long long n, double* partial) {
+    __shared__ double red[256];
+    double m = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const cd d = csub(A[e], B[e]);
+        const double r = sqrt(cabs2(d)) / sqrt(cabs2(A[e]));
+        if (r > m || r != r) m = r;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const double o = red[threadIdx.x + s];
+            if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// ---- 2-norm condition number of Hermitian matrices by power iteration: lam[b] = largest |eigenvalue|
+// of M[b] (run on A and on A^-1).  One workgroup per matrix.
+__global__ void __launch_bounds__(256) power_kernel(const cd* M, int n, int iters, double* lam) {
+    SPY_DYN_SMEM(cd, vec);   // x[n], y[n]
+    __shared__ double red[256];
+    cd* x = vec;
+    cd* y = vec + n;
+    const cd* A = M + (size_t)blockIdx.x * n * n;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) x[i] = make_double2(1.0 + 0.37 * ((i * 7919) % 13), 0.11 * ((i * 104729) % 7));
+    __syncthreads();
+    double nrm = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        for (int i = tid; i < n; i += 256) {
+            cd s = make_double2(0.0, 0.0);
+            for (int j = 0; j < n; ++j) s = cadd(s, cmul(A[(size_t)i * n + j], x[j]));
+            y[i] = s;
+        }
+        __syncthreads();
+        double p = 0.0;
+        for (int i = tid; i < n; i += 256) p += cabs2(y[i]);
+        red[tid] = p;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        nrm = sqrt(red[0]);
+        __syncthreads();
+        const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+        for (int i = tid; i < n; i += 256) x[i] = make_double2(y[i].x * inv, y[i].y * inv);
+        __syncthreads();
+    }
+    if (tid == 0) lam[blockIdx.x] = nrm;     // |A x| with |x| = 1 -> largest singular value
+}
+
+// ---- Granger-Geweke causality (granger.py:53-77); H: (F,n,n), Sigma: (n,n) complex128
+__global__ void __launch_bounds__(256) granger_kernel(const cd* CSD, const cd* H, const cd* Sigma, int F, int n, float* out) {
+    const long long tot = (long long)F * n * n;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
+        const int c = (int)(e % n), r = (int)((e / n) % n);
+        const long long f = e / ((long long)n * n);
+        const double Smat = sqrt(cabs2(CSD[((size_t)f * n + c) * n + c]));          // |S_cc|
+        const double Hmat = cabs2(H[((size_t)f * n + c) * n + r]);                   // |H[f,c,r]|^2
+        const double SigJI = sqrt(cabs2(Sigma[(size_t)c * n + r]));                  // |Sigma^T|[r,c]
+        const double SigII_rc = sqrt(cabs2(Sigma[(size_t)c * n + c]));               // SigmaII[r,c] = |Sigma_cc|
+        const double SigII_T = sqrt(cabs2(Sigma[(size_t)r * n + r]));                // SigmaII^T[r,c] = |Sigma_rr|
+        const double denom = Smat - (SigII_T - SigJI * SigJI / SigII_rc) * Hmat;
+        out[e] = (float)log(Smat / denom);
+    }
+}
+
+// out[f] = src (n x n) for every f  (np.tile(psi0, (nFreq,1,1)), wilson_sf.py:69)
+__global__ void __launch_bounds__(256) tile_kernel(const cd* src, cd* out, int F, int n) {
+    const long long tot = (long long)F * n * n, nn = (long long)n * n;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) out[e] = src[e % nn];
+}
+
+// out = in^T (plain transpose, n x n)
+__global__ void __launch_bounds__(256) transpose_kernel(const cd* in, cd* out, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * n) out[(size_t)(e % n) * n + e / n] = in[e];
+}
+
+}  // namespace spywil

@@ -190,3 +190,102 @@ def cwt_exec(data, seg_start, trial_lo, trial_hi, nsig, scales, dt, w0=6.0, detr
                        out.ctypes.data_as(C.c_void_p), C.c_int(0))
     assert rc == 0
     return out
+
+
+# ---------------------------------------------------------------- Wilson / Granger (mirror of the host loop in granger.hip)
+def _dp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def w_gemm(A, B, opB=0, addI=0):
+    A = np.ascontiguousarray(A, dtype=np.complex128)
+    B = np.ascontiguousarray(B, dtype=np.complex128)
+    batch, n = (A.shape[0], A.shape[1]) if A.ndim == 3 else (1, A.shape[0])
+    sB = 0 if B.ndim == 2 and A.ndim == 3 else n * n
+    out = np.zeros_like(A)
+    lib().emu_w_gemm(_dp(A), _dp(B), _dp(out), C.c_int(n), C.c_int(batch), C.c_longlong(n * n), C.c_longlong(sB),
+                     C.c_longlong(n * n), C.c_int(opB), C.c_int(addI))
+    return out
+
+
+def w_inv(M):
+    M = np.array(M, dtype=np.complex128, order="C")
+    batch, n = (M.shape[0], M.shape[1]) if M.ndim == 3 else (1, M.shape[0])
+    info = np.zeros(batch, dtype=np.int32)
+    lib().emu_w_inv(_dp(M), C.c_int(n), C.c_int(batch), _dp(info))
+    return M, info
+
+
+def w_chol(M):
+    M = np.array(M, dtype=np.complex128, order="C")
+    batch, n = (M.shape[0], M.shape[1]) if M.ndim == 3 else (1, M.shape[0])
+    info = np.zeros(batch, dtype=np.int32)
+    lib().emu_w_chol(_dp(M), C.c_int(n), C.c_int(batch), _dp(info))
+    return M, info
+
+
+def w_cond(A, iters=400):
+    F, n, _ = A.shape
+    Ai, info = w_inv(A)
+    l1, l2 = np.zeros(F), np.zeros(F)
+    lib().emu_w_power(_dp(np.ascontiguousarray(A)), C.c_int(n), C.c_int(F), C.c_int(iters), _dp(l1))
+    lib().emu_w_power(_dp(Ai), C.c_int(n), C.c_int(F), C.c_int(iters), _dp(l2))
+    c = l1 * l2
+    c[info != 0] = np.inf
+    return float(np.nanmax(np.where(np.isnan(c), np.inf, c)))
+
+
+def granger(csd64, rtol=5e-6, niter=100, cond_max=1e4, eps_max=1e-1, cond_iters=400):
+    """Emulated spyhip_granger: csd64 (F, n, n) complex64 -> (granger float32, H, Sigma, info[4])."""
+    csd64 = np.ascontiguousarray(csd64, dtype=np.complex64)
+    F, n, _ = csd64.shape
+    L = 2 * (F - 1)
+
+    def widen(eps):
+        out = np.zeros((F, n, n), dtype=np.complex128)
+        lib().emu_w_widen(_dp(csd64), _dp(out), C.c_int(n), C.c_longlong(F * n * n), C.c_double(eps))
+        return out
+    A = widen(0.0)
+    cond0 = w_cond(A, cond_iters)
+    factor = 0.0
+    if not cond0 < cond_max:
+        factor = -1.0
+        for s in range(15):
+            eps = 10.0 ** (-10.0 + (np.log10(eps_max) + 10.0) * s / 14)
+            A = widen(eps)
+            if w_cond(A, cond_iters) < cond_max:
+                factor = eps
+                break
+    U, info = w_chol(A)
+    assert not info.any()
+    g0m = np.zeros((n, n), dtype=np.complex128)
+    lib().emu_w_gamma0(_dp(A), C.c_int(F), C.c_int(n), _dp(g0m))
+    Lc, info = w_chol(g0m)
+    psi0 = np.ascontiguousarray(Lc.T)
+    psi = np.ascontiguousarray(np.tile(psi0, (F, 1, 1)))
+    m = np.arange(L)
+    tw = np.ascontiguousarray(np.exp(-2j * np.pi * m / L))
+    converged, err = False, np.inf
+    for _ in range(niter):
+        pinv, _i = w_inv(psi)
+        T2 = w_gemm(pinv, U)
+        g = w_gemm(T2, T2, opB=1, addI=1)
+        gp = np.zeros_like(g)
+        g0 = np.zeros((n, n), dtype=np.complex128)
+        lib().emu_w_plus(_dp(g), C.c_int(F), C.c_int(n), _dp(tw), _dp(gp), _dp(g0))
+        g0S = np.zeros((n, n), dtype=np.complex128)
+        lib().emu_w_addS(_dp(gp), _dp(g0), _dp(g0S), C.c_int(F), C.c_int(n))
+        psi = w_gemm(psi, gp)
+        psi0 = w_gemm(psi0, g0S)
+        rec = w_gemm(psi, psi, opB=1)
+        lib().emu_w_relerr.restype = C.c_double
+        err = lib().emu_w_relerr(_dp(A), _dp(rec), C.c_longlong(F * n * n))
+        if err < rtol:
+            converged = True
+            break
+    Sigma = w_gemm(psi0, psi0, opB=1)
+    p0i, _i = w_inv(psi0)
+    H = w_gemm(psi, p0i)
+    G = np.zeros((F, n, n), dtype=np.float32)
+    lib().emu_w_granger(_dp(A), _dp(H), _dp(np.ascontiguousarray(Sigma)), C.c_int(F), C.c_int(n), _dp(G))
+    return G, H, Sigma, np.array([float(converged), err, factor, cond0])

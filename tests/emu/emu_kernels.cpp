@@ -17,6 +17,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
 #include "../../syncopy_amd/csrc/csd_kernel.h"
 #include "../../syncopy_amd/csrc/cwt_kernel.h"
+#include "../../syncopy_amd/csrc/granger_kernels.h"
 
 namespace spy {
 void set_error(const char*, ...) {}
@@ -196,6 +197,52 @@ int emu_cwt(int log2n, int G, const float* data, long long ld, const int* chan_i
     CWT_CASE(10, 2) CWT_CASE(11, 2) CWT_CASE(12, 2) CWT_CASE(13, 1) CWT_CASE(14, 1)
 #undef CWT_CASE
     return -1;
+}
+
+// ---- Wilson / Granger kernels, one entry per kernel (the Python test re-creates the host loop of granger.hip)
+using spywil::cd;
+void emu_w_widen(const float* in, double* out, int C, long long n, double eps) {
+    emu::launch(dim3(4), dim3(256), 0, [&] { spywil::widen_kernel(reinterpret_cast<const float2*>(in), reinterpret_cast<cd*>(out), C, n, eps); });
+}
+void emu_w_gemm(const double* A, const double* B, double* Cm, int n, int batch, long long sA, long long sB, long long sC, int opB, int addI) {
+    dim3 grid((n + 31) / 32, (n + 31) / 32, batch);
+    emu::launch(grid, dim3(256), 0, [&] { spywil::zgemm_kernel(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI); });
+}
+void emu_w_inv(double* M, int n, int batch, int* info) {
+    emu::launch(dim3(batch), dim3(256), (size_t)n * 36, [&] { spywil::zinv_kernel(reinterpret_cast<cd*>(M), n, info); });
+}
+void emu_w_chol(double* M, int n, int batch, int* info) {
+    emu::launch(dim3(batch), dim3(256), (size_t)n * 16, [&] { spywil::zchol_kernel(reinterpret_cast<cd*>(M), n, info); });
+}
+void emu_w_gamma0(const double* A, int F, int n, double* out) {
+    emu::launch(dim3((n * n + 255) / 256), dim3(256), 0, [&] { spywil::gamma0_kernel(reinterpret_cast<const cd*>(A), F, n, reinterpret_cast<cd*>(out)); });
+}
+int emu_w_plus(const double* g, int F, int n, const double* tw, double* gp, double* g0) {
+    spywil::PlusPlan pl{};
+    const int L = 2 * (F - 1);
+    pl.L = L;
+    int k = 0, m = L;
+    const int cand[] = {4, 2, 3, 5, 7, 11, 13};
+    for (int c : cand) while (m % c == 0 && m > 1) { pl.radix[k++] = c; m /= c; }
+    for (int p = 17; m > 1; p += 2) while (m % p == 0) { pl.radix[k++] = p; m /= p; }
+    pl.nfac = k;
+    emu::launch(dim3(n * n), dim3(256), (size_t)2 * L * 16, [&] { spywil::plus_kernel(reinterpret_cast<const cd*>(g), F, n, pl, reinterpret_cast<const cd*>(tw), reinterpret_cast<cd*>(gp), reinterpret_cast<cd*>(g0)); });
+    return k;
+}
+void emu_w_addS(double* gp, const double* g0, double* out0, int F, int n) {
+    emu::launch(dim3(4), dim3(256), 0, [&] { spywil::add_S_kernel(reinterpret_cast<cd*>(gp), reinterpret_cast<const cd*>(g0), reinterpret_cast<cd*>(out0), F, n); });
+}
+double emu_w_relerr(const double* A, const double* B, long long n) {
+    std::vector<double> part(8);
+    emu::launch(dim3(8), dim3(256), 0, [&] { spywil::relerr_kernel(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), n, part.data()); });
+    double m = 0; for (double v : part) if (v > m || v != v) m = v;
+    return m;
+}
+void emu_w_power(const double* M, int n, int batch, int iters, double* lam) {
+    emu::launch(dim3(batch), dim3(256), (size_t)2 * n * 16, [&] { spywil::power_kernel(reinterpret_cast<const cd*>(M), n, iters, lam); });
+}
+void emu_w_granger(const double* CSD, const double* H, const double* Sigma, int F, int n, float* out) {
+    emu::launch(dim3(4), dim3(256), 0, [&] { spywil::granger_kernel(reinterpret_cast<const cd*>(CSD), reinterpret_cast<const cd*>(H), reinterpret_cast<const cd*>(Sigma), F, n, out); });
 }
 
 }  // extern "C"

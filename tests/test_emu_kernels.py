@@ -121,3 +121,46 @@ def test_cwt_kernel(nsig, scales, detrend, output):
     trial = O.detrend(np.array(data[5:5 + nsig + 20]), None if detrend < 0 else detrend)
     ref = O.convert_output(O.cwt(trial[pre0:pre0 + nsig], 1000.0, scales).transpose(1, 0, 2), output)
     assert_parity(out, ref, what="cwt")
+
+
+def test_wilson_building_blocks():
+    rng = np.random.default_rng(3)
+    n, B = 37, 3
+    A = rng.normal(size=(B, n, n)) + 1j * rng.normal(size=(B, n, n))
+    Bm = rng.normal(size=(B, n, n)) + 1j * rng.normal(size=(B, n, n))
+    np.testing.assert_allclose(E.w_gemm(A, Bm), A @ Bm, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(E.w_gemm(A, Bm, opB=1, addI=1), A @ Bm.conj().transpose(0, 2, 1) + np.eye(n), rtol=1e-12,
+                               atol=1e-12)
+    np.testing.assert_allclose(E.w_gemm(A, Bm[0]), A @ Bm[0], rtol=1e-12, atol=1e-12)        # broadcast B
+    inv, info = E.w_inv(A)
+    assert not info.any()
+    np.testing.assert_allclose(inv @ A, np.tile(np.eye(n), (B, 1, 1)), atol=1e-9)
+    P = A @ A.conj().transpose(0, 2, 1) + n * np.eye(n)
+    Lc, info = E.w_chol(P)
+    assert not info.any()
+    np.testing.assert_allclose(Lc, np.linalg.cholesky(P), rtol=1e-10, atol=1e-10)
+    assert abs(E.w_cond(P[:1, :9, :9].copy(), iters=40) / np.linalg.cond(P[0, :9, :9]) - 1) < 5e-2
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("SPY_EMU_SLOW"),
+                    reason="~5 min of thread emulation; set SPY_EMU_SLOW=1 (the GPU suite covers the same chain)")
+def test_wilson_granger_small_vs_oracle():
+    """Whole Wilson/Granger chain on emulated kernels for a small problem (the golden-vector comparison of
+    the real C++ driver runs on the GPU: tests/test_gpu_golden.py)."""
+    adj = np.zeros((3, 3))
+    adj[0, 1] = 0.3
+    trials = O.ar2_network(adj, 32, 40, seed=3)
+    acc = np.zeros((17, 3, 3), np.complex64)
+    for x in trials:
+        cs, _ = O.csd(O.detrend(x, 0), 200.0, 32, "dpss", {"NW": 2, "Kmax": 3}, demean_taper=True)
+        acc += cs
+    acc /= len(trials)
+    G, H, Sigma, info = E.granger(acc, cond_iters=25)
+    Gr, meta = O.granger_cF(acc[None])
+    assert bool(info[0]) == bool(meta["converged--bool"]) and info[2] == float(meta["reg. factor--float"])
+    np.testing.assert_allclose(info[3], float(meta["initial cond. num--float"]), rtol=0.2)   # 25 power iterations only
+    assert info[1] < 5e-6
+    rec = H @ Sigma @ H.conj().transpose(0, 2, 1)
+    assert O.max_rel_err(acc.astype(np.complex128), rec) < 1e-5
+    np.testing.assert_allclose(G[2:-1], Gr[0, 2:-1], rtol=5e-3, atol=5e-4)
+    np.testing.assert_allclose(G, Gr[0], atol=1e-2)
