@@ -1,0 +1,105 @@
+"""Timing of the BASELINE.json configurations 2, 4, 5 on one GPU (development aid -> gpurun_out/configs.json)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scipy.signal import windows  # noqa: E402
+
+from syncopy_amd import backend as be  # noqa: E402
+from syncopy_amd import synthdata  # noqa: E402
+
+
+def sync_time(fn, n=3):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+res = {}
+which = sys.argv[1:] or ["c2", "conv", "wav", "granger"]
+
+if "c2" in which:
+    C, N, T, K = 256, 4096, 1000, 7
+    data = synthdata.ar2_uncoupled_fast(C, N, T, seed=1)
+    starts = torch.arange(T, device="cuda", dtype=torch.int64) * N
+    plan = be.FFTPlan(N, N, C, windows.dpss(N, 4.096, K) * np.sqrt(N), np.sqrt(2) / N, 0, False, None, "pow", False)
+    out = torch.empty(plan.out_shape(T), dtype=torch.float32, device="cuda")
+    dt = sync_time(lambda: plan.execute(data, starts, out=out))
+    byt = T * (N * C * 4 + (N // 2 + 1) * C * 4)
+    res["c2_mtmfft_pow"] = {"trials_per_s": T / dt, "us_per_trial": 1e6 * dt / T, "GBps": byt / dt / 1e9,
+                            "kernel": plan.kernel_name}
+    print("c2", res["c2_mtmfft_pow"], flush=True)
+    del data, out
+
+if "conv" in which:
+    C, N, T = 128, 16384, 100
+    data = synthdata.ar2_uncoupled_fast(C, N, T, seed=2)
+    nperseg, step = 512, 256
+    w = windows.hann(nperseg)
+    w = w * np.sqrt(4 / 3) * np.sqrt(nperseg / w.sum())
+    plan = be.FFTPlan(nperseg, nperseg, C, w[None], np.sqrt(2) / nperseg, 0, False, None, "pow", False)
+    nT = int(np.ceil(N / step))
+    fr = torch.arange(nT, device="cuda", dtype=torch.int64) * step - nperseg // 2
+    tr = torch.arange(T, device="cuda", dtype=torch.int64) * N
+    starts = (tr[:, None] + fr[None, :]).reshape(-1).contiguous()
+    lo = tr[:, None].expand(T, nT).reshape(-1).contiguous()
+    hi = (lo + N).contiguous()
+    out = torch.empty(plan.out_shape(T * nT), dtype=torch.float32, device="cuda")
+    dt = sync_time(lambda: plan.execute(data, starts, lo, hi, out=out))
+    byt = T * (N * C * 4 + nT * 257 * C * 4)
+    res["c4_mtmconvol"] = {"trials_per_s": T / dt, "us_per_trial": 1e6 * dt / T, "GBps": byt / dt / 1e9,
+                           "kernel": plan.kernel_name}
+    print("conv", res["c4_mtmconvol"], flush=True)
+    del data, out
+
+if "wav" in which:
+    C, N, T = 128, 16384, 8
+    data = synthdata.ar2_uncoupled_fast(C, N, T, seed=3)
+    foi = np.arange(4, 104, 4, dtype=float)
+    scales = (1 / foi) * (6 + np.sqrt(38)) / (4 * np.pi)
+    plan = be.CWTPlan(N, C, scales, 1e-3, 6.0, 0, "pow")
+    tr = torch.arange(T, device="cuda", dtype=torch.int64) * N
+    out = torch.zeros(plan.out_shape(1), dtype=torch.float32, device="cuda")
+
+    def run():
+        for t in range(T):
+            plan.execute(data, tr[t:t + 1], tr[t:t + 1], tr[t:t + 1] + N, out=out, accumulate=True)
+    dt = sync_time(run, n=2)
+    byt = T * (N * C * 4 + N * 25 * C * 4)
+    res["c4_wavelet"] = {"trials_per_s": T / dt, "ms_per_trial": 1e3 * dt / T, "GBps_alg": byt / dt / 1e9}
+    print("wav", res["c4_wavelet"], flush=True)
+    del data, out
+
+if "granger" in which:
+    for C, N, T in ((64, 1024, 700), (256, 4096, 300)):
+        data = synthdata.ar2_uncoupled_fast(C, N, T, seed=4)
+        K = 7
+        F = N // 2 + 1
+        starts = torch.arange(T, device="cuda", dtype=torch.int64) * N
+        plan = be.FFTPlan(N, N, C, windows.dpss(N, 4.096, K) * np.sqrt(N), np.sqrt(2) / N, 0, True, None, "fourier", True)
+        acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+        B = 50
+        for b0 in range(0, T, B):
+            be.csd_accumulate(plan.execute(data, starts[b0:b0 + B]), acc)
+        be.csd_finalize(acc, 1.0 / (K * T))
+        torch.cuda.synchronize()
+        del data
+        t0 = time.perf_counter()
+        G, meta = be.granger(acc, niter=100)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[f"granger_C{C}_F{F}"] = {"seconds": dt, **meta, "finite": bool(torch.isfinite(G).all())}
+        print("granger", C, res[f"granger_C{C}_F{F}"], flush=True)
+        del acc, G
+
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/configs.json", "w"), indent=1)
