@@ -1,5 +1,6 @@
 // Host side of K3: Morlet kernel spectra (fp64 on the host, once per plan) and launch of the
 // overlap-save CWT kernel (spyhip_cwt_plan_create / spyhip_cwt_exec).
+#include <algorithm>
 #include <cmath>
 #include <string>
 
@@ -16,8 +17,10 @@ struct spyhip_cwt_plan {
     bool identity_time = true;
     spy::DevBuf<float2> tw, hspec;
     spy::DevBuf<int> cshift, tpos;
-    spy::DevBuf<double> trend;
+    spy::DevBuf<double> trend, trend_part;
     size_t trend_cap = 0;
+    spy::DevBuf<char> stage;      // time-contiguous staging of one chunk of segments
+    int chunk = 0;                // segments per chunk the staging buffer holds
 };
 
 namespace {
@@ -152,24 +155,56 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         const size_t need = (size_t)nseg * p->nchan * 2;
         if (need > p->trend_cap) {
             if (p->trend.p) { (void)hipFree(p->trend.p); p->trend.p = nullptr; }
-            if (p->trend.alloc(need)) return -2;
+            if (p->trend_part.p) { (void)hipFree(p->trend_part.p); p->trend_part.p = nullptr; }
+            if (p->trend.alloc(need) || p->trend_part.alloc(need * spyfft::CWT_TREND_SPLITS)) return -2;
             p->trend_cap = need;
         }
         a.trend = p->trend.p;
-        hipLaunchKernelGGL(spyfft::cwt_trend_kernel, dim3((p->nchan + 63) / 64, nseg), dim3(256), 0, p->ctx->stream,
-                           a, p->trend.p);
+        if (nseg > 65535) { spy::set_error("cwt_exec: more than 65535 segments per call"); return -1; }
+        hipLaunchKernelGGL(spyfft::cwt_trend_partial_kernel, dim3((p->nchan + 63) / 64, spyfft::CWT_TREND_SPLITS, nseg),
+                           dim3(256), 0, p->ctx->stream, a, p->trend_part.p);
+        hipLaunchKernelGGL(spyfft::cwt_trend_final_kernel, dim3((unsigned)(((size_t)nseg * p->nchan + 255) / 256)), dim3(256),
+                           0, p->ctx->stream, a, p->trend_part.p, p->trend.p);
         SPY_HIP_CHECK(hipGetLastError());
     }
-    const long long ngrp = (p->nchan + p->G - 1) / p->G;
-    const long long grid = (long long)nseg * ngrp * p->nblocks;
-    if (grid > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
-    const unsigned g = (unsigned)grid;
-    switch (p->log2n) {
-        case 10: return launch_cwt_out<10, 2>(p, a, g);
-        case 11: return launch_cwt_out<11, 2>(p, a, g);
-        case 12: return launch_cwt_out<12, 2>(p, a, g);
-        case 13: return launch_cwt_out<13, 1>(p, a, g);
-        case 14: return launch_cwt_out<14, 1>(p, a, g);
-        default: spy::set_error("cwt_exec: unsupported block length 2^%d", p->log2n); return -1;
+    // staging buffer: as many segments per chunk as fit ~1 GiB (at least one)
+    const size_t esz = (p->output == SPYHIP_OUT_FOURIER) ? 8 : 4;
+    const size_t per_seg = (size_t)p->nscales * p->nchan * p->nsig * esz;
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nseg, ((size_t)1 << 30) / std::max<size_t>(per_seg, 1)));
+    if (chunk > p->chunk) {
+        if (p->stage.p) { (void)hipFree(p->stage.p); p->stage.p = nullptr; }
+        if (p->stage.alloc(per_seg * chunk)) return -2;
+        p->chunk = chunk;
     }
+    chunk = p->chunk;
+    a.stage = p->stage.p;
+    const long long ngrp = (p->nchan + p->G - 1) / p->G;
+    for (int s0 = 0; s0 < nseg; s0 += chunk) {
+        const int ns = std::min(chunk, nseg - s0);
+        CwtArgs c = a;
+        c.seg0 = s0;
+        c.seg_start = a.seg_start + s0;
+        c.trial_lo = a.trial_lo + s0;
+        c.trial_hi = a.trial_hi + s0;
+        if (a.trend) c.trend = a.trend + (size_t)s0 * p->nchan * 2;
+        c.nseg = ns;
+        const long long grid = (long long)ns * ngrp * p->nblocks;
+        if (grid > 0x7fffffffLL || p->nscales > 65535 || ns > 65535) { spy::set_error("cwt_exec: grid too large"); return -1; }
+        const unsigned g = (unsigned)grid;
+        int rc;
+        switch (p->log2n) {
+            case 10: rc = launch_cwt_out<10, 2>(p, c, g); break;
+            case 11: rc = launch_cwt_out<11, 2>(p, c, g); break;
+            case 12: rc = launch_cwt_out<12, 2>(p, c, g); break;
+            case 13: rc = launch_cwt_out<13, 1>(p, c, g); break;
+            case 14: rc = launch_cwt_out<14, 1>(p, c, g); break;
+            default: spy::set_error("cwt_exec: unsupported block length 2^%d", p->log2n); return -1;
+        }
+        if (rc) return rc;
+        const dim3 sg((p->nsig + 63) / 64, p->nscales, ns);
+        if (esz == 8) hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float2>, sg, dim3(256), 0, p->ctx->stream, c);
+        else hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float>, sg, dim3(256), 0, p->ctx->stream, c);
+        SPY_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
 }

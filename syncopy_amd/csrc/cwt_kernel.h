@@ -38,19 +38,31 @@ struct CwtArgs {
     int ntime_out;
     void* out;                    // (nseg, ntime_out, nscales, nchan)
     int accumulate;
+    void* stage;                  // (chunk segments, nscales, nchan, nsig): time-contiguous staging of the
+                                  // converted values; cwt_scatter_kernel transposes it into `out`
+    int seg0;                     // first segment of the chunk being processed
 };
 
-// per (segment, channel): mean and least-squares slope over the trial rows [lo, hi)
-__global__ void __launch_bounds__(256) cwt_trend_kernel(CwtArgs a, double* trend) {
+// per (segment, channel): mean and least-squares slope over the trial rows [lo, hi), in two
+// deterministic stages: partial sums over CWT_TREND_SPLITS slices of the trial (many workgroups in
+// flight: the trial is read at HBM rate instead of one dependent row at a time), then a fixed-order
+// reduction.  Trial lengths live on the device, so the slice length is derived in the kernel.
+constexpr int CWT_TREND_SPLITS = 64;
+__global__ void __launch_bounds__(256) cwt_trend_partial_kernel(CwtArgs a, double* part) {
+    constexpr int nsplit = CWT_TREND_SPLITS;
     __shared__ double red[4][64][2];
     const int tid = threadIdx.x, cl = tid & 63, ph = tid >> 6;
-    const int b = blockIdx.y, c = blockIdx.x * 64 + cl;
+    const int b = blockIdx.z, sp = blockIdx.y, c = blockIdx.x * 64 + cl;
     const long long lo = a.trial_lo[b], hi = a.trial_hi[b];
     const double mid = 0.5 * (double)(hi - lo - 1);
+    const long long rows = (hi - lo + nsplit - 1) / nsplit;
+    const long long r0 = lo + (long long)sp * rows;
+    const long long r1 = (r0 + rows < hi) ? r0 + rows : hi;
     double s0 = 0.0, s1 = 0.0;
     if (c < a.nchan) {
         const long long col = a.chan_idx ? a.chan_idx[c] : c;
-        for (long long r = lo + ph; r < hi; r += 4) {
+#pragma unroll 8
+        for (long long r = r0 + ph; r < r1; r += 4) {
             const double x = a.data[r * a.ld + col];
             s0 += x;
             s1 += ((double)(r - lo) - mid) * x;
@@ -60,16 +72,32 @@ __global__ void __launch_bounds__(256) cwt_trend_kernel(CwtArgs a, double* trend
     red[ph][cl][1] = s1;
     __syncthreads();
     if (ph == 0 && c < a.nchan) {
-        const double n = (double)(hi - lo);
         double t0 = 0.0, t1 = 0.0;
         for (int p = 0; p < 4; ++p) {
             t0 += red[p][cl][0];
             t1 += red[p][cl][1];
         }
-        double* o = trend + ((size_t)b * a.nchan + c) * 2;
-        o[0] = t0 / n;
-        o[1] = (a.detrend == 1 && n > 1.0) ? t1 * 12.0 / (n * (n * n - 1.0)) : 0.0;
+        double* o = part + (((size_t)b * nsplit + sp) * a.nchan + c) * 2;
+        o[0] = t0;
+        o[1] = t1;
     }
+}
+
+__global__ void __launch_bounds__(256) cwt_trend_final_kernel(CwtArgs a, const double* part, double* trend) {
+    constexpr int nsplit = CWT_TREND_SPLITS;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.nseg * a.nchan) return;
+    const int b = (int)(i / a.nchan), c = (int)(i % a.nchan);
+    const long long len = a.trial_hi[b] - a.trial_lo[b];
+    double t0 = 0.0, t1 = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const double* q = part + (((size_t)b * nsplit + sp) * a.nchan + c) * 2;
+        t0 += q[0];
+        t1 += q[1];
+    }
+    const double n = (double)len;
+    trend[i * 2] = t0 / n;
+    trend[i * 2 + 1] = (a.detrend == 1 && n > 1.0) ? t1 * 12.0 / (n * (n * n - 1.0)) : 0.0;
 }
 
 template <int LOG2N, int G, int OUTK>
@@ -118,31 +146,60 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) cwt_kernel(CwtArgs 
 #pragma unroll
     for (int e = 0; e < 16; ++e) Z[e] = v[e];
 
+    // Results leave the workgroup time-contiguous (lanes = consecutive samples of one (scale, channel)
+    // row of the staging buffer: full 256-byte wave stores); the channel-fastest layout of the
+    // reference's output is produced by cwt_scatter_kernel.
     const int nend = min(o0 + a.V, a.nsig);
-    constexpr unsigned OSZ = CPLX ? 8u : 4u;
     for (int s = 0; s < a.nscales; ++s) {
         const float2* H = a.hspec + (size_t)s * N;
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = cmul(Z[e], ldg<float2>(H, (unsigned)(j + T * e) * 8u));
         fft_inverse<LOG2N, G>(v, lds, j, h, a.tw);
         const int sh = a.cshift[s];
+        const size_t rowo = (((size_t)b * a.nscales + s) * a.nchan + c) * (size_t)a.nsig;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int n = j + T * e - sh + o0;
             if (!has || n < o0 || n >= nend) continue;
-            const int slot = a.tpos ? a.tpos[n] : n;
-            if (slot < 0) continue;
-            const size_t o = (((size_t)b * a.ntime_out + slot) * a.nscales + s) * a.nchan + c;
-            if (CPLX) {
-                float2* out = reinterpret_cast<float2*>(a.out) + o;
-                *out = a.accumulate ? cadd(*out, v[e]) : v[e];
-            } else {
-                float* out = reinterpret_cast<float*>(a.out) + o;
-                const float val = convert_real<OUTK>(v[e], a.out_kind);
-                *out = a.accumulate ? *out + val : val;
-            }
+            if (CPLX) reinterpret_cast<float2*>(a.stage)[rowo + n] = v[e];
+            else reinterpret_cast<float*>(a.stage)[rowo + n] = convert_real<OUTK>(v[e], a.out_kind);
         }
-        (void)OSZ;
+    }
+}
+
+// staging (segment, scale, channel, time) -> out (segment, slot(time), scale, channel), 64 x 64 tiles
+// through LDS so that both sides move >= 256 contiguous bytes per wave; applies the post-selection
+// (tpos) and the trial accumulation.
+template <typename V>
+__global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
+    __shared__ V tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64, s = blockIdx.y, bl = blockIdx.z;
+    const V* const st = reinterpret_cast<const V*>(a.stage) + ((size_t)bl * a.nscales + s) * a.nchan * (size_t)a.nsig;
+    V* const out = reinterpret_cast<V*>(a.out);
+    const int n = n0 + tx;
+    for (int c0 = 0; c0 < a.nchan; c0 += 64) {
+        if (c0) __syncthreads();
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4)
+            if (c0 + r < a.nchan && n < a.nsig) tile[r][tx] = st[(size_t)(c0 + r) * a.nsig + n];
+        __syncthreads();
+        const int c = c0 + tx;
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4) {
+            const int m = n0 + r;
+            if (m >= a.nsig || c >= a.nchan) continue;
+            const int slot = a.tpos ? a.tpos[m] : m;
+            if (slot < 0) continue;
+            V* const o = out + (((size_t)(a.seg0 + bl) * a.ntime_out + slot) * a.nscales + s) * a.nchan + c;
+            V val = tile[tx][r];
+            if (a.accumulate) {
+                const V old = *o;
+                if constexpr (sizeof(V) == 8) val = cadd(old, val);
+                else val = old + val;
+            }
+            *o = val;
+        }
     }
 }
 

@@ -41,6 +41,15 @@ __device__ __forceinline__ int opaque(int v) {
     return v;
 }
 
+// value of the neighbouring lane (lane ^ 1): one DPP move, no LDS traffic
+__device__ __forceinline__ float lane_swap1(float v) {
+#ifndef SPY_HOST_EMU
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
+#else
+    return __shfl_xor(v, 1);
+#endif
+}
+
 __device__ __forceinline__ void sched_fence() {
 #ifndef SPY_HOST_EMU
     __builtin_amdgcn_sched_barrier(0);
@@ -158,12 +167,16 @@ __device__ __forceinline__ void fft_forward(float2 (&v)[16], float2* lds, int j,
             // more dependent L2 round trips per pass
             const unsigned kb = (unsigned)(k * (C::N / (Ns * 16))) * 8u;   // byte offset of tw[k*stride]
             float2 wb[4], wa[4];
+#if defined(SPYFFT_ABL) && (SPYFFT_ABL & 2)
+            wb[1] = wb[2] = wb[3] = wa[1] = wa[2] = wa[3] = make_float2(__uint_as_float(kb), 0.5f);
+#else
             wb[1] = ldg<float2>(tw, kb);
             wb[2] = ldg<float2>(tw, kb * 2u);
             wb[3] = ldg<float2>(tw, kb * 3u);
             wa[1] = ldg<float2>(tw, kb * 4u);
             wa[2] = ldg<float2>(tw, kb * 8u);
             wa[3] = ldg<float2>(tw, kb * 12u);
+#endif
 #pragma unroll
             for (int r = 1; r < 16; ++r) {
                 const int hi = r >> 2, lo = r & 3;

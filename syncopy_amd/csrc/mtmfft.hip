@@ -7,6 +7,7 @@
 #include "spy_common.h"
 #include "host_fft.h"
 #include "mtmfft_kernel.h"
+#include "mtmfft2_kernel.h"
 #include "mtmfft_generic.h"
 
 using spyfft::GenPlan;
@@ -85,6 +86,35 @@ int launch_pow2_mode(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) 
     }
 }
 
+template <int LOG2N, int G, int OUTK, bool MEAN>
+int launch_quad(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
+    using C = spyfft::Cfg2<LOG2N, G>;
+    auto kern = spyfft::mtmfft_quad_kernel<LOG2N, G, OUTK, MEAN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int LOG2N, int G>
+int launch_quad_mode(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
+    const bool mean = !p->keeptapers;
+    const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+    switch (outk * 2 + (mean ? 1 : 0)) {
+        case 0: return launch_quad<LOG2N, G, 0, false>(p, a, grid);
+        case 1: return launch_quad<LOG2N, G, 0, true>(p, a, grid);
+        case 2: return launch_quad<LOG2N, G, 1, false>(p, a, grid);
+        case 3: return launch_quad<LOG2N, G, 1, true>(p, a, grid);
+        case 4: return launch_quad<LOG2N, G, 2, false>(p, a, grid);
+        default: return launch_quad<LOG2N, G, 2, true>(p, a, grid);
+    }
+}
+
 template <int OUTK, bool MEAN>
 int launch_generic(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     auto kern = spyfft::mtmfft_generic_kernel<OUTK, MEAN>;
@@ -95,28 +125,15 @@ int launch_generic(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     return 0;
 }
 
-// preferred pair-interleave G per power-of-two length (workgroup = N/16*G threads)
-int default_G(int log2n, int nchan) {
-    int g;
+// channel quads interleaved per workgroup of the packed kernel (256 threads up to N = 4096)
+int default_G(int log2n) {
     switch (log2n) {
-        case 8: g = 16; break;
-        case 9: g = 8; break;
-        case 10: g = 4; break;
-        case 11: g = 4; break;
-        case 12: g = 2; break;
-        case 13: g = 2; break;
-        default: g = 1; break;
+        case 8: return 16;
+        case 9: return 8;
+        case 10: return 4;
+        case 11: return 2;
+        default: return 1;
     }
-    if (log2n == 12) {
-        const char* e = std::getenv("SPYHIP_FFT_G");
-        if (e) {
-            const int v = std::atoi(e);
-            if (v == 1 || v == 2 || v == 4) g = v;
-        }
-        const int npairs = (nchan + 1) / 2;
-        while (g > 1 && g > npairs) g >>= 1;
-    }
-    return g;
 }
 
 }  // namespace
@@ -169,10 +186,11 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
     p->pow2 = spy::is_pow2((unsigned)nfft) && nfft >= 256 && nfft <= 16384 && !std::getenv("SPYHIP_FORCE_GENERIC");
     if (p->pow2) {
         p->log2n = spy::ilog2((unsigned)nfft);
-        p->G = default_G(p->log2n, nchan);
+        p->G = default_G(p->log2n);
         if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
         char buf[128];
-        std::snprintf(buf, sizeof buf, "mtmfft_pow2_kernel<%d, %d, %s>", p->log2n, p->G, mode);
+        std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
+                      p->log2n, p->G, mode);
         p->kernel_name = buf;
     } else {
         GenPlan& g = p->gen;
@@ -249,26 +267,27 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     a.nfsel = p->nfsel; a.out_kind = p->output; a.out = out_d;
     const int npairs = (p->nchan + 1) / 2;
     if (p->pow2) {
+        // work items per segment: channel quads (packed kernel) or channel pairs (2^14)
+        const bool quad = p->log2n <= 13;
         const int G = p->G;
-        a.npg = (npairs + G - 1) / G;
-        int S = 16 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+        const int nitem = quad ? (p->nchan + 3) / 4 : npairs;
+        a.npg = (nitem + G - 1) / G;
+        int S = (quad ? 8 : 16) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;   // workgroups sharing 128-byte rows
         a.S = S;
         a.ncl = (a.npg + S - 1) / S;
         const long long nclusters = (long long)nseg * a.ncl;
         const long long grid = ((nclusters + 7) / 8) * S * 8;
         if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
         const unsigned g = (unsigned)grid;
-        switch (p->log2n * 100 + G) {
-            case 816: return launch_pow2_mode<8, 16>(p, a, g);
-            case 908: return launch_pow2_mode<9, 8>(p, a, g);
-            case 1004: return launch_pow2_mode<10, 4>(p, a, g);
-            case 1104: return launch_pow2_mode<11, 4>(p, a, g);
-            case 1201: return launch_pow2_mode<12, 1>(p, a, g);
-            case 1202: return launch_pow2_mode<12, 2>(p, a, g);
-            case 1204: return launch_pow2_mode<12, 4>(p, a, g);
-            case 1302: return launch_pow2_mode<13, 2>(p, a, g);
-            case 1401: return launch_pow2_mode<14, 1>(p, a, g);
-            default: spy::set_error("no kernel for log2n=%d G=%d", p->log2n, G); return -1;
+        switch (p->log2n) {
+            case 8: return launch_quad_mode<8, 16>(p, a, g);
+            case 9: return launch_quad_mode<9, 8>(p, a, g);
+            case 10: return launch_quad_mode<10, 4>(p, a, g);
+            case 11: return launch_quad_mode<11, 2>(p, a, g);
+            case 12: return launch_quad_mode<12, 1>(p, a, g);
+            case 13: return launch_quad_mode<13, 1>(p, a, g);
+            case 14: return launch_pow2_mode<14, 1>(p, a, g);
+            default: spy::set_error("no kernel for log2n=%d", p->log2n); return -1;
         }
     }
     const long long grid = (long long)nseg * npairs;

@@ -1,0 +1,341 @@
+// K1/K2 (power-of-two lengths 256..8192): fused detrend -> taper -> packed real FFT -> scale ->
+// output conversion (-> taper mean) for segments of a (rows x ld) float32 trial matrix.
+//
+// Reference semantics: specest/mtmfft.py:16-129 + specest/compRoutines.py:169-189 (and
+// specest/stft.py:101-154 when one segment = one STFT frame).
+//
+// One thread serves FOUR adjacent real channels c0..c3 of one segment: channels (c0, c2) are packed
+// as (re, im) of complex FFT "a", (c1, c3) of FFT "b", and a/b travel in the two halves of packed
+// fp32 registers (fft2_device.h), i.e. r = samples of (c0, c1), i = samples of (c2, c3): exactly the
+// halves of the 16-byte row read, so neither the load nor the butterflies need a shuffle.
+// Separation afterwards:  X(c0,c1)[f] = (Z[f] + conj(Z[N-f]))/2,  X(c2,c3)[f] = (Z[f] - conj(Z[N-f]))/(2i).
+// The segment is read from HBM exactly once (kept in registers across tapers); the spectra never
+// leave registers/LDS before the output conversion.
+#pragma once
+#include "fft2_device.h"
+#include "mtmfft_kernel.h"
+
+namespace spyfft {
+
+// OUTK: 0 = power (inlined), 1 = any other real conversion, 2 = complex; MEAN: average over tapers
+template <int LOG2N, int G, int OUTK, bool MEAN>
+__global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmfft_quad_kernel(MtmArgs a) {
+    using C = Cfg2<LOG2N, G>;
+    constexpr bool CPLX = (OUTK == 2);
+    constexpr int N = C::N, T = C::T;
+    SPY_DYN_SMEM(v2f, lds);
+    v2f* const lre = lds;
+    v2f* const lim = lds + C::PLANE;
+
+    const int tid = threadIdx.x;
+    const int h = tid % G, j0 = tid / G;
+
+    // XCD-aware block -> (segment, quad group): the S workgroups that share 128-byte lines of the
+    // (time x channel) rows get ids congruent mod 8 (same XCD / L2) and adjacent in dispatch order.
+    const long long id = blockIdx.x;
+    const int xcd = (int)(id & 7);
+    const long long y = id >> 3;
+    const long long cidx = (y / a.S) * 8 + xcd;
+    const int q = (int)(y % a.S);
+    if (cidx >= (long long)a.nseg * a.ncl) return;
+    const int b = (int)(cidx / a.ncl);
+    const int pg = (int)(cidx % a.ncl) * a.S + q;
+    if (pg >= a.npg) return;
+
+    const int c0 = 4 * (pg * G + h);
+    bool has[4];
+    unsigned col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        has[i] = c0 + i < a.nchan;
+        col[i] = has[i] ? (unsigned)(a.chan_idx ? a.chan_idx[c0 + i] : c0 + i) : 0u;
+    }
+    const bool full = has[3];
+    const long long start = a.seg_start[b];
+    const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
+    const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
+    const int rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
+    const unsigned rowb = (unsigned)a.ld * 4u;        // bytes per row
+    const float* seg = a.data + start * a.ld;         // wave-uniform; only rows in [rlo, rhi) are dereferenced
+
+    // ---- load the segment once: x[e] = sample n = j + T*e; r = (c0, c1), i = (c2, c3)
+    C2 x[16];
+    if (rhi > rlo) {
+        const bool vec4 = (a.chan_idx == nullptr) && full && ((a.ld & 3) == 0) &&
+                          ((reinterpret_cast<size_t>(a.data) & 15) == 0);
+        if (vec4) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = j0 + T * e;
+                const int nc = min(max(n, rlo), rhi - 1);
+                const float4 t = ldg<float4>(seg, (unsigned)nc * rowb + col[0] * 4u);
+                const bool ok = (n == nc);
+                x[e].r = v2f{ok ? t.x : 0.f, ok ? t.y : 0.f};
+                x[e].i = v2f{ok ? t.z : 0.f, ok ? t.w : 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = j0 + T * e;
+                const int nc = min(max(n, rlo), rhi - 1);
+                float u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = ldg<float>(seg, (unsigned)nc * rowb + col[i] * 4u);
+                    u[i] = (n == nc && has[i]) ? t : 0.f;
+                }
+                x[e].r = v2f{u[0], u[1]};
+                x[e].i = v2f{u[2], u[3]};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e].r = x[e].i = splat(0.f);
+    }
+
+    // ---- polynomial removal over the nsig samples (float64 sums, branch-free)
+    if (a.detrend >= 0) {
+        const float mid = 0.5f * (float)(a.nsig - 1);
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = j0 + T * e;
+            const float m = (n < a.nsig) ? 1.f : 0.f;
+            const float u[4] = {m * x[e].r[0], m * x[e].r[1], m * x[e].i[0], m * x[e].i[1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += (double)u[i];
+            if (a.detrend == 1) {
+                const double dn = (double)(m * ((float)n - mid));   // exact: half-integers < 2^23
+                s[4] += dn * x[e].r[0];
+                s[5] += dn * x[e].r[1];
+                s[6] += dn * x[e].i[0];
+                s[7] += dn * x[e].i[1];
+            }
+        }
+        block_sum<C::NTHREADS, G, 8>(s, reinterpret_cast<double*>(lds), tid, h);
+        const double inv = 1.0 / a.nsig;
+        if (a.detrend == 1 && a.nsig > 1) {
+            const double den = 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = j0 + T * e;
+                const double dn = (double)((float)n - mid);
+                const bool in = n < a.nsig;
+                float t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = in ? (float)(s[i] * inv + s[4 + i] * den * dn) : 0.f;
+                x[e].r -= v2f{t[0], t[1]};
+                x[e].i -= v2f{t[2], t[3]};
+            }
+        } else {
+            const v2f mr = v2f{(float)(s[0] * inv), (float)(s[1] * inv)};
+            const v2f mi = v2f{(float)(s[2] * inv), (float)(s[3] * inv)};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool in = j0 + T * e < a.nsig;
+                x[e].r -= in ? mr : splat(0.f);
+                x[e].i -= in ? mi : splat(0.f);
+            }
+        }
+    }
+
+    // accumulators for the taper mean (bins e<8 plus the Nyquist bin on j == 0):
+    // real outputs: ma.r = sum conv(X(c0,c1)), ma.i = sum conv(X(c2,c3)); complex: ma = X(c0,c1), mb = X(c2,c3)
+    C2 ma[MEAN ? 9 : 1], mb[(MEAN && CPLX) ? 9 : 1];
+    if (MEAN) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            ma[e].r = ma[e].i = splat(0.f);
+            if (CPLX) mb[e].r = mb[e].i = splat(0.f);
+        }
+    }
+    const int kout = MEAN ? 1 : a.ntaper;
+    const float hs = 0.5f * a.scale;
+    const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
+    constexpr unsigned OSZ = CPLX ? 8u : 4u;   // bytes per output element
+    // straight-line epilogue: all four channels present, every bin kept, 16-byte aligned rows
+    const bool fast = full && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) &&
+                      ((a.nchan & (CPLX ? 1 : 3)) == 0);
+
+    // taper weights of the first taper; later tapers are prefetched while the previous FFT runs
+    float wn[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const unsigned n = (unsigned)(j0 + T * e);
+        const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(a.tapers, min(n, nsig_m1) * 4u);
+        wn[e] = (n <= nsig_m1) ? wl : 0.f;
+    }
+
+    for (int k = 0; k < a.ntaper; ++k) {
+        const int j = opaque(j0);
+        C2 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            v[e].r = x[e].r * wn[e];
+            v[e].i = x[e].i * wn[e];
+        }
+        if (k + 1 < a.ntaper) {
+            const float* w = a.tapers + (size_t)(k + 1) * a.nsig;   // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned n = (unsigned)(j + T * e);
+                const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, min(n, nsig_m1) * 4u);
+                wn[e] = (n <= nsig_m1) ? wl : 0.f;
+            }
+        }
+        if (a.demean_taper) {
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[0] += v[e].r[0];
+                s[1] += v[e].r[1];
+                s[2] += v[e].i[0];
+                s[3] += v[e].i[1];
+            }
+            block_sum<C::NTHREADS, G, 4>(s, reinterpret_cast<double*>(lds), tid, h);
+            const v2f mr = v2f{(float)(s[0] / a.nsig), (float)(s[1] / a.nsig)};
+            const v2f mi = v2f{(float)(s[2] / a.nsig), (float)(s[3] / a.nsig)};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool in = j + T * e < a.nsig;
+                v[e].r -= in ? mr : splat(0.f);
+                v[e].i -= in ? mi : splat(0.f);
+            }
+        }
+
+        fft2_forward<LOG2N, G>(v, lds, j, h, a.tw);
+
+        // ---- separate the real channels: partner bin N-f lives in the upper half
+        {
+            const int wb = C::rbase(j, h);
+#pragma unroll
+            for (int e = 8; e < 16; ++e) {
+                lre[wb + e * C::ESTRIDE] = v[e].r;
+                lim[wb + e * C::ESTRIDE] = v[e].i;
+            }
+        }
+        __syncthreads();
+        // output slab of (segment b, taper k): wave-uniform base, 32-bit lane offsets
+        char* const slab = reinterpret_cast<char*>(a.out) +
+                           ((size_t)b * kout + (MEAN ? 0 : k)) * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
+        // partner of f = j + T*e is N - f: idx(N - j, h) - e*ESTRIDE (index N = spare slot, unused value)
+        const int pb = C::idx(N - j, h) - 7 * C::ESTRIDE;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            C2 xa, xb;   // xa = X(c0, c1), xb = X(c2, c3)
+            int f;
+            if (e < 8) {
+                f = j + T * e;
+                const C2 z = v[e];
+                C2 zp;
+                zp.r = lre[pb + (7 - e) * C::ESTRIDE];
+                zp.i = lim[pb + (7 - e) * C::ESTRIDE];
+                if (f == 0) zp = z;
+                xa.r = (z.r + zp.r) * hs;
+                xa.i = (z.i - zp.i) * hs;
+                xb.r = (z.i + zp.i) * hs;
+                xb.i = (zp.r - z.r) * hs;
+            } else {
+                if (j != 0) break;
+                f = N / 2;
+                xa.r = v[8].r * a.scale;
+                xb.r = v[8].i * a.scale;
+                xa.i = xb.i = splat(0.f);
+            }
+            if (MEAN) {
+                if (CPLX) {
+                    ma[e] = cadd(ma[e], xa);
+                    mb[e] = cadd(mb[e], xb);
+                } else if (OUTK == 0) {
+                    ma[e].r += xa.r * xa.r + xa.i * xa.i;
+                    ma[e].i += xb.r * xb.r + xb.i * xb.i;
+                } else {
+                    ma[e].r += v2f{convert_real_slow(make_float2(xa.r[0], xa.i[0]), a.out_kind),
+                                   convert_real_slow(make_float2(xa.r[1], xa.i[1]), a.out_kind)};
+                    ma[e].i += v2f{convert_real_slow(make_float2(xb.r[0], xb.i[0]), a.out_kind),
+                                   convert_real_slow(make_float2(xb.r[1], xb.i[1]), a.out_kind)};
+                }
+                continue;
+            }
+            if (fast) {
+                const unsigned o = ((unsigned)f * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+                if ((SPYFFT_ABL & 4) && xa.r[0] + xa.r[1] + xa.i[0] + xa.i[1] + xb.r[0] + xb.r[1] + xb.i[0] + xb.i[1] != 12345.f)
+                    continue;
+                if (CPLX) {
+                    const float4 lo = make_float4(xa.r[0], xa.i[0], xa.r[1], xa.i[1]);
+                    const float4 hi = make_float4(xb.r[0], xb.i[0], xb.r[1], xb.i[1]);
+                    if (G == 1 && e < 8) {
+                        // The L2 accepts one write request per line and clock whatever its size, and every lane
+                        // owns a different row (bin): let lanes (2i, 2i+1) write the two 16-byte halves of the
+                        // SAME row with one instruction (one 32-byte request instead of two 16-byte ones):
+                        // the even lane hands over its upper half, the odd lane its lower half.
+                        const bool odd = (j & 1) != 0;
+                        const float4 give = odd ? lo : hi;
+                        const float4 got = make_float4(lane_swap1(give.x), lane_swap1(give.y), lane_swap1(give.z),
+                                                       lane_swap1(give.w));
+                        const unsigned rb = (unsigned)a.nchan * OSZ;     // bytes per bin row
+                        const unsigned oe = odd ? o - rb + 16u : o;      // row of the even lane, this lane's half
+                        stg<float4>(slab, oe, odd ? got : lo);
+                        stg<float4>(slab, oe + rb, odd ? hi : got);
+                    } else {
+                        stg<float4>(slab, o, lo);
+                        stg<float4>(slab, o + 16u, hi);
+                    }
+                } else if (OUTK == 0) {
+                    const v2f pa = xa.r * xa.r + xa.i * xa.i, pb2 = xb.r * xb.r + xb.i * xb.i;
+                    stg<float4>(slab, o, make_float4(pa[0], pa[1], pb2[0], pb2[1]));
+                } else {
+                    stg<float4>(slab, o, make_float4(convert_real_slow(make_float2(xa.r[0], xa.i[0]), a.out_kind),
+                                                     convert_real_slow(make_float2(xa.r[1], xa.i[1]), a.out_kind),
+                                                     convert_real_slow(make_float2(xb.r[0], xb.i[0]), a.out_kind),
+                                                     convert_real_slow(make_float2(xb.r[1], xb.i[1]), a.out_kind)));
+                }
+            } else {
+                const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
+                if (fi >= 0) {
+                    const float2 X[4] = {make_float2(xa.r[0], xa.i[0]), make_float2(xa.r[1], xa.i[1]),
+                                         make_float2(xb.r[0], xb.i[0]), make_float2(xb.r[1], xb.i[1])};
+                    const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!has[i]) continue;
+                        if (CPLX) stg<float2>(slab, o + i * OSZ, X[i]);
+                        else stg<float>(slab, o + i * OSZ, convert_real<OUTK>(X[i], a.out_kind));
+                    }
+                }
+            }
+        }
+        __syncthreads();  // LDS is reused by the next taper
+    }
+
+    if (MEAN) {
+        const float kk = 1.0f / (float)a.ntaper;
+        char* const slab = reinterpret_cast<char*>(a.out) + (size_t)b * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            if (e == 8 && j0 != 0) break;
+            const int f = (e < 8) ? j0 + T * e : N / 2;
+            const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
+            if (fi < 0) continue;
+            const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+            const float nt = (float)a.ntaper;
+            if (CPLX) {
+                const float2 X[4] = {make_float2(ma[e].r[0] / nt, ma[e].i[0] / nt), make_float2(ma[e].r[1] / nt, ma[e].i[1] / nt),
+                                     make_float2(mb[e].r[0] / nt, mb[e].i[0] / nt), make_float2(mb[e].r[1] / nt, mb[e].i[1] / nt)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (has[i]) stg<float2>(slab, o + i * OSZ, X[i]);
+            } else if (fast) {
+                stg<float4>(slab, o, make_float4(ma[e].r[0] / nt, ma[e].r[1] / nt, ma[e].i[0] / nt, ma[e].i[1] / nt));
+            } else {
+                const float X[4] = {ma[e].r[0] / nt, ma[e].r[1] / nt, ma[e].i[0] / nt, ma[e].i[1] / nt};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (has[i]) stg<float>(slab, o + i * OSZ, X[i]);
+            }
+            (void)kk;
+        }
+    }
+}
+
+}  // namespace spyfft

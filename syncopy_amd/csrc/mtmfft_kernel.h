@@ -12,6 +12,14 @@
 #pragma once
 #include "fft_device.h"
 
+// development probes (tools/fft_probe.hip): extra kernel attributes / ablation bits, off in the library
+#ifndef SPYFFT_KATTR
+#define SPYFFT_KATTR
+#endif
+#ifndef SPYFFT_ABL
+#define SPYFFT_ABL 0
+#endif
+
 namespace spyfft {
 
 struct MtmArgs {
@@ -71,7 +79,7 @@ __device__ __forceinline__ float convert_real(float2 x, int kind) {
 //  - loads are branch-free (clamped index + select): the 16 row loads of a
 //    thread are all in flight together.
 template <int LOG2N, int G, int OUTK, bool MEAN>
-__global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) mtmfft_pow2_kernel(MtmArgs a) {
+__global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmfft_pow2_kernel(MtmArgs a) {
     using C = Cfg<LOG2N, G>;
     constexpr bool CPLX = (OUTK == 2);
     constexpr int N = C::N, T = C::T;
@@ -196,7 +204,7 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) mtmfft_pow2_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const unsigned n = (unsigned)(j + T * e);
-            const float wl = ldg<float>(w, min(n, nsig_m1) * 4u);
+            const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, min(n, nsig_m1) * 4u);
             const float wn = (n <= nsig_m1) ? wl : 0.f;
             v[e] = make_float2(wn * x0[e], wn * x1[e]);
         }
@@ -258,7 +266,7 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) mtmfft_pow2_kernel(
                 }
             } else {
                 const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
-                if (fi >= 0) {
+                if (fi >= 0 && !((SPYFFT_ABL & 4) && xa.x != 12345.f)) {
                     const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
                     if (CPLX) {
                         if (has1 && pair16) {

@@ -74,7 +74,7 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
     if pow2:
         log2n = int(np.log2(nfft))
         if G is None:
-            G = {8: 16, 9: 8, 10: 4, 11: 4, 12: 2, 13: 2, 14: 1}[log2n]
+            G = {8: 16, 9: 8, 10: 4, 11: 2, 12: 1, 13: 1, 14: 1}[log2n]
         tw = twiddles(nfft)
         rc = lib().emu_mtmfft_pow2(
             C.c_int(log2n), C.c_int(G), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),

@@ -16,6 +16,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
 #include "../../syncopy_amd/csrc/csd_kernel.h"
+#include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
 #include "../../syncopy_amd/csrc/cwt_kernel.h"
 #include "../../syncopy_amd/csrc/granger_kernels.h"
 
@@ -47,11 +48,31 @@ void run_pow2_mode(const MtmArgs& a, unsigned grid, int outk, int mean, long onl
     }
 }
 
+template <int LOG2N, int G, int OUTK, bool MEAN>
+void run_quad(const MtmArgs& a, unsigned grid, long only_block) {
+    using C = spyfft::Cfg2<LOG2N, G>;
+    emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES,
+                [&] { spyfft::mtmfft_quad_kernel<LOG2N, G, OUTK, MEAN>(a); }, only_block);
+}
+
+template <int LOG2N, int G>
+void run_quad_mode(const MtmArgs& a, unsigned grid, int outk, int mean, long only_block) {
+    switch (outk * 2 + mean) {
+        case 0: run_quad<LOG2N, G, 0, false>(a, grid, only_block); break;
+        case 1: run_quad<LOG2N, G, 0, true>(a, grid, only_block); break;
+        case 2: run_quad<LOG2N, G, 1, false>(a, grid, only_block); break;
+        case 3: run_quad<LOG2N, G, 1, true>(a, grid, only_block); break;
+        case 4: run_quad<LOG2N, G, 2, false>(a, grid, only_block); break;
+        default: run_quad<LOG2N, G, 2, true>(a, grid, only_block); break;
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-// Mirrors the argument marshalling of spyhip_fft_exec for the power-of-two kernel.
+// Mirrors the argument marshalling of spyhip_fft_exec for the power-of-two kernels
+// (packed quad kernel up to 2^13, pair kernel for 2^14).
 // All pointers are host pointers.  Returns 0, or -1 for an unsupported (log2n, G).
 int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int* chan_idx,
                     const long long* seg_start, const long long* seg_lo, const long long* seg_hi, int nseg,
@@ -65,9 +86,10 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
     a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
     a.out_kind = out_kind; a.out = out;
-    const int npairs = (nchan + 1) / 2;
-    a.npg = (npairs + G - 1) / G;
-    int S = 16 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+    const bool quad = log2n <= 13;
+    const int nitem = quad ? (nchan + 3) / 4 : (nchan + 1) / 2;
+    a.npg = (nitem + G - 1) / G;
+    int S = (quad ? 8 : 16) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
     a.S = S;
     a.ncl = (a.npg + S - 1) / S;
     const long long nclusters = (long long)nseg * a.ncl;
@@ -75,14 +97,12 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
     const int mean = keeptapers ? 0 : 1;
     switch (log2n * 100 + G) {
-        case 816: run_pow2_mode<8, 16>(a, grid, outk, mean, -1); break;
-        case 908: run_pow2_mode<9, 8>(a, grid, outk, mean, -1); break;
-        case 1004: run_pow2_mode<10, 4>(a, grid, outk, mean, -1); break;
-        case 1104: run_pow2_mode<11, 4>(a, grid, outk, mean, -1); break;
-        case 1201: run_pow2_mode<12, 1>(a, grid, outk, mean, -1); break;
-        case 1202: run_pow2_mode<12, 2>(a, grid, outk, mean, -1); break;
-        case 1204: run_pow2_mode<12, 4>(a, grid, outk, mean, -1); break;
-        case 1302: run_pow2_mode<13, 2>(a, grid, outk, mean, -1); break;
+        case 816: run_quad_mode<8, 16>(a, grid, outk, mean, -1); break;
+        case 908: run_quad_mode<9, 8>(a, grid, outk, mean, -1); break;
+        case 1004: run_quad_mode<10, 4>(a, grid, outk, mean, -1); break;
+        case 1102: run_quad_mode<11, 2>(a, grid, outk, mean, -1); break;
+        case 1201: run_quad_mode<12, 1>(a, grid, outk, mean, -1); break;
+        case 1301: run_quad_mode<13, 1>(a, grid, outk, mean, -1); break;
         case 1401: run_pow2_mode<14, 1>(a, grid, outk, mean, -1); break;
         default: return -1;
     }
@@ -182,16 +202,28 @@ int emu_cwt(int log2n, int G, const float* data, long long ld, const int* chan_i
     a.ntime_out = ntime_out; a.out = out; a.accumulate = accumulate;
     std::vector<double> trend((size_t)nseg * nchan * 2, 0.0);
     a.trend = trend.data();
-    if (detrend >= 0)
-        emu::launch(dim3((nchan + 63) / 64, nseg), dim3(256), 0, [&] { spyfft::cwt_trend_kernel(a, trend.data()); });
+    if (detrend >= 0) {
+        std::vector<double> part(trend.size() * spyfft::CWT_TREND_SPLITS, 0.0);
+        emu::launch(dim3((nchan + 63) / 64, spyfft::CWT_TREND_SPLITS, nseg), dim3(256), 0,
+                    [&] { spyfft::cwt_trend_partial_kernel(a, part.data()); });
+        emu::launch(dim3((unsigned)(((size_t)nseg * nchan + 255) / 256)), dim3(256), 0,
+                    [&] { spyfft::cwt_trend_final_kernel(a, part.data(), trend.data()); });
+    }
     const unsigned grid = (unsigned)nseg * (unsigned)((nchan + G - 1) / G) * (unsigned)nblocks;
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    // one chunk holding every segment (cwt.hip sizes chunks by memory; the kernels are the same)
+    std::vector<float> stage((size_t)nseg * nscales * nchan * nsig * (outk == 2 ? 2 : 1), 0.f);
+    a.stage = stage.data();
+    a.seg0 = 0;
+    const dim3 sgrid((nsig + 63) / 64, nscales, nseg);
 #define CWT_CASE(L, GG) \
     if (log2n == L && G == GG) { \
         using C = spyfft::Cfg<L, GG>; \
         if (outk == 2) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt_kernel<L, GG, 2>(a); }); \
         else if (outk == 0) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt_kernel<L, GG, 0>(a); }); \
         else emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt_kernel<L, GG, 1>(a); }); \
+        if (outk == 2) emu::launch(sgrid, dim3(256), 0, [&] { spyfft::cwt_scatter_kernel<float2>(a); }); \
+        else emu::launch(sgrid, dim3(256), 0, [&] { spyfft::cwt_scatter_kernel<float>(a); }); \
         return 0; \
     }
     CWT_CASE(10, 2) CWT_CASE(11, 2) CWT_CASE(12, 2) CWT_CASE(13, 1) CWT_CASE(14, 1)

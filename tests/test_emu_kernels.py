@@ -31,11 +31,20 @@ def _fft_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=Fa
         assert_parity(out[b], ref[0], what=f"segment {b}")
 
 
-@pytest.mark.parametrize("log2n,G", [(8, 16), (9, 8), (10, 4), (11, 4), (12, 1), (12, 2), (12, 4), (13, 2), (14, 1)])
+@pytest.mark.parametrize("log2n,G", [(8, 16), (9, 8), (10, 4), (11, 2), (12, 1), (13, 1), (14, 1)])
 def test_pow2_kernel_every_length(log2n, G):
     n = 1 << log2n
-    nchan = 2 * G + 1 if n <= 4096 else 3          # odd channel count: dummy partner in the last pair
+    nchan = 4 * G + 1 if n <= 2048 else (5 if n == 4096 else 3)   # ragged channel count: padded quads / pairs
     _fft_case(n, n, nchan, 2, "pow", False, 0, G=G, nseg=1)
+
+
+def test_pow2_kernel_full_quads_fast_epilogue():
+    # channel counts that are multiples of 4 with every bin kept take the straight-line store path
+    _fft_case(1024, 1024, 8, 2, "pow", True, 0)
+    _fft_case(512, 512, 4, 2, "fourier", True, 0)
+    _fft_case(256, 256, 8, 3, "pow", False, 1)
+    _fft_case(512, 512, 8, 2, "abs", True, -1)
+    _fft_case(300, 512, 6, 2, "fourier", True, 0)       # even, not a multiple of 4
 
 
 def test_pow2_kernel_modes():
@@ -82,7 +91,7 @@ def test_fp32_fft_error_level():
     n = 4096
     data = rng.normal(size=(n, 4)).astype("f4")
     z = np.array([0])
-    out = E.fft_exec(data, z, z, z + n, n, n, np.ones((1, n)), 1.0, -1, False, None, "fourier", True, G=2)[0, 0]
+    out = E.fft_exec(data, z, z, z + n, n, n, np.ones((1, n)), 1.0, -1, False, None, "fourier", True)[0, 0]
     ref = np.fft.rfft(data.astype("f8"), axis=0)
     rms = np.sqrt((np.abs(ref) ** 2).mean())
     assert np.abs(out - ref).max() / rms < 1e-6
