@@ -42,6 +42,7 @@ extern "C" int spyhip_ctx_create(int device, spyhip_ctx** out) {
 }
 
 extern "C" int spyhip_ctx_destroy(spyhip_ctx* ctx) {
+    if (ctx && ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
     return 0;
 }

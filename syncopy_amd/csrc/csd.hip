@@ -1,5 +1,7 @@
 // Host side of K4/K5: cross-spectral accumulation, finalisation and coherence
 // normalisation (spyhip_csd_accumulate / spyhip_csd_finalize / spyhip_coh_normalize).
+#include <algorithm>
+
 #include "spy_common.h"
 #include "csd_kernel.h"
 
@@ -8,7 +10,7 @@ using spycsd::CsdArgs;
 namespace {
 
 template <int TA, int TB>
-int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item_end) {
+int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item_end, int nsplit = 1) {
     auto kern = spycsd::csd_accum_kernel<TA, TB>;
     const int per = 4 * (TA + TB);
     // frequencies a workgroup can touch: items [i0, i0+per) span at most this many f
@@ -16,25 +18,26 @@ int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item
     if (per % a.ntiles != 0 && a.ntiles > 1) nfb += 1;
     if (nfb > a.F) nfb = a.F;
     const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
-    // a chunk holds at most 512 threads x CSD_PF staged elements; LDS is double buffered
+    // a chunk holds at most 512 threads x CSD_PF staged elements; LDS holds three chunks
     const size_t chunk_max = (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2);
     int kb = 32;
-    while (kb > 2 && (size_t)kb * rowbytes > chunk_max) kb -= 2;
-    if ((size_t)kb * rowbytes > chunk_max || 2 * (size_t)kb * rowbytes > ctx->lds_per_block) {
+    while (kb > 4 && (size_t)kb * rowbytes > chunk_max) kb -= 4;
+    if ((size_t)kb * rowbytes > chunk_max || 3 * (size_t)kb * rowbytes > ctx->lds_per_block) {
         spy::set_error("csd_accumulate: %d channels do not fit the LDS staging buffer", a.C);
         return -3;
     }
-    if (kb > a.nrows) kb = (int)((a.nrows + 1) & ~1LL);
+    const long long rows_wg = nsplit > 1 ? a.rows_per_split : a.nrows;
+    if (kb > rows_wg) kb = (int)((rows_wg + 3) & ~3LL);
     a.kb = kb;
     a.item_base = item_base;
     a.item_end = item_end;
-    const size_t lds = 2 * (size_t)kb * rowbytes;
+    const size_t lds = 3 * (size_t)kb * rowbytes;
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long grid = (item_end - item_base + per - 1) / per;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(spycsd::CSD_THREADS), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nsplit), dim3(spycsd::CSD_THREADS), lds, ctx->stream, a);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -63,9 +66,37 @@ extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_
         const long long per = 36, nwg = (a.nitems + per - 1) / per;
         const long long full = (nwg / ctx->num_cu) * ctx->num_cu, rem = nwg - full;
         if (full > 0 && rem > 0 && rem * 4 <= ctx->num_cu) {
-            const int rc = launch_accum<5, 4>(ctx, a, 0, full * per);
+            int rc = launch_accum<5, 4>(ctx, a, 0, full * per);
             if (rc) return rc;
-            return launch_accum<1, 1>(ctx, a, full * per, a.nitems);
+            // tail: 1 tile per wave AND the rows split over blockIdx.y, so that its rem*4.5*nsplit short
+            // workgroups fill the chip once; splits > 0 leave partial sums in library scratch that a
+            // fixed-order reduction adds afterwards (deterministic, no atomics)
+            const long long tail_wg = (a.nitems - full * per + 7) / 8;
+            long long nsplit = ctx->num_cu / tail_wg;
+            const long long max_split = (nrows + 63) / 64;          // at least 64 rows per split
+            if (nsplit > max_split) nsplit = max_split;
+            if (nsplit < 2) return launch_accum<1, 1>(ctx, a, full * per, a.nitems);
+            const int f0 = (int)(full * per / a.ntiles), nf = nfreq - f0;
+            const size_t need = (size_t)(nsplit - 1) * nf * nchan * nchan * sizeof(float2);
+            if (need > ctx->scratch_bytes) {
+                if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+                SPY_HIP_CHECK(hipMalloc(&ctx->scratch, need));
+                ctx->scratch_bytes = need;
+            }
+            a.rows_per_split = ((nrows + nsplit - 1) / nsplit + 3) & ~3LL;
+            nsplit = (nrows + a.rows_per_split - 1) / a.rows_per_split;
+            a.part = reinterpret_cast<float2*>(ctx->scratch);
+            a.part_f0 = f0;
+            a.part_nf = nf;
+            rc = launch_accum<1, 1>(ctx, a, full * per, a.nitems, (int)nsplit);
+            if (rc) return rc;
+            if (nsplit > 1) {
+                const long long n = (long long)nf * nchan * nchan;
+                hipLaunchKernelGGL(spycsd::csd_reduce_parts_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)),
+                                   dim3(256), 0, ctx->stream, a.acc, a.part, (int)nsplit - 1, f0, nf, nchan);
+                SPY_HIP_CHECK(hipGetLastError());
+            }
+            return 0;
         }
         return launch_accum<5, 4>(ctx, a, 0, a.nitems);
     }

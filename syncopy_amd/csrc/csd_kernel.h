@@ -35,7 +35,12 @@ struct CsdArgs {
     long long item_base;  // this launch covers items [item_base, item_end)
     long long item_end;
     int cpad;             // nt*32
-    int kb;               // rows per LDS chunk (even)
+    int kb;               // rows per LDS chunk (multiple of 4)
+    // row split (tail re-cut): blockIdx.y = s works on rows [s*rows_per_split, (s+1)*rows_per_split);
+    // split 0 adds into acc, split s > 0 stores its partial tile sums into part[s-1][f - part_f0]
+    long long rows_per_split;   // 0 = no split
+    float2* part;
+    int part_f0, part_nf;
 };
 
 __device__ __forceinline__ void tile_of(int tt, int& ti, int& tj) {
@@ -79,6 +84,11 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     const int ntile_w = wave < 4 ? TA : TB;                                  // wave-uniform
     const int first_w = wave < 4 ? wave * TA : 4 * TA + (wave - 4) * TB;
 
+    const int split = a.rows_per_split > 0 ? (int)blockIdx.y : 0;
+    const long long row_lo = (long long)split * a.rows_per_split;
+    if (row_lo >= a.nrows && split > 0) return;
+    const long long nrows = (a.rows_per_split > 0 && row_lo + a.rows_per_split < a.nrows) ? a.rows_per_split
+                                                                                          : a.nrows - row_lo;
     const long long item0 = a.item_base + (long long)blockIdx.x * PER;
     long long last = item0 + PER;
     if (last > a.item_end) last = a.item_end;
@@ -112,7 +122,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     const int kr0 = tid / rowlen, cc0 = tid % rowlen;
     const size_t rowstride = (size_t)a.F * a.C;            // float2 elements between rows r and r+1
     const unsigned rowbytes = (unsigned)rowstride * 8u;    // a chunk spans < 4 GiB: 32-bit lane offsets
-    const float2* fbase = a.spec + (size_t)f_lo * a.C;
+    const float2* fbase = a.spec + (size_t)row_lo * rowstride + (size_t)f_lo * a.C;
 
     float2 pf[CSD_PF];
     unsigned okmask = 0;
@@ -122,7 +132,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         // row loop into ~100 long-lived VGPRs (offsets + predicates of all CSD_PF elements)
         int kr = opaque_i(kr0), cc = opaque_i(cc0);
         const char* base = reinterpret_cast<const char*>(fbase + (size_t)r0 * rowstride);   // wave-uniform
-        const long long rleft = a.nrows - r0;
+        const long long rleft = nrows - r0;
 #pragma unroll
         for (int i = 0; i < CSD_PF; ++i) {
             // branch-free: clamp to a valid element, load unconditionally, select afterwards - a load
@@ -148,54 +158,96 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         }
     };
 
-    // LDS is double buffered: chunk i+1 is written into the other half while chunk i is being
-    // multiplied, so there is ONE barrier per chunk and no wave waits for the stage.
-    // (buffers addressed as X[buf*total + ...]: a pointer array would decay to flat addressing)
+    // LDS holds THREE chunks.  Iteration c multiplies chunk c out of buffer c%3 while chunk c+2 (fetched
+    // into registers during iteration c-1) is written into buffer (c+2)%3 and chunk c+3 is being fetched:
+    //  - write-after-read: buffer (c+2)%3 was last read in iteration c-1, behind that iteration's barrier;
+    //  - read-after-write: buffer (c+1)%3 was written at the top of iteration c-1, also behind that barrier,
+    // so the operand fragments of the NEXT row pair - including the first pair of chunk c+1 - are read
+    // while the MFMA chain of the current pair runs and no wave ever waits on LDS latency; one barrier
+    // per chunk remains.  (buffers addressed as X[b*total + ...]: a pointer array decays to flat addressing)
+    const long long nchunk = (nrows + a.kb - 1) / a.kb;
     fetch(0);
 #pragma unroll
     for (int i = 0; i < CSD_PF; ++i)
         if (tid + CSD_THREADS * i < total)
             X[tid + CSD_THREADS * i] = ((okmask >> i) & 1u) ? pf[i] : make_float2(0.f, 0.f);
-    if (a.kb < a.nrows) fetch(a.kb);
-    __syncthreads();
-    int buf = 0;
-    for (long long r0 = 0; r0 < a.nrows; r0 += a.kb, buf ^= 1) {
-        bool more = r0 + a.kb < a.nrows;
-#ifdef CSD_DBG_NOSTAGE
-        more = false;
-#endif
-        if (more) {
-            // chunk r0+kb (fetched during the previous iteration) -> other buffer; then start fetching r0+2kb
-            const int nxt = (buf ^ 1) * total;
+    if (nchunk > 1) {
+        fetch(a.kb);
 #pragma unroll
-            for (int i = 0; i < CSD_PF; ++i)
-                if (tid + CSD_THREADS * i < total)
-                    X[nxt + tid + CSD_THREADS * i] = ((okmask >> i) & 1u) ? pf[i] : make_float2(0.f, 0.f);
-            if (r0 + 2 * a.kb < a.nrows) fetch(r0 + 2 * a.kb);
+        for (int i = 0; i < CSD_PF; ++i)
+            if (tid + CSD_THREADS * i < total)
+                X[total + tid + CSD_THREADS * i] = ((okmask >> i) & 1u) ? pf[i] : make_float2(0.f, 0.f);
+    }
+    if (nchunk > 2) fetch(2LL * a.kb);
+    __syncthreads();
+
+    // Operand fragments of the first NPRE tiles of the NEXT row pair are read while the current pair's
+    // MFMA chain runs (registers for all TA tiles of two row pairs do not fit beside the accumulators):
+    // their MFMAs (>= 512 cycles) then cover the LDS latency of the remaining tiles' reads.
+    constexpr int NPRE = TA >= 4 ? 2 : 1;
+    float2 pa[NPRE], pb[NPRE];
+    auto prefetch = [&](int base, int ks) {
+        const float2* xr = X + (base + (ks + lhi) * rowlen);
+#pragma unroll
+        for (int t = 0; t < NPRE; ++t) {
+            pa[t] = xr[aoff[t]];
+            pb[t] = xr[boff[t]];
         }
-        // ---- rank-2 updates: all operand reads of a row pair are issued before its first MFMA
-        const int cur = buf * total;
+    };
+    auto mfma4 = [&](int t, float2 av, float2 bv) {
+        accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accr[t], 0, 0, 0);
+        acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acci[t], 0, 0, 0);
+        accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, accr[t], 0, 0, 0);
+        acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av.x, bv.y, acci[t], 0, 0, 0);
+    };
+
+    prefetch(0, 0);
+    int b0 = 0;                                            // buffer of the current chunk (c % 3)
+    for (long long c = 0; c < nchunk; ++c) {
+        const int b1 = (b0 == 2) ? 0 : b0 + 1, b2 = (b1 == 2) ? 0 : b1 + 1;
+        bool stage = c + 2 < nchunk;
+#ifdef CSD_DBG_NOSTAGE
+        stage = false;
+#endif
+        const int cur = b0 * total, nx1 = b1 * total;
         for (int ks = 0; ks < a.kb; ks += 2) {
+            if (stage && ks == 0) {
+                const int nxt = b2 * total;
+#pragma unroll
+                for (int i = 0; i < CSD_PF; ++i)
+                    if (tid + CSD_THREADS * i < total)
+                        X[nxt + tid + CSD_THREADS * i] = ((okmask >> i) & 1u) ? pf[i] : make_float2(0.f, 0.f);
+                if (c + 3 < nchunk) fetch((c + 3) * a.kb);
+            }
             const float2* xr = X + (cur + (ks + lhi) * rowlen);
             float2 av[TA], bv[TA];
 #pragma unroll
-            for (int t = 0; t < TA; ++t) {
+            for (int t = 0; t < NPRE; ++t) {
+                av[t] = pa[t];
+                bv[t] = pb[t];
+            }
+#pragma unroll
+            for (int t = NPRE; t < TA; ++t) {
                 av[t] = xr[aoff[t]];
                 bv[t] = xr[boff[t]];
             }
             sched_fence_csd();      // keep the reads ahead of the MFMA chain (hipcc otherwise re-sinks them)
 #pragma unroll
-            for (int t = 0; t < TA; ++t) {
+            for (int t = 0; t < NPRE; ++t) mfma4(t, av[t], bv[t]);
+            sched_fence_csd();
+            if (ks + 2 < a.kb) prefetch(cur, ks + 2);
+            else if (c + 1 < nchunk) prefetch(nx1, 0);
+            sched_fence_csd();
+#pragma unroll
+            for (int t = NPRE; t < TA; ++t) {
                 if (t >= TB && t >= ntile_w) break;           // waves 4-7 own TB tiles
-                accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv[t].x, accr[t], 0, 0, 0);
-                acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[t].x, acci[t], 0, 0, 0);
-                accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[t].y, accr[t], 0, 0, 0);
-                acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[t].x, bv[t].y, acci[t], 0, 0, 0);
+                mfma4(t, av[t], bv[t]);
             }
         }
 #ifndef CSD_DBG_NOBARRIER
         __syncthreads();
 #endif
+        b0 = b1;
     }
 
     // ---- acc += tile (each (f, tile) is owned by exactly one wave: plain read-modify-write)
@@ -209,18 +261,46 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         const int j = tj * 32 + l31;
         // read-modify-write of the 16 rows this lane holds: all loads first (clamped, branch-free), then stores
         const int jc = j < a.C ? j : a.C - 1;
-        float2* const pbase = a.acc + (size_t)f * a.C * a.C + jc;
-        float2 old[16];
+        float2* const pbase = (split == 0 ? a.acc + (size_t)f * a.C * a.C
+                                          : a.part + ((size_t)(split - 1) * a.part_nf + (f - a.part_f0)) * a.C * a.C) + jc;
+        if (split == 0) {
+            float2 old[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            old[r] = pbase[(size_t)(i < a.C ? i : a.C - 1) * a.C];
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                old[r] = pbase[(size_t)(i < a.C ? i : a.C - 1) * a.C];
+            }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (i < a.C && j < a.C) pbase[(size_t)i * a.C] = make_float2(old[r].x + accr[t][r], old[r].y + acci[t][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (i < a.C && j < a.C) pbase[(size_t)i * a.C] = make_float2(old[r].x + accr[t][r], old[r].y + acci[t][r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (i < a.C && j < a.C) pbase[(size_t)i * a.C] = make_float2(accr[t][r], acci[t][r]);
+            }
         }
+    }
+}
+
+// acc[f, i, j] += sum_s part[s][f - f0][i][j] over the lower-triangle tiles (fixed order: deterministic)
+__global__ void __launch_bounds__(256) csd_reduce_parts_kernel(float2* acc, const float2* part, int nparts, int f0, int nf,
+                                                               int C) {
+    const long long n = (long long)nf * C * C;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int j = (int)(e % C);
+        const int i = (int)((e / C) % C);
+        if ((i >> 5) < (j >> 5)) continue;
+        float2 v = acc[(long long)f0 * C * C + e];
+        for (int s = 0; s < nparts; ++s) {
+            const float2 p = part[(long long)s * n + e];
+            v.x += p.x;
+            v.y += p.y;
+        }
+        acc[(long long)f0 * C * C + e] = v;
     }
 }
 

@@ -21,6 +21,8 @@ struct spyhip_ctx {
     int device = 0;
 #ifndef SPY_HOST_EMU
     hipStream_t stream = nullptr;
+    void* scratch = nullptr;        // library-owned device scratch (partial sums of split launches), grown on demand
+    size_t scratch_bytes = 0;
 #endif
     int num_cu = 256;
     size_t lds_per_block = 160 * 1024;

@@ -165,11 +165,11 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     if (nfb > F) nfb = F;
     const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
     int kb = 32;
-    while (kb > 2 && (size_t)kb * rowbytes > (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2)) kb -= 2;
-    if (kb > nrows) kb = (int)((nrows + 1) & ~1LL);
+    while (kb > 4 && (size_t)kb * rowbytes > (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2)) kb -= 4;
+    if (kb > nrows) kb = (int)((nrows + 3) & ~3LL);
     a.kb = kb;
     a.item_base = 0; a.item_end = a.nitems;
-    const size_t lds = 2 * (size_t)kb * rowbytes;
+    const size_t lds = 3 * (size_t)kb * rowbytes;
     const unsigned grid = (unsigned)((a.nitems + per - 1) / per);
     const unsigned T = spycsd::CSD_THREADS;
     if (ta == 5) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4>(a); });

@@ -119,6 +119,28 @@ def test_fft_zero_extended_segments(be):
         assert_parity(out[b, 0], ref, what=f"segment {b}")
 
 
+def test_csd_tail_row_split(be):
+    """259 workgroups on 256 CUs with enough rows that the re-cut tail is also split over rows (partial sums in
+    library scratch + fixed-order reduction); reference = complex128 matrix products of the same spectra."""
+    C, F, R = 256, 259, 300
+    g = torch.Generator(device="cuda").manual_seed(3)
+    spec = torch.view_as_complex(torch.randn((R, F, C, 2), generator=g, device="cuda", dtype=torch.float32))
+    acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    be.csd_accumulate(spec[:130].contiguous(), acc)
+    be.csd_accumulate(spec[130:].contiguous(), acc)
+    be.csd_finalize(acc, 1.0 / R)
+    got = acc.cpu().numpy()
+    for f in (0, 100, 255, 256, 257, 258):
+        x = spec[:, f, :].to(torch.complex128)
+        ref = (x.T @ x.conj() / R).cpu().numpy()
+        assert_parity(got[f], ref.astype(np.complex64), what=f"csd f={f}")
+    be.csd_accumulate(spec, acc)                      # same call again: results must be bit-identical (deterministic)
+    a1 = acc.clone()
+    acc.copy_(torch.from_numpy(got).cuda())
+    be.csd_accumulate(spec, acc)
+    assert torch.equal(torch.view_as_real(a1), torch.view_as_real(acc))
+
+
 @pytest.mark.parametrize("C,F,R", [(5, 33, 14), (16, 101, 140), (40, 17, 35), (70, 9, 64), (256, 5, 70),
                                    (256, 259, 10)])    # 259 workgroups on 256 CUs: exercises the re-cut tail
 def test_csd_accumulate_vs_oracle(be, C, F, R):

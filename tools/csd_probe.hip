@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
     hipMemset(acc, 0, (size_t)F * C * C * 8);
     a.spec = (const float2*)spec; a.nrows = rows; a.F = F; a.C = C; a.acc = (float2*)acc;
     a.nt = 8; a.ntiles = 36; a.nitems = (long long)F * 36; a.cpad = 256; a.kb = 16; a.item_base = 0; a.item_end = a.nitems;
-    const size_t lds = 2 * 16 * 256 * 8;
+    const size_t lds = 3 * 16 * 256 * 8;
     auto kern = spycsd::csd_accum_kernel<5, 4>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
