@@ -116,6 +116,7 @@ def main():
     starts_all = torch.arange(T, device="cuda", dtype=torch.int64) * N
     plan = be.FFTPlan(N, N, C, tapers, scale, detrend=0, demean_taper=False, freq_idx=None, output="fourier",
                       keeptapers=True)
+    blocked = plan.set_blocked(True)       # FFT -> CSD hand-over in the channel-blocked layout (as CrossSpectra.compute_hip)
     B = min(args.batch, T)
     spec = torch.empty(plan.out_shape(B), dtype=torch.complex64, device="cuda")
     acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
@@ -125,14 +126,14 @@ def main():
         acc.zero_()
         for b0 in range(0, T, B):
             nb = min(B, T - b0)
-            sp = spec[:nb]
+            sp = spec[:nb * (K if blocked else 1)]
             if timed:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
             plan.execute(data, starts_all[b0:b0 + nb], out=sp)
             if timed:
                 e1.record()
-            be.csd_accumulate(sp, acc)
+            be.csd_accumulate(sp, acc, blocked=blocked)
             if timed:
                 e2.record()
                 ev_fft.append((e0, e1, nb))

@@ -94,6 +94,12 @@ int spyhip_fft_plan_destroy(spyhip_fft_plan* plan);
 int spyhip_fft_exec(spyhip_fft_plan* plan, const float* data_d, int64_t ld,
                     const int32_t* chan_idx_d, const int64_t* seg_start_d, const int64_t* seg_lo_d,
                     const int64_t* seg_hi_d, int nseg, void* out_d);
+/* Internal hand-over layout between spyhip_fft_exec and spyhip_csd_accumulate_blocked (the coherence path
+ * never shows the per-trial spectra to the host): with on != 0 a FOURIER / keeptapers=1 plan writes
+ * (nseg*ntaper, ceil(nchan/4), nfsel, 4) complex64 - the four channels of a quad contiguous in frequency -
+ * so that every wave stores whole 2-KiB runs.  Channels beyond nchan in the last quad are written as 0.
+ * Returns -3 for plans that cannot use it (other outputs, nfft not a power of two in 256..8192). */
+int spyhip_fft_plan_set_blocked(spyhip_fft_plan* plan, int on);
 /* name of the dominant kernel a plan launches (for rocprof matching) */
 const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* plan);
 
@@ -111,6 +117,10 @@ const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* plan);
  * diagonal, 32x32 tile granularity) is maintained until spyhip_csd_finalize. */
 int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
                           void* acc_d);
+/* same accumulation from spectra in the channel-blocked layout of spyhip_fft_plan_set_blocked:
+ * spec_d = (nrows, ceil(nchan/4), nfreq, 4) complex64.  Bit-identical results. */
+int spyhip_csd_accumulate_blocked(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                                  void* acc_d);
 /* acc[f,i,j] *= scale on the lower triangle and acc[f,j,i] = conj(acc[f,i,j]):
  * scale = 1/(ntaper*ntrials) turns the sum into the taper- and trial-mean. */
 int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, double scale);

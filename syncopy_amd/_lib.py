@@ -30,7 +30,9 @@ SIGNATURES = {
     "spyhip_fft_plan_destroy": (C.c_int, [vp]),
     "spyhip_fft_exec": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp]),
     "spyhip_fft_plan_kernel_name": (C.c_char_p, [vp]),
+    "spyhip_fft_plan_set_blocked": (C.c_int, [vp, C.c_int]),
     "spyhip_csd_accumulate": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    "spyhip_csd_accumulate_blocked": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "spyhip_csd_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double]),
     "spyhip_coh_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "spyhip_cwt_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_f64p, C.c_double, C.c_double, C.c_int,

@@ -86,12 +86,23 @@ class FFTPlan:
         self.handle = h
         self.kout = self.ntaper if self.keeptapers else 1
         self.out_dtype = torch.complex64 if self.kind == 2 else torch.float32
+        self.blocked = False
+
+    def set_blocked(self, on=True):
+        """Channel-quad-blocked hand-over layout (nseg*ntaper, ceil(nchan/4), nfsel, 4) for csd_accumulate(...,
+        blocked=True); returns False (layout unchanged) when the plan cannot use it."""
+        rc = self.ctx.lib.spyhip_fft_plan_set_blocked(self.handle, int(bool(on)))
+        if rc == 0:
+            self.blocked = bool(on)
+        return rc == 0
 
     @property
     def kernel_name(self):
         return self.ctx.lib.spyhip_fft_plan_kernel_name(self.handle).decode()
 
     def out_shape(self, nseg):
+        if self.blocked:
+            return (nseg * self.kout, (self.nchan + 3) // 4, self.nfsel, 4)
         return (nseg, self.kout, self.nfsel, self.nchan)
 
     def execute(self, data, seg_start, seg_lo=None, seg_hi=None, chan_idx=None, out=None):
@@ -183,16 +194,24 @@ class CWTPlan:
             pass
 
 
-def csd_accumulate(spec, acc):
+def csd_accumulate(spec, acc, blocked=False):
     """acc[f,i,j] += sum_r spec[r,f,i] conj(spec[r,f,j]) on the lower triangle (MFMA).
-    spec: (..., F, C) complex64 (leading dims flattened to rows); acc: (F, C, C) complex64."""
+    spec: (..., F, C) complex64 (leading dims flattened to rows), or with blocked=True the hand-over layout
+    (rows, ceil(C/4), F, 4) of FFTPlan.set_blocked; acc: (F, C, C) complex64."""
     assert spec.is_cuda and spec.dtype == torch.complex64 and spec.is_contiguous()
     assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous()
+    ctx = context(spec.device)
+    ctx.bind_stream()
+    if blocked:
+        F, Cn = acc.shape[0], acc.shape[1]
+        assert spec.dim() == 4 and tuple(spec.shape[1:]) == ((Cn + 3) // 4, F, 4) and acc.shape[2] == Cn, \
+            (tuple(spec.shape), tuple(acc.shape))
+        check(ctx.lib.spyhip_csd_accumulate_blocked(ctx.handle, _ptr(spec), int(spec.shape[0]), F, Cn, _ptr(acc)),
+              "spyhip_csd_accumulate_blocked")
+        return acc
     F, Cn = spec.shape[-2], spec.shape[-1]
     assert tuple(acc.shape) == (F, Cn, Cn), (tuple(acc.shape), (F, Cn, Cn))
     nrows = spec.numel() // (F * Cn)
-    ctx = context(spec.device)
-    ctx.bind_stream()
     check(ctx.lib.spyhip_csd_accumulate(ctx.handle, _ptr(spec), nrows, F, Cn, _ptr(acc)), "spyhip_csd_accumulate")
     return acc
 

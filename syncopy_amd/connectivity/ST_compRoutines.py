@@ -26,12 +26,18 @@ def _freq_selection(nSamples, samplerate, foi):
     return freqs, freq_idx
 
 
-def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, polyremoval, freq_idx, acc_of_trial):
-    """Accumulate sum_k X_k X_k^H of every trial in `rows` into `acc_of_trial(i)` (device (F,C,C) c64)."""
+def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, polyremoval, freq_idx, acc_of_trial,
+                 single_acc=False):
+    """Accumulate sum_k X_k X_k^H of every trial in `rows` into `acc_of_trial(i)` (device (F,C,C) c64).
+    `single_acc`: every trial lands in the same accumulator, so the spectra may take the channel-blocked
+    hand-over layout between the FFT and the CSD kernel (coalesced stores, identical results)."""
     ntaper = 1
     for sel, spec in hs.run_mtmfft_batches(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, False,
-                                           polyremoval, freq_idx, "fourier", True):
-        ntaper = spec.shape[1]
+                                           polyremoval, freq_idx, "fourier", True, blocked=single_acc):
+        ntaper = spec.spyhip_ntaper
+        if spec.spyhip_blocked:
+            backend.csd_accumulate(spec, acc_of_trial(sel[0]), blocked=True)
+            continue
         groups = {}
         for k, i in enumerate(sel):
             groups.setdefault(id(acc_of_trial(i)), (acc_of_trial(i), []))[1].append(k)
@@ -60,7 +66,7 @@ def cross_spectra_cF(trl_dat, samplerate=1, nSamples=None, foi=None, taper="hann
     acc = torch.zeros(outShape[1:], dtype=torch.complex64, device=dev.device)
     pr = polyremoval if polyremoval in (0, 1) and polyremoval is not False else None
     K = _csd_of_rows(dev, [(0, dev.shape[0])], None, nSamples, taper, taper_opt, demean_taper, pr, freq_idx,
-                     lambda i: acc)
+                     lambda i: acc, single_acc=True)
     backend.csd_finalize(acc, 1.0 / K)
     return acc.cpu().numpy()[np.newaxis], {"freqs_hash": _freqs_hash(freqs)}
 
@@ -90,7 +96,7 @@ class CrossSpectra(ComputationalRoutine):
             acc = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
             getter = lambda i: acc                         # noqa: E731
         K = _csd_of_rows(dev, rows, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"], cfg["demean_taper"], pr,
-                         freq_idx, getter) if rows else 1
+                         freq_idx, getter, single_acc=not self.keeptrials) if rows else 1
         K = int(cfg["taper_opt"].get("Kmax", K)) if cfg["taper_opt"] else K
         self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T
         if self.keeptrials:

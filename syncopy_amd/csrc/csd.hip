@@ -44,8 +44,21 @@ int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item
 
 }  // namespace
 
+static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan, void* acc_d,
+                               int blocked);
+
 extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
                                      void* acc_d) {
+    return csd_accumulate_impl(ctx, spec_d, nrows, nfreq, nchan, acc_d, 0);
+}
+
+extern "C" int spyhip_csd_accumulate_blocked(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                                             void* acc_d) {
+    return csd_accumulate_impl(ctx, spec_d, nrows, nfreq, nchan, acc_d, 1);
+}
+
+static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan, void* acc_d,
+                               int blocked) {
     if (!ctx || !spec_d || !acc_d) { spy::set_error("csd_accumulate: null argument"); return -1; }
     if (nrows < 0 || nfreq < 1 || nchan < 1) { spy::set_error("csd_accumulate: bad shape"); return -1; }
     if (nrows == 0) return 0;
@@ -58,6 +71,7 @@ extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_
     a.ntiles = a.nt * (a.nt + 1) / 2;
     a.nitems = (long long)nfreq * a.ntiles;
     a.cpad = a.nt * 32;
+    a.blocked = blocked;
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
     if (a.ntiles >= 21) {
         // One workgroup per CU: F = 2049 frequencies on 256 CUs would leave a 9th, almost empty round.

@@ -41,6 +41,7 @@ struct CsdArgs {
     long long rows_per_split;   // 0 = no split
     float2* part;
     int part_f0, part_nf;
+    int blocked;                // spec = (nrows, ceil(C/4), F, 4): channel quads contiguous in frequency
 };
 
 __device__ __forceinline__ void tile_of(int tt, int& ti, int& tj) {
@@ -89,7 +90,15 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     if (row_lo >= a.nrows && split > 0) return;
     const long long nrows = (a.rows_per_split > 0 && row_lo + a.rows_per_split < a.nrows) ? a.rows_per_split
                                                                                           : a.nrows - row_lo;
-    const long long item0 = a.item_base + (long long)blockIdx.x * PER;
+    // Blocked spectra keep 4 neighbouring frequencies of a channel quad in one 128-byte line: give those 4
+    // workgroups block ids that are congruent mod 8 (same XCD, same L2) and adjacent in dispatch order, so the
+    // line is fetched from HBM once instead of by four L2s.
+    long long wg = blockIdx.x;
+    if (a.blocked) {
+        const long long g32 = ((long long)gridDim.x >> 5) << 5;
+        if (wg < g32) wg = (wg & ~31LL) + 4 * (wg & 7) + ((wg & 31) >> 3);
+    }
+    const long long item0 = a.item_base + wg * PER;
     long long last = item0 + PER;
     if (last > a.item_end) last = a.item_end;
     if (item0 >= a.item_end) return;
@@ -120,9 +129,10 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     const int total = a.kb * rowlen;                       // <= 512 * CSD_PF
     const int step_q = CSD_THREADS / rowlen, step_r = CSD_THREADS % rowlen;
     const int kr0 = tid / rowlen, cc0 = tid % rowlen;
-    const size_t rowstride = (size_t)a.F * a.C;            // float2 elements between rows r and r+1
+    // float2 elements between rows r and r+1 (blocked: quads are padded to 4 channels)
+    const size_t rowstride = a.blocked ? (size_t)a.F * (size_t)(((a.C + 3) >> 2) << 2) : (size_t)a.F * a.C;
     const unsigned rowbytes = (unsigned)rowstride * 8u;    // a chunk spans < 4 GiB: 32-bit lane offsets
-    const float2* fbase = a.spec + (size_t)row_lo * rowstride + (size_t)f_lo * a.C;
+    const float2* fbase = a.spec + (size_t)row_lo * rowstride + (a.blocked ? (size_t)f_lo * 4 : (size_t)f_lo * a.C);
 
     float2 pf[CSD_PF];
     unsigned okmask = 0;
@@ -147,7 +157,10 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
             const int krc = (int)(kr < rleft ? kr : rleft - 1);
             const int fbc = fb < nfb ? fb : nfb - 1;
             const int cc_c = c < a.C ? c : a.C - 1;
-            pf[i] = *reinterpret_cast<const float2*>(base + ((unsigned)krc * rowbytes + (unsigned)(fbc * a.C + cc_c) * 8u));
+            // standard: row-major (r, f, c); blocked: (r, c/4, f, c%4) with 32-bit offsets from the chunk base
+            const unsigned eoff = a.blocked ? ((unsigned)(cc_c >> 2) * (unsigned)a.F + (unsigned)fbc) * 32u + (unsigned)(cc_c & 3) * 8u
+                                            : (unsigned)(fbc * a.C + cc_c) * 8u;
+            pf[i] = *reinterpret_cast<const float2*>(base + ((unsigned)krc * rowbytes + eoff));
             okmask |= ok ? (1u << i) : 0u;      // the zero-fill select happens at LDS-write time: no early wait
             cc += step_r;
             kr += step_q;

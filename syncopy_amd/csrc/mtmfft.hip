@@ -26,6 +26,7 @@ struct spyhip_fft_plan {
     spy::DevBuf<float2> tw, chirp, bhat;
     spy::DevBuf<int> fpos;
     bool identity_freq = true;
+    bool blocked = false;
     std::string kernel_name;
 };
 
@@ -245,6 +246,17 @@ extern "C" int spyhip_fft_plan_destroy(spyhip_fft_plan* p) {
     return 0;
 }
 
+extern "C" int spyhip_fft_plan_set_blocked(spyhip_fft_plan* p, int on) {
+    if (!p) { spy::set_error("fft_plan_set_blocked: null plan"); return -1; }
+    if (on && !(p->pow2 && p->log2n <= 13 && p->output == SPYHIP_OUT_FOURIER && p->keeptapers)) {
+        spy::set_error("fft_plan_set_blocked: the channel-blocked layout needs output=FOURIER, keeptapers=1 and a "
+                       "power-of-two nfft in 256..8192");
+        return -3;
+    }
+    p->blocked = on != 0;
+    return 0;
+}
+
 extern "C" const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* p) {
     return p ? p->kernel_name.c_str() : "";
 }
@@ -265,6 +277,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     a.detrend = p->detrend; a.demean_taper = p->demean_taper;
     a.fpos = p->identity_freq ? nullptr : p->fpos.p;
     a.nfsel = p->nfsel; a.out_kind = p->output; a.out = out_d;
+    a.blocked = p->blocked ? 1 : 0;
     const int npairs = (p->nchan + 1) / 2;
     if (p->pow2) {
         // work items per segment: channel quads (packed kernel) or channel pairs (2^14)

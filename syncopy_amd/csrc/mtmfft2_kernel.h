@@ -257,6 +257,19 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                 }
                 continue;
             }
+            if (CPLX && a.blocked) {
+                // channel-quad-blocked layout for the CSD kernel: the 32 bytes of this thread's four channels
+                // are contiguous in f, so a wave writes whole 2-KiB runs instead of 64 scattered pieces
+                const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
+                if (fi >= 0 && has[0]) {               // has[0]: the quad exists (padding lanes of a group write nothing)
+                    char* const bs = reinterpret_cast<char*>(a.out) +
+                                     (((size_t)b * kout + k) * (size_t)((a.nchan + 3) >> 2) + (size_t)(c0 >> 2)) *
+                                         (size_t)a.nfsel * 32u;
+                    stg<float4>(bs, (unsigned)fi * 32u, make_float4(xa.r[0], xa.i[0], xa.r[1], xa.i[1]));
+                    stg<float4>(bs, (unsigned)fi * 32u + 16u, make_float4(xb.r[0], xb.i[0], xb.r[1], xb.i[1]));
+                }
+                continue;
+            }
             if (fast) {
                 const unsigned o = ((unsigned)f * (unsigned)a.nchan + (unsigned)c0) * OSZ;
                 if ((SPYFFT_ABL & 4) && xa.r[0] + xa.r[1] + xa.i[0] + xa.i[1] + xb.r[0] + xb.r[1] + xb.i[0] + xb.i[1] != 12345.f)

@@ -45,6 +45,8 @@ struct MtmArgs {
     int npg;                    // pair groups per segment
     int S;                      // pair groups sharing 128-byte lines (XCD cluster)
     int ncl;                    // clusters per segment
+    int blocked;                // complex keeptapers output in the channel-quad-blocked layout
+                                // (nseg*ntaper, ceil(nchan/4), nfsel, 4) instead of (nseg, ntaper, nfsel, nchan)
 };
 
 // output conversions of const_def.py:25-37; `kind` is wave-uniform.  Kept out of

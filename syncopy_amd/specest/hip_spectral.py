@@ -41,14 +41,19 @@ def spec_scale(nsig, nfft, ft_compat=False):
 
 
 def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_taper, freq_idx, output, keeptapers,
-             device):
+             device, blocked=False):
+    """Cached FFTPlan; `blocked` asks for the channel-blocked hand-over layout of the CSD path (the plan's
+    `.blocked` tells whether the kernel serving this length supports it)."""
     fkey = None if freq_idx is None else np.asarray(freq_idx, dtype=np.int32).tobytes()
     key = (int(nsig), int(nfft), int(nchan), taper, tuple(sorted((taper_opt or {}).items())), int(nnorm),
-           float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device))
+           float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device), bool(blocked))
     if key not in _plan_cache:
         tp = taper_table(taper, nsig, nnorm, taper_opt)
-        _plan_cache[key] = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
-                                           keeptapers, device=device)
+        plan = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
+                               keeptapers, device=device)
+        if blocked:
+            plan.set_blocked(True)
+        _plan_cache[key] = plan
     return _plan_cache[key]
 
 
@@ -107,9 +112,11 @@ def run_stft(dev_data, row0, soi_start, soi_stop, frames, nperseg, step, boundar
 
 
 def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_taper, ft_compat, polyremoval,
-                       freq_idx, output, keeptapers, max_bytes=8 << 30):
+                       freq_idx, output, keeptapers, max_bytes=8 << 30, blocked=False):
     """Generator over (trial indices, (B, Kout, F, C) device tensor) batches: trials of equal length share a
-    plan; a batch is bounded by `max_bytes` of spectra so the intermediate stays a small part of HBM."""
+    plan; a batch is bounded by `max_bytes` of spectra so the intermediate stays a small part of HBM.
+    With `blocked` the tensor is in the plan's hand-over layout whenever `tensor.dim() == 4 and
+    tensor.shape[-1] == 4 and plan supports it` - callers check `spyhip_blocked` on the yielded tensor."""
     device = dev_data.device
     nchan = dev_data.shape[1] if chan_idx is None else len(chan_idx)
     ci = None if chan_idx is None else torch.tensor(np.asarray(chan_idx), dtype=torch.int32, device=device)
@@ -119,10 +126,13 @@ def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_
         n = int(n)
         N = n if nfft is None else int(nfft)
         plan = get_plan(n, N, nchan, taper, taper_opt, N, spec_scale(n, N, ft_compat), polyremoval, demean_taper,
-                        full_freq_idx(freq_idx, N), output, keeptapers, device)
+                        full_freq_idx(freq_idx, N), output, keeptapers, device, blocked=blocked)
         per_trial = int(np.prod(plan.out_shape(1))) * (8 if plan.kind == 2 else 4)
         bmax = max(1, int(max_bytes // per_trial))
         for i in range(0, which.size, bmax):
             sel = which[i:i + bmax]
             starts = torch.tensor([rows[j][0] for j in sel], dtype=torch.int64, device=device)
-            yield sel, plan.execute(dev_data, starts, chan_idx=ci)
+            spec = plan.execute(dev_data, starts, chan_idx=ci)
+            spec.spyhip_blocked = plan.blocked
+            spec.spyhip_ntaper = plan.kout
+            yield sel, spec

@@ -47,8 +47,9 @@ OUT_KINDS = {"pow": 0, "abs": 1, "fourier": 2, "complex": 2, "real": 3, "imag": 
 
 
 def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
-             freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False):
-    """Emulated spyhip_fft_exec.  data: (rows, ld) float32; tapers: (K, nsig) float64."""
+             freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False):
+    """Emulated spyhip_fft_exec.  data: (rows, ld) float32; tapers: (K, nsig) float64.
+    blocked: channel-blocked hand-over layout (nseg*K, ceil(nchan/4), nfsel, 4) (fourier, keeptapers)."""
     data = np.ascontiguousarray(data, dtype=np.float32)
     ld = data.shape[1]
     nchan = ld if chan_idx is None else len(chan_idx)
@@ -70,18 +71,23 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
     kind = OUT_KINDS[output]
     kout = K if keeptapers else 1
     out = np.full((nseg, kout, nfsel, nchan), np.nan, dtype=np.complex64 if kind == 2 else np.float32)
+    if blocked:
+        assert kind == 2 and keeptapers
+        out = np.full((nseg * kout, (nchan + 3) // 4, nfsel, 4), np.nan, dtype=np.complex64)
     pow2 = (nfft & (nfft - 1)) == 0 and 256 <= nfft <= 16384 and not force_generic
     if pow2:
         log2n = int(np.log2(nfft))
         if G is None:
             G = {8: 16, 9: 8, 10: 4, 11: 2, 12: 1, 13: 1, 14: 1}[log2n]
         tw = twiddles(nfft)
+        set_blocked(blocked)
         rc = lib().emu_mtmfft_pow2(
             C.c_int(log2n), C.c_int(G), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
             _p(ss, C.c_longlong), _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg),
             C.c_int(nsig), C.c_int(nchan), C.c_int(K), _p(tp, C.c_float), _p(tw, C.c_float),
             C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), _p(fpos, C.c_int),
             C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
+        set_blocked(False)
         assert rc == 0, f"no emulated kernel for log2n={log2n} G={G}"
         return out
     rad, ok = factorize(nfft)
@@ -113,10 +119,25 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
     return out
 
 
-def csd_accumulate(spec, acc, force_tpw=0):
-    """Emulated spyhip_csd_accumulate: spec (R, F, C) complex64, acc (F, C, C) complex64 (in place)."""
+def set_blocked(on):
+    """Channel-blocked hand-over layout for the following fft_exec / csd_accumulate calls."""
+    lib().emu_set_blocked(C.c_int(int(bool(on))))
+
+
+def csd_accumulate(spec, acc, force_tpw=0, blocked=False):
+    """Emulated spyhip_csd_accumulate: spec (R, F, C) complex64 - or (R, ceil(C/4), F, 4) with blocked=True -,
+    acc (F, C, C) complex64 (in place)."""
     spec = np.ascontiguousarray(spec, dtype=np.complex64)
     assert acc.dtype == np.complex64 and acc.flags.c_contiguous
+    if blocked:
+        R, F, Cn = spec.shape[0], acc.shape[0], acc.shape[1]
+        assert spec.shape == (R, (Cn + 3) // 4, F, 4)
+        set_blocked(True)
+        try:
+            return lib().emu_csd_accumulate(spec.ctypes.data_as(C.c_void_p), C.c_longlong(R), C.c_int(F), C.c_int(Cn),
+                                            acc.ctypes.data_as(C.c_void_p), C.c_int(force_tpw))
+        finally:
+            set_blocked(False)
     R, F, Cn = spec.shape
     return lib().emu_csd_accumulate(spec.ctypes.data_as(C.c_void_p), C.c_longlong(R), C.c_int(F), C.c_int(Cn),
                                     acc.ctypes.data_as(C.c_void_p), C.c_int(force_tpw))

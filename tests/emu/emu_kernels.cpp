@@ -69,7 +69,11 @@ void run_quad_mode(const MtmArgs& a, unsigned grid, int outk, int mean, long onl
 
 }  // namespace
 
+static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD entry points
+
 extern "C" {
+
+void emu_set_blocked(int on) { g_blocked = on; }
 
 // Mirrors the argument marshalling of spyhip_fft_exec for the power-of-two kernels
 // (packed quad kernel up to 2^13, pair kernel for 2^14).
@@ -86,6 +90,7 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
     a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
     a.out_kind = out_kind; a.out = out;
+    a.blocked = g_blocked;
     const bool quad = log2n <= 13;
     const int nitem = quad ? (nchan + 3) / 4 : (nchan + 1) / 2;
     a.npg = (nitem + G - 1) / G;
@@ -153,6 +158,7 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     a.ntiles = a.nt * (a.nt + 1) / 2;
     a.nitems = (long long)F * a.ntiles;
     a.cpad = a.nt * 32;
+    a.blocked = g_blocked;
     int ta = 1, tb = 1;
     if (a.ntiles >= 21) { ta = 5; tb = 4; }
     else if (a.ntiles >= 6) { ta = 3; tb = 2; }

@@ -47,6 +47,27 @@ def test_pow2_kernel_full_quads_fast_epilogue():
     _fft_case(300, 512, 6, 2, "fourier", True, 0)       # even, not a multiple of 4
 
 
+@pytest.mark.parametrize("C,N,B,K", [(5, 256, 2, 1), (8, 512, 2, 2), (37, 256, 3, 1)])
+def test_blocked_handover_layout(C, N, B, K):
+    """Channel-blocked FFT -> CSD hand-over: a pure re-ordering of the spectra, identical accumulator."""
+    rng = np.random.default_rng(C)
+    data = rng.normal(size=(B * N, C)).astype("f4")
+    ss = np.arange(B) * N
+    tapers = O.taper_table("dpss", N, N, {"NW": 2.0, "Kmax": K}) if K > 1 else O.taper_table("hann", N, N)
+    F = N // 2 + 1
+    std = E.fft_exec(data, ss, ss, ss + N, N, N, tapers, np.sqrt(2) / N, 0, False, None, "fourier", True)
+    blk = E.fft_exec(data, ss, ss, ss + N, N, N, tapers, np.sqrt(2) / N, 0, False, None, "fourier", True, blocked=True)
+    nq = (C + 3) // 4
+    got = blk.transpose(0, 2, 1, 3).reshape(B * K, F, 4 * nq)      # back to (rows, F, padded channels)
+    np.testing.assert_array_equal(got[:, :, :C], std.reshape(B * K, F, C))
+    assert np.abs(got[:, :, C:]).max(initial=0.0) < 1e-5            # padding channels: rounding residue only
+    a_std = np.zeros((F, C, C), np.complex64)
+    a_blk = np.zeros((F, C, C), np.complex64)
+    E.csd_accumulate(std.reshape(B * K, F, C), a_std)
+    E.csd_accumulate(np.ascontiguousarray(blk), a_blk, blocked=True)
+    np.testing.assert_array_equal(a_std, a_blk)
+
+
 def test_pow2_kernel_modes():
     _fft_case(1000, 1024, 5, 3, "fourier", True, 1, demean_taper=True)
     _fft_case(1024, 1024, 5, 3, "fourier", False, 0)

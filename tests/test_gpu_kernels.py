@@ -119,6 +119,34 @@ def test_fft_zero_extended_segments(be):
         assert_parity(out[b, 0], ref, what=f"segment {b}")
 
 
+@pytest.mark.parametrize("C,N,B,K", [(256, 4096, 3, 2), (6, 512, 5, 3), (37, 1024, 4, 1), (8, 8192, 2, 2)])
+def test_blocked_handover_layout_is_bit_identical(be, C, N, B, K):
+    """FFT -> CSD through the channel-blocked hand-over layout (coalesced stores) gives exactly the accumulator of
+    the (B, K, F, C) path, and the blocked spectra are a pure re-ordering of the standard ones."""
+    rng = np.random.default_rng(C)
+    data = torch.from_numpy(rng.normal(size=(B * N, C)).astype(np.float32)).cuda()
+    starts = torch.arange(B, device="cuda", dtype=torch.int64) * N
+    tapers = O.taper_table("dpss", N, N, {"NW": 2.0, "Kmax": K}) if K > 1 else O.taper_table("hann", N, N)
+    F = N // 2 + 1
+    mk = lambda: be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, False, None, "fourier", True)   # noqa: E731
+    p_std, p_blk = mk(), mk()
+    assert p_blk.set_blocked(True)
+    s_std = p_std.execute(data, starts)
+    s_blk = p_blk.execute(data, starts)
+    assert tuple(s_blk.shape) == (B * K, (C + 3) // 4, F, 4)
+    got = s_blk.permute(0, 2, 1, 3).reshape(B * K, F, 4 * ((C + 3) // 4))     # back to (rows, F, padded channels)
+    assert torch.equal(torch.view_as_real(got[:, :, :C].contiguous()),
+                       torch.view_as_real(s_std.reshape(B * K, F, C)))
+    if C % 4:
+        assert float(got[:, :, C:].abs().max()) < 1e-5                        # padding channels: rounding residue only
+    a_std = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    a_blk = torch.zeros_like(a_std)
+    be.csd_accumulate(s_std, a_std)
+    be.csd_accumulate(s_blk, a_blk, blocked=True)
+    assert torch.equal(torch.view_as_real(a_std), torch.view_as_real(a_blk))
+    assert not be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, False, None, "pow", True).set_blocked(True)
+
+
 def test_csd_tail_row_split(be):
     """259 workgroups on 256 CUs with enough rows that the re-cut tail is also split over rows (partial sums in
     library scratch + fixed-order reduction); reference = complex128 matrix products of the same spectra."""

@@ -61,6 +61,28 @@ if "conv" in which:
     print("conv", res["c4_mtmconvol"], flush=True)
     del data, out
 
+if "conv500" in which:
+    # the same sliding-window analysis with a 500-sample window (0.5 s at 1 kHz): mixed-radix kernel (4*5*5*5)
+    C, N, T = 128, 16384, 100
+    data = synthdata.ar2_uncoupled_fast(C, N, T, seed=2)
+    nperseg, step = 500, 250
+    w = windows.hann(nperseg)
+    w = w * np.sqrt(4 / 3) * np.sqrt(nperseg / w.sum())
+    plan = be.FFTPlan(nperseg, nperseg, C, w[None], np.sqrt(2) / nperseg, 0, False, None, "pow", False)
+    nT = int(np.ceil(N / step))
+    fr = torch.arange(nT, device="cuda", dtype=torch.int64) * step - nperseg // 2
+    tr = torch.arange(T, device="cuda", dtype=torch.int64) * N
+    starts = (tr[:, None] + fr[None, :]).reshape(-1).contiguous()
+    lo = tr[:, None].expand(T, nT).reshape(-1).contiguous()
+    hi = (lo + N).contiguous()
+    out = torch.empty(plan.out_shape(T * nT), dtype=torch.float32, device="cuda")
+    dt = sync_time(lambda: plan.execute(data, starts, lo, hi, out=out))
+    byt = T * (N * C * 4 + nT * 251 * C * 4)
+    res["c4_mtmconvol_500"] = {"trials_per_s": T / dt, "us_per_trial": 1e6 * dt / T, "GBps": byt / dt / 1e9,
+                               "kernel": plan.kernel_name}
+    print("conv500", res["c4_mtmconvol_500"], flush=True)
+    del data, out
+
 if "wav" in which:
     C, N, T = 128, 16384, 8
     data = synthdata.ar2_uncoupled_fast(C, N, T, seed=3)
