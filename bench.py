@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=500, help="trials per FFT/CSD launch pair")
+    ap.add_argument("--blocked", action="store_true",
+                    help="FFT -> CSD hand-over in the channel-blocked layout (faster FFT stores, slower CSD fetch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -68,16 +70,21 @@ def pmc_traffic(nrows, nfreq, nchan):
     """HBM bytes per CSD launch from the committed counter passes (profiles/r1_pmc_counters_final.txt:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/pmc_harness.cpp, same launch
     shape).  Units are KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM) prescribes for 16-byte
-    per-lane streaming reads on gfx950.  Counters are only valid for the shape they were taken on."""
+    per-lane streaming reads on gfx950.  Counters are only valid for the shape they were taken on
+    (first line of the file)."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_counters_final.txt")
-    if (nrows, nfreq, nchan) != (875, 2049, 256) or not os.path.exists(path):
+    if not os.path.exists(path):
         return None
     total, cur = 0.0, None
     for ln in open(path):
+        if ln.startswith("#"):
+            if f"rows={nrows} F={nfreq} C={nchan} " not in ln:
+                return None
+            continue
         if not ln.startswith(" "):
             cur = ln.strip()
             continue
-        if cur is None or "csd_accum_kernel" not in cur:
+        if cur is None or ("csd_accum_kernel" not in cur and "csd_reduce_parts" not in cur):
             continue
         name, rest = ln.split()[0], ln.split("mean=")[1]
         if name == "FETCH_SIZE":
@@ -116,7 +123,7 @@ def main():
     starts_all = torch.arange(T, device="cuda", dtype=torch.int64) * N
     plan = be.FFTPlan(N, N, C, tapers, scale, detrend=0, demean_taper=False, freq_idx=None, output="fourier",
                       keeptapers=True)
-    blocked = plan.set_blocked(True)       # FFT -> CSD hand-over in the channel-blocked layout (as CrossSpectra.compute_hip)
+    blocked = args.blocked and plan.set_blocked(True)
     B = min(args.batch, T)
     spec = torch.empty(plan.out_shape(B), dtype=torch.complex64, device="cuda")
     acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
@@ -190,7 +197,7 @@ def main():
                 "workload": "BASELINE configs[2]: connectivityanalysis method='coh' on AR(2) AnalogData, "
                             f"{C} ch x {N} samp x {T} trials per GPU, tapsmofrq=1 Hz (NW={NW:.3f}, 7 tapers), "
                             "polyremoval=0, output='abs', inputs resident in HBM",
-                "trials_per_gpu": T, "channels": C, "samples": N, "tapers": K, "freqs": F, "batch": B,
+                "trials_per_gpu": T, "channels": C, "samples": N, "tapers": K, "freqs": F, "batch": B, "handover_layout": "blocked" if blocked else "standard",
                 "channel_samples_per_s": value * N * C,
                 "fft_kernel": plan.kernel_name,
                 "fft_ms_per_trial": sum(fft_ms) / (T * args.steps),
@@ -199,7 +206,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "spycsd::csd_accum_kernel<5, 4> (+ <1, 1> tail re-cut)",
+                "kernel": "spycsd::csd_accum_kernel<5, 4> (+ row-split <1, 1> tail and its reduction)",
                 "achieved": achieved,
                 "peak": PEAK_MFMA_F32_TFLOPS,
                 "unit": "TFLOP/s",

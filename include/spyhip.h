@@ -147,7 +147,9 @@ int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int nscales, co
                            int ntime_out, spyhip_cwt_plan** plan);
 int spyhip_cwt_plan_destroy(spyhip_cwt_plan* plan);
 /* seg_start_d: row of sample 0 of each pre-selected signal; trial_lo_d/trial_hi_d: rows of the
- * whole trial (detrending range); accumulate != 0: out_d += result (trial averaging). */
+ * whole trial (detrending range); accumulate: 0 = store, 1 = out_d[b] += result of segment b,
+ * 2 = out_d[0] += sum over the nseg segments (trial averaging: one read-modify-write of the output per chunk
+ * of segments instead of one per trial). */
 int spyhip_cwt_exec(spyhip_cwt_plan* plan, const float* data_d, int64_t ld,
                     const int32_t* chan_idx_d, const int64_t* seg_start_d, const int64_t* trial_lo_d,
                     const int64_t* trial_hi_d, int nseg, void* out_d, int accumulate);

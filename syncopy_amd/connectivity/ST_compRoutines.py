@@ -33,7 +33,8 @@ def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, pol
     hand-over layout between the FFT and the CSD kernel (coalesced stores, identical results)."""
     ntaper = 1
     for sel, spec in hs.run_mtmfft_batches(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, False,
-                                           polyremoval, freq_idx, "fourier", True, blocked=single_acc):
+                                           polyremoval, freq_idx, "fourier", True,
+                                           blocked=single_acc and backend.USE_BLOCKED_HANDOVER):
         ntaper = spec.spyhip_ntaper
         if spec.spyhip_blocked:
             backend.csd_accumulate(spec, acc_of_trial(sel[0]), blocked=True)

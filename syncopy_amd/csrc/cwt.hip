@@ -37,6 +37,24 @@ int launch_cwt(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
     return 0;
 }
 
+template <int LOG2N, int G, int OUTK>
+int launch_cwt2(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
+    using C = spyfft::Cfg2<LOG2N, G>;
+    auto kern = spyfft::cwt2_kernel<LOG2N, G, OUTK>;
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int LOG2N, int G>
+int launch_cwt2_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
+    if (p->output == SPYHIP_OUT_FOURIER) return launch_cwt2<LOG2N, G, 2>(p, a, grid);
+    if (p->output == SPYHIP_OUT_POW) return launch_cwt2<LOG2N, G, 0>(p, a, grid);
+    return launch_cwt2<LOG2N, G, 1>(p, a, grid);
+}
+
 template <int LOG2N, int G>
 int launch_cwt_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
     if (p->output == SPYHIP_OUT_FOURIER) return launch_cwt<LOG2N, G, 2>(p, a, grid);
@@ -97,7 +115,8 @@ extern "C" int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int 
     p->ctx = ctx; p->nsig = nsig; p->nchan = nchan; p->nscales = nscales;
     p->detrend = detrend; p->output = output;
     p->log2n = spy::ilog2((unsigned)NB);
-    p->G = (p->log2n <= 12) ? 2 : 1;
+    // channel PAIRS per workgroup of the packed kernel (<= 2^13); channels per workgroup of the 2^14 kernel
+    p->G = p->log2n == 10 ? 4 : (p->log2n == 11 ? 2 : 1);
     p->V = V; p->halo = halo; p->nblocks = (nsig + V - 1) / V;
 
     std::vector<float2> tw(NB), hs((size_t)nscales * NB);
@@ -178,7 +197,8 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
     }
     chunk = p->chunk;
     a.stage = p->stage.p;
-    const long long ngrp = (p->nchan + p->G - 1) / p->G;
+    const long long nunit = p->log2n <= 13 ? (p->nchan + 1) / 2 : p->nchan;   // channel pairs / channels
+    const long long ngrp = (nunit + p->G - 1) / p->G;
     for (int s0 = 0; s0 < nseg; s0 += chunk) {
         const int ns = std::min(chunk, nseg - s0);
         CwtArgs c = a;
@@ -193,15 +213,15 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         const unsigned g = (unsigned)grid;
         int rc;
         switch (p->log2n) {
-            case 10: rc = launch_cwt_out<10, 2>(p, c, g); break;
-            case 11: rc = launch_cwt_out<11, 2>(p, c, g); break;
-            case 12: rc = launch_cwt_out<12, 2>(p, c, g); break;
-            case 13: rc = launch_cwt_out<13, 1>(p, c, g); break;
+            case 10: rc = launch_cwt2_out<10, 4>(p, c, g); break;
+            case 11: rc = launch_cwt2_out<11, 2>(p, c, g); break;
+            case 12: rc = launch_cwt2_out<12, 1>(p, c, g); break;
+            case 13: rc = launch_cwt2_out<13, 1>(p, c, g); break;
             case 14: rc = launch_cwt_out<14, 1>(p, c, g); break;
             default: spy::set_error("cwt_exec: unsupported block length 2^%d", p->log2n); return -1;
         }
         if (rc) return rc;
-        const dim3 sg((p->nsig + 63) / 64, p->nscales, ns);
+        const dim3 sg((p->nsig + 63) / 64, p->nscales, accumulate == 2 ? 1 : ns);
         if (esz == 8) hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float2>, sg, dim3(256), 0, p->ctx->stream, c);
         else hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float>, sg, dim3(256), 0, p->ctx->stream, c);
         SPY_HIP_CHECK(hipGetLastError());

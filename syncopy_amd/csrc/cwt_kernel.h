@@ -14,6 +14,7 @@
 // linear convolution the reference computes.
 #pragma once
 #include "mtmfft_kernel.h"
+#include "fft2_device.h"
 
 namespace spyfft {
 
@@ -167,6 +168,90 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) cwt_kernel(CwtArgs 
     }
 }
 
+// Packed variant (block lengths up to 8192): one thread carries TWO channels in the halves of packed fp32
+// registers (fft2_device.h) - both share the kernel spectrum H_s, so the spectral multiply and every butterfly
+// of the forward and the nscales inverse transforms run on v_pk_* instructions for two channels at once.
+template <int LOG2N, int G, int OUTK>
+__global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArgs a) {
+    using C = Cfg2<LOG2N, G>;
+    constexpr int N = C::N, T = C::T;
+    constexpr bool CPLX = (OUTK == 2);
+    SPY_DYN_SMEM(v2f, lds);
+    const int tid = threadIdx.x;
+    const int h = tid % G, j = tid / G;
+    const int npair = (a.nchan + 1) / 2;
+    const int ngrp = (npair + G - 1) / G;
+    long long id = blockIdx.x;
+    const int blk = (int)(id % a.nblocks);
+    id /= a.nblocks;
+    const int cg = (int)(id % ngrp);
+    const int b = (int)(id / ngrp);
+    const int c0 = 2 * (cg * G + h);
+    const bool has[2] = {c0 < a.nchan, c0 + 1 < a.nchan};
+    long long col[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) col[i] = has[i] ? (a.chan_idx ? a.chan_idx[c0 + i] : c0 + i) : 0;
+    const long long start = a.seg_start[b], tlo = a.trial_lo[b];
+    const int o0 = blk * a.V;
+
+    double mean[2] = {0.0, 0.0}, slope[2] = {0.0, 0.0}, mid = 0.0;
+    if (a.detrend >= 0) {
+        mid = 0.5 * (double)(a.trial_hi[b] - tlo - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (has[i]) {
+                const double* t = a.trend + ((size_t)b * a.nchan + c0 + i) * 2;
+                mean[i] = t[0];
+                slope[i] = t[1];
+            }
+    }
+
+    // ---- block samples u = o0 - halo + i, zero outside the signal (fftconvolve's zero padding)
+    C2 v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int u = o0 - a.halo + j + T * e;
+        float x[2] = {0.f, 0.f};
+        if (u >= 0 && u < a.nsig) {
+            const long long row = start + u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (has[i]) {
+                    x[i] = a.data[row * a.ld + col[i]];
+                    if (a.detrend >= 0) x[i] -= (float)(mean[i] + slope[i] * ((double)(row - tlo) - mid));
+                }
+        }
+        v[e].r = v2f{x[0], x[1]};
+        v[e].i = splat(0.f);
+    }
+    fft2_forward<LOG2N, G>(v, lds, j, h, a.tw);
+    C2 Z[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Z[e] = v[e];
+
+    const int nend = min(o0 + a.V, a.nsig);
+    for (int s = 0; s < a.nscales; ++s) {
+        const float2* H = a.hspec + (size_t)s * N;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = cmul_s(Z[e], ldg<float2>(H, (unsigned)(j + T * e) * 8u));
+        fft2_inverse<LOG2N, G>(v, lds, j, h, a.tw);
+        const int sh = a.cshift[s];
+        const size_t rowo = (((size_t)b * a.nscales + s) * a.nchan + c0) * (size_t)a.nsig;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = j + T * e - sh + o0;
+            if (n < o0 || n >= nend) continue;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!has[i]) continue;
+                const float2 y = make_float2(v[e].r[i], v[e].i[i]);
+                if (CPLX) reinterpret_cast<float2*>(a.stage)[rowo + (size_t)i * a.nsig + n] = y;
+                else reinterpret_cast<float*>(a.stage)[rowo + (size_t)i * a.nsig + n] = convert_real<OUTK>(y, a.out_kind);
+            }
+        }
+    }
+}
+
 // staging (segment, scale, channel, time) -> out (segment, slot(time), scale, channel), 64 x 64 tiles
 // through LDS so that both sides move >= 256 contiguous bytes per wave; applies the post-selection
 // (tpos) and the trial accumulation.
@@ -174,15 +259,30 @@ template <typename V>
 __global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
     __shared__ V tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 64, s = blockIdx.y, bl = blockIdx.z;
-    const V* const st = reinterpret_cast<const V*>(a.stage) + ((size_t)bl * a.nscales + s) * a.nchan * (size_t)a.nsig;
+    const int n0 = blockIdx.x * 64, s = blockIdx.y;
+    // accumulate == 2: the segments of the chunk are summed into output slot 0 (trial averaging with ONE
+    // read-modify-write of the output per chunk); otherwise blockIdx.z = segment of the chunk
+    const bool sum_segs = a.accumulate == 2;
+    const int bl0 = sum_segs ? 0 : blockIdx.z, bl1 = sum_segs ? a.nseg : bl0 + 1;
+    const size_t seg_stride = (size_t)a.nscales * a.nchan * (size_t)a.nsig;
+    const V* const st0 = reinterpret_cast<const V*>(a.stage) + (size_t)s * a.nchan * (size_t)a.nsig;
     V* const out = reinterpret_cast<V*>(a.out);
+    const int oseg = sum_segs ? 0 : a.seg0 + bl0;
     const int n = n0 + tx;
     for (int c0 = 0; c0 < a.nchan; c0 += 64) {
         if (c0) __syncthreads();
 #pragma unroll 4
-        for (int r = ty; r < 64; r += 4)
-            if (c0 + r < a.nchan && n < a.nsig) tile[r][tx] = st[(size_t)(c0 + r) * a.nsig + n];
+        for (int r = ty; r < 64; r += 4) {
+            if (c0 + r < a.nchan && n < a.nsig) {
+                V acc = st0[(size_t)bl0 * seg_stride + (size_t)(c0 + r) * a.nsig + n];
+                for (int bl = bl0 + 1; bl < bl1; ++bl) {
+                    const V x = st0[(size_t)bl * seg_stride + (size_t)(c0 + r) * a.nsig + n];
+                    if constexpr (sizeof(V) == 8) acc = cadd(acc, x);
+                    else acc = acc + x;
+                }
+                tile[r][tx] = acc;
+            }
+        }
         __syncthreads();
         const int c = c0 + tx;
 #pragma unroll 4
@@ -191,7 +291,7 @@ __global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
             if (m >= a.nsig || c >= a.nchan) continue;
             const int slot = a.tpos ? a.tpos[m] : m;
             if (slot < 0) continue;
-            V* const o = out + (((size_t)(a.seg0 + bl) * a.ntime_out + slot) * a.nscales + s) * a.nchan + c;
+            V* const o = out + (((size_t)oseg * a.ntime_out + slot) * a.nscales + s) * a.nchan + c;
             V val = tile[tx][r];
             if (a.accumulate) {
                 const V old = *o;

@@ -208,9 +208,10 @@ def _postselect_map(nsig, postselect):
 _cwt_plans = {}
 
 
-def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwargs):
+def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwargs, sum_trials=False):
     """Wavelet spectra of trials `rows` (absolute [start, stop)) with per-trial pre/post-selections.
-    Returns a list of (nTime, 1, nScales, C) device tensors."""
+    Returns a list of (nTime, 1, nScales, C) device tensors - or, with `sum_trials`, their sum as ONE such
+    tensor accumulated on the fly (None when the trials do not share one plan: the caller then sums the list)."""
     device = dev.device
     nchan = dev.shape[1] if chans is None else len(chans)
     ci = None if chans is None else torch.tensor(np.asarray(chans), dtype=torch.int32, device=device)
@@ -225,6 +226,8 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
         tpos, nuniq, gather = _postselect_map(nsig, qs)
         key = (nsig, None if tpos is None else tpos.tobytes(), None if gather is None else gather.tobytes())
         groups.setdefault(key, (nsig, tpos, nuniq, gather, []))[4].append((k, a + s0, a, b))
+    if sum_trials and (len(groups) != 1 or next(iter(groups.values()))[3] is not None):
+        return None
     for nsig, tpos, nuniq, gather, members in groups.values():
         pkey = (nsig, nchan, scales.tobytes(), dt, w0, polyremoval, output, None if tpos is None else tpos.tobytes(),
                 str(device))
@@ -235,6 +238,10 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
         starts = torch.tensor([m[1] for m in members], dtype=torch.int64, device=device)
         lo = torch.tensor([m[2] for m in members], dtype=torch.int64, device=device)
         hi = torch.tensor([m[3] for m in members], dtype=torch.int64, device=device)
+        if sum_trials:
+            total = torch.zeros(plan.out_shape(1), dtype=plan.out_dtype, device=device)
+            plan.execute(dev, starts, lo, hi, chan_idx=ci, out=total, accumulate=2)
+            return total[0].unsqueeze(1)
         out = plan.execute(dev, starts, lo, hi, chan_idx=ci)
         for i, m in enumerate(members):
             r = out[i]
@@ -272,6 +279,17 @@ class WaveletTransform(ComputationalRoutine):
         mine = list(self.my_trials())
         pre = [self._argv(k)[0] for k in mine]
         post = [self._argv(k)[1] for k in mine]
+        if not self.keeptrials and mine:
+            # trial average accumulated on the device while the trials are transformed (no per-trial outputs)
+            total = _wavelet_device(dev, [rows[k] for k in mine], pre, post, chans, cfg["polyremoval"], cfg["output"],
+                                    cfg["method_kwargs"], sum_trials=True)
+            if total is not None:
+                if tuple(total.shape) != tuple(self.targetShapes[mine[0]]):
+                    raise ValueError(f"result shape {tuple(total.shape)} != dry-run shape {self.targetShapes[mine[0]]}")
+                total = total.contiguous()
+                parallel.allreduce_sum_(total)
+                out.data = (total / self.numTrials).cpu().numpy().reshape(self.outputShape)
+                return
         parts = _wavelet_device(dev, [rows[k] for k in mine], pre, post, chans, cfg["polyremoval"], cfg["output"],
                                 cfg["method_kwargs"])
         _store_trials(self, out, parts)

@@ -197,7 +197,7 @@ def cwt_exec(data, seg_start, trial_lo, trial_hi, nsig, scales, dt, w0=6.0, detr
     ss, tl, th = (np.ascontiguousarray(a, dtype=np.int64) for a in (seg_start, trial_lo, trial_hi))
     NB, V, halo, cshift, hspec = cwt_plan_tables(nsig, scales, dt, w0)
     log2n = int(np.log2(NB))
-    G = 2 if log2n <= 12 else 1
+    G = {10: 4, 11: 2}.get(log2n, 1)      # channel pairs per workgroup (packed kernel), 2^14: channels
     tw = twiddles(NB)
     kind = OUT_KINDS[output]
     tp = None if tpos is None else np.ascontiguousarray(tpos, dtype=np.int32)

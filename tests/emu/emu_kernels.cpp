@@ -215,13 +215,14 @@ int emu_cwt(int log2n, int G, const float* data, long long ld, const int* chan_i
         emu::launch(dim3((unsigned)(((size_t)nseg * nchan + 255) / 256)), dim3(256), 0,
                     [&] { spyfft::cwt_trend_final_kernel(a, part.data(), trend.data()); });
     }
-    const unsigned grid = (unsigned)nseg * (unsigned)((nchan + G - 1) / G) * (unsigned)nblocks;
+    const int nunit = log2n <= 13 ? (nchan + 1) / 2 : nchan;      // packed kernel: channel pairs
+    const unsigned grid = (unsigned)nseg * (unsigned)((nunit + G - 1) / G) * (unsigned)nblocks;
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
     // one chunk holding every segment (cwt.hip sizes chunks by memory; the kernels are the same)
     std::vector<float> stage((size_t)nseg * nscales * nchan * nsig * (outk == 2 ? 2 : 1), 0.f);
     a.stage = stage.data();
     a.seg0 = 0;
-    const dim3 sgrid((nsig + 63) / 64, nscales, nseg);
+    const dim3 sgrid((nsig + 63) / 64, nscales, accumulate == 2 ? 1 : nseg);
 #define CWT_CASE(L, GG) \
     if (log2n == L && G == GG) { \
         using C = spyfft::Cfg<L, GG>; \
@@ -232,8 +233,20 @@ int emu_cwt(int log2n, int G, const float* data, long long ld, const int* chan_i
         else emu::launch(sgrid, dim3(256), 0, [&] { spyfft::cwt_scatter_kernel<float>(a); }); \
         return 0; \
     }
-    CWT_CASE(10, 2) CWT_CASE(11, 2) CWT_CASE(12, 2) CWT_CASE(13, 1) CWT_CASE(14, 1)
+    CWT_CASE(14, 1)
 #undef CWT_CASE
+#define CWT2_CASE(L, GG) \
+    if (log2n == L && G == GG) { \
+        using C = spyfft::Cfg2<L, GG>; \
+        if (outk == 2) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2_kernel<L, GG, 2>(a); }); \
+        else if (outk == 0) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2_kernel<L, GG, 0>(a); }); \
+        else emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2_kernel<L, GG, 1>(a); }); \
+        if (outk == 2) emu::launch(sgrid, dim3(256), 0, [&] { spyfft::cwt_scatter_kernel<float2>(a); }); \
+        else emu::launch(sgrid, dim3(256), 0, [&] { spyfft::cwt_scatter_kernel<float>(a); }); \
+        return 0; \
+    }
+    CWT2_CASE(10, 4) CWT2_CASE(11, 2) CWT2_CASE(12, 1) CWT2_CASE(13, 1)
+#undef CWT2_CASE
     return -1;
 }
 

@@ -61,6 +61,16 @@ def test_conn5_coherence_outputs(n5, output):
                   what=output)
 
 
+def test_conn5_blocked_handover_front_end(n5, monkeypatch):
+    """The opt-in channel-blocked FFT -> CSD hand-over through the front end (pad to a power of two so the packed
+    kernel - the one that supports the layout - serves it) reproduces the reference's coherence."""
+    from syncopy_amd import backend
+    z, data = n5
+    monkeypatch.setattr(backend, "USE_BLOCKED_HANDOVER", True)
+    assert_parity(spy.connectivityanalysis(data, method="coh", taper="hann", pad="nextpow2").data, z["coh_hann_pad"],
+                  what="hann pad, blocked hand-over")
+
+
 def test_conn5_csd_variants(n5):
     z, data = n5
     assert_parity(spy.connectivityanalysis(data, method="csd", tapsmofrq=3).data, z["csd"], what="csd")
@@ -112,6 +122,19 @@ def test_timefreq_variants(tf, name, how):
     assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
     assert_parity(out.data, ref, what=f"{name} ({how})")
     np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
+
+
+def test_wavelet_trial_average_on_the_fly(tf):
+    """keeptrials=False accumulates the trial sum on the device while transforming (CWT accumulate mode 2):
+    must equal the average of the reference's per-trial spectra."""
+    z, data = tf
+    kw = dict(TF_VARIANTS["wav_all"])
+    out = spy.freqanalysis(data, keeptrials=False, **kw)
+    ref = z["wav_all"]
+    nT = ref.shape[0] // 3
+    avg = ref.reshape(3, nT, *ref.shape[1:]).astype(np.float64).mean(axis=0).astype(np.float32)
+    assert out.data.shape == avg.shape
+    assert_parity(out.data, avg, what="wavelet trial average")
 
 
 def test_random_inputs_vs_oracle():

@@ -192,3 +192,20 @@ def test_csd_accumulate_vs_oracle(be, C, F, R):
             assert np.abs(np.exp(1j * coh) - np.exp(1j * cref)).max() < 1e-4
         else:
             assert_parity(coh, cref, what=f"coh {output}")
+
+
+def test_cwt_trial_sum_mode(be):
+    """accumulate=2 (out[0] += sum over segments, the keeptrials=False path) equals the sum of the per-segment
+    outputs of the plain mode; 5 channels exercise the padded channel pair of the packed kernel."""
+    rng = np.random.default_rng(11)
+    nsig, C, T = 700, 5, 7
+    data = torch.from_numpy(rng.normal(size=(T * nsig, C)).astype(np.float32)).cuda()
+    scales = (1 / np.array([10., 25., 60.])) * (6 + np.sqrt(38)) / (4 * np.pi)
+    plan = be.CWTPlan(nsig, C, scales, 1e-3, 6.0, 0, "pow")
+    st = torch.arange(T, device="cuda", dtype=torch.int64) * nsig
+    each = plan.execute(data, st, st, st + nsig)
+    total = torch.zeros(plan.out_shape(1), dtype=torch.float32, device="cuda")
+    plan.execute(data, st[:4].contiguous(), st[:4].contiguous(), (st[:4] + nsig).contiguous(), out=total, accumulate=2)
+    plan.execute(data, st[4:].contiguous(), st[4:].contiguous(), (st[4:] + nsig).contiguous(), out=total, accumulate=2)
+    ref = each.double().sum(dim=0, keepdim=True).float()
+    assert_parity(total.cpu().numpy(), ref.cpu().numpy(), what="cwt trial sum")

@@ -1,6 +1,6 @@
 // Torch-free driver of the C ABI for rocprofv3 counter passes (PMC collection crashes inside
 // torch's own kernels on this image).  Runs the coherence front half on synthetic trials:
-//   spyhip_fft_exec (fourier, all tapers) -> spyhip_csd_accumulate, `reps` times.
+//   spyhip_fft_exec (fourier, all tapers) -> spyhip_csd_accumulate[_blocked], `reps` times.
 // build: hipcc -O2 tools/pmc_harness.cpp -Iinclude -Lsyncopy_amd -lspyhip -Wl,-rpath,$PWD/syncopy_amd -o gpurun_out/pmc_harness
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -14,17 +14,19 @@
 #define SK(x) do { int r = (x); if (r) { fprintf(stderr, "%s -> %d: %s\n", #x, r, spyhip_last_error()); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 125, reps = argc > 2 ? atoi(argv[2]) : 2;
+    const int B = argc > 1 ? atoi(argv[1]) : 500, reps = argc > 2 ? atoi(argv[2]) : 2;
     const int which = argc > 3 ? atoi(argv[3]) : 3;   // bit 0: fft, bit 1: csd
+    const int blocked = argc > 4 ? atoi(argv[4]) : 0; // 1: channel-blocked hand-over layout (bench.py --blocked)
     const int C = 256, N = 4096, K = 7, F = N / 2 + 1;
     spyhip_ctx* ctx;
     SK(spyhip_ctx_create(0, &ctx));
     std::mt19937 rng(1);
     std::normal_distribution<float> nd(0.f, 1.f);
-    std::vector<float> h((size_t)B * N * C);
+    // one random trial, replicated on the device (counter collection does not care about the values)
+    std::vector<float> h((size_t)N * C);
     for (auto& v : h) v = nd(rng);
-    float* data; CK(hipMalloc(&data, h.size() * 4));
-    CK(hipMemcpy(data, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    float* data; CK(hipMalloc(&data, (size_t)B * h.size() * 4));
+    for (int b = 0; b < B; ++b) CK(hipMemcpy(data + (size_t)b * h.size(), h.data(), h.size() * 4, hipMemcpyHostToDevice));
     std::vector<int64_t> st(B), hi(B);
     for (int b = 0; b < B; ++b) { st[b] = (int64_t)b * N; hi[b] = st[b] + N; }
     int64_t *dst, *dhi; CK(hipMalloc(&dst, B * 8)); CK(hipMalloc(&dhi, B * 8));
@@ -36,6 +38,7 @@ int main(int argc, char** argv) {
         for (int n = 0; n < N; ++n) tp[(size_t)k * N + n] = std::sin(M_PI * (k + 1) * (n + 0.5) / N) * std::sqrt(2.0);
     spyhip_fft_plan* plan;
     SK(spyhip_fft_plan_create(ctx, N, N, C, K, tp.data(), std::sqrt(2.0) / N, 0, 0, nullptr, 0, SPYHIP_OUT_FOURIER, 1, &plan));
+    if (blocked) SK(spyhip_fft_plan_set_blocked(plan, 1));
     void *spec, *acc;
     CK(hipMalloc(&spec, (size_t)B * K * F * C * 8));
     CK(hipMalloc(&acc, (size_t)F * C * C * 8));
@@ -43,7 +46,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(spec, 0, (size_t)B * K * F * C * 8));
     for (int r = 0; r < reps; ++r) {
         if (which & 1) SK(spyhip_fft_exec(plan, data, C, nullptr, dst, dst, dhi, B, spec));
-        if (which & 2) SK(spyhip_csd_accumulate(ctx, spec, (int64_t)B * K, F, C, acc));
+        if (which & 2) SK(blocked ? spyhip_csd_accumulate_blocked(ctx, spec, (int64_t)B * K, F, C, acc)
+                               : spyhip_csd_accumulate(ctx, spec, (int64_t)B * K, F, C, acc));
     }
     SK(spyhip_ctx_synchronize(ctx));
     printf("kernel %s; done B=%d reps=%d\n", spyhip_fft_plan_kernel_name(plan), B, reps);
