@@ -41,7 +41,20 @@ int check_info(spyhip_ctx* ctx, int* info_d, int batch, const char* what) {
     return 0;
 }
 
-int invert(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d) {
+// blocked = true: the block Gauss-Jordan kernel (pivots inside 16 x 16 diagonal blocks only; info = 2 where a
+// tiny pivot showed up and the caller must repeat with blocked = false); false: partial pivoting, 16x the traffic
+int invert(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d, bool blocked = false) {
+    if (blocked && n >= 2 * spywil::ZB) {
+        const int npad = ((n + spywil::ZB - 1) / spywil::ZB) * spywil::ZB;
+        const size_t lds = ((size_t)spywil::ZB * npad + spywil::ZB * spywil::ZB) * sizeof(cd);
+        if (lds <= ctx->lds_per_block) {
+            SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::zinv_blocked_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(spywil::zinv_blocked_kernel, dim3(batch), dim3(256), lds, ctx->stream, M, n, info_d);
+            SPY_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     const size_t lds = (size_t)n * (2 * sizeof(cd) + sizeof(int));
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::zinv_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -59,18 +72,23 @@ int cholesky(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d) {
 // max_f cond_2(A_f) for Hermitian A_f: |lambda|_max(A) * |lambda|_max(A^-1) by power iteration
 int max_cond(spyhip_ctx* ctx, const cd* A, cd* work, int n, int F, double* lam_d, int* info_d, double* out) {
     const size_t bytes = (size_t)F * n * n * sizeof(cd);
-    SPY_HIP_CHECK(hipMemcpyAsync(work, A, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    if (invert(ctx, work, n, F, info_d)) return -2;
     const size_t lds = (size_t)2 * n * sizeof(cd);
     const int iters = 400;
-    hipLaunchKernelGGL(spywil::power_kernel, dim3(F), dim3(256), lds, ctx->stream, A, n, iters, lam_d);
-    hipLaunchKernelGGL(spywil::power_kernel, dim3(F), dim3(256), lds, ctx->stream, work, n, iters, lam_d + F);
-    SPY_HIP_CHECK(hipGetLastError());
     std::vector<double> h(2 * (size_t)F);
     std::vector<int> hi(F);
-    SPY_HIP_CHECK(hipMemcpyAsync(h.data(), lam_d, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SPY_HIP_CHECK(hipMemcpyAsync(hi.data(), info_d, F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL(spywil::power_kernel, dim3(F), dim3(256), lds, ctx->stream, A, n, iters, lam_d);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        SPY_HIP_CHECK(hipMemcpyAsync(work, A, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (invert(ctx, work, n, F, info_d, attempt == 0)) return -2;
+        hipLaunchKernelGGL(spywil::power_kernel, dim3(F), dim3(256), lds, ctx->stream, work, n, iters, lam_d + F);
+        SPY_HIP_CHECK(hipGetLastError());
+        SPY_HIP_CHECK(hipMemcpyAsync(h.data(), lam_d, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SPY_HIP_CHECK(hipMemcpyAsync(hi.data(), info_d, F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        bool retry = false;
+        for (int f = 0; f < F; ++f) retry = retry || hi[f] == 2;
+        if (!retry) break;
+    }
     double m = 0.0;
     for (int f = 0; f < F; ++f) {
         double c = hi[f] ? INFINITY : h[f] * h[F + f];
@@ -115,7 +133,7 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
     cd* psi = dev.alloc<cd>(tot);
     cd* T1 = dev.alloc<cd>(tot);
     cd* T2 = dev.alloc<cd>(tot);
-    cd* small = dev.alloc<cd>(6 * nn);        // g0, psi0, psi0 next, g0+S, Sigma, scratch
+    cd* small = dev.alloc<cd>(7 * nn);        // g0, psi0, psi0 next, g0+S, Sigma, scratch, psi0 of iteration 0
     cd* tw = dev.alloc<cd>(L);
     double* lam = dev.alloc<double>(2 * (size_t)F);
     int* inf = dev.alloc<int>(F);
@@ -126,7 +144,7 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
         return -2;
     }
     cd *g0 = small, *psi0 = small + nn, *psi0n = small + 2 * nn, *g0S = small + 3 * nn, *Sig = small + 4 * nn,
-       *scr = small + 5 * nn;
+       *scr = small + 5 * nn, *scr2 = small + 6 * nn;
     {
         std::vector<cd> h(L);
         for (int m = 0; m < L; ++m) { const double a = -2.0 * PI * m / L; h[m] = make_double2(std::cos(a), std::sin(a)); }
@@ -161,15 +179,25 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
     if (cholesky(ctx, scr, n, 1, inf)) return -2;
     if (int rc = check_info(ctx, inf, 1, "Cholesky factorisation of gamma_0 (not positive definite)")) return rc;
     hipLaunchKernelGGL(spywil::transpose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, scr, psi0, n);
-    hipLaunchKernelGGL(spywil::tile_kernel, dim3(eb), dim3(256), 0, ctx->stream, psi0, psi, F, n);
-    SPY_HIP_CHECK(hipGetLastError());
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::plus_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * L * sizeof(cd))));
+    SPY_HIP_CHECK(hipMemcpyAsync(scr2, psi0, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));   // keep psi0 of iteration 0
     bool converged = false;
     double err = INFINITY;
+    std::vector<int> hinf(F);
+  for (int attempt = 0; attempt < 2 && !converged; ++attempt) {
+    // attempt 0 inverts psi with the block Gauss-Jordan kernel; if one of its diagonal blocks was (nearly)
+    // singular anywhere, the whole iteration restarts with the partially pivoted kernel
+    const bool blocked = attempt == 0;
+    bool tiny_pivot = false;
+    SPY_HIP_CHECK(hipMemcpyAsync(psi0, scr2, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(spywil::tile_kernel, dim3(eb), dim3(256), 0, ctx->stream, psi0, psi, F, n);
+    SPY_HIP_CHECK(hipGetLastError());
+    err = INFINITY;
     for (int it = 0; it < niter; ++it) {
         SPY_HIP_CHECK(hipMemcpyAsync(T1, psi, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
-        if (invert(ctx, T1, n, F, inf)) return -2;                                        // psi^-1
+        if (invert(ctx, T1, n, F, inf, blocked)) return -2;                               // psi^-1
+        SPY_HIP_CHECK(hipMemcpyAsync(hinf.data(), inf, F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         if (gemm(ctx, T1, U, T2, n, F, nn, nn, nn, 0, 0)) return -2;                       // psi^-1 U
         if (gemm(ctx, T2, T2, T1, n, F, nn, nn, nn, 1, 1)) return -2;                      // g + I
         hipLaunchKernelGGL(spywil::plus_kernel, dim3((unsigned)nn), dim3(256), 2 * L * sizeof(cd), ctx->stream,
@@ -188,8 +216,12 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
         SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         err = 0.0;
         for (double v : hp) if (v > err || v != v) err = v;
+        for (int f = 0; f < F; ++f) tiny_pivot = tiny_pivot || hinf[f] == 2;
+        if (tiny_pivot) break;
         if (err < rtol) { converged = true; break; }
     }
+    if (!tiny_pivot) break;
+  }
     // ---- noise covariance, transfer function, Granger causality (wilson_sf.py:113-120, granger.py:53-77)
     if (gemm(ctx, psi0, psi0, Sig, n, 1, nn, nn, nn, 1, 0)) return -2;                     // psi0 psi0^T (psi0 is real)
     SPY_HIP_CHECK(hipMemcpyAsync(scr, psi0, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));

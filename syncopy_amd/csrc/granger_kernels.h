@@ -83,6 +83,105 @@ __global__ void __launch_bounds__(256) zgemm_kernel(const cd* A, const cd* B, cd
         }
 }
 
+// ---- batched in-place inverse, blocked: Gauss-Jordan on ZB x ZB blocks.  The unblocked kernel below
+// sweeps the whole matrix once per pivot (n sweeps of n*n*16 bytes: HBM/L2-bound, 230 ms for 2049
+// matrices of 256 x 256); here one sweep serves ZB pivots:
+//   for every block row k:  D = A_kk^-1;  R = D A_k* (with R_kk = D);  A_i* <- [A_i* off block k] - A_ik R  (i != k);  A_k* <- R
+// The row block R (ZB x n) and D live in LDS.  Pivots are taken inside the diagonal block only, in
+// order: `info[b] = 2` flags a (relatively) tiny pivot - the caller then repeats with the pivoted
+// kernel.  Hermitian positive definite inputs (the CSD itself) never trip it.
+constexpr int ZB = 16;
+__global__ void __launch_bounds__(256) zinv_blocked_kernel(cd* M, int n, int* info) {
+    SPY_DYN_SMEM(char, raw);
+    const int npad = ((n + ZB - 1) / ZB) * ZB;
+    cd* Rk = reinterpret_cast<cd*>(raw);             // ZB x npad
+    cd* D = Rk + (size_t)ZB * npad;                  // ZB x ZB
+    __shared__ double s_scale;
+    cd* A = M + (size_t)blockIdx.x * n * n;
+    const int tid = threadIdx.x;
+    const int r = tid >> 4, c = tid & 15;            // element of the diagonal block
+    const int cg = tid & 7, rl = tid >> 3;           // 32 rows x 8 column groups of the trailing update
+    int bad = 0;
+    for (int k0 = 0; k0 < npad; k0 += ZB) {
+        // (a) D = A_kk (identity padding beyond n), inverted in LDS
+        {
+            const int i = k0 + r, j = k0 + c;
+            D[r * ZB + c] = (i < n && j < n) ? A[(size_t)i * n + j] : make_double2(i == j ? 1.0 : 0.0, 0.0);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double m = 0.0;
+            for (int e = 0; e < ZB * ZB; ++e) m = fmax(m, cabs2(D[e]));
+            s_scale = m;
+        }
+        __syncthreads();
+        for (int p = 0; p < ZB; ++p) {
+            const cd piv = D[p * ZB + p], prow = D[p * ZB + c], pcol = D[r * ZB + p], own = D[r * ZB + c];
+            __syncthreads();
+            const double d = cabs2(piv);
+            if (!(d > 1e-26 * s_scale)) bad = 1;
+            const cd pinv = d > 0.0 ? make_double2(piv.x / d, -piv.y / d) : make_double2(0.0, 0.0);
+            cd v;
+            if (r == p) {
+                v = (c == p) ? pinv : cmul(prow, pinv);
+            } else {
+                const cd f = cmul(pcol, pinv);
+                v = (c == p) ? make_double2(-f.x, -f.y) : csub(own, cmul(f, prow));
+            }
+            D[r * ZB + c] = v;
+            __syncthreads();
+        }
+        // (b) R = D A_k*, block k of R = D
+        for (int j = tid; j < npad; j += 256) {
+            if (j >= k0 && j < k0 + ZB) {
+#pragma unroll
+                for (int m = 0; m < ZB; ++m) Rk[(size_t)m * npad + j] = D[m * ZB + (j - k0)];
+            } else {
+                cd a[ZB];
+#pragma unroll
+                for (int q = 0; q < ZB; ++q)
+                    a[q] = (k0 + q < n && j < n) ? A[(size_t)(k0 + q) * n + j] : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int m = 0; m < ZB; ++m) {
+                    cd acc = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int q = 0; q < ZB; ++q) acc = cadd(acc, cmul(D[m * ZB + q], a[q]));
+                    Rk[(size_t)m * npad + j] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        // (c) rows outside block k: A_ij <- (j in block k ? 0 : A_ij) - sum_m A_i,k0+m R_mj
+        //     (the 8 threads of a row all hold T = A_i,block k before any of them overwrites it: barrier)
+        for (int i0 = 0; i0 < n; i0 += 32) {
+            const int i = i0 + rl;
+            const bool valid = i < n && !(i >= k0 && i < k0 + ZB);
+            cd T[ZB];
+#pragma unroll
+            for (int m = 0; m < ZB; ++m)
+                T[m] = (valid && k0 + m < n) ? A[(size_t)i * n + k0 + m] : make_double2(0.0, 0.0);
+            __syncthreads();
+            if (valid) {
+                for (int j = cg; j < n; j += 8) {
+                    cd acc = (j >= k0 && j < k0 + ZB) ? make_double2(0.0, 0.0) : A[(size_t)i * n + j];
+#pragma unroll
+                    for (int m = 0; m < ZB; ++m) acc = csub(acc, cmul(T[m], Rk[(size_t)m * npad + j]));
+                    A[(size_t)i * n + j] = acc;
+                }
+            }
+        }
+        // (d) rows of block k
+        for (int e = tid; e < ZB * n; e += 256) {
+            const int m = e / n, j = e - m * n;
+            if (k0 + m < n) A[(size_t)(k0 + m) * n + j] = Rk[(size_t)m * npad + j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) info[blockIdx.x] = 0;
+    __syncthreads();
+    if (bad) info[blockIdx.x] = 2;
+}
+
 // ---- batched in-place inverse: Gauss-Jordan with partial pivoting, one workgroup per matrix.
 // `info[b]` = 1 if a zero pivot was met.
 __global__ void __launch_bounds__(256) zinv_kernel(cd* M, int n, int* info) {

@@ -229,11 +229,11 @@ def w_gemm(A, B, opB=0, addI=0):
     return out
 
 
-def w_inv(M):
+def w_inv(M, blocked=False):
     M = np.array(M, dtype=np.complex128, order="C")
     batch, n = (M.shape[0], M.shape[1]) if M.ndim == 3 else (1, M.shape[0])
     info = np.zeros(batch, dtype=np.int32)
-    lib().emu_w_inv(_dp(M), C.c_int(n), C.c_int(batch), _dp(info))
+    (lib().emu_w_inv_blocked if blocked else lib().emu_w_inv)(_dp(M), C.c_int(n), C.c_int(batch), _dp(info))
     return M, info
 
 

@@ -262,6 +262,11 @@ void emu_w_gemm(const double* A, const double* B, double* Cm, int n, int batch, 
 void emu_w_inv(double* M, int n, int batch, int* info) {
     emu::launch(dim3(batch), dim3(256), (size_t)n * 36, [&] { spywil::zinv_kernel(reinterpret_cast<cd*>(M), n, info); });
 }
+void emu_w_inv_blocked(double* M, int n, int batch, int* info) {
+    const int npad = ((n + spywil::ZB - 1) / spywil::ZB) * spywil::ZB;
+    emu::launch(dim3(batch), dim3(256), ((size_t)spywil::ZB * npad + spywil::ZB * spywil::ZB) * 16,
+                [&] { spywil::zinv_blocked_kernel(reinterpret_cast<cd*>(M), n, info); });
+}
 void emu_w_chol(double* M, int n, int batch, int* info) {
     emu::launch(dim3(batch), dim3(256), (size_t)n * 16, [&] { spywil::zchol_kernel(reinterpret_cast<cd*>(M), n, info); });
 }

@@ -153,6 +153,21 @@ def test_cwt_kernel(nsig, scales, detrend, output):
     assert_parity(out, ref, what="cwt")
 
 
+@pytest.mark.parametrize("n", [32, 37, 70])
+def test_blocked_inverse(n):
+    """Block Gauss-Jordan inverse (16 x 16 diagonal blocks): ragged sizes, identity padding, tiny-pivot flag."""
+    rng = np.random.default_rng(n)
+    B = 2
+    A = rng.normal(size=(B, n, n)) + 1j * rng.normal(size=(B, n, n)) + 3 * np.sqrt(n) * np.eye(n)
+    inv, info = E.w_inv(A, blocked=True)
+    assert not info.any()
+    np.testing.assert_allclose(inv @ A, np.tile(np.eye(n), (B, 1, 1)), atol=1e-10)
+    P = np.zeros((1, n, n), complex)
+    P[0] = np.eye(n)[::-1]                     # anti-diagonal permutation: every leading block is singular
+    _, info = E.w_inv(P, blocked=True)
+    assert info[0] == 2
+
+
 def test_wilson_building_blocks():
     rng = np.random.default_rng(3)
     n, B = 37, 3
