@@ -343,6 +343,45 @@ __device__ __forceinline__ void po_pass(const cd* in, cd* out, int L, int R, int
     }
 }
 
+// radix-2 / radix-4 Stockham passes with real butterflies (the lag-domain length is a power of two whenever the
+// trial length is): one table twiddle per input instead of the R^2 table products of the generic pass
+template <int R>
+__device__ __forceinline__ void po_pass_r24(const cd* in, cd* out, int L, int Ns, const cd* tw, int sign, int tid) {
+    const int nb = L / R, tws = L / (Ns * R);
+    for (int jb = tid; jb < nb; jb += 256) {
+        const int k = jb % Ns;
+        const int base = (jb / Ns) * Ns * R + k;
+        cd x[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            x[r] = in[jb + r * nb];
+            if (r > 0 && Ns > 1) {
+                cd w = tw[r * k * tws];
+                if (sign > 0) w.y = -w.y;
+                x[r] = cmul(x[r], w);
+            }
+        }
+        if (R == 2) {
+            out[base] = cadd(x[0], x[1]);
+            out[base + Ns] = csub(x[0], x[1]);
+        } else {
+            const cd a0 = cadd(x[0], x[2]), a1 = csub(x[0], x[2]), a2 = cadd(x[1], x[3]), d = csub(x[1], x[3]);
+            // forward: multiply d by -i; inverse: by +i
+            const cd a3 = sign > 0 ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
+            out[base] = cadd(a0, a2);
+            out[base + Ns] = cadd(a1, a3);
+            out[base + 2 * Ns] = csub(a0, a2);
+            out[base + 3 * Ns] = csub(a1, a3);
+        }
+    }
+}
+
+__device__ __forceinline__ void po_pass_any(const cd* in, cd* out, int L, int R, int Ns, const cd* tw, int sign, int tid) {
+    if (R == 4) po_pass_r24<4>(in, out, L, Ns, tw, sign, tid);
+    else if (R == 2) po_pass_r24<2>(in, out, L, Ns, tw, sign, tid);
+    else po_pass(in, out, L, R, Ns, tw, sign, tid);
+}
+
 __global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, int n, PlusPlan pl, const cd* tw, cd* gp, cd* g0) {
     SPY_DYN_SMEM(cd, buf);          // 2 x L
     const int L = pl.L, tid = threadIdx.x;
@@ -358,7 +397,7 @@ __global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, int n, Pl
     __syncthreads();
     int Ns = 1;
     for (int p = 0; p < pl.nfac; ++p) {          // inverse DFT (unnormalised)
-        po_pass(a, b, L, pl.radix[p], Ns, tw, +1, tid);
+        po_pass_any(a, b, L, pl.radix[p], Ns, tw, +1, tid);
         __syncthreads();
         Ns *= pl.radix[p];
         cd* t = a; a = b; b = t;
@@ -376,7 +415,7 @@ __global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, int n, Pl
     __syncthreads();
     Ns = 1;
     for (int p = 0; p < pl.nfac; ++p) {          // forward DFT
-        po_pass(a, b, L, pl.radix[p], Ns, tw, -1, tid);
+        po_pass_any(a, b, L, pl.radix[p], Ns, tw, -1, tid);
         __syncthreads();
         Ns *= pl.radix[p];
         cd* t = a; a = b; b = t;

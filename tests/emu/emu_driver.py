@@ -237,6 +237,18 @@ def w_inv(M, blocked=False):
     return M, info
 
 
+def w_plus(g):
+    """Emulated plus operator on a half spectrum g (F, n, n) complex128 -> (gp (F, n, n), g0 (n, n))."""
+    g = np.ascontiguousarray(g, dtype=np.complex128)
+    F, n, _ = g.shape
+    L = 2 * (F - 1)
+    tw = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(L) / L))
+    gp = np.zeros_like(g)
+    g0 = np.zeros((n, n), dtype=np.complex128)
+    lib().emu_w_plus(_dp(g), C.c_int(F), C.c_int(n), _dp(tw), _dp(gp), _dp(g0))     # returns the number of passes
+    return gp, g0
+
+
 def w_chol(M):
     M = np.array(M, dtype=np.complex128, order="C")
     batch, n = (M.shape[0], M.shape[1]) if M.ndim == 3 else (1, M.shape[0])

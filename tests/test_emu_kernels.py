@@ -168,6 +168,20 @@ def test_blocked_inverse(n):
     assert info[0] == 2
 
 
+@pytest.mark.parametrize("F", [9, 17, 11, 8])       # L = 16 (4*4), 32 (4*4*2), 20 (4*5), 14 (2*7)
+def test_plus_operator(F):
+    rng = np.random.default_rng(F)
+    n, L = 3, 2 * (F - 1)
+    g = rng.normal(size=(F, n, n)) + 1j * rng.normal(size=(F, n, n))
+    full = np.zeros((L, n, n), complex)
+    full[:F] = g
+    full[F:] = np.conj(g[1:F - 1][::-1])
+    ref, ref0 = O.plus_operator(full)
+    gp, g0 = E.w_plus(g)
+    np.testing.assert_allclose(gp, ref[:F], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g0, ref0, rtol=1e-12, atol=1e-12)
+
+
 def test_wilson_building_blocks():
     rng = np.random.default_rng(3)
     n, B = 37, 3
