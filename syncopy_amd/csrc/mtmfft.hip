@@ -8,6 +8,7 @@
 #include "host_fft.h"
 #include "mtmfft_kernel.h"
 #include "mtmfft2_kernel.h"
+#include "mtmfft_blue_kernel.h"
 #include "mtmfft_generic.h"
 
 using spyfft::GenPlan;
@@ -19,6 +20,7 @@ struct spyhip_fft_plan {
     int detrend = -1, demean_taper = 0;
     float scale = 1.f;
     bool pow2 = false;
+    bool blue = false;          // Bluestein on the packed power-of-two engine (nfft <= 4096, not a power of two)
     int log2n = 0, G = 1;
     GenPlan gen{};
     size_t lds_bytes = 0;
@@ -116,6 +118,35 @@ int launch_quad_mode(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) 
     }
 }
 
+template <int LOG2N, int G, int OUTK, bool MEAN>
+int launch_blue(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
+    using C = spyfft::Cfg2<LOG2N, G>;
+    auto kern = spyfft::mtmfft_blue_kernel<LOG2N, G, OUTK, MEAN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int LOG2N, int G>
+int launch_blue_mode(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
+    const bool mean = !p->keeptapers;
+    const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+    switch (outk * 2 + (mean ? 1 : 0)) {
+        case 0: return launch_blue<LOG2N, G, 0, false>(p, a, grid);
+        case 1: return launch_blue<LOG2N, G, 0, true>(p, a, grid);
+        case 2: return launch_blue<LOG2N, G, 1, false>(p, a, grid);
+        case 3: return launch_blue<LOG2N, G, 1, true>(p, a, grid);
+        case 4: return launch_blue<LOG2N, G, 2, false>(p, a, grid);
+        default: return launch_blue<LOG2N, G, 2, true>(p, a, grid);
+    }
+}
+
 template <int OUTK, bool MEAN>
 int launch_generic(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     auto kern = spyfft::mtmfft_generic_kernel<OUTK, MEAN>;
@@ -192,6 +223,31 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         char buf[128];
         std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
                       p->log2n, p->G, mode);
+        p->kernel_name = buf;
+    } else if (nfft >= 8 && 2 * nfft - 1 <= 8192 && !std::getenv("SPYHIP_FORCE_GENERIC")) {
+        // Bluestein on the packed power-of-two engine: M = 2^log2n >= 2 nfft - 1 (at least 256)
+        int M = 256;
+        while (M < 2 * nfft - 1) M <<= 1;
+        p->blue = true;
+        p->log2n = spy::ilog2((unsigned)M);
+        p->G = default_G(p->log2n);
+        std::vector<float2> chirp(nfft);
+        std::vector<double> br(M, 0.0), bi(M, 0.0);
+        for (long long n = 0; n < nfft; ++n) {
+            const long long m = (n * n) % (2LL * nfft);  // exact phase reduction
+            const double ang = PI * (double)m / (double)nfft;
+            chirp[n] = make_float2((float)std::cos(ang), (float)-std::sin(ang));
+            br[n] = std::cos(ang);
+            bi[n] = std::sin(ang);
+            if (n > 0) { br[M - n] = br[n]; bi[M - n] = bi[n]; }
+        }
+        spy::fft_host(br, bi);
+        std::vector<float2> bhat(M);
+        for (int i = 0; i < M; ++i) bhat[i] = make_float2((float)(br[i] / M), (float)(bi[i] / M));
+        if (p->chirp.upload(chirp, ctx->stream) || p->bhat.upload(bhat, ctx->stream) ||
+            p->tw.upload(twiddle_table(M), ctx->stream)) { delete p; return -2; }
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "mtmfft_blue_kernel<%d, %d, %s>", p->log2n, p->G, mode);
         p->kernel_name = buf;
     } else {
         GenPlan& g = p->gen;
@@ -301,6 +357,28 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             case 13: return launch_quad_mode<13, 1>(p, a, g);
             case 14: return launch_pow2_mode<14, 1>(p, a, g);
             default: spy::set_error("no kernel for log2n=%d", p->log2n); return -1;
+        }
+    }
+    if (p->blue) {
+        a.nfft = p->nfft; a.chirp = p->chirp.p; a.bhat = p->bhat.p;
+        const int G = p->G;
+        const int nitem = (p->nchan + 3) / 4;
+        a.npg = (nitem + G - 1) / G;
+        int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+        a.S = S;
+        a.ncl = (a.npg + S - 1) / S;
+        const long long nclusters = (long long)nseg * a.ncl;
+        const long long grid = ((nclusters + 7) / 8) * S * 8;
+        if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
+        const unsigned g = (unsigned)grid;
+        switch (p->log2n) {
+            case 8: return launch_blue_mode<8, 16>(p, a, g);
+            case 9: return launch_blue_mode<9, 8>(p, a, g);
+            case 10: return launch_blue_mode<10, 4>(p, a, g);
+            case 11: return launch_blue_mode<11, 2>(p, a, g);
+            case 12: return launch_blue_mode<12, 1>(p, a, g);
+            case 13: return launch_blue_mode<13, 1>(p, a, g);
+            default: spy::set_error("no Bluestein kernel for M=2^%d", p->log2n); return -1;
         }
     }
     const long long grid = (long long)nseg * npairs;

@@ -45,6 +45,10 @@ struct MtmArgs {
     int npg;                    // pair groups per segment
     int S;                      // pair groups sharing 128-byte lines (XCD cluster)
     int ncl;                    // clusters per segment
+    // Bluestein (mtmfft_blue_kernel.h): logical FFT length and chirp tables; tw then belongs to the length-M FFT
+    int nfft;
+    const float2* chirp;        // nfft entries exp(-i pi n^2 / nfft)
+    const float2* bhat;         // M entries: FFT_M of the wrapped conjugate chirp, / M
     int blocked;                // complex keeptapers output in the channel-quad-blocked layout
                                 // (nseg*ntaper, ceil(nchan/4), nfsel, 4) instead of (nseg, ntaper, nfsel, nchan)
 };

@@ -90,6 +90,30 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
         set_blocked(False)
         assert rc == 0, f"no emulated kernel for log2n={log2n} G={G}"
         return out
+    if 2 * nfft - 1 <= 8192 and nfft >= 8 and not force_generic:
+        # Bluestein on the packed power-of-two engine (mirror of spyhip_fft_plan_create)
+        M = 256
+        while M < 2 * nfft - 1:
+            M *= 2
+        k = np.arange(nfft, dtype=np.int64)
+        ang = np.pi * ((k * k) % (2 * nfft)) / nfft
+        chirp = np.stack([np.cos(ang), -np.sin(ang)], axis=1).astype(np.float32).copy()
+        bq = np.zeros(M, dtype=np.complex128)
+        bq[:nfft] = np.exp(1j * ang)
+        bq[M - nfft + 1:] = bq[1:nfft][::-1]
+        bh = np.fft.fft(bq) / M
+        bhat = np.stack([bh.real, bh.imag], axis=1).astype(np.float32).copy()
+        log2m = int(np.log2(M))
+        Gb = {8: 16, 9: 8, 10: 4, 11: 2, 12: 1, 13: 1}[log2m]
+        tw = twiddles(M)
+        rc = lib().emu_mtmfft_blue(
+            C.c_int(log2m), C.c_int(Gb), C.c_int(nfft), _p(chirp, C.c_float), _p(bhat, C.c_float),
+            _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int), _p(ss, C.c_longlong), _p(sl, C.c_longlong),
+            _p(sh, C.c_longlong), C.c_int(nseg), C.c_int(nsig), C.c_int(nchan), C.c_int(K), _p(tp, C.c_float),
+            _p(tw, C.c_float), C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), _p(fpos, C.c_int),
+            C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return out
     rad, ok = factorize(nfft)
     n, blu, chirp, bhat = nfft, 0, None, None
     if not ok:

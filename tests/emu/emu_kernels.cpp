@@ -17,6 +17,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
 #include "../../syncopy_amd/csrc/csd_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
+#include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
 #include "../../syncopy_amd/csrc/cwt_kernel.h"
 #include "../../syncopy_amd/csrc/granger_kernels.h"
 
@@ -67,6 +68,20 @@ void run_quad_mode(const MtmArgs& a, unsigned grid, int outk, int mean, long onl
     }
 }
 
+template <int LOG2N, int G>
+void run_blue_mode(const MtmArgs& a, unsigned grid, int outk, int mean) {
+    using C = spyfft::Cfg2<LOG2N, G>;
+    auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, fn); };
+    switch (outk * 2 + mean) {
+        case 0: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 0, false>(a); }); break;
+        case 1: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 0, true>(a); }); break;
+        case 2: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 1, false>(a); }); break;
+        case 3: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 1, true>(a); }); break;
+        case 4: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 2, false>(a); }); break;
+        default: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 2, true>(a); }); break;
+    }
+}
+
 }  // namespace
 
 static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD entry points
@@ -109,6 +124,40 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
         case 1201: run_quad_mode<12, 1>(a, grid, outk, mean, -1); break;
         case 1301: run_quad_mode<13, 1>(a, grid, outk, mean, -1); break;
         case 1401: run_pow2_mode<14, 1>(a, grid, outk, mean, -1); break;
+        default: return -1;
+    }
+    return 0;
+}
+
+// Mirrors spyhip_fft_exec for the Bluestein kernel (tables built by the Python mirror of mtmfft.hip).
+int emu_mtmfft_blue(int log2m, int G, int nfft, const float* chirp, const float* bhat, const float* data, long long ld,
+                    const int* chan_idx, const long long* seg_start, const long long* seg_lo, const long long* seg_hi,
+                    int nseg, int nsig, int nchan, int ntaper, const float* tapers, const float* tw, float scale,
+                    int detrend, int demean_taper, const int* fpos, int nfsel, int out_kind, int keeptapers, void* out) {
+    MtmArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
+    a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
+    a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
+    a.out_kind = out_kind; a.out = out;
+    a.nfft = nfft; a.chirp = reinterpret_cast<const float2*>(chirp); a.bhat = reinterpret_cast<const float2*>(bhat);
+    const int nitem = (nchan + 3) / 4;
+    a.npg = (nitem + G - 1) / G;
+    int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+    a.S = S;
+    a.ncl = (a.npg + S - 1) / S;
+    const long long nclusters = (long long)nseg * a.ncl;
+    const unsigned grid = (unsigned)(((nclusters + 7) / 8) * S * 8);
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    const int mean = keeptapers ? 0 : 1;
+    switch (log2m * 100 + G) {
+        case 816: run_blue_mode<8, 16>(a, grid, outk, mean); break;
+        case 908: run_blue_mode<9, 8>(a, grid, outk, mean); break;
+        case 1004: run_blue_mode<10, 4>(a, grid, outk, mean); break;
+        case 1102: run_blue_mode<11, 2>(a, grid, outk, mean); break;
+        case 1201: run_blue_mode<12, 1>(a, grid, outk, mean); break;
+        case 1301: run_blue_mode<13, 1>(a, grid, outk, mean); break;
         default: return -1;
     }
     return 0;

@@ -77,9 +77,18 @@ def test_pow2_kernel_modes():
 
 @pytest.mark.parametrize("nsig,nfft", [(2000, 2000), (500, 1000), (360, 360), (77, 154), (101, 202), (64, 64)])
 def test_generic_kernel_lengths(nsig, nfft):
-    # 2000 = 16*5^3 (BASELINE config 1), 154 = 2*7*11, 202 = 2*101 -> Bluestein
+    # lengths that are not powers of two: Bluestein on the packed engine (M = 256 ... 4096) ...
     _fft_case(nsig, nfft, 3, 2, "pow", False, 0)
     _fft_case(nsig, nfft, 2, 1, "fourier", True, 1, demean_taper=True, nseg=1)
+    # ... and the mixed-radix / Bluestein LDS kernel that still serves nfft > 4096
+    _fft_case(nsig, nfft, 3, 2, "pow", False, 0, generic=True, nseg=1)
+
+
+def test_bluestein_kernel_modes():
+    _fft_case(500, 500, 8, 1, "pow", True, 0)                     # full quads: float4 stores
+    _fft_case(500, 500, 5, 3, "abs", False, 1)
+    _fft_case(300, 360, 6, 2, "fourier", False, -1)
+    _fft_case(77, 77, 4, 2, "real", True, 0, freq_idx=np.array([3, 0, 38, 20]), chan_idx=[3, 3, 0, 1])
 
 
 def test_generic_kernel_matches_pow2_kernel():
