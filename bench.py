@@ -94,6 +94,23 @@ def pmc_traffic(nrows, nfreq, nchan):
     return total or None
 
 
+class _QuietStdout:
+    """RCCL prints a version banner to stdout when the first communicator is created; the contract is ONE JSON
+    line on stdout, so file descriptor 1 points at /dev/null while the process group comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null, 1)
+        os.close(null)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     args = parse()
     import torch
@@ -105,9 +122,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: syncopy_amd has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
+    # SPY_BENCH_FORCE_DIST=1: run the process-group path (init, all-reduce, barrier) even with one rank - lets the
+    # collective code be exercised on a 1-GPU box under torch.distributed.run
+    dist_on = world > 1 or bool(os.environ.get("SPY_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        with _QuietStdout():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            warm = torch.zeros(8, device="cuda")
+            dist.all_reduce(warm)                  # creates the communicator (and its banner) here
+            torch.cuda.synchronize()
 
     from scipy.signal import windows
     from syncopy_amd import backend as be
@@ -145,14 +169,14 @@ def main():
                 e2.record()
                 ev_fft.append((e0, e1, nb))
                 ev_csd.append((e1, e2, nb))
-        if world > 1:
+        if dist_on:
             dist.all_reduce(torch.view_as_real(acc))
         be.csd_finalize(acc, 1.0 / (K * T * world))
         return be.coh_normalize(acc, "abs")
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +189,7 @@ def main():
     fence()
     el = time.perf_counter() - t0
     tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
 
@@ -220,7 +244,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(C, N)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
