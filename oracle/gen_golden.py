@@ -29,6 +29,7 @@ from syncopy.specest.wavelet import wavelet as ref_wavelet
 from syncopy.specest.wavelets import Morlet
 
 OUT = sys.argv[1] if len(sys.argv) > 1 else "tests/golden"
+ONLY = set(sys.argv[2:])          # optional: names of the fixture files to (re)write, default all
 os.makedirs(OUT, exist_ok=True)
 
 
@@ -46,6 +47,8 @@ def ca(data, sl=slice(None), **opts):
 
 
 def save(name, **kw):
+    if ONLY and name not in ONLY:
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **kw)
     print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB")
@@ -91,6 +94,23 @@ kw["granger_info"] = np.array(
 )
 kw["freq"] = g.freq
 save("conn5", adj=adj, data=np.stack(trials_of(n5)), samplerate=n5.samplerate, **kw)
+
+# ---------------------------------------------------------------- jackknife (connectivity_analysis.py:601-606,736-757; jackknifing.py)
+kw = {}
+n5j = n5.selectdata(trials=np.arange(20))          # 20 trials: 20 leave-one-out replicates
+
+
+def jk(name, **opts):
+    r = spy.connectivityanalysis(n5j, jackknife=True, **opts)
+    kw[name] = r.data[()]
+    kw[name + "_jack_var"] = np.array(r.jack_var)
+    kw[name + "_jack_bias"] = np.array(r.jack_bias)
+
+
+jk("coh_abs", method="coh", tapsmofrq=3)
+jk("coh_complex", method="coh", tapsmofrq=3, output="complex", foilim=[5, 60])
+jk("granger", method="granger", tapsmofrq=3)
+save("jackknife", adj=adj, data=np.stack(trials_of(n5j)), samplerate=n5j.samplerate, **kw)
 
 # ---------------------------------------------------------------- mtmfft option sweep (incl. unequal trial lengths + selections)
 rng = np.random.default_rng(2024)
@@ -158,6 +178,13 @@ tfa("wav_toi", method="wavelet", wavelet="Morlet", width=4, foi=np.array([8.0, 3
     toi=np.arange(-0.8, 0.8, 0.05), output="fourier")
 tfa("wav_auto_scales", method="wavelet", wavelet="Morlet", toi="all", output="abs", keeptrials=False)
 save("tf_variants", **kw)
+
+# ---------------------------------------------------------------- welch = mtmconvol + spy.mean(dim="time") (freqanalysis.py:1054-1056)
+kw = {"data": np.stack(trials_of(tf)), "samplerate": tf.samplerate, "trialdefinition": tf.trialdefinition}
+tfa("welch_hann_half", method="welch", taper="hann", t_ftimwin=0.5, toi=0.5)
+tfa("welch_dpss_avg", method="welch", tapsmofrq=4, t_ftimwin=0.4, toi=0.25, foilim=[0, 150], keeptrials=False)
+tfa("welch_pow2_nooverlap", method="welch", taper="hann", t_ftimwin=0.256, toi=0.0, polyremoval=1)
+save("welch_variants", **kw)
 
 # ---------------------------------------------------------------- backend-level vectors
 kw = {}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerate tests/golden/*.npz from the real reference.  Build container only
+# Regenerate tests/golden/*.npz from the real reference (optional arguments: names of the fixture files to write).  Build container only
 # (needs /root/reference and /opt/conda/bin/python3.9 = numpy 1.26 / scipy 1.7 /
 # h5py 3.3, the closest available match to the reference's lock file).
 # TEST INFRASTRUCTURE ONLY.
@@ -15,4 +15,4 @@ echo "class FOOOF: pass" > "$tmp/stubs/fooof/__init__.py"
 cd "$tmp"
 SPYDIR="$tmp/spydir" SPYSILENTSTARTUP=1 SPYLOGLEVEL=ERROR \
 PYTHONPATH="$tmp/stubs:/root/reference" \
-  /opt/conda/bin/python3.9 -W ignore "$here/oracle/gen_golden.py" "$here/tests/golden"
+  /opt/conda/bin/python3.9 -W ignore "$here/oracle/gen_golden.py" "$here/tests/golden" "$@"

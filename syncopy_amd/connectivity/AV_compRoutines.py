@@ -89,10 +89,13 @@ class GrangerCausality(_AverageRoutine):
 
     def compute_hip(self, data, out):
         dev = self._device_input(data)
-        G, meta = backend.granger(dev[0].contiguous(), rtol=self.cfg["rtol"], niter=self.cfg["nIter"],
-                                  cond_max=self.cfg["cond_max"], eps_max=1e-1)
-        self.metadata = [_granger_metadata(meta)]
-        out._dev = G.unsqueeze(0)
+        res, self.metadata = [], []
+        for t in range(dev.shape[0]):            # one trial average, or the jackknife's leave-one-out replicates
+            G, meta = backend.granger(dev[t].contiguous(), rtol=self.cfg["rtol"], niter=self.cfg["nIter"],
+                                      cond_max=self.cfg["cond_max"], eps_max=1e-1)
+            res.append(G)
+            self.metadata.append(_granger_metadata(meta))
+        out._dev = torch.stack(res, dim=0)
         out.data = out._dev.cpu().numpy()
 
     def process_metadata(self, data, out):

@@ -29,8 +29,9 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
         raise SPYValueError("one of " + ", ".join(connectivityMethods), varname="method", actual=method)
     if not isinstance(jackknife, bool):
         raise SPYTypeError(jackknife, "jackknife", "boolean")
-    if jackknife:
-        raise NotImplementedError("jackknife replicates are listed as 'next' in SURVEY.md section 8f")
+    if jackknife and method not in ("coh", "granger"):
+        SPYWarning(f"Jackknife is not available for method {method}")       # connectivity_analysis.py:310-317
+        jackknife = False
     if polyremoval is not None:
         if not isinstance(polyremoval, numbers.Number) or polyremoval not in (0, 1):
             raise SPYValueError("0, 1 or None", varname="polyremoval", actual=polyremoval)
@@ -44,13 +45,35 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     data.selectdata(select)
     try:
         return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
-                             nTaper, taper, taper_opt, compute_method)
+                             nTaper, taper, taper_opt, compute_method, jackknife)
     finally:
         data.selection = None
 
 
+def _trial_average(x):
+    """`spy.mean(dim="trials")`: sequential accumulation in the data dtype, then one division
+    (statistics/summary_stats.py:321-400)."""
+    acc = np.zeros(x.shape[1:], dtype=x.dtype)
+    for t in range(x.shape[0]):
+        acc += x[t]
+    acc /= x.shape[0]
+    return acc
+
+
+def _as_single_trials(template, arr):
+    """CrossSpectralData whose trials are the slices arr[t] (stacked along the time axis)."""
+    T = arr.shape[0]
+    obj = CrossSpectralData(dimord=template.dimord)
+    obj.data = np.ascontiguousarray(arr)
+    obj.samplerate = template.samplerate
+    k = np.arange(T, dtype=float)[:, None]
+    obj.trialdefinition = np.hstack((k, k + 1, np.zeros((T, 1))))
+    obj.freq, obj.channel_i, obj.channel_j = template.freq, template.channel_i, template.channel_j
+    return obj
+
+
 def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq, nTaper, taper,
-                  taper_opt, compute_method):
+                  taper_opt, compute_method, jackknife=False):
     fs = data.samplerate
     timeAxis = data.dimord.index("time")
     trl = selected_trialdefinition(data)
@@ -99,12 +122,44 @@ def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, p
         av = None
 
     st_out = CrossSpectralData(dimord=CrossSpectra.dimord)
-    st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=bool(keeptrials))
+    # single trials are needed for the jackknife (connectivity_analysis.py:589-590)
+    st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=bool(keeptrials) or jackknife)
     st.compute(data, st_out, parallel=False, log_dict=log_dict, method=compute_method)
     if av is None:
         return st_out
+    replicates = None
+    if jackknife:
+        # leave-one-out trial averages (statistics/jackknifing.py:14-108): (T * mean - trial) / (T - 1)
+        S = np.asarray(st_out.data)
+        T = S.shape[0]
+        mean = _trial_average(S)
+        rep = np.empty_like(S)
+        for t in range(T):
+            loo = T * mean - S[t]
+            loo /= T - 1
+            rep[t] = loo
+        replicates = _as_single_trials(st_out, rep)
+        st_out = _as_single_trials(st_out, mean[None])
+        st_out.trialdefinition = np.array([[0, 1.0, 0]])
     out = CrossSpectralData(dimord=st_out.dimord)
     av.initialize(st_out, out._stackingDim, chan_per_worker=None, keeptrials=False)
     av.pre_check()
     av.compute(st_out, out, parallel=False, log_dict=log_dict, method=compute_method)
+    if jackknife:
+        # the same AV routine on every replicate, then bias and variance (jackknifing.py:111-184)
+        jack_rep = CrossSpectralData(dimord=st_out.dimord)
+        av_rep = av.__class__(**av.cfg)
+        av_rep.initialize(replicates, jack_rep._stackingDim, chan_per_worker=None, keeptrials=True)
+        av_rep.compute(replicates, jack_rep, parallel=False, log_dict=log_dict, method=compute_method)
+        R = np.asarray(jack_rep.data)
+        T = R.shape[0]
+        direct = np.asarray(out.data)
+        jack_avg = _trial_average(R)[None]
+        prefac = (T - 1) + 0j if np.issubdtype(direct.dtype, np.complexfloating) else (T - 1)
+        out.jack_bias = (prefac * (jack_avg - direct)).astype(direct.dtype)
+        var = np.zeros(direct.shape, dtype=np.float32)
+        for t in range(T):
+            var += (np.abs(jack_avg - R[t])) ** 2
+        var *= T - 1
+        out.jack_var = var
     return out

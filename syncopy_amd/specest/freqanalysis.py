@@ -95,6 +95,12 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
         if method in ("mtmconvol", "welch"):
             _scalar(t_ftimwin, "t_ftimwin", [dt, minTrialLength])
             minSampleNum = int(t_ftimwin * fs)
+            if method == "welch":                       # freqanalysis.py:584-596
+                if keeptapers:
+                    raise SPYValueError("keeptapers='False' with method='welch'", varname="keeptapers",
+                                        actual=keeptapers)
+                if output != "pow":
+                    raise SPYValueError("output='pow' with method='welch'", varname="output", actual=output)
         freqs = np.fft.rfftfreq(int(minSampleNum), dt)
         if foi is not None:
             foi, _ = best_match(freqs, foi, squash_duplicates=True)
@@ -116,8 +122,11 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
                                output=output, method_kwargs=method_kwargs)
 
     elif method in ("mtmconvol", "welch"):
+        if method == "welch" and (isinstance(toi, str) or not isinstance(toi, numbers.Number)):
+            raise SPYValueError("toi to be a float in range [0, 1] for method='welch'", varname="toi",
+                                actual=str(toi))      # freqanalysis.py:684-701
         if isinstance(toi, str):
-            if toi != "all" or method == "welch":
+            if toi != "all":
                 raise SPYValueError("`toi = 'all'` to center analysis windows on all time-points", varname="toi",
                                     actual=toi)
             equidistant, overlap = True, np.inf
@@ -223,5 +232,19 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
     cr.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=keeptrials)
     cr.compute(data, out, parallel=False, log_dict=log_dct, method=compute_method)
     if method == "welch":
-        raise NotImplementedError("welch (time-average of mtmconvol) is listed as 'next' in SURVEY.md section 8f")
+        out = _time_mean(out)
     return out
+
+
+def _time_mean(spec):
+    """`spy.mean(spec, dim="time")` as freqanalysis.py:1054-1056 applies it for method='welch':
+    np.nanmean over the time axis of every trial (statistics/compRoutines.py:36-57, float32 in, float32 out);
+    each trial keeps ONE stacked sample (trialdefinition [[k, k+1, 0]], statistics/compRoutines.py:98-117)."""
+    td = np.asarray(spec.trialdefinition)
+    rows = [np.nanmean(spec.data[int(a):int(b)], axis=0, keepdims=True) for a, b in td[:, :2]]
+    n = len(rows)
+    k = np.arange(n, dtype=float)[:, None]
+    res = SpectralData(np.concatenate(rows, axis=0).astype(spec.data.dtype, copy=False), samplerate=spec.samplerate,
+                       trialdefinition=np.hstack((k, k + 1, np.zeros((n, 1)))), dimord=spec.dimord)
+    res.freq, res.taper, res.channel = spec.freq, spec.taper, spec.channel
+    return res

@@ -8,7 +8,7 @@ import pytest
 import syncopy_amd as spy
 from oracle_routines import ORACLE_CONN, ORACLE_FREQ
 from parity import assert_parity
-from test_oracle_golden import TF_VARIANTS, VARIANTS
+from test_oracle_golden import JACK_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, check_jackknife
 
 pytestmark = pytest.mark.gpu
 
@@ -59,6 +59,18 @@ def test_conn5_coherence_outputs(n5, output):
     z, data = n5
     assert_parity(spy.connectivityanalysis(data, method="coh", tapsmofrq=3, output=output).data, z["coh_" + output],
                   what=output)
+
+
+@pytest.mark.parametrize("name", sorted(JACK_VARIANTS))
+def test_jackknife(golden_dir, name):
+    """jackknife=True for coh / granger: single-trial CSDs, leave-one-out averages, AV stage per replicate on the
+    device, bias and variance as statistics/jackknifing.py - against the reference's vectors."""
+    z = _load(golden_dir, "jackknife")
+    data = spy.AnalogData(np.concatenate(list(z["data"])), samplerate=float(z["samplerate"]),
+                          trialdefinition=np.stack([np.arange(20) * 1000, np.arange(1, 21) * 1000,
+                                                    np.zeros(20)], axis=1))
+    out = spy.connectivityanalysis(data, jackknife=True, **JACK_VARIANTS[name])
+    check_jackknife(out, z, name, rtol=3e-3, atol_rel=3e-4)
 
 
 def test_conn5_blocked_handover_front_end(n5, monkeypatch):
@@ -118,6 +130,20 @@ def tf(golden_dir):
 def test_timefreq_variants(tf, name, how):
     z, data = tf
     out = spy.freqanalysis(data, compute_method=how, **TF_VARIANTS[name])
+    ref = z[name]
+    assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
+    assert_parity(out.data, ref, what=f"{name} ({how})")
+    np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
+
+
+@pytest.mark.parametrize("how", ["hip", "sequential"])
+@pytest.mark.parametrize("name", sorted(WELCH_VARIANTS))
+def test_welch_variants(golden_dir, name, how):
+    """method='welch' = sliding-window kernel (K2) + time mean, against the reference's vectors."""
+    z = _load(golden_dir, "welch_variants")
+    data = spy.AnalogData(np.concatenate(list(z["data"])), samplerate=float(z["samplerate"]),
+                          trialdefinition=z["trialdefinition"])
+    out = spy.freqanalysis(data, compute_method=how, **WELCH_VARIANTS[name])
     ref = z[name]
     assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
     assert_parity(out.data, ref, what=f"{name} ({how})")

@@ -102,6 +102,45 @@ def test_conn5_granger(n5):
     assert np.array_equal(g.freq, z["freq"])
 
 
+JACK_VARIANTS = {
+    "coh_abs": dict(method="coh", tapsmofrq=3),
+    "coh_complex": dict(method="coh", tapsmofrq=3, output="complex", foilim=[5, 60]),
+    "granger": dict(method="granger", tapsmofrq=3),
+}
+
+
+def check_jackknife(out, z, name, rtol, atol_rel):
+    """direct estimate + jackknife variance and bias (SURVEY 8f 'next' row 1) against the reference's vectors.
+    Variance and bias are built from differences of nearly equal replicates: their tolerance is wider."""
+    if name == "granger":
+        # 20 trials x 5 channels: a noisier factorisation than conn5's 60 trials; the reference's own
+        # tolerance for Granger is atol=1e-2 (tests/test_connectivity.py:149)
+        np.testing.assert_allclose(out.data[:, 2:], z[name][:, 2:], rtol=2e-3, atol=1e-3)
+        np.testing.assert_allclose(out.jack_var[:, 2:], z[name + "_jack_var"][:, 2:], rtol=0.05,
+                                   atol=0.02 * np.abs(z[name + "_jack_var"]).max())
+        np.testing.assert_allclose(out.jack_bias[:, 2:], z[name + "_jack_bias"][:, 2:], rtol=0.05,
+                                   atol=0.02 * np.abs(z[name + "_jack_bias"]).max())
+        return
+    assert_parity(out.data, z[name], what=name)
+    assert out.jack_var.dtype == np.float32 and out.jack_bias.dtype == z[name + "_jack_bias"].dtype
+    assert_parity(out.jack_var, z[name + "_jack_var"], what=name + " jack_var", rtol=rtol, atol_rel=atol_rel)
+    # bias = (T-1) (mean of replicates - direct): float32 rounding of the estimates (1e-7 relative) is amplified
+    # by (T-1) |estimate| / |bias| - an absolute floor of (T-1) * 3e-6 * max|estimate| reflects that
+    T = 20
+    np.testing.assert_allclose(out.jack_bias, z[name + "_jack_bias"], rtol=10 * rtol,
+                               atol=(T - 1) * 3e-6 * np.abs(z[name]).max())
+
+
+@pytest.mark.parametrize("name", sorted(JACK_VARIANTS))
+def test_jackknife(golden_dir, name):
+    z = _load(golden_dir, "jackknife")
+    data = spy.AnalogData(np.concatenate(list(z["data"])), samplerate=float(z["samplerate"]),
+                          trialdefinition=np.stack([np.arange(20) * 1000, np.arange(1, 21) * 1000,
+                                                    np.zeros(20)], axis=1))
+    out = ca(data, jackknife=True, **JACK_VARIANTS[name])
+    check_jackknife(out, z, name, rtol=1e-3, atol_rel=1e-4)
+
+
 # ------------------------------------------------------------------ mtmfft option sweep
 @pytest.fixture(scope="module")
 def uneq(golden_dir):
@@ -183,6 +222,42 @@ def test_tf_variants(tf, name):
     assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
     assert_parity(out.data, ref, what=name)
     np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
+
+
+WELCH_VARIANTS = {
+    "welch_hann_half": dict(method="welch", taper="hann", t_ftimwin=0.5, toi=0.5),
+    "welch_dpss_avg": dict(method="welch", tapsmofrq=4, t_ftimwin=0.4, toi=0.25, foilim=[0, 150], keeptrials=False),
+    "welch_pow2_nooverlap": dict(method="welch", taper="hann", t_ftimwin=0.256, toi=0.0, polyremoval=1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WELCH_VARIANTS))
+def test_welch_variants(golden_dir, name):
+    """method='welch' (SURVEY 8f 'next' row): mtmconvol + time mean, through the front end on the oracle."""
+    z = _load(golden_dir, "welch_variants")
+    data = spy.AnalogData(np.concatenate(list(z["data"])), samplerate=float(z["samplerate"]),
+                          trialdefinition=z["trialdefinition"])
+    out = fa(data, **WELCH_VARIANTS[name])
+    ref = z[name]
+    assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
+    assert_parity(out.data, ref, what=name)
+    np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
+    np.testing.assert_allclose(out.freq, z[name + "_freq"])
+
+
+def test_welch_argument_checks(golden_dir):
+    z = _load(golden_dir, "welch_variants")
+    data = spy.AnalogData(np.concatenate(list(z["data"])), samplerate=float(z["samplerate"]),
+                          trialdefinition=z["trialdefinition"])
+    from syncopy_amd.shared.errors import SPYValueError
+    for bad in (dict(toi="all"), dict(toi=np.array([0.1, 0.2])), dict(toi=0.5, keeptapers=True, tapsmofrq=4),
+                dict(toi=0.5, output="abs")):
+        kw = dict(method="welch", taper="hann", t_ftimwin=0.5, toi=0.5)
+        if "tapsmofrq" in bad:
+            kw.pop("taper")
+        kw.update(bad)
+        with pytest.raises(SPYValueError):
+            fa(data, **kw)
 
 
 # ------------------------------------------------------------------ backend-level vectors + known answers
