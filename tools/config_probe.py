@@ -25,7 +25,7 @@ def sync_time(fn, n=3):
 
 
 res = {}
-which = sys.argv[1:] or ["c2", "conv", "wav", "granger"]
+which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "h2d", "granger"]
 
 if "c2" in which:
     C, N, T, K = 256, 4096, 1000, 7
@@ -99,6 +99,25 @@ if "wav" in which:
     res["c4_wavelet"] = {"trials_per_s": T / dt, "ms_per_trial": 1e3 * dt / T, "GBps_alg": byt / dt / 1e9}
     print("wav", res["c4_wavelet"], flush=True)
     del data, out
+
+if "h2d" in which:
+    # PCIe-inclusive view of the headline config: upload of the trial queue (host -> HBM) next to its compute time
+    C, N, T = 256, 4096, 250
+    host = np.random.default_rng(0).standard_normal((T * N, C), dtype=np.float32)
+    t0 = time.perf_counter()
+    dev = torch.from_numpy(host).cuda()
+    torch.cuda.synchronize()
+    t_page = time.perf_counter() - t0
+    pinned = torch.from_numpy(host).pin_memory()
+    t0 = time.perf_counter()
+    dev2 = pinned.cuda(non_blocking=True)
+    torch.cuda.synchronize()
+    t_pin = time.perf_counter() - t0
+    gb = host.nbytes / 1e9
+    res["h2d_upload"] = {"GB": gb, "pageable_GBps": gb / t_page, "pinned_GBps": gb / t_pin,
+                         "trials_per_s_pageable": T / t_page, "trials_per_s_pinned": T / t_pin}
+    print("h2d", res["h2d_upload"], flush=True)
+    del dev, dev2, pinned, host
 
 if "granger" in which:
     for C, N, T in ((64, 1024, 700), (256, 4096, 300)):
