@@ -26,6 +26,12 @@ struct Dev {
 
 int gemm(spyhip_ctx* ctx, const cd* A, const cd* B, cd* C, int n, int batch, long long sA, long long sB, long long sC,
          int opB, int addI) {
+    if (n >= 48) {      // fp64 matrix cores, 64 x 64 tiles
+        dim3 grid((n + spywil::MT - 1) / spywil::MT, (n + spywil::MT - 1) / spywil::MT, batch);
+        hipLaunchKernelGGL(spywil::zgemm_mfma_kernel, grid, dim3(256), 0, ctx->stream, A, B, C, n, sA, sB, sC, opB, addI);
+        SPY_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     dim3 grid((n + spywil::GT - 1) / spywil::GT, (n + spywil::GT - 1) / spywil::GT, batch);
     hipLaunchKernelGGL(spywil::zgemm_kernel, grid, dim3(256), 0, ctx->stream, A, B, C, n, sA, sB, sC, opB, addI);
     SPY_HIP_CHECK(hipGetLastError());

@@ -83,6 +83,88 @@ __global__ void __launch_bounds__(256) zgemm_kernel(const cd* A, const cd* B, cd
         }
 }
 
+// ---- the same product on the fp64 matrix cores: 64 x 64 output tile per workgroup, wave w owns the 32 x 32
+// quadrant (w>>1, w&1) as 2 x 2 sub-tiles of v_mfma_f64_16x16x4_f64 (A: one double per lane at
+// [row = lane&15][k = lane>>4], B: [k = lane>>4][col = lane&15], D: 4 doubles per lane at
+// row = (lane>>4) + 4*reg, col = lane&15).  Complex product = 4 real MFMAs per k-step of 4:
+//   Cr += Ar Br ; Cr += (-Ai) Bi ; Ci += Ar Bi ; Ci += Ai Br.
+// The 32 x 32 VALU tile above moves 16 bytes per 16 flop through L2 and stalls at ~28 TFLOP/s; this tile
+// halves the traffic per flop and leaves the multiply-adds to the matrix pipe.
+#ifndef SPY_HOST_EMU
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#endif
+constexpr int MT = 64;   // output tile
+constexpr int MK = 8;    // k per stage
+__global__ void __launch_bounds__(256) zgemm_mfma_kernel(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB,
+                                                         long long sC, int opB, int addI) {
+    __shared__ cd As[MT][MK + 1];
+    __shared__ cd Bs[MK][MT + 1];
+    const int b = blockIdx.z, ti = blockIdx.y * MT, tj = blockIdx.x * MT;
+    const cd* Ab = A + (size_t)b * sA;
+    const cd* Bb = B + (size_t)b * sB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;     // quadrant of this wave
+    const int l15 = lane & 15, l4 = lane >> 4;
+    f64x4 cr[2][2], ci[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cr[u][w][r] = 0.0; ci[u][w][r] = 0.0; }
+    for (int k0 = 0; k0 < n; k0 += MK) {
+        // 256 threads stage 64 x 8 of A and 8 x 64 of op(B): two elements each
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e >> 3, kk = e & 7;
+            const int gi = ti + r, gk = k0 + kk;
+            As[r][kk] = (gi < n && gk < n) ? Ab[(size_t)gi * n + gk] : make_double2(0.0, 0.0);
+            const int kk2 = e >> 6, cc = e & 63;
+            const int gk2 = k0 + kk2, gj = tj + cc;
+            cd v = make_double2(0.0, 0.0);
+            if (gk2 < n && gj < n) {
+                if (opB == 0) v = Bb[(size_t)gk2 * n + gj];
+                else { v = Bb[(size_t)gj * n + gk2]; v.y = -v.y; }
+            }
+            Bs[kk2][cc] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < MK; ks += 4) {
+            cd a[2], bb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) a[u] = As[wr + 16 * u + l15][ks + l4];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) bb[w] = Bs[ks + l4][wc + 16 * w + l15];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    cr[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, bb[w].x, cr[u][w], 0, 0, 0);
+                    ci[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, bb[w].y, ci[u][w], 0, 0, 0);
+                    cr[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u].y, bb[w].y, cr[u][w], 0, 0, 0);
+                    ci[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, bb[w].x, ci[u][w], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    cd* Cb = Cm + (size_t)b * sC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = ti + wr + 16 * u + l4 + 4 * r, gj = tj + wc + 16 * w + l15;
+                if (gi < n && gj < n) {
+                    cd v = make_double2(cr[u][w][r], ci[u][w][r]);
+                    if (addI && gi == gj) v.x += 1.0;
+                    Cb[(size_t)gi * n + gj] = v;
+                }
+            }
+}
+
 // ---- batched in-place inverse, blocked: Gauss-Jordan on ZB x ZB blocks.  The unblocked kernel below
 // sweeps the whole matrix once per pivot (n sweeps of n*n*16 bytes: HBM/L2-bound, 230 ms for 2049
 // matrices of 256 x 256); here one sweep serves ZB pivots:

@@ -305,6 +305,11 @@ void emu_w_widen(const float* in, double* out, int C, long long n, double eps) {
     emu::launch(dim3(4), dim3(256), 0, [&] { spywil::widen_kernel(reinterpret_cast<const float2*>(in), reinterpret_cast<cd*>(out), C, n, eps); });
 }
 void emu_w_gemm(const double* A, const double* B, double* Cm, int n, int batch, long long sA, long long sB, long long sC, int opB, int addI) {
+    if (n >= 48) {      // as granger.hip: fp64 MFMA tiles
+        dim3 g((n + 63) / 64, (n + 63) / 64, batch);
+        emu::launch(g, dim3(256), 0, [&] { spywil::zgemm_mfma_kernel(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI); });
+        return;
+    }
     dim3 grid((n + 31) / 32, (n + 31) / 32, batch);
     emu::launch(grid, dim3(256), 0, [&] { spywil::zgemm_kernel(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI); });
 }

@@ -191,6 +191,18 @@ def test_plus_operator(F):
     np.testing.assert_allclose(g0, ref0, rtol=1e-12, atol=1e-12)
 
 
+def test_zgemm_on_f64_matrix_cores():
+    """n >= 48 takes the v_mfma_f64_16x16x4_f64 tiles (asymmetric operands catch row/column swaps; n = 50 leaves
+    ragged tiles)."""
+    rng = np.random.default_rng(50)
+    n = 50
+    A = rng.normal(size=(1, n, n)) + 1j * rng.normal(size=(1, n, n))
+    Bm = rng.normal(size=(1, n, n)) + 1j * rng.normal(size=(1, n, n))
+    np.testing.assert_allclose(E.w_gemm(A, Bm), A @ Bm, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(E.w_gemm(A, Bm, opB=1, addI=1), A @ Bm.conj().transpose(0, 2, 1) + np.eye(n), rtol=1e-12,
+                               atol=1e-12)
+
+
 def test_wilson_building_blocks():
     rng = np.random.default_rng(3)
     n, B = 37, 3
