@@ -5,7 +5,7 @@
 One "step" = one complete pass of the hot path over the rank's in-HBM trial queue:
     for every batch of trials:  detrend -> taper -> FFT (complex spectra, all tapers)   [K1]
                                  acc += X X^H on the fp32 matrix cores                     [K4]
-    (N > 1) RCCL all-reduce of the CSD accumulator over xGMI                               [C1]
+    (N > 1) RCCL all-reduce of the accumulator's packed lower triangle over xGMI           [C1]
     scale + Hermitian mirror, coherence normalisation -> (F, C, C) float32                 [K5]
 Trials shard across ranks with no other exchange (weak scaling: 1000 trials per GPU).
 
@@ -170,7 +170,10 @@ def main():
                 ev_fft.append((e0, e1, nb))
                 ev_csd.append((e1, e2, nb))
         if dist_on:
-            dist.all_reduce(torch.view_as_real(acc))
+            # the accumulator carries its lower triangle only: pack -> all-reduce -> unpack (0.54 GB instead of 1.07)
+            packed = be.csd_tril_pack(acc)
+            dist.all_reduce(torch.view_as_real(packed))
+            be.csd_tril_unpack(packed, acc)
         be.csd_finalize(acc, 1.0 / (K * T * world))
         return be.coh_normalize(acc, "abs")
 

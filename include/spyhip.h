@@ -121,6 +121,12 @@ int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, in
  * spec_d = (nrows, ceil(nchan/4), nfreq, 4) complex64.  Bit-identical results. */
 int spyhip_csd_accumulate_blocked(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
                                   void* acc_d);
+/* Lower triangle (i >= j) of the accumulator <-> packed (nfreq, nchan(nchan+1)/2) complex64: what the multi-GPU
+ * path all-reduces between spyhip_csd_accumulate and spyhip_csd_finalize (the mutex-guarded `+=` of
+ * shared/kwarg_decorators.py:723-735 ships 0.54 GB instead of 1.07 GB at 256 channels).  Unpack writes only the lower
+ * triangle of acc_d. */
+int spyhip_csd_tril_pack(spyhip_ctx* ctx, const void* acc_d, int nfreq, int nchan, void* packed_d);
+int spyhip_csd_tril_unpack(spyhip_ctx* ctx, const void* packed_d, int nfreq, int nchan, void* acc_d);
 /* acc[f,i,j] *= scale on the lower triangle and acc[f,j,i] = conj(acc[f,i,j]):
  * scale = 1/(ntaper*ntrials) turns the sum into the taper- and trial-mean. */
 int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, double scale);

@@ -223,6 +223,43 @@ def csd_accumulate(spec, acc, blocked=False):
     return acc
 
 
+def csd_allreduce_(acc):
+    """Sum the (lower-triangle) CSD accumulator over all ranks in place: the ONE collective of the coherence path.
+    Only the lower triangle carries data before csd_finalize, so it is packed to (F, C(C+1)/2), all-reduced over
+    RCCL and unpacked (half the bytes on xGMI).  No-op for a single process."""
+    from . import parallel
+    if parallel.world()[1] == 1:
+        return acc
+    assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and acc.dim() == 3
+    F, Cn, _ = acc.shape
+    ctx = context(acc.device)
+    ctx.bind_stream()
+    packed = torch.empty((F, Cn * (Cn + 1) // 2), dtype=torch.complex64, device=acc.device)
+    check(ctx.lib.spyhip_csd_tril_pack(ctx.handle, _ptr(acc), F, Cn, _ptr(packed)), "spyhip_csd_tril_pack")
+    parallel.allreduce_sum_(packed)
+    check(ctx.lib.spyhip_csd_tril_unpack(ctx.handle, _ptr(packed), F, Cn, _ptr(acc)), "spyhip_csd_tril_unpack")
+    return acc
+
+
+def csd_tril_pack(acc):
+    """(F, C, C) complex64 -> packed lower triangle (F, C(C+1)/2)."""
+    F, Cn, _ = acc.shape
+    ctx = context(acc.device)
+    ctx.bind_stream()
+    packed = torch.empty((F, Cn * (Cn + 1) // 2), dtype=torch.complex64, device=acc.device)
+    check(ctx.lib.spyhip_csd_tril_pack(ctx.handle, _ptr(acc), F, Cn, _ptr(packed)), "spyhip_csd_tril_pack")
+    return packed
+
+
+def csd_tril_unpack(packed, acc):
+    """Write the packed lower triangle back into acc (F, C, C); the upper triangle is left alone."""
+    F, Cn, _ = acc.shape
+    ctx = context(acc.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_csd_tril_unpack(ctx.handle, _ptr(packed), F, Cn, _ptr(acc)), "spyhip_csd_tril_unpack")
+    return acc
+
+
 def csd_finalize(acc, scale):
     """Scale the accumulated lower triangle and mirror it: acc becomes the full Hermitian CSD."""
     assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and acc.dim() == 3

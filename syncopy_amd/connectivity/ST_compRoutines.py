@@ -106,7 +106,8 @@ class CrossSpectra(ComputationalRoutine):
             out._dev = None
             out.data = parallel.gather_trials(acc.cpu().numpy()).reshape(self.outputShape)
         else:
-            parallel.allreduce_sum_(acc)                   # the ONE collective of the path (RCCL over xGMI)
+            backend.csd_allreduce_(acc)                    # the ONE collective of the path (RCCL over xGMI,
+                                                           # lower triangle only)
             backend.csd_finalize(acc, 1.0 / (K * T))
             out._dev = acc.reshape(self.outputShape)
             out.data = out._dev.cpu().numpy()

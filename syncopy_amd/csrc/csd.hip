@@ -130,6 +130,30 @@ extern "C" int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int 
     return 0;
 }
 
+static int tril_move(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, void* packed_d, bool unpack) {
+    if (!ctx || !acc_d || !packed_d) { spy::set_error("csd_tril: null argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long n = (long long)nfreq * nchan * nchan;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (unpack)
+        hipLaunchKernelGGL(spycsd::csd_tril_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<float2*>(acc_d), reinterpret_cast<float2*>(packed_d), nfreq, nchan);
+    else
+        hipLaunchKernelGGL(spycsd::csd_tril_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<float2*>(acc_d), reinterpret_cast<float2*>(packed_d), nfreq, nchan);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int spyhip_csd_tril_pack(spyhip_ctx* ctx, const void* acc_d, int nfreq, int nchan, void* packed_d) {
+    return tril_move(ctx, const_cast<void*>(acc_d), nfreq, nchan, packed_d, false);
+}
+
+extern "C" int spyhip_csd_tril_unpack(spyhip_ctx* ctx, const void* packed_d, int nfreq, int nchan, void* acc_d) {
+    return tril_move(ctx, acc_d, nfreq, nchan, const_cast<void*>(packed_d), true);
+}
+
 extern "C" int spyhip_coh_normalize(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, int output,
                                     void* out_d) {
     if (!ctx || !csd_d || !out_d) { spy::set_error("coh_normalize: null argument"); return -1; }
