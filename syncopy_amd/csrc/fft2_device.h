@@ -149,16 +149,19 @@ __device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h,
     using C = Cfg2<LOG2N, G>;
     v2f* const im = re + C::PLANE;
     const int rb = C::rbase(j, h);
+    Tw6 tnext;                       // twiddles of the NEXT radix-16 pass: requested before the exchange of the
+                                     // current one, so their L2 round trip hides behind the LDS traffic and barriers
 #pragma unroll
     for (int p = 0; p < C::NP16; ++p) {
         const int Ns = 1 << (4 * p);
         const int k = j & (Ns - 1);
-        if (p > 0) {
-            const unsigned kb = (unsigned)(k * (C::N / (Ns * 16))) * 8u;   // byte offset of tw[k*stride]
-            const Tw6 t = load_tw6(tw, kb);
-            apply_tw(v, t);
-        }
+        if (p > 0) apply_tw(v, tnext);
         dft16p(v);
+        if (p + 1 < C::NP16) {
+            const int Ns1 = Ns * 16;
+            const int k1 = j & (Ns1 - 1);
+            tnext = load_tw6(tw, (unsigned)(k1 * (C::N / (Ns1 * 16))) * 8u);   // byte offset of tw[k*stride]
+        }
         const bool last = (p == C::NP16 - 1) && (C::RLAST == 1);
         if (!last) {
             const int B = ((j >> (4 * p)) << (4 * p + 4)) + k;
