@@ -143,7 +143,10 @@ __device__ __forceinline__ void apply_tw(C2 (&v)[16], const Tw6& t) {
 
 // Forward FFT of the 16 packed values per thread; on return v[e] = Z[j + T*e] (both FFTs).
 // `tw[m] = exp(-2 pi i m / N)`.  Contains __syncthreads(): every thread of the workgroup must call
-// it.  `re`/`im` = the two LDS planes; the caller may reuse them after return.
+// it.  `re`/`im` = the two LDS planes.  Barrier discipline: every LDS write phase is PRECEDED by a barrier
+// (so earlier reads of the planes by any thread - also the caller's - are finished) and followed by one
+// before the reads; there is NO barrier after the last reads: a caller that writes the planes itself
+// must put a __syncthreads() in front of its writes.
 template <int LOG2N, int G>
 __device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h, const float2* __restrict__ tw) {
     using C = Cfg2<LOG2N, G>;
@@ -167,6 +170,9 @@ __device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h,
             const int B = ((j >> (4 * p)) << (4 * p + 4)) + k;
             const int wb = C::idx(B, h);
             const int ws = (p == 0) ? G : (Ns + Ns / 16) * G;
+            // write-after-read barrier placed HERE, behind this pass's butterflies, instead of right after the
+            // previous reads: a wave that is done reading starts computing at once and meets the others later
+            __syncthreads();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 re[wb + r * ws] = v[r].r;
@@ -178,7 +184,6 @@ __device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h,
                 v[e].r = re[rb + e * C::ESTRIDE];
                 v[e].i = im[rb + e * C::ESTRIDE];
             }
-            __syncthreads();
         }
     }
     if constexpr (C::RLAST > 1) {

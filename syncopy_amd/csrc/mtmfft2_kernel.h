@@ -184,6 +184,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
             }
         }
         if (a.demean_taper) {
+            __syncthreads();          // block_sum writes its scratch into the planes other waves may still be reading
             double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -206,6 +207,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         fft2_forward<LOG2N, G>(v, lds, j, h, a.tw);
 
         // ---- separate the real channels: partner bin N-f lives in the upper half
+        __syncthreads();              // the FFT's last reads of the planes are done everywhere
         {
             const int wb = C::rbase(j, h);
 #pragma unroll
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                 }
             }
         }
-        __syncthreads();  // LDS is reused by the next taper
+        // no barrier here: the next taper's first LDS write sits behind one (fft2_forward / block_sum)
     }
 
     if (MEAN) {

@@ -163,6 +163,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
             v[e].i = x[e].i * wn;
         }
         if (a.demean_taper) {
+            __syncthreads();          // block_sum writes its scratch into the planes other waves may still be reading
             double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         for (int e = 0; e < 16; ++e) v[e] = cmul_s(v[e], ldg<float2>(a.bhat, (unsigned)(j + T * e) * 8u));
         fft2_inverse<LOG2N, G>(v, lds, j, h, a.tw);
         // Z[k] = conv[k] c[k] for k < nfft, parked in LDS in natural order for the channel separation
+        __syncthreads();              // the inverse FFT's last reads of the planes are done everywhere
         {
             const int wb = C::rbase(j, h);
 #pragma unroll
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                 }
             }
         }
-        __syncthreads();  // LDS is reused by the next taper
+        // no barrier here: the next taper's first LDS write sits behind one (fft2_forward / block_sum)
     }
 
     if (MEAN) {
