@@ -68,7 +68,7 @@ __device__ __forceinline__ void sched_fence_csd() {
 
 constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chunk <= 32 KiB of LDS)
 
-// Waves 0-3 own TA tiles each, waves 4-7 TB tiles each (TA >= TB): with (5,4) a workgroup
+// Four waves own TA tiles each, four own TB tiles each (TA >= TB): with (5,4) a workgroup
 // covers the 36 lower-triangle tiles of one frequency at C=256 and every SIMD (waves w and
 // w+4) carries 9 tiles.  5 x 32 accumulator registers per wave fit the AGPR file, so the
 // MFMA chain never leaves it (9 tiles on ONE wave need 288 and made hipcc rotate accumulators
@@ -82,8 +82,11 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int ntile_w = wave < 4 ? TA : TB;                                  // wave-uniform
-    const int first_w = wave < 4 ? wave * TA : 4 * TA + (wave - 4) * TB;
+    // waves {0,2,5,7} own TA tiles, {1,3,4,6} own TB: every SIMD carries TA+TB tiles whether the hardware places
+    // waves w and w+4 or waves 2s and 2s+1 of a workgroup on the same SIMD
+    constexpr unsigned BIG = 0xA5u;
+    const int ntile_w = ((BIG >> wave) & 1u) ? TA : TB;                      // wave-uniform
+    const int first_w = wave * TB + __builtin_popcount(BIG & ((1u << wave) - 1u)) * (TA - TB);
 
     const int split = a.rows_per_split > 0 ? (int)blockIdx.y : 0;
     const long long row_lo = (long long)split * a.rows_per_split;
@@ -253,7 +256,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
             sched_fence_csd();
 #pragma unroll
             for (int t = NPRE; t < TA; ++t) {
-                if (t >= TB && t >= ntile_w) break;           // waves 4-7 own TB tiles
+                if (t >= TB && t >= ntile_w) break;           // half of the waves own TB tiles only
                 mfma4(t, av[t], bv[t]);
             }
         }
