@@ -9,9 +9,9 @@ using spycsd::CsdArgs;
 
 namespace {
 
-template <int TA, int TB>
+template <int TA, int TB, bool FAST = false>
 int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item_end, int nsplit = 1) {
-    auto kern = spycsd::csd_accum_kernel<TA, TB>;
+    auto kern = spycsd::csd_accum_kernel<TA, TB, FAST>;
     const int per = 4 * (TA + TB);
     // frequencies a workgroup can touch: items [i0, i0+per) span at most this many f
     int nfb = (per + a.ntiles - 1) / a.ntiles;
@@ -27,7 +27,8 @@ int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item
         return -3;
     }
     const long long rows_wg = nsplit > 1 ? a.rows_per_split : a.nrows;
-    if (kb > rows_wg) kb = (int)((rows_wg + 3) & ~3LL);
+    if (kb > rows_wg && !FAST) kb = (int)((rows_wg + 3) & ~3LL);
+    if (FAST && kb != 16) { spy::set_error("csd_accumulate: internal error (fast path needs 16-row chunks)"); return -1; }
     a.kb = kb;
     a.item_base = item_base;
     a.item_end = item_end;
@@ -80,7 +81,9 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
         const long long per = 36, nwg = (a.nitems + per - 1) / per;
         const long long full = (nwg / ctx->num_cu) * ctx->num_cu, rem = nwg - full;
         if (full > 0 && rem > 0 && rem * 4 <= ctx->num_cu) {
-            int rc = launch_accum<5, 4>(ctx, a, 0, full * per);
+            // C = 256, row-major spectra: the specialised instruction-lean path
+            int rc = (nchan == 256 && !blocked) ? launch_accum<5, 4, true>(ctx, a, 0, full * per)
+                                                : launch_accum<5, 4>(ctx, a, 0, full * per);
             if (rc) return rc;
             // tail: 1 tile per wave AND the rows split over blockIdx.y, so that its rem*4.5*nsplit short
             // workgroups fill the chip once; splits > 0 leave partial sums in library scratch that a
@@ -112,7 +115,8 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
             }
             return 0;
         }
-        return launch_accum<5, 4>(ctx, a, 0, a.nitems);
+        return (nchan == 256 && !blocked) ? launch_accum<5, 4, true>(ctx, a, 0, a.nitems)
+                                          : launch_accum<5, 4>(ctx, a, 0, a.nitems);
     }
     if (a.ntiles >= 6) return launch_accum<3, 2>(ctx, a, 0, a.nitems);
     return launch_accum<1, 1>(ctx, a, 0, a.nitems);

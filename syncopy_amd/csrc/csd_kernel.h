@@ -75,7 +75,14 @@ constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chu
 // through VGPRs inside the loop).
 // One chunk of kb rows is fetched into registers (all loads in flight together) while the
 // previous chunk is being multiplied, then written to LDS.
-template <int TA, int TB>
+//
+// FAST (host-selected: C = cpad = 256, one frequency per workgroup, kb = 16, row-major spectra): the matrix pipe
+// and every other instruction of a SIMD's two waves share one issue port, so what is not an MFMA costs matrix
+// time (ablations: staging instructions -12 %, loop overhead -12 %).  The fast path keeps the non-MFMA count
+// minimal: 16-byte staging loads/stores addressed by a scalar base + one lane offset (4 + 4 instructions per
+// chunk instead of ~250), the row-pair loop fully unrolled with every LDS fragment address = one register per
+// tile + an immediate, the three LDS buffers reached by bumping those registers once per chunk.
+template <int TA, int TB, bool FAST = false>
 __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     SPY_DYN_SMEM(float2, X);   // 2 x [kb][rowlen]
     constexpr int PER = 4 * (TA + TB);
@@ -84,7 +91,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     const int l31 = lane & 31, lhi = lane >> 5;
     // waves {0,2,5,7} own TA tiles, {1,3,4,6} own TB: every SIMD carries TA+TB tiles whether the hardware places
     // waves w and w+4 or waves 2s and 2s+1 of a workgroup on the same SIMD
-    constexpr unsigned BIG = 0xA5u;
+    constexpr unsigned BIG = FAST ? 0xA5u : 0x0Fu;   // (generic path: waves 0-3, one live register less)
     const int ntile_w = ((BIG >> wave) & 1u) ? TA : TB;                      // wave-uniform
     const int first_w = wave * TB + __builtin_popcount(BIG & ((1u << wave) - 1u)) * (TA - TB);
 
@@ -128,6 +135,126 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         }
     }
 
+    if constexpr (FAST) {
+        constexpr int ROWLEN = 256, KB = 16, CHUNK = KB * ROWLEN;   // float2 elements per LDS buffer (32 KiB)
+        constexpr int NPRE = 2;
+        float4* const X4 = reinterpret_cast<float4*>(X);
+        const size_t rowstride = (size_t)a.F * a.C;                 // float2 elements between rows
+        const unsigned rowbytes = (unsigned)rowstride * 8u;
+        const char* const fb = reinterpret_cast<const char*>(a.spec + (size_t)row_lo * rowstride + (size_t)f_lo * a.C);
+        const int srow = tid >> 7;                                  // this thread stages rows srow + 4v, v < 4
+        const unsigned coff = (unsigned)(tid & 127) * 16u;          // ... columns 2*(tid&127), +1 (16 bytes)
+        const long long nchunk = (nrows + KB - 1) / KB;
+        float4 pf[4];
+        unsigned okmask = 0;
+        auto fetch = [&](long long c) {
+            const long long r0 = c * KB;
+            const long long left = nrows - r0;
+            const int rleft = left < KB ? (int)left : KB;           // >= 1 valid rows in this chunk
+            const char* base = fb + (size_t)r0 * rowbytes;          // wave-uniform
+            okmask = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = srow + 4 * v;
+                const int rc = row < rleft ? row : rleft - 1;       // clamped: the load is unconditional
+                pf[v] = *reinterpret_cast<const float4*>(base + ((unsigned)rc * rowbytes + coff));
+                okmask |= (row < rleft) ? (1u << v) : 0u;
+            }
+        };
+        auto put = [&](int buf) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                X4[buf * (CHUNK / 2) + tid + CSD_THREADS * v] = ((okmask >> v) & 1u) ? pf[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        fetch(0);
+        put(0);
+        if (nchunk > 1) {
+            fetch(1);
+            put(1);
+        }
+        if (nchunk > 2) fetch(2);
+        __syncthreads();
+
+        // byte address (inside X) of this lane's A / B fragment of row pair 0 in the CURRENT buffer
+        unsigned aA[TA], aB[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            aA[t] = (unsigned)(lhi * ROWLEN + aoff[t]) * 8u;
+            aB[t] = (unsigned)(lhi * ROWLEN + boff[t]) * 8u;
+        }
+        const char* const Xb = reinterpret_cast<const char*>(X);
+        auto lds2 = [&](unsigned addr, int imm) { return *reinterpret_cast<const float2*>(Xb + addr + imm); };
+        auto mfma4 = [&](int t, float2 av, float2 bv) {
+            accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accr[t], 0, 0, 0);
+            acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acci[t], 0, 0, 0);
+            accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, accr[t], 0, 0, 0);
+            acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av.x, bv.y, acci[t], 0, 0, 0);
+        };
+        float2 pa[NPRE], pb[NPRE];
+#pragma unroll
+        for (int t = 0; t < NPRE; ++t) {
+            pa[t] = lds2(aA[t], 0);
+            pb[t] = lds2(aB[t], 0);
+        }
+        int b0 = 0;
+        for (long long c = 0; c < nchunk; ++c) {
+            const int b2 = b0 == 0 ? 2 : b0 - 1;                    // (b0 + 2) % 3
+            if (c + 2 < nchunk) {
+                put(b2);
+                if (c + 3 < nchunk) fetch(c + 3);
+            }
+#pragma unroll
+            for (int st = 0; st < KB / 2; ++st) {
+                constexpr int RP = 2 * ROWLEN * 8;                  // bytes per row pair
+                float2 av[TA], bv[TA];
+#pragma unroll
+                for (int t = 0; t < NPRE; ++t) {
+                    av[t] = pa[t];
+                    bv[t] = pb[t];
+                }
+#pragma unroll
+                for (int t = NPRE; t < TA; ++t) {
+                    av[t] = lds2(aA[t], st * RP);
+                    bv[t] = lds2(aB[t], st * RP);
+                }
+                sched_fence_csd();
+#pragma unroll
+                for (int t = 0; t < NPRE; ++t) mfma4(t, av[t], bv[t]);
+                sched_fence_csd();
+                if (st + 1 < KB / 2) {
+#pragma unroll
+                    for (int t = 0; t < NPRE; ++t) {
+                        pa[t] = lds2(aA[t], (st + 1) * RP);
+                        pb[t] = lds2(aB[t], (st + 1) * RP);
+                    }
+                } else {
+                    // last row pair of the chunk: move every fragment address to the next buffer (+32 KiB, or
+                    // back by 64 KiB), then fetch the first fragments of the next chunk from there
+                    const int delta = (b0 == 2) ? -2 * CHUNK * 8 : CHUNK * 8;
+#pragma unroll
+                    for (int t = 0; t < TA; ++t) {
+                        aA[t] += (unsigned)delta;
+                        aB[t] += (unsigned)delta;
+                    }
+                    if (c + 1 < nchunk) {
+#pragma unroll
+                        for (int t = 0; t < NPRE; ++t) {
+                            pa[t] = lds2(aA[t], 0);
+                            pb[t] = lds2(aB[t], 0);
+                        }
+                    }
+                }
+                sched_fence_csd();
+#pragma unroll
+                for (int t = NPRE; t < TA; ++t) {
+                    if (t >= TB && t >= ntile_w) break;
+                    mfma4(t, av[t], bv[t]);
+                }
+            }
+            __syncthreads();
+            b0 = b0 == 2 ? 0 : b0 + 1;
+        }
+    } else {
     // element i of this thread = LDS slot u = tid + 512*i = (row kr, column cc) of the chunk
     const int total = a.kb * rowlen;                       // <= 512 * CSD_PF
     const int step_q = CSD_THREADS / rowlen, step_r = CSD_THREADS % rowlen;
@@ -264,6 +391,8 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         __syncthreads();
 #endif
         b0 = b1;
+    }
+
     }
 
     // ---- acc += tile (each (f, tile) is owned by exactly one wave: plain read-modify-write)

@@ -221,13 +221,15 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
     int kb = 32;
     while (kb > 4 && (size_t)kb * rowbytes > (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2)) kb -= 4;
-    if (kb > nrows) kb = (int)((nrows + 3) & ~3LL);
+    const bool fast = (ta == 5 && C == 256 && !g_blocked);     // as csd.hip: the instruction-lean path
+    if (kb > nrows && !fast) kb = (int)((nrows + 3) & ~3LL);
     a.kb = kb;
     a.item_base = 0; a.item_end = a.nitems;
     const size_t lds = 3 * (size_t)kb * rowbytes;
     const unsigned grid = (unsigned)((a.nitems + per - 1) / per);
     const unsigned T = spycsd::CSD_THREADS;
-    if (ta == 5) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4>(a); });
+    if (ta == 5 && fast) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, true>(a); });
+    else if (ta == 5) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4>(a); });
     else if (ta == 3) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<3, 2>(a); });
     else emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<1, 1>(a); });
     return ta;

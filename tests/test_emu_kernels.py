@@ -129,7 +129,7 @@ def test_fp32_fft_error_level():
 
 
 @pytest.mark.parametrize("C,F,R,tpw", [(5, 9, 6, 0), (40, 5, 7, 0), (70, 3, 10, 5), (130, 2, 4, 0), (33, 4, 5, 1),
-                                       (100, 3, 5, 0), (256, 2, 4, 0)])
+                                       (100, 3, 5, 0), (256, 2, 4, 0), (256, 1, 37, 0), (240, 1, 6, 0)])
 def test_csd_mfma_kernel(C, F, R, tpw):
     rng = np.random.default_rng(C)
     spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)

@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
     double fl = 8.0 * rows * F * C * (C + 1) / 2;
-    printf("rows=%d F=%d: %.3f ms, %.1f TF algorithmic, %.1f TF issued\n", rows, F, ms, fl / ms / 1e9, fl * 36 / 32.5 / ms / 1e9 * 1.0 * (256.0*256/(256*257/2*36/32.5*2)) );
+    printf("rows=%d F=%d: %.3f ms, %.1f TF algorithmic, %.1f TF issued (36 tiles)\n", rows, F, ms, fl / ms / 1e9,
+           8.0 * rows * F * 36.0 * 1024 / ms / 1e9);
     return 0;
 }
