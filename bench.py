@@ -233,7 +233,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "spycsd::csd_accum_kernel<5, 4> (+ row-split <1, 1> tail and its reduction)",
+                "kernel": "spycsd::csd_accum_kernel<5, 4, true> (+ row-split <1, 1> tail and its reduction)",
                 "achieved": achieved,
                 "peak": PEAK_MFMA_F32_TFLOPS,
                 "unit": "TFLOP/s",

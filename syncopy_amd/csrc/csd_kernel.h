@@ -87,7 +87,12 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     SPY_DYN_SMEM(float2, X);   // 2 x [kb][rowlen]
     constexpr int PER = 4 * (TA + TB);
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+#ifndef SPY_HOST_EMU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile-count tests become s_cbranch, not exec masks
+#else
+    const int wave = tid >> 6;
+#endif
     const int l31 = lane & 31, lhi = lane >> 5;
     // waves {0,2,5,7} own TA tiles, {1,3,4,6} own TB: every SIMD carries TA+TB tiles whether the hardware places
     // waves w and w+4 or waves 2s and 2s+1 of a workgroup on the same SIMD
