@@ -112,6 +112,21 @@ jk("coh_complex", method="coh", tapsmofrq=3, output="complex", foilim=[5, 60])
 jk("granger", method="granger", tapsmofrq=3)
 save("jackknife", adj=adj, data=np.stack(trials_of(n5j)), samplerate=n5j.samplerate, **kw)
 
+# ---------------------------------------------------------------- SpectralData-input connectivity (connectivity_analysis.py:475-538,
+# ST_compRoutines.py:30-117): freqanalysis(output="fourier", keeptapers=True) chained into connectivityanalysis
+kw = {}
+spec5 = spy.freqanalysis(n5j, method="mtmfft", tapsmofrq=3, output="fourier", keeptapers=True, foilim=[0, 60])
+kw["spec_freq"] = spec5.freq
+kw["spec_first_trial"] = spec5.data[0:1]            # the full (20, 29, 301, 5) spectra are 7 MB: the tests chain their own
+kw["chain_coh"] = ca(spec5, method="coh")
+kw["chain_coh_complex"] = ca(spec5, method="coh", output="complex")
+kw["chain_csd"] = ca(spec5, method="csd")
+kw["chain_csd_keeptrials_first3"] = ca(spec5, slice(0, 3), method="csd", keeptrials=True)
+spec5g = spy.freqanalysis(n5j, method="mtmfft", tapsmofrq=3, output="fourier", keeptapers=True, demean_taper=True)
+gg = spy.connectivityanalysis(spec5g, method="granger")
+kw["chain_granger"] = gg.data[()]
+save("chain", data=np.stack(trials_of(n5j)), samplerate=n5j.samplerate, **kw)
+
 # ---------------------------------------------------------------- mtmfft option sweep (incl. unequal trial lengths + selections)
 rng = np.random.default_rng(2024)
 lens = [1500, 2000, 1800, 2000]

@@ -72,6 +72,67 @@ def cross_spectra_cF(trl_dat, samplerate=1, nSamples=None, foi=None, taper="hann
     return acc.cpu().numpy()[np.newaxis], {"freqs_hash": _freqs_hash(freqs)}
 
 
+def spectral_dyadic_product_cF(specs, send_idx=None, send_N=None, rec_idx=None, rec_N=None, chunkShape=None,
+                               noCompute=False):
+    """Single-trial cross spectra straight from complex spectra (nTime, nTaper, nFreq, N): the outer product
+    over channels, averaged over tapers (syncopy/connectivity/ST_compRoutines.py:30-117) - the MFMA kernel with
+    the tapers of one time sample as rows.  Returns (nTime, nFreq, N, N) complex64."""
+    if send_idx is not None:
+        raise NotImplementedError("channelcmb (rectangular sender/receiver blocks) is listed as 'next' in SURVEY.md 8f")
+    nTime, nTaper, nFreq, nChannels = specs.shape
+    outShape = (nTime, nFreq, nChannels, nChannels)
+    if noCompute:
+        return outShape, spectralDTypes["fourier"]
+    backend.require_gpu()
+    dev = torch.from_numpy(np.ascontiguousarray(specs, dtype=np.complex64)).cuda()
+    acc = torch.zeros(outShape, dtype=torch.complex64, device=dev.device)
+    for t in range(nTime):
+        backend.csd_accumulate(dev[t].contiguous(), acc[t])
+        backend.csd_finalize(acc[t], 1.0 / nTaper)
+    return acc.cpu().numpy()
+
+
+class SpectralDyadicProduct(ComputationalRoutine):
+    """CrossSpectra's sibling for SpectralData input (`freqanalysis(output="fourier", keeptapers=True)` chained into
+    `connectivityanalysis`): nothing but K4 on spectra that already exist."""
+    dimord = ["time", "freq", "channel_i", "channel_j"]
+    computeFunction = staticmethod(spectral_dyadic_product_cF)
+    valid_kws = ["send_idx", "send_N", "rec_idx", "rec_N", "output"]
+
+    def compute_hip(self, data, out):
+        """All trials in one go: the whole (rows, nFreq, N) block of a rank's trials goes through the MFMA kernel
+        (keeptrials=False), or one launch per time sample (keeptrials=True)."""
+        rows, chans = trial_rows(data), selected_channels(data)
+        T = self.numTrials
+        mine = self.my_trials()
+        host = np.asarray(data.data)
+        if chans is not None:
+            host = host[..., chans]
+        F, C = self.targetShapes[0][1], self.targetShapes[0][2]
+        K = host.shape[1]
+        lens = {rows[k][1] - rows[k][0] for k in range(T)}
+        if self.keeptrials or lens != {1}:
+            # time-resolved spectra or kept trials: per-trial compute function (one launch per time sample)
+            parts = [torch.from_numpy(self.computeFunction(host[rows[k][0]:rows[k][1]])).cuda() for k in mine]
+            from ..specest.compRoutines import _store_trials
+            _store_trials(self, out, parts)
+            return
+        acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+        if len(mine):
+            sel = np.concatenate([np.arange(rows[k][0], rows[k][1]) for k in mine])
+            dev = torch.from_numpy(np.ascontiguousarray(host[sel], dtype=np.complex64)).cuda()
+            backend.csd_accumulate(dev, acc)            # rows = trials x tapers
+        backend.csd_allreduce_(acc)
+        backend.csd_finalize(acc, 1.0 / (K * T))
+        out._dev = acc.reshape(self.outputShape)
+        out.data = out._dev.cpu().numpy()
+
+    def process_metadata(self, data, out):
+        time_axis = bool(np.any(np.diff(data.trialdefinition)[:, 0] != 1))
+        propagate_properties(data, out, self.keeptrials, time_axis)
+        out.freq = data.freq
+
+
 class CrossSpectra(ComputationalRoutine):
     dimord = ["time", "freq", "channel_i", "channel_j"]
     computeFunction = staticmethod(cross_spectra_cF)

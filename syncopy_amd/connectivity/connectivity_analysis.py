@@ -9,13 +9,13 @@ import numbers
 
 import numpy as np
 
-from ..datatype import AnalogData, CrossSpectralData, selected_channels, selected_trialdefinition
+from ..datatype import AnalogData, CrossSpectralData, SpectralData, selected_channels, selected_trialdefinition
 from ..shared.const_def import connectivity_outputs, connectivityMethods
 from ..shared.errors import SPYTypeError, SPYValueError, SPYWarning
 from ..shared.input_processors import process_foi, process_padding, process_taper
 from ..shared.tools import best_match
 from .AV_compRoutines import NormalizeCrossSpectra
-from .ST_compRoutines import CrossSpectra
+from .ST_compRoutines import CrossSpectra, SpectralDyadicProduct
 
 
 def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi=None, foilim=None, pad="maxperlen",
@@ -23,7 +23,7 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
                          select=None, compute_method=None, routine_classes=None, **kwargs):
     """Cross-spectral connectivity of AnalogData on MI355X (arguments as spy.connectivityanalysis,
     connectivity_analysis.py:51-67)."""
-    if not isinstance(data, AnalogData) or data.data is None:
+    if not isinstance(data, (AnalogData, SpectralData)) or data.data is None:
         raise SPYValueError("either AnalogData or SpectralData as input", "data", data.__class__.__name__)
     if method not in connectivityMethods:
         raise SPYValueError("one of " + ", ".join(connectivityMethods), varname="method", actual=method)
@@ -35,7 +35,7 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     if polyremoval is not None:
         if not isinstance(polyremoval, numbers.Number) or polyremoval not in (0, 1):
             raise SPYValueError("0, 1 or None", varname="polyremoval", actual=polyremoval)
-    classes = {"csd": CrossSpectra, "coh": NormalizeCrossSpectra}
+    classes = {"csd": CrossSpectra, "coh": NormalizeCrossSpectra, "dyadic": SpectralDyadicProduct}
     try:
         from .AV_compRoutines import GrangerCausality
         classes["granger"] = GrangerCausality
@@ -72,6 +72,19 @@ def _as_single_trials(template, arr):
     return obj
 
 
+def _connectivity_from_spectra(data, classes, method, keeptrials, output, compute_method, jackknife):
+    """SpectralData input (connectivity_analysis.py:475-538): the spectra exist already, the ST stage is the dyadic
+    product; everything about tapers / padding / frequencies was decided in freqanalysis."""
+    if not np.issubdtype(np.asarray(data.data).dtype, np.complexfloating):
+        raise SPYValueError("complex valued spectra, set `output='fourier'` in spy.freqanalysis!", "data",
+                            "real valued spectral data")
+    if method == "granger" and data.data.shape[data.dimord.index("time")] != len(data.sampleinfo):
+        raise NotImplementedError("Time resolved Granger causality from tf-spectra not available atm")
+    log_dict = {"method": method, "output": output, "keeptrials": keeptrials}
+    st = classes["dyadic"]()
+    return _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
+
+
 def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq, nTaper, taper,
                   taper_opt, compute_method, jackknife=False):
     fs = data.samplerate
@@ -85,6 +98,8 @@ def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, p
     if keeptrials is not False and method in ("coh", "granger"):
         raise SPYValueError(f"False, trial averaging needed for method {method}!", varname="keeptrials",
                             actual=keeptrials)
+    if isinstance(data, SpectralData):
+        return _connectivity_from_spectra(data, classes, method, keeptrials, output, compute_method, jackknife)
     nSamples = process_padding(pad, lenTrials, fs)
     foi, foilim = process_foi(foi, foilim, fs)
     if method == "granger":
@@ -110,6 +125,11 @@ def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, p
 
     st = classes["csd"](samplerate=fs, nSamples=nSamples, taper=taper, taper_opt=taper_opt,
                         demean_taper=(method == "granger"), polyremoval=polyremoval, timeAxis=timeAxis, foi=foi)
+    return _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
+
+
+def _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict):
+    """ST stage (single-trial cross spectra, trial-averaged unless kept) -> AV stage, plus the jackknife."""
     if method == "coh":
         if output not in connectivity_outputs:
             raise SPYValueError(f"one of {sorted(connectivity_outputs)}", varname="output", actual=output)

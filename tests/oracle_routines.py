@@ -8,7 +8,7 @@ import numpy as np
 
 from oracle import spy_oracle as O
 from syncopy_amd.connectivity.AV_compRoutines import NormalizeCrossSpectra, _AverageRoutine
-from syncopy_amd.connectivity.ST_compRoutines import CrossSpectra
+from syncopy_amd.connectivity.ST_compRoutines import CrossSpectra, SpectralDyadicProduct
 from syncopy_amd.specest.compRoutines import MultiTaperFFT, MultiTaperFFTConvol, _make_trialdef
 from syncopy_amd.shared.computational_routine import ComputationalRoutine, propagate_properties
 
@@ -46,6 +46,16 @@ class OracleCrossSpectra(CrossSpectra):
     computeFunction = staticmethod(_cross_spectra_cF)
 
 
+def _dyadic_cF(specs, send_idx=None, send_N=None, rec_idx=None, rec_N=None, chunkShape=None, noCompute=False):
+    if noCompute:
+        return (specs.shape[0], specs.shape[2], specs.shape[3], specs.shape[3]), np.complex64
+    return O.spectral_dyadic_product(np.asarray(specs), send_idx, rec_idx)
+
+
+class OracleSpectralDyadicProduct(SpectralDyadicProduct):
+    computeFunction = staticmethod(_dyadic_cF)
+
+
 def _normalize_cF(csd_av_dat, output="abs", chunkShape=None, noCompute=False):
     if noCompute:
         return csd_av_dat.shape, np.complex64 if output in ("complex", "fourier") else np.float32
@@ -68,4 +78,5 @@ class OracleGrangerCausality(_AverageRoutine):
 
 ORACLE_FREQ = {"mtmfft": OracleMultiTaperFFT, "mtmconvol": OracleMultiTaperFFTConvol,
                "wavelet": OracleWaveletTransform}
-ORACLE_CONN = {"csd": OracleCrossSpectra, "coh": OracleNormalizeCrossSpectra, "granger": OracleGrangerCausality}
+ORACLE_CONN = {"csd": OracleCrossSpectra, "coh": OracleNormalizeCrossSpectra, "granger": OracleGrangerCausality,
+               "dyadic": OracleSpectralDyadicProduct}

@@ -8,7 +8,7 @@ import pytest
 import syncopy_amd as spy
 from oracle_routines import ORACLE_CONN, ORACLE_FREQ
 from parity import assert_parity
-from test_oracle_golden import JACK_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, check_jackknife
+from test_oracle_golden import JACK_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, chain_checks, check_jackknife
 
 pytestmark = pytest.mark.gpu
 
@@ -59,6 +59,15 @@ def test_conn5_coherence_outputs(n5, output):
     z, data = n5
     assert_parity(spy.connectivityanalysis(data, method="coh", tapsmofrq=3, output=output).data, z["coh_" + output],
                   what=output)
+
+
+@pytest.mark.parametrize("how", ["hip", "sequential"])
+def test_chained_spectraldata_input(golden_dir, how):
+    """freqanalysis(output='fourier', keeptapers=True) -> connectivityanalysis on SpectralData: the dyadic product is
+    the MFMA kernel on spectra that already exist (all trials in one launch for compute_method='hip')."""
+    chain_checks(_load(golden_dir, "chain"),
+                 lambda d, **kw: spy.freqanalysis(d, compute_method=how, **kw),
+                 lambda d, **kw: spy.connectivityanalysis(d, compute_method=how, **kw))
 
 
 @pytest.mark.parametrize("name", sorted(JACK_VARIANTS))

@@ -102,6 +102,34 @@ def test_conn5_granger(n5):
     assert np.array_equal(g.freq, z["freq"])
 
 
+def chain_checks(z, freq, conn):
+    """freqanalysis(output='fourier', keeptapers=True) chained into connectivityanalysis (SpectralData input,
+    SURVEY 8f 'next' row 2) against the reference's chained results.  `freq` / `conn` = the two front ends."""
+    data = spy.AnalogData(np.concatenate(list(z["data"])), samplerate=float(z["samplerate"]),
+                          trialdefinition=np.stack([np.arange(20) * 1000, np.arange(1, 21) * 1000,
+                                                    np.zeros(20)], axis=1))
+    spec = freq(data, method="mtmfft", tapsmofrq=3, output="fourier", keeptapers=True, foilim=[0, 60])
+    assert_parity(spec.data[0:1], z["spec_first_trial"], what="chained spectra")
+    np.testing.assert_allclose(spec.freq, z["spec_freq"])
+    assert_parity(conn(spec, method="coh").data, z["chain_coh"], what="chain coh")
+    assert_parity(conn(spec, method="coh", output="complex").data, z["chain_coh_complex"], what="chain coh complex")
+    csd = conn(spec, method="csd")
+    assert_parity(csd.data, z["chain_csd"], what="chain csd")
+    np.testing.assert_allclose(csd.freq, z["spec_freq"])
+    assert_parity(conn(spec, method="csd", keeptrials=True).data[:3], z["chain_csd_keeptrials_first3"],
+                  what="chain csd keeptrials")
+    specg = freq(data, method="mtmfft", tapsmofrq=3, output="fourier", keeptapers=True, demean_taper=True)
+    g = conn(specg, method="granger")
+    np.testing.assert_allclose(g.data[:, 2:], z["chain_granger"][:, 2:], rtol=2e-3, atol=1e-3)
+    real = freq(data, method="mtmfft", tapsmofrq=3, foilim=[0, 60])
+    with pytest.raises(Exception):
+        conn(real, method="coh")                     # real-valued spectra are rejected (connectivity_analysis.py:477-480)
+
+
+def test_chained_spectraldata_input(golden_dir):
+    chain_checks(_load(golden_dir, "chain"), fa, ca)
+
+
 JACK_VARIANTS = {
     "coh_abs": dict(method="coh", tapsmofrq=3),
     "coh_complex": dict(method="coh", tapsmofrq=3, output="complex", foilim=[5, 60]),
