@@ -6,7 +6,7 @@ One "step" = one complete pass of the hot path over the rank's in-HBM trial queu
     for every batch of trials:  detrend -> taper -> FFT (complex spectra, all tapers)   [K1]
                                  acc += X X^H on the fp32 matrix cores                     [K4]
     (N > 1) RCCL all-reduce of the accumulator's packed lower triangle over xGMI           [C1]
-    scale + Hermitian mirror, coherence normalisation -> (F, C, C) float32                 [K5]
+    scale + coherence normalisation + Hermitian mirror (one fused pass) -> (F, C, C) float32 [K5]
 Trials shard across ranks with no other exchange (weak scaling: 1000 trials per GPU).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
@@ -174,8 +174,8 @@ def main():
             packed = be.csd_tril_pack(acc)
             dist.all_reduce(torch.view_as_real(packed))
             be.csd_tril_unpack(packed, acc)
-        be.csd_finalize(acc, 1.0 / (K * T * world))
-        return be.coh_normalize(acc, "abs")
+        # K5 fused: scale + coherency + |.| + Hermitian mirror straight from the raw accumulator
+        return be.coh_from_accumulator(acc, 1.0 / (K * T * world), "abs")
 
     def fence():
         torch.cuda.synchronize()

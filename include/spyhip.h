@@ -139,6 +139,13 @@ int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, doub
 int spyhip_coh_normalize(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, int output,
                          void* out_d);
 
+/* K5 fused for the coherence pipeline: out = conv( (acc*scale)[f,i,j] / sqrt((acc*scale)[f,i,i] (acc*scale)[f,j,j]) ) for the
+ * whole Hermitian (nfreq, nchan, nchan) output, read from the RAW lower-triangle accumulator of
+ * spyhip_csd_accumulate (acc_d is not modified).  Equals spyhip_csd_finalize + spyhip_coh_normalize bit for bit
+ * at a third of the HBM traffic. */
+int spyhip_coh_from_accumulator(spyhip_ctx* ctx, const void* acc_d, int nfreq, int nchan, double scale, int output,
+                                void* out_d);
+
 /* ---- K3: Morlet continuous wavelet transform ------------------------------
  * Replaces cwt_time (specest/wavelets/transform.py:88-108) with Morlet.time
  * (specest/wavelets/wavelets.py:27-86) and the tail of wavelet_cF

@@ -282,6 +282,20 @@ def coh_normalize(csd, output="abs"):
     return out
 
 
+def coh_from_accumulator(acc, scale, output="abs"):
+    """Coherence straight from the RAW lower-triangle accumulator of csd_accumulate (scale = 1/(tapers*trials)):
+    csd_finalize + coh_normalize fused, bit-identical, a third of the traffic.  acc is left untouched."""
+    assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and acc.dim() == 3
+    F, Cn, _ = acc.shape
+    kind = OUTPUT_KIND[output]
+    out = torch.empty((F, Cn, Cn), dtype=torch.complex64 if kind == 2 else torch.float32, device=acc.device)
+    ctx = context(acc.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_coh_from_accumulator(ctx.handle, _ptr(acc), F, Cn, float(scale), kind, _ptr(out)),
+          "spyhip_coh_from_accumulator")
+    return out
+
+
 def granger(csd, rtol=5e-6, niter=100, cond_max=1e4, eps_max=1e-1, want_factors=False):
     """Wilson spectral factorisation + Granger causality of a trial-averaged CSD (F, C, C) complex64.
     Returns (granger float32 (F,C,C), info dict[, H complex128 (F,C,C), Sigma complex128 (C,C)])."""

@@ -52,6 +52,13 @@ class NormalizeCrossSpectra(_AverageRoutine):
     valid_kws = ["output"]
 
     def compute_hip(self, data, out):
+        raw = getattr(data, "_acc_raw", None)
+        if raw is not None:
+            # straight from the ST stage's raw accumulator: scale + normalise + convert + mirror in one pass
+            res = backend.coh_from_accumulator(raw, data._acc_scale, self.cfg["output"]).unsqueeze(0)
+            out._dev = res
+            out.data = res.cpu().numpy()
+            return
         dev = self._device_input(data)
         res = torch.stack([backend.coh_normalize(dev[t].contiguous(), self.cfg["output"])
                            for t in range(dev.shape[0])], dim=0)

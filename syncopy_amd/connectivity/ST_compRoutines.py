@@ -169,9 +169,21 @@ class CrossSpectra(ComputationalRoutine):
         else:
             backend.csd_allreduce_(acc)                    # the ONE collective of the path (RCCL over xGMI,
                                                            # lower triangle only)
-            backend.csd_finalize(acc, 1.0 / (K * T))
-            out._dev = acc.reshape(self.outputShape)
-            out.data = out._dev.cpu().numpy()
+            # The trial-averaged CSD is finalised (scaled + mirrored) and copied to the host only if somebody asks
+            # for it: the coherence stage reads the raw lower-triangle accumulator through the fused kernel.
+            scale, shape = 1.0 / (K * T), self.outputShape
+            state = {"acc": acc, "final": None}
+
+            def device_csd():
+                if state["final"] is None:
+                    backend.csd_finalize(state["acc"], scale)
+                    state["final"] = state["acc"].reshape(shape)
+                    out._acc_raw = None
+                return state["final"]
+
+            out._acc_raw, out._acc_scale = acc, scale
+            out._dev_thunk = device_csd
+            out.set_pending(lambda: device_csd().cpu().numpy(), shape, np.complex64)
 
     def process_metadata(self, data, out):
         propagate_properties(data, out, self.keeptrials)

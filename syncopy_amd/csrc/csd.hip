@@ -134,6 +134,23 @@ extern "C" int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int 
     return 0;
 }
 
+extern "C" int spyhip_coh_from_accumulator(spyhip_ctx* ctx, const void* acc_d, int nfreq, int nchan, double scale,
+                                           int output, void* out_d) {
+    if (!ctx || !acc_d || !out_d) { spy::set_error("coh_from_accumulator: null argument"); return -1; }
+    if (output < SPYHIP_OUT_POW || output > SPYHIP_OUT_ABSIMAG) { spy::set_error("coh_from_accumulator: bad output %d", output); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long nt = (nchan + 31) / 32, blocks = (long long)nfreq * (nt * (nt + 1) / 2);
+    if (blocks > 0x7fffffffLL) { spy::set_error("coh_from_accumulator: grid too large"); return -1; }
+    if (output == SPYHIP_OUT_FOURIER)
+        hipLaunchKernelGGL(spycsd::coh_from_acc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float2*>(acc_d), nfreq, nchan, (float)scale, output, out_d);
+    else
+        hipLaunchKernelGGL(spycsd::coh_from_acc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float2*>(acc_d), nfreq, nchan, (float)scale, output, out_d);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int tril_move(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, void* packed_d, bool unpack) {
     if (!ctx || !acc_d || !packed_d) { spy::set_error("csd_tril: null argument"); return -1; }
     SPY_HIP_CHECK(hipSetDevice(ctx->device));

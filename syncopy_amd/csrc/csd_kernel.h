@@ -522,4 +522,71 @@ __global__ void __launch_bounds__(256) coh_normalize_kernel(const float2* csd, i
     }
 }
 
+// K5 fused: coherence straight from the raw lower-triangle accumulator - scale, normalise, convert and mirror in
+// one pass (reads 0.54 GB + writes 0.54 GB at C = 256 instead of the 3.2 GB of csd_finalize + coh_normalize).
+// Same float operations in the same order as the two-step path: bit-identical results.
+__device__ __forceinline__ float coh_convert(float2 c, int kind) {
+    switch (kind) {
+        case SPYHIP_OUT_POW: return c.x * c.x + c.y * c.y;
+        case SPYHIP_OUT_ABS: return sqrtf(c.x * c.x + c.y * c.y);
+        case SPYHIP_OUT_REAL: return c.x;
+        case SPYHIP_OUT_IMAG: return c.y;
+        case SPYHIP_OUT_ANGLE: return atan2f(c.y, c.x);
+        case SPYHIP_OUT_ABSREAL: return fabsf(c.x);
+        default: return fabsf(c.y);
+    }
+}
+// One workgroup per (frequency, lower-triangle 32 x 32 tile): the tile is read row-wise, its coherence written
+// row-wise, and the Hermitian mirror goes through an LDS transpose so that it is written row-wise too (a direct
+// mirror store scatters 4-byte writes over C rows and costs more than the whole rest of the pass).
+template <bool CPLX>
+__global__ void __launch_bounds__(256) coh_from_acc_kernel(const float2* acc, int F, int C, float scale, int kind, void* out) {
+    __shared__ float2 tile[32][33];
+    __shared__ float drow[32], dcol[32];
+    const int nt = (C + 31) / 32, ntiles = nt * (nt + 1) / 2;
+    const long long item = blockIdx.x;
+    const int f = (int)(item / ntiles);
+    int ti, tj;
+    tile_of((int)(item % ntiles), ti, tj);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float2* A = acc + (size_t)f * C * C;
+    if (threadIdx.x < 32) {
+        const int i = ti * 32 + threadIdx.x;
+        drow[threadIdx.x] = i < C ? A[(size_t)i * C + i].x * scale : 1.f;
+    } else if (threadIdx.x < 64) {
+        const int j = tj * 32 + threadIdx.x - 32;
+        dcol[threadIdx.x - 32] = j < C ? A[(size_t)j * C + j].x * scale : 1.f;
+    }
+    __syncthreads();
+    const size_t obase = (size_t)f * C * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = ty + 8 * k, c = tx;
+        const int i = ti * 32 + r, j = tj * 32 + c;
+        float2 up = make_float2(0.f, 0.f);
+        if (i < C && j < C && j <= i) {                          // the accumulator's lower triangle
+            float2 v = A[(size_t)i * C + j];
+            v.x *= scale;
+            v.y = (i == j) ? 0.f : v.y * scale;
+            const float s = sqrtf(drow[r] * dcol[c]);
+            const float2 lo = make_float2(v.x / s, v.y / s);
+            up = make_float2(v.x / s, -v.y / s);                 // (f, j, i) = conjugate
+            if (CPLX) reinterpret_cast<float2*>(out)[obase + (size_t)i * C + j] = lo;
+            else reinterpret_cast<float*>(out)[obase + (size_t)i * C + j] = coh_convert(lo, kind);
+        }
+        tile[c][r] = up;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = ty + 8 * k, c = tx;                        // element (r, c) of the mirrored tile (tj, ti)
+        const int i = tj * 32 + r, j = ti * 32 + c;
+        if (i < C && j < C && j > i) {                           // strictly upper part only
+            const float2 u = tile[r][c];
+            if (CPLX) reinterpret_cast<float2*>(out)[obase + (size_t)i * C + j] = u;
+            else reinterpret_cast<float*>(out)[obase + (size_t)i * C + j] = coh_convert(u, kind);
+        }
+    }
+}
+
 }  // namespace spycsd

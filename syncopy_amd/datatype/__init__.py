@@ -22,6 +22,9 @@ class _Base:
     def __init__(self, data=None, samplerate=None, trialdefinition=None, dimord=None):
         self.dimord = list(dimord) if dimord is not None else list(self._defaultDimord)
         self.samplerate = None if samplerate is None else float(samplerate)
+        self._data = None
+        self._pending = None          # (thunk, shape, dtype): host array produced on first access (results that
+                                      # may never leave the device, e.g. the CSD between the ST and the AV stage)
         self.data = data
         self._trialdefinition = None
         if trialdefinition is not None:
@@ -34,6 +37,31 @@ class _Base:
     @property
     def _stackingDim(self):
         return 0
+
+    @property
+    def data(self):
+        if self._data is None and self._pending is not None:
+            thunk, self._pending = self._pending[0], None
+            self._data = thunk()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+        self._pending = None
+
+    def set_pending(self, thunk, shape, dtype):
+        """The host array is `thunk()` - evaluated only if somebody reads `.data`."""
+        self._data = None
+        self._pending = (thunk, tuple(shape), np.dtype(dtype))
+
+    @property
+    def data_shape(self):
+        return self._pending[1] if (self._data is None and self._pending is not None) else self.data.shape
+
+    @property
+    def data_dtype(self):
+        return self._pending[2] if (self._data is None and self._pending is not None) else self.data.dtype
 
     @property
     def trialdefinition(self):
@@ -142,6 +170,22 @@ class CrossSpectralData(_Base):
         self.freq = None
         self.channel_i = None
         self.channel_j = None
+        self._acc_raw = None          # raw lower-triangle accumulator still on the device (+ its scale), see
+        self._acc_scale = None        # connectivity/ST_compRoutines.py: CrossSpectra.compute_hip
+        self._dev_thunk = None
+        self._dev_value = None
+
+    @property
+    def _dev(self):
+        """Device copy of `.data` if there is one (finalised on first access)."""
+        if self._dev_value is None and self._dev_thunk is not None:
+            self._dev_value = self._dev_thunk()
+        return self._dev_value
+
+    @_dev.setter
+    def _dev(self, value):
+        self._dev_value = value
+        self._dev_thunk = None
 
 
 class FauxTrial:

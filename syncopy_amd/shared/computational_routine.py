@@ -57,11 +57,11 @@ class ComputationalRoutine(ABC):
         tax = data.dimord.index("time") if "time" in data.dimord else 0
         shapes, dtp = [], None
         for k, (a, b) in enumerate(rows):
-            shp = list(data.data.shape)
+            shp = list(data.data_shape)
             shp[tax] = b - a
             if chans is not None and "channel" in data.dimord:
                 shp[data.dimord.index("channel")] = len(chans)
-            trial = FauxTrial(shp, data.data.dtype)
+            trial = FauxTrial(shp, data.data_dtype)
             chk, dt = self.computeFunction(trial, *self._argv(k), noCompute=True, chunkShape=None, **self.cfg)
             shapes.append(tuple(int(s) for s in chk))
             dtp = np.dtype(dt)

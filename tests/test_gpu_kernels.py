@@ -147,6 +147,25 @@ def test_blocked_handover_layout_is_bit_identical(be, C, N, B, K):
     assert not be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, False, None, "pow", True).set_blocked(True)
 
 
+@pytest.mark.parametrize("C,F", [(37, 9), (256, 3)])
+def test_coh_from_accumulator_is_bit_identical(be, C, F):
+    """Fused K5 (scale + normalise + convert + mirror from the raw lower-triangle accumulator) against
+    csd_finalize + coh_normalize: same float operations, identical bits, accumulator untouched."""
+    R = 40
+    g = torch.Generator(device="cuda").manual_seed(C)
+    spec = torch.view_as_complex(torch.randn((R, F, C, 2), generator=g, device="cuda", dtype=torch.float32))
+    acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    be.csd_accumulate(spec, acc)
+    raw = acc.clone()
+    fused = {o: be.coh_from_accumulator(acc, 1.0 / R, o) for o in ("abs", "pow", "complex", "imag", "real", "angle")}
+    assert torch.equal(torch.view_as_real(acc), torch.view_as_real(raw))
+    be.csd_finalize(acc, 1.0 / R)
+    for o, got in fused.items():
+        ref = be.coh_normalize(acc, o)
+        a, b = (torch.view_as_real(got), torch.view_as_real(ref)) if got.is_complex() else (got, ref)
+        assert torch.equal(a, b), o
+
+
 def test_csd_tril_pack_roundtrip(be):
     """Packed lower triangle (what the multi-GPU all-reduce ships): pack -> unpack restores the lower triangle
     bit-exactly and leaves the upper one alone; the finalised CSD is unchanged."""
