@@ -125,9 +125,8 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
 extern "C" int spyhip_csd_finalize(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan, double scale) {
     if (!ctx || !acc_d) { spy::set_error("csd_finalize: null argument"); return -1; }
     SPY_HIP_CHECK(hipSetDevice(ctx->device));
-    const long long n = (long long)nfreq * nchan * nchan;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    const long long nt = (nchan + 31) / 32, blocks = (long long)nfreq * (nt * (nt + 1) / 2);
+    if (blocks > 0x7fffffffLL) { spy::set_error("csd_finalize: grid too large"); return -1; }
     hipLaunchKernelGGL(spycsd::csd_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
                        reinterpret_cast<float2*>(acc_d), nfreq, nchan, (float)scale);
     SPY_HIP_CHECK(hipGetLastError());

@@ -472,20 +472,38 @@ __global__ void __launch_bounds__(256) csd_tril_kernel(float2* acc, float2* pack
     }
 }
 
-// acc[f,i,j] *= scale (i >= j), zero the diagonal's imaginary part, mirror to the upper triangle
+// acc[f,i,j] *= scale (i >= j), zero the diagonal's imaginary part, mirror to the upper triangle.
+// One workgroup per (frequency, lower-triangle 32 x 32 tile); the mirror goes through an LDS transpose so that
+// both triangles are written row-wise.
 __global__ void __launch_bounds__(256) csd_finalize_kernel(float2* acc, int F, int C, float scale) {
-    const long long n = (long long)F * C * C;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const int j = (int)(e % C);
-        const long long fi = e / C;
-        const int i = (int)(fi % C);
-        if (i < j) continue;
-        float2 v = acc[e];
-        v.x *= scale;
-        v.y = (i == j) ? 0.f : v.y * scale;
-        acc[e] = v;
-        if (i != j) acc[(fi - i + j) * C + i] = make_float2(v.x, -v.y);
+    __shared__ float2 tile[32][33];
+    const int nt = (C + 31) / 32, ntiles = nt * (nt + 1) / 2;
+    const long long item = blockIdx.x;
+    const int f = (int)(item / ntiles);
+    int ti, tj;
+    tile_of((int)(item % ntiles), ti, tj);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float2* A = acc + (size_t)f * C * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = ty + 8 * k, c = tx;
+        const int i = ti * 32 + r, j = tj * 32 + c;
+        float2 up = make_float2(0.f, 0.f);
+        if (i < C && j < C && j <= i) {
+            float2 v = A[(size_t)i * C + j];
+            v.x *= scale;
+            v.y = (i == j) ? 0.f : v.y * scale;
+            A[(size_t)i * C + j] = v;
+            up = make_float2(v.x, -v.y);
+        }
+        tile[c][r] = up;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = ty + 8 * k, c = tx;                        // element (r, c) of the mirrored tile (tj, ti)
+        const int i = tj * 32 + r, j = ti * 32 + c;
+        if (i < C && j < C && j > i) A[(size_t)i * C + j] = tile[r][c];
     }
 }
 

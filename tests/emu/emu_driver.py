@@ -172,6 +172,16 @@ def csd_finalize(acc, scale):
     lib().emu_csd_finalize(acc.ctypes.data_as(C.c_void_p), C.c_int(F), C.c_int(Cn), C.c_float(scale))
 
 
+def coh_from_accumulator(acc, scale, output="abs"):
+    """Emulated spyhip_coh_from_accumulator (raw lower-triangle accumulator -> coherence)."""
+    F, Cn, _ = acc.shape
+    kind = OUT_KINDS[output]
+    out = np.zeros((F, Cn, Cn), dtype=np.complex64 if kind == 2 else np.float32)
+    lib().emu_coh_from_accumulator(acc.ctypes.data_as(C.c_void_p), C.c_int(F), C.c_int(Cn), C.c_float(scale),
+                                   C.c_int(kind), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def coh_normalize(csd, output="abs"):
     F, Cn, _ = csd.shape
     kind = OUT_KINDS[output]

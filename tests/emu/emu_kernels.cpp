@@ -236,7 +236,18 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
 }
 
 void emu_csd_finalize(float* acc, int F, int C, float scale) {
-    emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::csd_finalize_kernel(reinterpret_cast<float2*>(acc), F, C, scale); });
+    const int nt = (C + 31) / 32;
+    emu::launch(dim3((unsigned)(F * (nt * (nt + 1) / 2))), dim3(256), 0,
+                [&] { spycsd::csd_finalize_kernel(reinterpret_cast<float2*>(acc), F, C, scale); });
+}
+
+void emu_coh_from_accumulator(const float* acc, int F, int C, float scale, int kind, void* out) {
+    const int nt = (C + 31) / 32;
+    const dim3 grid((unsigned)(F * (nt * (nt + 1) / 2)));
+    if (kind == SPYHIP_OUT_FOURIER)
+        emu::launch(grid, dim3(256), 0, [&] { spycsd::coh_from_acc_kernel<true>(reinterpret_cast<const float2*>(acc), F, C, scale, kind, out); });
+    else
+        emu::launch(grid, dim3(256), 0, [&] { spycsd::coh_from_acc_kernel<false>(reinterpret_cast<const float2*>(acc), F, C, scale, kind, out); });
 }
 
 void emu_coh_normalize(const float* csd, int F, int C, int kind, void* out) {

@@ -136,7 +136,10 @@ def test_csd_mfma_kernel(C, F, R, tpw):
     acc = np.zeros((F, C, C), np.complex64)
     E.csd_accumulate(spec[:R // 2], acc, tpw)
     E.csd_accumulate(spec[R // 2:], acc, tpw)
+    fused = {o: E.coh_from_accumulator(acc, 1.0 / R, o) for o in ("abs", "complex")}
     E.csd_finalize(acc, 1.0 / R)
+    for o, got in fused.items():                       # fused K5 = finalize + normalize, bit for bit
+        np.testing.assert_array_equal(got, E.coh_normalize(acc, o))
     ref = (np.einsum("rfi,rfj->fij", spec.astype(np.complex128), spec.conj().astype(np.complex128)) / R)
     assert_parity(acc, ref.astype(np.complex64), what="csd")
     assert np.array_equal(acc, acc.conj().transpose(0, 2, 1)) and np.all(acc.imag[:, range(C), range(C)] == 0)
