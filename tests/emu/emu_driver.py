@@ -79,6 +79,8 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
         log2n = int(np.log2(nfft))
         if G is None:
             G = {8: 16, 9: 8, 10: 4, 11: 2, 12: 1, 13: 1, 14: 1}[log2n]
+            if log2n == 12 and kind == 2 and keeptapers:
+                G = 2               # as spyhip_fft_plan_create: store-bound complex spectra take two quads per workgroup
         tw = twiddles(nfft)
         set_blocked(blocked)
         rc = lib().emu_mtmfft_pow2(

@@ -122,6 +122,7 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
         case 1004: run_quad_mode<10, 4>(a, grid, outk, mean, -1); break;
         case 1102: run_quad_mode<11, 2>(a, grid, outk, mean, -1); break;
         case 1201: run_quad_mode<12, 1>(a, grid, outk, mean, -1); break;
+        case 1202: if (outk != 2 || mean) return -1; run_quad<12, 2, 2, false>(a, grid, -1); break;
         case 1301: run_quad_mode<13, 1>(a, grid, outk, mean, -1); break;
         case 1401: run_pow2_mode<14, 1>(a, grid, outk, mean, -1); break;
         default: return -1;
