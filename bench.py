@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--trials", type=int, default=1000, help="trials per GPU")
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--samples", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=500, help="trials per FFT/CSD launch pair")
+    ap.add_argument("--batch", type=int, default=1000, help="trials per FFT/CSD launch pair")
     ap.add_argument("--blocked", action="store_true",
                     help="FFT -> CSD hand-over in the channel-blocked layout (faster FFT stores, slower CSD fetch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
