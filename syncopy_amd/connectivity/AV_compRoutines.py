@@ -18,7 +18,7 @@ def normalize_csd_cF(csd_av_dat, output="abs", chunkShape=None, noCompute=False)
     backend.require_gpu()
     dev = torch.from_numpy(np.ascontiguousarray(csd_av_dat, dtype=np.complex64)).cuda()
     res = [backend.coh_normalize(dev[t], output) for t in range(dev.shape[0])]
-    return torch.stack(res, dim=0).cpu().numpy()
+    return backend.to_host(torch.stack(res, dim=0))
 
 
 class _AverageRoutine(ComputationalRoutine):
@@ -57,13 +57,13 @@ class NormalizeCrossSpectra(_AverageRoutine):
             # straight from the ST stage's raw accumulator: scale + normalise + convert + mirror in one pass
             res = backend.coh_from_accumulator(raw, data._acc_scale, self.cfg["output"]).unsqueeze(0)
             out._dev = res
-            out.data = res.cpu().numpy()
+            out.data = backend.to_host(res)
             return
         dev = self._device_input(data)
         res = torch.stack([backend.coh_normalize(dev[t].contiguous(), self.cfg["output"])
                            for t in range(dev.shape[0])], dim=0)
         out._dev = res
-        out.data = res.cpu().numpy()
+        out.data = backend.to_host(res)
 
 
 def granger_cF(csd_av_dat, rtol=5e-6, nIter=100, cond_max=1e4, chunkShape=None, noCompute=False):
@@ -76,7 +76,7 @@ def granger_cF(csd_av_dat, rtol=5e-6, nIter=100, cond_max=1e4, chunkShape=None, 
     backend.require_gpu()
     dev = torch.from_numpy(np.ascontiguousarray(csd_av_dat[0], dtype=np.complex64)).cuda()
     G, meta = backend.granger(dev, rtol=rtol, niter=nIter, cond_max=cond_max, eps_max=1e-1)
-    return G.cpu().numpy()[None, ...], _granger_metadata(meta)
+    return backend.to_host(G)[None, ...], _granger_metadata(meta)
 
 
 def _granger_metadata(meta):
@@ -103,7 +103,7 @@ class GrangerCausality(_AverageRoutine):
             res.append(G)
             self.metadata.append(_granger_metadata(meta))
         out._dev = torch.stack(res, dim=0)
-        out.data = out._dev.cpu().numpy()
+        out.data = backend.to_host(out._dev)
 
     def process_metadata(self, data, out):
         super().process_metadata(data, out)

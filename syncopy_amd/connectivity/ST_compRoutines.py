@@ -34,7 +34,7 @@ def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, pol
     ntaper = 1
     for sel, spec in hs.run_mtmfft_batches(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, False,
                                            polyremoval, freq_idx, "fourier", True,
-                                           blocked=single_acc and backend.USE_BLOCKED_HANDOVER):
+                                           blocked=single_acc and backend.USE_BLOCKED_HANDOVER, reuse=True):
         ntaper = spec.spyhip_ntaper
         if spec.spyhip_blocked:
             backend.csd_accumulate(spec, acc_of_trial(sel[0]), blocked=True)
@@ -69,7 +69,7 @@ def cross_spectra_cF(trl_dat, samplerate=1, nSamples=None, foi=None, taper="hann
     K = _csd_of_rows(dev, [(0, dev.shape[0])], None, nSamples, taper, taper_opt, demean_taper, pr, freq_idx,
                      lambda i: acc, single_acc=True)
     backend.csd_finalize(acc, 1.0 / K)
-    return acc.cpu().numpy()[np.newaxis], {"freqs_hash": _freqs_hash(freqs)}
+    return backend.to_host(acc)[np.newaxis], {"freqs_hash": _freqs_hash(freqs)}
 
 
 def spectral_dyadic_product_cF(specs, send_idx=None, send_N=None, rec_idx=None, rec_N=None, chunkShape=None,
@@ -89,7 +89,7 @@ def spectral_dyadic_product_cF(specs, send_idx=None, send_N=None, rec_idx=None, 
     for t in range(nTime):
         backend.csd_accumulate(dev[t].contiguous(), acc[t])
         backend.csd_finalize(acc[t], 1.0 / nTaper)
-    return acc.cpu().numpy()
+    return backend.to_host(acc)
 
 
 class SpectralDyadicProduct(ComputationalRoutine):
@@ -125,7 +125,7 @@ class SpectralDyadicProduct(ComputationalRoutine):
         backend.csd_allreduce_(acc)
         backend.csd_finalize(acc, 1.0 / (K * T))
         out._dev = acc.reshape(self.outputShape)
-        out.data = out._dev.cpu().numpy()
+        out.data = backend.to_host(out._dev)
 
     def process_metadata(self, data, out):
         time_axis = bool(np.any(np.diff(data.trialdefinition)[:, 0] != 1))
@@ -165,7 +165,7 @@ class CrossSpectra(ComputationalRoutine):
             for t in range(len(rows)):
                 backend.csd_finalize(acc[t], 1.0 / K)
             out._dev = None
-            out.data = parallel.gather_trials(acc.cpu().numpy()).reshape(self.outputShape)
+            out.data = parallel.gather_trials(backend.to_host(acc)).reshape(self.outputShape)
         else:
             backend.csd_allreduce_(acc)                    # the ONE collective of the path (RCCL over xGMI,
                                                            # lower triangle only)
@@ -183,7 +183,7 @@ class CrossSpectra(ComputationalRoutine):
 
             out._acc_raw, out._acc_scale = acc, scale
             out._dev_thunk = device_csd
-            out.set_pending(lambda: device_csd().cpu().numpy(), shape, np.complex64)
+            out.set_pending(lambda: backend.to_host(device_csd()), shape, np.complex64)
 
     def process_metadata(self, data, out):
         propagate_properties(data, out, self.keeptrials)

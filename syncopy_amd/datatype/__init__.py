@@ -137,7 +137,9 @@ class AnalogData(_Base):
         from ..backend import require_gpu
         require_gpu()                      # loud failure: there is no CPU path
         dev = torch.device("cuda" if device is None else device)
-        if self._device is None or self._device.device != dev and self._device.device.index != dev.index:
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if self._device is None or self._device.device != dev:
             host = self.data if self.dimord.index("time") == 0 else self.data.T
             host = np.ascontiguousarray(host, dtype=np.float32)
             self._device = torch.from_numpy(host).to(dev)

@@ -56,13 +56,21 @@ class ComputationalRoutine(ABC):
         self.keeptrials = keeptrials
         tax = data.dimord.index("time") if "time" in data.dimord else 0
         shapes, dtp = [], None
+        per_trial_args = any(isinstance(a, (list, tuple, np.ndarray)) and len(a) == self.numTrials for a in self.argv)
+        seen = {}                        # dry runs of equally shaped trials are identical (unless argv is per trial)
         for k, (a, b) in enumerate(rows):
             shp = list(data.data_shape)
             shp[tax] = b - a
             if chans is not None and "channel" in data.dimord:
                 shp[data.dimord.index("channel")] = len(chans)
-            trial = FauxTrial(shp, data.data_dtype)
-            chk, dt = self.computeFunction(trial, *self._argv(k), noCompute=True, chunkShape=None, **self.cfg)
+            key = None if per_trial_args else tuple(shp)
+            if key is not None and key in seen:
+                chk, dt = seen[key]
+            else:
+                trial = FauxTrial(shp, data.data_dtype)
+                chk, dt = self.computeFunction(trial, *self._argv(k), noCompute=True, chunkShape=None, **self.cfg)
+                if key is not None:
+                    seen[key] = (chk, dt)
             shapes.append(tuple(int(s) for s in chk))
             dtp = np.dtype(dt)
         self.targetShapes = shapes

@@ -48,7 +48,7 @@ def mtmfft_cF(trl_dat, foi=None, timeAxis=0, keeptapers=True, polyremoval=None, 
     res = hs.run_mtmfft(dev, [(0, dev.shape[0])], None, nSamples, method_kwargs["taper"], method_kwargs["taper_opt"],
                         method_kwargs.get("demean_taper", False), method_kwargs.get("ft_compat", False), polyremoval,
                         freq_idx, output, keeptapers)[0]
-    spec = res.cpu().numpy()[np.newaxis]
+    spec = hs.backend.to_host(res)[np.newaxis]
     return spec, {"freqs_hash": _freqs_hash(freqs)}
 
 
@@ -156,7 +156,7 @@ def mtmconvol_cF(trl_dat, soi, postselect, equidistant=True, toi=None, foi=None,
     dev = _as_device_trial(trl_dat, timeAxis)
     res = _mtmconvol_device(dev, 0, dev.shape[0], soi, postselect, equidistant, toi, foi, keeptapers, polyremoval,
                             output, method_kwargs, None)
-    return res.cpu().numpy()
+    return hs.backend.to_host(res)
 
 
 class MultiTaperFFTConvol(ComputationalRoutine):
@@ -264,7 +264,7 @@ def wavelet_cF(trl_dat, preselect, postselect, toi=None, timeAxis=0, polyremoval
     dev = _as_device_trial(trl_dat, timeAxis)
     res = _wavelet_device(dev, [(0, dev.shape[0])], [preselect], [postselect], None, polyremoval, output,
                           method_kwargs)[0]
-    return res.cpu().numpy()
+    return hs.backend.to_host(res)
 
 
 class WaveletTransform(ComputationalRoutine):
@@ -288,7 +288,7 @@ class WaveletTransform(ComputationalRoutine):
                     raise ValueError(f"result shape {tuple(total.shape)} != dry-run shape {self.targetShapes[mine[0]]}")
                 total = total.contiguous()
                 parallel.allreduce_sum_(total)
-                out.data = (total / self.numTrials).cpu().numpy().reshape(self.outputShape)
+                out.data = hs.backend.to_host((total / self.numTrials)).reshape(self.outputShape)
                 return
         parts = _wavelet_device(dev, [rows[k] for k in mine], pre, post, chans, cfg["polyremoval"], cfg["output"],
                                 cfg["method_kwargs"])
@@ -315,7 +315,7 @@ def _store_trials(cr, out, parts, stack=False):
     dtype = torch.complex64 if np.issubdtype(cr.dtype, np.complexfloating) else torch.float32
     if cr.keeptrials:
         tail = tuple(cr.outputShape[1:])
-        local = torch.cat(parts, dim=0).cpu().numpy() if parts else np.zeros((0,) + tail, dtype=cr.dtype)
+        local = hs.backend.to_host(torch.cat(parts, dim=0)) if parts else np.zeros((0,) + tail, dtype=cr.dtype)
         out.data = parallel.gather_trials(local).reshape(cr.outputShape)
         return
     if parts:
@@ -328,7 +328,7 @@ def _store_trials(cr, out, parts, stack=False):
     else:
         total = torch.zeros(cr.outputShape, dtype=dtype, device=dev)
     parallel.allreduce_sum_(total)
-    out.data = (total / cr.numTrials).cpu().numpy().reshape(cr.outputShape)
+    out.data = hs.backend.to_host((total / cr.numTrials)).reshape(cr.outputShape)
 
 
 def _make_trialdef(cfg, trialdefinition, samplerate):

@@ -112,7 +112,7 @@ def run_stft(dev_data, row0, soi_start, soi_stop, frames, nperseg, step, boundar
 
 
 def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_taper, ft_compat, polyremoval,
-                       freq_idx, output, keeptapers, max_bytes=8 << 30, blocked=False):
+                       freq_idx, output, keeptapers, max_bytes=32 << 30, blocked=False, reuse=False):
     """Generator over (trial indices, (B, Kout, F, C) device tensor) batches: trials of equal length share a
     plan; a batch is bounded by `max_bytes` of spectra so the intermediate stays a small part of HBM.
     With `blocked` the tensor is in the plan's hand-over layout whenever `tensor.dim() == 4 and
@@ -132,7 +132,10 @@ def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_
         for i in range(0, which.size, bmax):
             sel = which[i:i + bmax]
             starts = torch.tensor([rows[j][0] for j in sel], dtype=torch.int64, device=device)
-            spec = plan.execute(dev_data, starts, chan_idx=ci)
+            # reuse=True: the consumer is done with a batch before it asks for the next one (stream order), so all
+            # batches - and all later calls of the same shape - share one device buffer
+            buf = backend.handover_buffer(plan.out_shape(len(sel)), device) if reuse and plan.kind == 2 else None
+            spec = plan.execute(dev_data, starts, chan_idx=ci, out=buf)
             spec.spyhip_blocked = plan.blocked
             spec.spyhip_ntaper = plan.kout
             yield sel, spec

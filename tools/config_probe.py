@@ -100,6 +100,28 @@ if "wav" in which:
     print("wav", res["c4_wavelet"], flush=True)
     del data, out
 
+if "frontend" in which:
+    # the whole front end on the headline shape: spy.connectivityanalysis(method="coh") on host-resident AnalogData
+    # (first call: upload + plan creation + DPSS tapers; second call: trial queue already in HBM)
+    import syncopy_amd as spy
+    C, N, T = 256, 4096, 1000
+    dev = synthdata.ar2_uncoupled_fast(C, N, T, seed=5)
+    host = dev.cpu().numpy()
+    del dev
+    trl = np.stack([np.arange(T) * N, np.arange(1, T + 1) * N, np.zeros(T)], axis=1)
+    data = spy.AnalogData(host, samplerate=1000.0, trialdefinition=trl)
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        coh = spy.connectivityanalysis(data, method="coh", tapsmofrq=1, polyremoval=0)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    res["frontend_coh"] = {"first_call_s": ts[0], "warm_call_s": min(ts[1:]), "trials_per_s_warm": T / min(ts[1:]),
+                           "shape": list(coh.data.shape)}
+    print("frontend", res["frontend_coh"], flush=True)
+    del data, host, coh
+
 if "h2d" in which:
     # PCIe-inclusive view of the headline config: upload of the trial queue (host -> HBM) next to its compute time
     C, N, T = 256, 4096, 250
