@@ -120,7 +120,18 @@ if "frontend" in which:
     res["frontend_coh"] = {"first_call_s": ts[0], "warm_call_s": min(ts[1:]), "trials_per_s_warm": T / min(ts[1:]),
                            "shape": list(coh.data.shape)}
     print("frontend", res["frontend_coh"], flush=True)
-    del data, host, coh
+    del coh
+    ts = []
+    for kt in (True, True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pw = spy.freqanalysis(data, method="mtmfft", tapsmofrq=1, polyremoval=0, keeptrials=kt)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    res["frontend_mtmfft"] = {"keeptrials_first_s": ts[0], "keeptrials_warm_s": ts[1], "trial_average_s": ts[2],
+                              "shape": list(pw.data.shape)}
+    print("frontend_mtmfft", res["frontend_mtmfft"], flush=True)
+    del data, host, pw
 
 if "h2d" in which:
     # PCIe-inclusive view of the headline config: upload of the trial queue (host -> HBM) next to its compute time
