@@ -16,7 +16,7 @@ template <int LOG2N, int G, int OUTK, bool MEAN>
 __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmfft_blue_kernel(MtmArgs a) {
     using C = Cfg2<LOG2N, G>;
     constexpr bool CPLX = (OUTK == 2);
-    constexpr int N = C::N, T = C::T;
+    constexpr int T = C::T;
     SPY_DYN_SMEM(v2f, lds);
     v2f* const lre = lds;
     v2f* const lim = lds + C::PLANE;
