@@ -51,6 +51,10 @@ class NormalizeCrossSpectra(_AverageRoutine):
     method = ""
     valid_kws = ["output"]
 
+    def evaluate_device(self, csd):
+        """AV stage on one device CSD (F, C, C) -> (F, C, C); used by the streaming jackknife."""
+        return backend.coh_normalize(csd.contiguous(), self.cfg["output"])
+
     def compute_hip(self, data, out):
         raw = getattr(data, "_acc_raw", None)
         if raw is not None:
@@ -93,6 +97,15 @@ class GrangerCausality(_AverageRoutine):
     method = ""
     valid_kws = ["rtol", "nIter", "cond_max"]
     metadata_keys = ("converged", "max rel. err", "reg. factor", "initial cond. num")
+
+    def evaluate_device(self, csd):
+        """AV stage on one device CSD (F, C, C) -> Granger (F, C, C) float32; keeps the metadata of the first call
+        (the direct estimate) for `out.info`."""
+        G, meta = backend.granger(csd.contiguous(), rtol=self.cfg["rtol"], niter=self.cfg["nIter"],
+                                  cond_max=self.cfg["cond_max"], eps_max=1e-1)
+        if not self.metadata:
+            self.metadata = [_granger_metadata(meta)]
+        return G
 
     def compute_hip(self, data, out):
         dev = self._device_input(data)

@@ -185,6 +185,63 @@ class CrossSpectra(ComputationalRoutine):
             out._dev_thunk = device_csd
             out.set_pending(lambda: backend.to_host(device_csd()), shape, np.complex64)
 
+    def jackknife_hip(self, data, evaluate):
+        """Streaming jackknife on the device (connectivity_analysis.py:601-606,736-757; statistics/jackknifing.py):
+        never more than a handful of (F, C, C) arrays live at once instead of the reference's T single-trial CSDs.
+        Pass 1 accumulates the trial-averaged CSD S (one all-reduce); pass 2 re-computes every trial's own CSD S_t,
+        forms the leave-one-out average (T*S - S_t)/(T-1) in complex64 exactly as the reference does, evaluates the
+        AV stage on it (`evaluate`: (F, C, C) complex64 Hermitian -> (F, C, C) tensor) and keeps only the float64 sums
+        of d_t = replicate_t - direct and |d_t|^2.  Returns (S, direct, jack_bias, jack_var) device tensors:
+            bias = (T-1) * mean_t d_t,   var = (T-1) * (sum_t |d_t|^2 - |sum_t d_t|^2 / T)
+        (= the reference's (T-1) (jack_avg - direct) and (T-1) sum |jack_avg - replicate_t|^2)."""
+        cfg = self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
+        freqs, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
+        pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
+        F, C = self.targetShapes[0][1], self.targetShapes[0][2]
+        T = self.numTrials
+        mine = [rows[k] for k in self.my_trials()]
+        args = (dev, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"], cfg["demean_taper"], pr, freq_idx)
+
+        def batches(rr):
+            return hs.run_mtmfft_batches(args[0], rr, args[1], args[2], args[3], args[4], args[5], False, args[6],
+                                         args[7], "fourier", True, reuse=True)
+
+        # ---- pass 1: trial average
+        S = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
+        K = 1
+        for _, spec in batches(mine):
+            K = spec.spyhip_ntaper
+            backend.csd_accumulate(spec, S)
+        K = int(cfg["taper_opt"].get("Kmax", K)) if cfg["taper_opt"] else K
+        backend.csd_allreduce_(S)
+        backend.csd_finalize(S, 1.0 / (K * T))
+        direct = evaluate(S)
+        # ---- pass 2: leave-one-out replicates, one trial at a time
+        cplx = direct.is_complex()
+        sum_d = torch.zeros(direct.shape, dtype=torch.complex128 if cplx else torch.float64, device=dev.device)
+        sum_d2 = torch.zeros(direct.shape, dtype=torch.float64, device=dev.device)
+        St = torch.empty_like(S)
+        for _, spec in batches(mine):
+            for t in range(spec.shape[0]):
+                St.zero_()
+                backend.csd_accumulate(spec[t], St)
+                backend.csd_finalize(St, 1.0 / K)
+                loo = T * S - St                       # complex64, the reference's operation order
+                loo /= T - 1
+                d = (evaluate(loo) - direct).to(sum_d.dtype)
+                sum_d += d
+                sum_d2 += (d.real ** 2 + d.imag ** 2) if cplx else d * d
+        parallel.allreduce_sum_(sum_d)
+        parallel.allreduce_sum_(sum_d2)
+        bias = ((T - 1) * (sum_d / T)).to(direct.dtype)
+        mag2 = (sum_d.real ** 2 + sum_d.imag ** 2) if cplx else sum_d * sum_d
+        var = ((T - 1) * (sum_d2 - mag2 / T)).clamp_(min=0).to(torch.float32)
+        self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T
+        return S, direct, bias, var
+
     def process_metadata(self, data, out):
         propagate_properties(data, out, self.keeptrials)
         out.freq = self.cfg["foi"]

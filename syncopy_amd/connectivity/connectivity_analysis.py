@@ -128,6 +128,27 @@ def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, p
     return _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
 
 
+def _jackknife_on_device(data, st, av, st_out, log_dict):
+    """jackknife=True with the kernels: CrossSpectra.jackknife_hip streams the leave-one-out replicates through the
+    AV stage on the device; only the direct estimate, bias and variance come back."""
+    from .. import backend
+    st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=False)
+    av.metadata = []
+    S, direct, bias, var = st.jackknife_hip(data, av.evaluate_device)
+    st_out._dev = S.reshape(st.outputShape)
+    st_out.set_pending(lambda: backend.to_host(st_out._dev), st.outputShape, np.complex64)
+    st.process_metadata(data, st_out)
+    out = CrossSpectralData(dimord=st_out.dimord)
+    av.initialize(st_out, out._stackingDim, chan_per_worker=None, keeptrials=False)
+    out._dev = direct.unsqueeze(0)
+    out.data = backend.to_host(out._dev)
+    av.process_metadata(st_out, out)
+    out.cfg = dict(log_dict or {})
+    out.jack_bias = backend.to_host(bias)[None]
+    out.jack_var = backend.to_host(var)[None]
+    return out
+
+
 def _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict):
     """ST stage (single-trial cross spectra, trial-averaged unless kept) -> AV stage, plus the jackknife."""
     if method == "coh":
@@ -142,6 +163,9 @@ def _run_stages(data, classes, st, method, keeptrials, output, compute_method, j
         av = None
 
     st_out = CrossSpectralData(dimord=CrossSpectra.dimord)
+    if (jackknife and av is not None and compute_method in (None, "hip") and hasattr(st, "jackknife_hip")
+            and hasattr(av, "evaluate_device")):
+        return _jackknife_on_device(data, st, av, st_out, log_dict)
     # single trials are needed for the jackknife (connectivity_analysis.py:589-590)
     st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=bool(keeptrials) or jackknife)
     st.compute(data, st_out, parallel=False, log_dict=log_dict, method=compute_method)

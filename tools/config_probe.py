@@ -25,7 +25,7 @@ def sync_time(fn, n=3):
 
 
 res = {}
-which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "h2d", "granger"]
+which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "frontend", "jack", "h2d", "granger"]
 
 if "c2" in which:
     C, N, T, K = 256, 4096, 1000, 7
@@ -132,6 +132,24 @@ if "frontend" in which:
                               "shape": list(pw.data.shape)}
     print("frontend_mtmfft", res["frontend_mtmfft"], flush=True)
     del data, host, pw
+
+if "jack" in which:
+    # jackknife=True coherence on the headline channel count: streaming leave-one-out replicates on the device
+    import syncopy_amd as spy
+    C, N, T = 256, 4096, 200
+    host = synthdata.ar2_uncoupled_fast(C, N, T, seed=6).cpu().numpy()
+    trl = np.stack([np.arange(T) * N, np.arange(1, T + 1) * N, np.zeros(T)], axis=1)
+    data = spy.AnalogData(host, samplerate=1000.0, trialdefinition=trl)
+    spy.connectivityanalysis(data, method="coh", tapsmofrq=1, polyremoval=0)        # upload + plans
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    coh = spy.connectivityanalysis(data, method="coh", tapsmofrq=1, polyremoval=0, jackknife=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res["jackknife_coh"] = {"trials": T, "seconds": dt, "ms_per_replicate": 1e3 * dt / T,
+                            "var_max": float(coh.jack_var.max()), "finite": bool(np.isfinite(coh.jack_var).all())}
+    print("jack", res["jackknife_coh"], flush=True)
+    del data, host, coh
 
 if "h2d" in which:
     # PCIe-inclusive view of the headline config: upload of the trial queue (host -> HBM) next to its compute time
