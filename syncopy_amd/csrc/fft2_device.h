@@ -102,14 +102,17 @@ struct Cfg2 {
     static constexpr int NWAVES = (NTHREADS + 63) / 64;
     static constexpr int NP16 = LOG2N / 4;       // radix-16 passes
     static constexpr int RLAST = 1 << (LOG2N % 4);
-    static constexpr int ESTRIDE = (T + T / 16) * G;       // LDS distance of e -> e+1 (8-byte units)
-    static constexpr int PLANE = (N + N / 16) * G + G;      // 8-byte units per plane (+G: slot of index N)
+    // one pad element per 16 (conflict-free radix-16 scatter) needs T to be a multiple of 16 for the reads
+    // idx(j + T*e) = rbase(j) + e*ESTRIDE to stay affine: the short factor lengths 64 and 128 go unpadded
+    static constexpr bool PAD = (T % 16) == 0;
+    static constexpr int ESTRIDE = (T + (PAD ? T / 16 : 0)) * G;       // LDS distance of e -> e+1 (8-byte units)
+    static constexpr int PLANE = (N + (PAD ? N / 16 : 0)) * G + G;      // 8-byte units per plane (+G: slot of index N)
     static constexpr size_t LDS_BYTES = (size_t)PLANE * 16; // real plane + imaginary plane
-    static_assert(LOG2N >= 8 && LOG2N <= 13, "supported FFT lengths: 256..8192");
+    static_assert(LOG2N >= 6 && LOG2N <= 13, "supported FFT lengths: 64..8192 (64 and 128 only as factors of a long transform)");
     static_assert(NTHREADS >= 64 && NTHREADS <= 1024, "workgroup size");
     static_assert((64 % G) == 0, "G must divide the wave size");
-    __device__ static __forceinline__ int idx(int i, int h) { return (i + (i >> 4)) * G + h; }
-    __device__ static __forceinline__ int rbase(int j, int h) { return (j + (j >> 4)) * G + h; }
+    __device__ static __forceinline__ int idx(int i, int h) { return (i + (PAD ? (i >> 4) : 0)) * G + h; }
+    __device__ static __forceinline__ int rbase(int j, int h) { return (j + (PAD ? (j >> 4) : 0)) * G + h; }
 };
 
 // six table loads per pass (w^1, w^2, w^3, w^4, w^8, w^12); the other nine twiddles are products
@@ -169,7 +172,7 @@ __device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h,
         if (!last) {
             const int B = ((j >> (4 * p)) << (4 * p + 4)) + k;
             const int wb = C::idx(B, h);
-            const int ws = (p == 0) ? G : (Ns + Ns / 16) * G;
+            const int ws = (p == 0) ? G : (Ns + (C::PAD ? Ns / 16 : 0)) * G;
             // write-after-read barrier placed HERE, behind this pass's butterflies, instead of right after the
             // previous reads: a wave that is done reading starts computing at once and meets the others later
             __syncthreads();

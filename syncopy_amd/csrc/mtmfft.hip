@@ -1,5 +1,6 @@
 // Host side of K1/K2: plan construction and kernel dispatch for the tapered-FFT
 // kernels (spyhip_fft_plan_create / spyhip_fft_exec of include/spyhip.h).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -9,6 +10,7 @@
 #include "mtmfft_kernel.h"
 #include "mtmfft2_kernel.h"
 #include "mtmfft_blue_kernel.h"
+#include "mtmfft_long.h"
 #include "mtmfft_generic.h"
 
 using spyfft::GenPlan;
@@ -21,6 +23,13 @@ struct spyhip_fft_plan {
     float scale = 1.f;
     bool pow2 = false;
     bool blue = false;          // Bluestein on the packed power-of-two engine (nfft <= 4096, not a power of two)
+    bool longp = false;         // Bluestein with four-step length-M transforms through HBM (mtmfft_long.h)
+    bool long_direct = false;   // ... or, for power-of-two nfft, one plain four-step transform
+    int l1 = 0, l2 = 0;         // M1 = 2^l1, M2 = 2^l2
+    spy::DevBuf<float2> tw1, tw2, twM;
+    spy::DevBuf<double> wsum, stats;
+    spy::DevBuf<float4> scratch;
+    size_t stats_cap = 0, scratch_cap = 0;
     int log2n = 0, G = 1;
     GenPlan gen{};
     size_t lds_bytes = 0;
@@ -147,6 +156,50 @@ int launch_blue_mode(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) 
     }
 }
 
+// ---- long transforms (mtmfft_long.h): one instantiation per factor length
+// interleave per factor length: 64 -> 64 ... 1024 -> 4 (256 threads per workgroup, length/16 threads per FFT)
+template <int L>
+int launch_long_stage(spyhip_ctx* ctx, const spyfft::LongArgs& a, int stage, long long items) {
+    constexpr int G = 4096 >> L;
+    using C = spyfft::Cfg2<L, G>;
+    const long long grid = items * ((stage == 1 ? a.M1 : a.M2) / G);
+    if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large"); return -1; }
+    if (stage == 0) {
+        auto kern = spyfft::long_cols_kernel<L, G>;
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, ctx->stream, a);
+    } else if (stage == 1) {
+        auto kern = spyfft::long_rows_kernel<L, G>;
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, ctx->stream, a);
+    } else {
+        auto kern = spyfft::long_cols_inv_kernel<L, G>;
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, ctx->stream, a);
+    }
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_long(spyhip_ctx* ctx, const spyfft::LongArgs& a, int l, int stage, long long items) {
+    switch (l) {
+        case 6: return launch_long_stage<6>(ctx, a, stage, items);
+        case 7: return launch_long_stage<7>(ctx, a, stage, items);
+        case 8: return launch_long_stage<8>(ctx, a, stage, items);
+        case 9: return launch_long_stage<9>(ctx, a, stage, items);
+        case 10: return launch_long_stage<10>(ctx, a, stage, items);
+        default: spy::set_error("fft_exec: no long-transform stage for 2^%d", l); return -1;
+    }
+}
+
+template <int OUTK, bool MEAN>
+int launch_long_post(spyhip_ctx* ctx, const spyfft::LongArgs& a) {
+    const long long tot = (long long)a.nsegc * a.nquad * (a.m.nfft / 2 + 1);
+    hipLaunchKernelGGL((spyfft::long_post_kernel<OUTK, MEAN>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int OUTK, bool MEAN>
 int launch_generic(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     auto kern = spyfft::mtmfft_generic_kernel<OUTK, MEAN>;
@@ -252,6 +305,51 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
             p->tw.upload(twiddle_table(M), ctx->stream)) { delete p; return -2; }
         char buf[128];
         std::snprintf(buf, sizeof buf, "mtmfft_blue_kernel<%d, %d, %s>", p->log2n, p->G, mode);
+        p->kernel_name = buf;
+    } else if (nfft <= (1 << 19) && !std::getenv("SPYHIP_FORCE_GENERIC") &&
+               !(nfft <= 10240 && [&] { int r[spyfft::GEN_MAXFAC], nf2 = 0; return factorize(nfft, r, &nf2); }() &&
+                 !std::getenv("SPYHIP_FORCE_LONG"))) {
+        // (lengths up to 10240 with prime factors <= 13 stay on the mixed-radix LDS kernel below: measured 10-20 %
+        // faster than the HBM round trips of this path; everything longer, and awkward lengths, come here)
+        // Bluestein with four-step transforms through HBM: M = 2^m >= 2 nfft - 1 (>= 4096), M1 = 2^ceil(m/2), M2 = M / M1
+        int m = 12;
+        p->long_direct = spy::is_pow2((unsigned)nfft) && nfft >= 4096;
+        while ((1LL << m) < (p->long_direct ? (long long)nfft : 2LL * nfft - 1)) ++m;
+        const int M = 1 << m;
+        p->longp = true;
+        p->l1 = (m + 1) / 2;
+        p->l2 = m / 2;
+        const int M1 = 1 << p->l1, M2 = 1 << p->l2;
+        std::vector<float2> chirp(nfft);
+        std::vector<double> br(M, 0.0), bi(M, 0.0);
+        for (long long n = 0; n < nfft; ++n) {
+            const long long q = (n * n) % (2LL * nfft);  // exact phase reduction
+            const double ang = PI * (double)q / (double)nfft;
+            chirp[n] = make_float2((float)std::cos(ang), (float)-std::sin(ang));
+            br[n] = std::cos(ang);
+            bi[n] = std::sin(ang);
+            if (n > 0) { br[M - n] = br[n]; bi[M - n] = bi[n]; }
+        }
+        spy::fft_host(br, bi);
+        std::vector<float2> bhat((size_t)M);          // [k1][k2] order, 1/M folded in
+        for (int k1 = 0; k1 < M1; ++k1)
+            for (int k2 = 0; k2 < M2; ++k2) {
+                const size_t k = (size_t)k1 + (size_t)M1 * k2;
+                bhat[(size_t)k1 * M2 + k2] = make_float2((float)(br[k] / M), (float)(bi[k] / M));
+            }
+        std::vector<double> ws((size_t)2 * ntaper);
+        const double mid = 0.5 * (nsig - 1);
+        for (int k = 0; k < ntaper; ++k) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int n = 0; n < nsig; ++n) { const double w = tf[(size_t)k * nsig + n]; s0 += w; s1 += w * (n - mid); }
+            ws[2 * k] = s0;
+            ws[2 * k + 1] = s1;
+        }
+        if (p->chirp.upload(chirp, ctx->stream) || p->bhat.upload(bhat, ctx->stream) ||
+            p->tw1.upload(twiddle_table(M1), ctx->stream) || p->tw2.upload(twiddle_table(M2), ctx->stream) ||
+            p->twM.upload(twiddle_table(M), ctx->stream) || p->wsum.upload(ws, ctx->stream)) { delete p; return -2; }
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "mtmfft_long<%d x %d, %s>", M1, M2, mode);
         p->kernel_name = buf;
     } else {
         GenPlan& g = p->gen;
@@ -362,6 +460,60 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             case 14: return launch_pow2_mode<14, 1>(p, a, g);
             default: spy::set_error("no kernel for log2n=%d", p->log2n); return -1;
         }
+    }
+    if (p->longp) {
+        spyfft::LongArgs L{};
+        a.nfft = p->nfft;
+        L.m = a;
+        L.M1 = 1 << p->l1; L.M2 = 1 << p->l2;
+        L.tw1 = p->tw1.p; L.tw2 = p->tw2.p; L.twM = p->twM.p; L.chirp = p->chirp.p; L.bhat = p->bhat.p;
+        L.wsum = p->wsum.p;
+        L.direct = p->long_direct ? 1 : 0;
+        L.nquad = (p->nchan + 3) / 4;
+        const size_t M = (size_t)L.M1 * L.M2;
+        const size_t nstat = (size_t)nseg * p->nchan * (2 + p->ntaper);
+        if (nstat > p->stats_cap) {
+            if (p->stats.p) { (void)hipFree(p->stats.p); p->stats.p = nullptr; }
+            if (p->stats.alloc(nstat)) return -2;
+            p->stats_cap = nstat;
+        }
+        L.stats = p->stats.p;
+        if (p->detrend >= 0 || p->demean_taper) {
+            if (nseg > 65535) { spy::set_error("fft_exec: more than 65535 segments per call"); return -1; }
+            hipLaunchKernelGGL(spyfft::long_stats_kernel, dim3((p->nchan + 63) / 64, nseg, p->demean_taper ? p->ntaper + 1 : 1),
+                               dim3(256), 0, p->ctx->stream, a, p->stats.p);
+            SPY_HIP_CHECK(hipGetLastError());
+        }
+        // segments per chunk: scratch of ~2 GiB (at least one segment)
+        const size_t per_seg = (size_t)L.nquad * p->ntaper * M;          // float4 elements
+        size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nseg, (((size_t)2 << 30) / sizeof(float4)) / std::max<size_t>(per_seg, 1)));
+        if (chunk * per_seg > p->scratch_cap) {
+            if (p->scratch.p) { (void)hipFree(p->scratch.p); p->scratch.p = nullptr; }
+            if (p->scratch.alloc(chunk * per_seg)) return -2;
+            p->scratch_cap = chunk * per_seg;
+        }
+        L.scratch = p->scratch.p;
+        const bool mean = !p->keeptapers;
+        const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+        for (int s0 = 0; s0 < nseg; s0 += (int)chunk) {
+            L.seg0 = s0;
+            L.nsegc = std::min<int>((int)chunk, nseg - s0);
+            const long long items = (long long)L.nsegc * L.nquad * p->ntaper;
+            int rc = launch_long(p->ctx, L, p->l1, 0, items);
+            if (!rc) rc = launch_long(p->ctx, L, p->l2, 1, items);
+            if (!rc && !L.direct) rc = launch_long(p->ctx, L, p->l1, 2, items);
+            if (rc) return rc;
+            switch (outk * 2 + (mean ? 1 : 0)) {
+                case 0: rc = launch_long_post<0, false>(p->ctx, L); break;
+                case 1: rc = launch_long_post<0, true>(p->ctx, L); break;
+                case 2: rc = launch_long_post<1, false>(p->ctx, L); break;
+                case 3: rc = launch_long_post<1, true>(p->ctx, L); break;
+                case 4: rc = launch_long_post<2, false>(p->ctx, L); break;
+                default: rc = launch_long_post<2, true>(p->ctx, L); break;
+            }
+            if (rc) return rc;
+        }
+        return 0;
     }
     if (p->blue) {
         a.nfft = p->nfft; a.chirp = p->chirp.p; a.bhat = p->bhat.p;

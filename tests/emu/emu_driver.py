@@ -47,7 +47,8 @@ OUT_KINDS = {"pow": 0, "abs": 1, "fourier": 2, "complex": 2, "real": 3, "imag": 
 
 
 def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
-             freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False):
+             freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False,
+             force_long=False):
     """Emulated spyhip_fft_exec.  data: (rows, ld) float32; tapers: (K, nsig) float64.
     blocked: channel-blocked hand-over layout (nseg*K, ceil(nchan/4), nfsel, 4) (fourier, keeptapers)."""
     data = np.ascontiguousarray(data, dtype=np.float32)
@@ -91,6 +92,35 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
             C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
         set_blocked(False)
         assert rc == 0, f"no emulated kernel for log2n={log2n} G={G}"
+        return out
+    if force_long or (not pow2 and nfft > 4096 and not force_generic):
+        # Bluestein with four-step length-M transforms through (emulated) HBM - mirror of spyhip_fft_plan_create
+        m = 12
+        while (1 << m) < 2 * nfft - 1:
+            m += 1
+        M = 1 << m
+        l1, l2 = (m + 1) // 2, m // 2
+        M1, M2 = 1 << l1, 1 << l2
+        k = np.arange(nfft, dtype=np.int64)
+        ang = np.pi * ((k * k) % (2 * nfft)) / nfft
+        chirp = np.stack([np.cos(ang), -np.sin(ang)], axis=1).astype(np.float32).copy()
+        bq = np.zeros(M, dtype=np.complex128)
+        bq[:nfft] = np.exp(1j * ang)
+        bq[M - nfft + 1:] = bq[1:nfft][::-1]
+        bh = (np.fft.fft(bq) / M).reshape(M2, M1).T                 # [k1][k2] with k = k1 + M1*k2
+        bhat = np.stack([bh.real, bh.imag], axis=-1).astype(np.float32).copy()
+        tp64 = tp.astype(np.float64)
+        mid = 0.5 * (nsig - 1)
+        wsum = np.stack([tp64.sum(axis=1), (tp64 * (np.arange(nsig) - mid)).sum(axis=1)], axis=1).copy()
+        rc = lib().emu_mtmfft_long(
+            C.c_int(l1), C.c_int(l2), C.c_int(nfft), _p(chirp, C.c_float), _p(bhat, C.c_float),
+            _p(twiddles(M1), C.c_float), _p(twiddles(M2), C.c_float), _p(twiddles(M), C.c_float),
+            wsum.ctypes.data_as(C.POINTER(C.c_double)), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
+            _p(ss, C.c_longlong), _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg), C.c_int(nsig),
+            C.c_int(nchan), C.c_int(K), _p(tp, C.c_float), C.c_float(scale), C.c_int(detrend),
+            C.c_int(int(demean_taper)), _p(fpos, C.c_int), C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)),
+            out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
         return out
     if 2 * nfft - 1 <= 8192 and nfft >= 8 and not force_generic:
         # Bluestein on the packed power-of-two engine (mirror of spyhip_fft_plan_create)

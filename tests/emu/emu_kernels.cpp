@@ -18,6 +18,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/csd_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
+#include "../../syncopy_amd/csrc/mtmfft_long.h"
 #include "../../syncopy_amd/csrc/cwt_kernel.h"
 #include "../../syncopy_amd/csrc/granger_kernels.h"
 
@@ -79,6 +80,24 @@ void run_blue_mode(const MtmArgs& a, unsigned grid, int outk, int mean) {
         case 3: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 1, true>(a); }); break;
         case 4: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 2, false>(a); }); break;
         default: go([&] { spyfft::mtmfft_blue_kernel<LOG2N, G, 2, true>(a); }); break;
+    }
+}
+
+template <int L>
+void run_long_stage(const spyfft::LongArgs& a, int stage, long long items) {
+    constexpr int G = 4096 >> L;
+    using C = spyfft::Cfg2<L, G>;
+    const unsigned grid = (unsigned)(items * ((stage == 1 ? a.M1 : a.M2) / G));
+    if (stage == 0) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::long_cols_kernel<L, G>(a); });
+    else if (stage == 1) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::long_rows_kernel<L, G>(a); });
+    else emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::long_cols_inv_kernel<L, G>(a); });
+}
+int run_long(const spyfft::LongArgs& a, int l, int stage, long long items) {
+    switch (l) {
+        case 6: run_long_stage<6>(a, stage, items); return 0;
+        case 7: run_long_stage<7>(a, stage, items); return 0;
+        case 8: run_long_stage<8>(a, stage, items); return 0;
+        default: return -1;          // longer factors are exercised on the GPU only (emulation time)
     }
 }
 
@@ -160,6 +179,50 @@ int emu_mtmfft_blue(int log2m, int G, int nfft, const float* chirp, const float*
         case 1201: run_blue_mode<12, 1>(a, grid, outk, mean); break;
         case 1301: run_blue_mode<13, 1>(a, grid, outk, mean); break;
         default: return -1;
+    }
+    return 0;
+}
+
+// Mirrors the long-transform branch of spyhip_fft_exec (one chunk holding every segment).
+int emu_mtmfft_long(int l1, int l2, int nfft, const float* chirp, const float* bhat, const float* tw1, const float* tw2,
+                    const float* twM, const double* wsum, const float* data, long long ld, const int* chan_idx,
+                    const long long* seg_start, const long long* seg_lo, const long long* seg_hi, int nseg, int nsig,
+                    int nchan, int ntaper, const float* tapers, float scale, int detrend, int demean_taper,
+                    const int* fpos, int nfsel, int out_kind, int keeptapers, void* out) {
+    MtmArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
+    a.tapers = tapers; a.scale = scale; a.detrend = detrend; a.demean_taper = demean_taper;
+    a.fpos = fpos; a.nfsel = nfsel; a.out_kind = out_kind; a.out = out; a.nfft = nfft;
+    spyfft::LongArgs L{};
+    L.m = a;
+    L.M1 = 1 << l1; L.M2 = 1 << l2;
+    L.tw1 = reinterpret_cast<const float2*>(tw1); L.tw2 = reinterpret_cast<const float2*>(tw2);
+    L.twM = reinterpret_cast<const float2*>(twM); L.chirp = reinterpret_cast<const float2*>(chirp);
+    L.bhat = reinterpret_cast<const float2*>(bhat); L.wsum = wsum;
+    L.nquad = (nchan + 3) / 4;
+    std::vector<double> stats((size_t)nseg * nchan * (2 + ntaper), 0.0);
+    L.stats = stats.data();
+    if (detrend >= 0 || demean_taper)
+        emu::launch(dim3((nchan + 63) / 64, nseg, demean_taper ? ntaper + 1 : 1), dim3(256), 0,
+                    [&] { spyfft::long_stats_kernel(a, stats.data()); });
+    const size_t M = (size_t)L.M1 * L.M2;
+    const long long items = (long long)nseg * L.nquad * ntaper;
+    std::vector<float4> scratch((size_t)items * M);
+    L.scratch = scratch.data();
+    L.seg0 = 0; L.nsegc = nseg;
+    if (run_long(L, l1, 0, items) || run_long(L, l2, 1, items) || run_long(L, l1, 2, items)) return -1;
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    const bool mean = !keeptapers;
+    const unsigned grid = (unsigned)(((long long)nseg * L.nquad * (nfft / 2 + 1) + 255) / 256);
+    switch (outk * 2 + (mean ? 1 : 0)) {
+        case 0: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::long_post_kernel<0, false>(L); }); break;
+        case 1: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::long_post_kernel<0, true>(L); }); break;
+        case 2: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::long_post_kernel<1, false>(L); }); break;
+        case 3: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::long_post_kernel<1, true>(L); }); break;
+        case 4: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::long_post_kernel<2, false>(L); }); break;
+        default: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::long_post_kernel<2, true>(L); }); break;
     }
     return 0;
 }

@@ -11,14 +11,14 @@ from parity import assert_parity, excess
 
 
 def _fft_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=False, G=None, generic=False,
-              freq_idx=None, chan_idx=None, nseg=2, seed=1):
+              freq_idx=None, chan_idx=None, nseg=2, seed=1, long=False):
     rng = np.random.default_rng(seed)
     data = rng.normal(size=(nsig * nseg + 9, nchan)).astype("f4")
     ss = np.array([4 + i * nsig for i in range(nseg)])
     taper, topt = ("dpss", {"NW": (K + 1) / 2, "Kmax": K}) if K > 1 else ("hann", {})
     tapers = O.taper_table(taper, nsig, nfft, topt)
     out = E.fft_exec(data, ss, ss, ss + nsig, nsig, nfft, tapers, O.spec_scale(nsig, nfft), detrend, demean_taper,
-                     freq_idx, output, keeptapers, chan_idx=chan_idx, G=G, force_generic=generic)
+                     freq_idx, output, keeptapers, chan_idx=chan_idx, G=G, force_generic=generic, force_long=long)
     freqs = np.fft.rfftfreq(nfft, 1e-3)
     foi = freqs if freq_idx is None else freqs[freq_idx]
     for b in range(nseg):
@@ -82,6 +82,14 @@ def test_generic_kernel_lengths(nsig, nfft):
     _fft_case(nsig, nfft, 2, 1, "fourier", True, 1, demean_taper=True, nseg=1)
     # ... and the mixed-radix / Bluestein LDS kernel that still serves nfft > 4096
     _fft_case(nsig, nfft, 3, 2, "pow", False, 0, generic=True, nseg=1)
+
+
+def test_long_transform_path():
+    """Bluestein with four-step transforms through HBM (the path of nfft > 4096 non-powers-of-two and of
+    nfft > 16384), forced onto small lengths: M = 4096 = 64 x 64 and M = 8192 = 128 x 64."""
+    _fft_case(1500, 1500, 5, 2, "pow", False, 1, demean_taper=True, long=True, nseg=1)
+    _fft_case(700, 900, 4, 1, "fourier", True, 0, long=True, nseg=2)
+    _fft_case(2500, 2500, 3, 1, "abs", True, -1, long=True, nseg=1, freq_idx=np.array([7, 0, 1250, 333]))
 
 
 def test_bluestein_kernel_modes():

@@ -58,6 +58,13 @@ CASES = [
     (16384, 16384, 3, "dpss", {"NW": 3, "Kmax": 5}, "pow", False, 0, False),
     (2000, 2000, 16, "dpss", {"NW": 4, "Kmax": 7}, "pow", False, 0, False),          # BASELINE config 1 shape
     (500, 500, 8, "hann", {}, "pow", True, 0, False),
+    # long transforms (Bluestein + four-step FFTs through HBM): not powers of two above 4096, anything above 16384
+    (5003, 5003, 6, "dpss", {"NW": 3, "Kmax": 3}, "pow", False, 1, True),             # prime
+    (11000, 11000, 4, "hann", {}, "fourier", True, 0, False),
+    (5000, 5000, 6, "dpss", {"NW": 3, "Kmax": 3}, "pow", False, 1, True),             # 8*5^4: mixed-radix LDS kernel
+    (32768, 32768, 3, "dpss", {"NW": 2, "Kmax": 2}, "pow", False, 0, False),           # power of two: plain four-step
+    (30000, 30000, 5, "dpss", {"NW": 2, "Kmax": 2}, "abs", True, 0, False),
+    (20000, 32768, 2, "hann", {}, "pow", True, None, False),
     (1800, 2000, 4, "dpss", {"NW": 3.6, "Kmax": 6}, "fourier", True, 1, True),
     (360, 360, 3, None, {}, "angle", True, None, False),
     (1009, 1009, 2, "hann", {}, "pow", True, 0, False),                                # prime: Bluestein
