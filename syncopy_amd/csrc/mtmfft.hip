@@ -27,7 +27,7 @@ struct spyhip_fft_plan {
     bool long_direct = false;   // ... or, for power-of-two nfft, one plain four-step transform
     int l1 = 0, l2 = 0;         // M1 = 2^l1, M2 = 2^l2
     spy::DevBuf<float2> tw1, tw2, twM;
-    spy::DevBuf<double> wsum, stats;
+    spy::DevBuf<double> wsum, stats, stats_part;
     spy::DevBuf<float4> scratch;
     size_t stats_cap = 0, scratch_cap = 0;
     int log2n = 0, G = 1;
@@ -472,16 +472,21 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         L.nquad = (p->nchan + 3) / 4;
         const size_t M = (size_t)L.M1 * L.M2;
         const size_t nstat = (size_t)nseg * p->nchan * (2 + p->ntaper);
+        const int nz = p->demean_taper ? p->ntaper + 1 : 1;
         if (nstat > p->stats_cap) {
             if (p->stats.p) { (void)hipFree(p->stats.p); p->stats.p = nullptr; }
-            if (p->stats.alloc(nstat)) return -2;
+            if (p->stats_part.p) { (void)hipFree(p->stats_part.p); p->stats_part.p = nullptr; }
+            if (p->stats.alloc(nstat) ||
+                p->stats_part.alloc((size_t)nseg * (p->ntaper + 1) * spyfft::LONG_SPLITS * p->nchan * 2)) return -2;
             p->stats_cap = nstat;
         }
         L.stats = p->stats.p;
         if (p->detrend >= 0 || p->demean_taper) {
-            if (nseg > 65535) { spy::set_error("fft_exec: more than 65535 segments per call"); return -1; }
-            hipLaunchKernelGGL(spyfft::long_stats_kernel, dim3((p->nchan + 63) / 64, nseg, p->demean_taper ? p->ntaper + 1 : 1),
-                               dim3(256), 0, p->ctx->stream, a, p->stats.p);
+            if (nseg > 65535 || nz * spyfft::LONG_SPLITS > 65535) { spy::set_error("fft_exec: too many segments / tapers per call"); return -1; }
+            hipLaunchKernelGGL(spyfft::long_stats_kernel, dim3((p->nchan + 63) / 64, nseg, nz * spyfft::LONG_SPLITS),
+                               dim3(256), 0, p->ctx->stream, a, p->stats_part.p, nz);
+            hipLaunchKernelGGL(spyfft::long_stats_final_kernel, dim3((unsigned)(((size_t)nseg * p->nchan + 255) / 256)), dim3(256),
+                               0, p->ctx->stream, a, p->stats_part.p, nz, p->stats.p);
             SPY_HIP_CHECK(hipGetLastError());
         }
         // segments per chunk: scratch of ~2 GiB (at least one segment)

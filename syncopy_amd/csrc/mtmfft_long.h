@@ -45,18 +45,25 @@ __device__ __forceinline__ C2 ld_c2(const float4* p) {
 __device__ __forceinline__ void st_c2(float4* p, C2 v) { *p = make_float4(v.r[0], v.r[1], v.i[0], v.i[1]); }
 __device__ __forceinline__ C2 conj2(C2 a) { return C2{a.r, -a.i}; }
 
-// ---- sums over the valid samples of every (segment, channel): z = 0 -> (sum x, sum (n-mid) x); z = k+1 -> sum w_k x
-__global__ void __launch_bounds__(256) long_stats_kernel(MtmArgs a, double* stats) {
+// ---- sums over the valid samples of every (segment, channel): z = 0 -> (sum x, sum (n-mid) x); z = k+1 -> sum w_k x.
+// Two deterministic stages: LONG_SPLITS slices of the segment in parallel (a single workgroup walking 30000 rows
+// is latency-bound), then a fixed-order reduction.
+constexpr int LONG_SPLITS = 32;
+__global__ void __launch_bounds__(256) long_stats_kernel(MtmArgs a, double* part, int nz) {
     __shared__ double red[4][64][2];
     const int tid = threadIdx.x, cl = tid & 63, ph = tid >> 6;
-    const int b = blockIdx.y, c = blockIdx.x * 64 + cl, z = blockIdx.z;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + cl;
+    const int z = blockIdx.z / LONG_SPLITS, sp = blockIdx.z % LONG_SPLITS;
     const long long start = a.seg_start[b], lo = a.seg_lo[b], hi = a.seg_hi[b];
     const double mid = 0.5 * (double)(a.nsig - 1);
+    const int per = (a.nsig + LONG_SPLITS - 1) / LONG_SPLITS;
+    const int n0 = sp * per, n1 = min(a.nsig, n0 + per);
     double s0 = 0.0, s1 = 0.0;
     if (c < a.nchan) {
         const long long col = a.chan_idx ? a.chan_idx[c] : c;
         const float* w = z > 0 ? a.tapers + (size_t)(z - 1) * a.nsig : nullptr;
-        for (int n = ph; n < a.nsig; n += 4) {
+#pragma unroll 4
+        for (int n = n0 + ph; n < n1; n += 4) {
             const long long row = start + n;
             if (row < lo || row >= hi) continue;
             const double x = a.data[row * a.ld + col];
@@ -77,7 +84,25 @@ __global__ void __launch_bounds__(256) long_stats_kernel(MtmArgs a, double* stat
             t0 += red[p][cl][0];
             t1 += red[p][cl][1];
         }
-        double* o = stats + ((size_t)b * a.nchan + c) * (2 + a.ntaper);
+        double* o = part + ((((size_t)b * nz + z) * LONG_SPLITS + sp) * a.nchan + c) * 2;
+        o[0] = t0;
+        o[1] = t1;
+    }
+}
+
+// stats[seg][chan][0..1] = sum x, sum (n-mid) x; [2 + k] = sum w_k x
+__global__ void __launch_bounds__(256) long_stats_final_kernel(MtmArgs a, const double* part, int nz, double* stats) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.nseg * a.nchan) return;
+    const int b = (int)(i / a.nchan), c = (int)(i % a.nchan);
+    double* o = stats + (size_t)i * (2 + a.ntaper);
+    for (int z = 0; z < nz; ++z) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int sp = 0; sp < LONG_SPLITS; ++sp) {
+            const double* q = part + ((((size_t)b * nz + z) * LONG_SPLITS + sp) * a.nchan + c) * 2;
+            t0 += q[0];
+            t1 += q[1];
+        }
         if (z == 0) {
             o[0] = t0;
             o[1] = t1;
@@ -132,6 +157,9 @@ __global__ void __launch_bounds__((Cfg2<LOG2L, G>::NTHREADS)) long_cols_kernel(L
             dm[i] = (float)((st[2 + k] - mean[i] * a.wsum[2 * k] - slope[i] * a.wsum[2 * k + 1]) / m.nsig);
     }
     const float* w = m.tapers + (size_t)k * m.nsig;
+    // all four channels adjacent and 16-byte aligned: one load per sample instead of four
+    const bool vec4 = (m.chan_idx == nullptr) && has[3] && ((m.ld & 3) == 0) &&
+                      ((reinterpret_cast<size_t>(m.data) & 15) == 0);
     C2 v[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -142,10 +170,15 @@ __global__ void __launch_bounds__((Cfg2<LOG2L, G>::NTHREADS)) long_cols_kernel(L
             const long long row = start + n;
             float x[4] = {0.f, 0.f, 0.f, 0.f};
             const bool in = row >= lo && row < hi;
+            float raw[4] = {0.f, 0.f, 0.f, 0.f};
+            if (in && vec4) {
+                const float4 t = *reinterpret_cast<const float4*>(m.data + row * m.ld + c0);
+                raw[0] = t.x; raw[1] = t.y; raw[2] = t.z; raw[3] = t.w;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (!has[i]) continue;
-                float u = in ? m.data[row * m.ld + col[i]] : 0.f;
+                float u = vec4 ? raw[i] : (in ? m.data[row * m.ld + col[i]] : 0.f);
                 if (m.detrend >= 0) u -= (float)(mean[i] + slope[i] * ((double)n - mid));
                 x[i] = w[n] * u - dm[i];
             }

@@ -204,9 +204,14 @@ int emu_mtmfft_long(int l1, int l2, int nfft, const float* chirp, const float* b
     L.nquad = (nchan + 3) / 4;
     std::vector<double> stats((size_t)nseg * nchan * (2 + ntaper), 0.0);
     L.stats = stats.data();
-    if (detrend >= 0 || demean_taper)
-        emu::launch(dim3((nchan + 63) / 64, nseg, demean_taper ? ntaper + 1 : 1), dim3(256), 0,
-                    [&] { spyfft::long_stats_kernel(a, stats.data()); });
+    if (detrend >= 0 || demean_taper) {
+        const int nz = demean_taper ? ntaper + 1 : 1;
+        std::vector<double> part((size_t)nseg * nz * spyfft::LONG_SPLITS * nchan * 2, 0.0);
+        emu::launch(dim3((nchan + 63) / 64, nseg, nz * spyfft::LONG_SPLITS), dim3(256), 0,
+                    [&] { spyfft::long_stats_kernel(a, part.data(), nz); });
+        emu::launch(dim3((unsigned)(((size_t)nseg * nchan + 255) / 256)), dim3(256), 0,
+                    [&] { spyfft::long_stats_final_kernel(a, part.data(), nz, stats.data()); });
+    }
     const size_t M = (size_t)L.M1 * L.M2;
     const long long items = (long long)nseg * L.nquad * ntaper;
     std::vector<float4> scratch((size_t)items * M);
