@@ -10,17 +10,25 @@
 
 using spyfft::CwtArgs;
 
+// scales whose (trimmed) kernel support needs the same block length share one launch: short kernels run on short
+// blocks (less FFT work per output sample, two workgroups per CU) instead of on the block the longest one needs
+struct CwtGroup {
+    int log2n = 0, G = 1, V = 0, halo = 0, nblocks = 0, nscales = 0;
+    spy::DevBuf<float2> tw, hspec;
+    spy::DevBuf<int> cshift, sidx;
+};
+
 struct spyhip_cwt_plan {
     spyhip_ctx* ctx = nullptr;
     int nsig = 0, nchan = 0, nscales = 0, detrend = -1, output = 0, ntime_out = 0;
-    int log2n = 0, G = 1, V = 0, halo = 0, nblocks = 0;
+    std::vector<CwtGroup*> groups;
     bool identity_time = true;
-    spy::DevBuf<float2> tw, hspec;
-    spy::DevBuf<int> cshift, tpos;
+    spy::DevBuf<int> tpos;
     spy::DevBuf<double> trend, trend_part;
     size_t trend_cap = 0;
     spy::DevBuf<char> stage;      // time-contiguous staging of one chunk of segments
     int chunk = 0;                // segments per chunk the staging buffer holds
+    ~spyhip_cwt_plan() { for (auto* g : groups) delete g; }
 };
 
 namespace {
@@ -74,7 +82,6 @@ extern "C" int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int 
     // ---- sampled kernels (transform.py:96-103), trimmed to the taps that can overlap the signal
     struct Ker { std::vector<double> re, im; int c; };
     std::vector<Ker> kers(nscales);
-    int lmax = 1, halo = 0, right = 0;
     for (int s = 0; s < nscales; ++s) {
         const double sc = scales[s];
         const double M = 10.0 * sc / dt;
@@ -97,44 +104,65 @@ extern "C" int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int 
             k.re[m - m0] = g * (std::cos(w0 * x) - corr);
             k.im[m - m0] = g * std::sin(w0 * x);
         }
-        const int Lt = (int)(m1 - m0);
-        lmax = std::max(lmax, Lt);
-        halo = std::max(halo, Lt - 1 - k.c);                        // reach to the left: L-1-c
-        right = std::max(right, k.c);
-    }
-    // block length: power of two >= 2x the longest (trimmed) kernel, within what the LDS FFT supports
-    int NB = 1024;
-    while (NB < 2 * (halo + right + 1) && NB < 16384) NB <<= 1;
-    const int V = NB - halo - right;
-    if (V < 1) {
-        spy::set_error("cwt_plan_create: kernel support of %d taps exceeds the %d-point block FFT "
-                       "(scale too large for this signal length)", lmax, NB);
-        return -3;
     }
     auto* p = new spyhip_cwt_plan();
     p->ctx = ctx; p->nsig = nsig; p->nchan = nchan; p->nscales = nscales;
     p->detrend = detrend; p->output = output;
-    p->log2n = spy::ilog2((unsigned)NB);
-    // channel PAIRS per workgroup of the packed kernel (<= 2^13); channels per workgroup of the 2^14 kernel
-    p->G = p->log2n == 10 ? 4 : (p->log2n == 11 ? 2 : 1);
-    p->V = V; p->halo = halo; p->nblocks = (nsig + V - 1) / V;
-
-    std::vector<float2> tw(NB), hs((size_t)nscales * NB);
-    for (int m = 0; m < NB; ++m) {
-        const double ang = -2.0 * PI * m / NB;
-        tw[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-    }
-    std::vector<int> cshift(nscales);
+    // block length per scale, within what the LDS FFTs support
+    std::vector<int> need(nscales);
     for (int s = 0; s < nscales; ++s) {
-        std::vector<double> re(NB, 0.0), im(NB, 0.0);
-        for (size_t m = 0; m < kers[s].re.size(); ++m) { re[m] = kers[s].re[m]; im[m] = kers[s].im[m]; }
-        spy::fft_host(re, im);
-        for (int k = 0; k < NB; ++k) hs[(size_t)s * NB + k] = make_float2((float)(re[k] / NB), (float)(im[k] / NB));
-        cshift[s] = halo + kers[s].c;
+        const int Lt = (int)kers[s].re.size();
+        // >= 4x the kernel (>= 75 % of a block is output) while that stays on the packed engine (<= 8192),
+        // else >= 2x, up to the 16384-point engine
+        int NB = 1024;
+        while (NB < 4 * (Lt + 1) && NB < 8192) NB <<= 1;
+        while (NB < 2 * (Lt + 1) && NB < 16384) NB <<= 1;
+        need[s] = NB;
     }
-    if (p->tw.upload(tw, ctx->stream) || p->hspec.upload(hs, ctx->stream) || p->cshift.upload(cshift, ctx->stream)) {
-        delete p;
-        return -2;
+    for (int NB = 1024; NB <= 16384; NB <<= 1) {
+        std::vector<int> ids;
+        for (int s = 0; s < nscales; ++s)
+            if (need[s] == NB) ids.push_back(s);
+        if (ids.empty()) continue;
+        int halo = 0, right = 0, lmax = 1;
+        for (int s : ids) {
+            const int Lt = (int)kers[s].re.size();
+            lmax = std::max(lmax, Lt);
+            halo = std::max(halo, Lt - 1 - kers[s].c);               // reach to the left: L-1-c
+            right = std::max(right, kers[s].c);
+        }
+        const int V = NB - halo - right;
+        if (V < 1) {
+            spy::set_error("cwt_plan_create: kernel support of %d taps exceeds the %d-point block FFT "
+                           "(scale too large for this signal length)", lmax, NB);
+            delete p;
+            return -3;
+        }
+        auto* g = new CwtGroup();
+        p->groups.push_back(g);
+        g->log2n = spy::ilog2((unsigned)NB);
+        // channel PAIRS per workgroup of the packed kernel (<= 2^13); channels per workgroup of the 2^14 kernel
+        g->G = g->log2n == 10 ? 4 : (g->log2n == 11 ? 2 : 1);
+        g->V = V; g->halo = halo; g->nblocks = (nsig + V - 1) / V; g->nscales = (int)ids.size();
+        std::vector<float2> tw(NB), hs(ids.size() * (size_t)NB);
+        for (int m = 0; m < NB; ++m) {
+            const double ang = -2.0 * PI * m / NB;
+            tw[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+        std::vector<int> cshift(ids.size());
+        for (size_t q = 0; q < ids.size(); ++q) {
+            const int sc = ids[q];
+            std::vector<double> re(NB, 0.0), im(NB, 0.0);
+            for (size_t m = 0; m < kers[sc].re.size(); ++m) { re[m] = kers[sc].re[m]; im[m] = kers[sc].im[m]; }
+            spy::fft_host(re, im);
+            for (int k = 0; k < NB; ++k) hs[q * NB + k] = make_float2((float)(re[k] / NB), (float)(im[k] / NB));
+            cshift[q] = halo + kers[sc].c;
+        }
+        if (g->tw.upload(tw, ctx->stream) || g->hspec.upload(hs, ctx->stream) || g->cshift.upload(cshift, ctx->stream) ||
+            g->sidx.upload(ids, ctx->stream)) {
+            delete p;
+            return -2;
+        }
     }
     p->identity_time = (tpos == nullptr);
     p->ntime_out = tpos ? ntime_out : nsig;
@@ -165,8 +193,7 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
     a.trial_lo = reinterpret_cast<const long long*>(trial_lo_d);
     a.trial_hi = reinterpret_cast<const long long*>(trial_hi_d);
     a.nseg = nseg; a.nsig = p->nsig; a.nchan = p->nchan; a.nscales = p->nscales;
-    a.tw = p->tw.p; a.hspec = p->hspec.p; a.cshift = p->cshift.p;
-    a.V = p->V; a.halo = p->halo; a.nblocks = p->nblocks;
+    a.nscales_total = p->nscales;
     a.detrend = p->detrend; a.out_kind = p->output;
     a.tpos = p->identity_time ? nullptr : p->tpos.p;
     a.ntime_out = p->ntime_out; a.out = out_d; a.accumulate = accumulate;
@@ -186,10 +213,11 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
                            0, p->ctx->stream, a, p->trend_part.p, p->trend.p);
         SPY_HIP_CHECK(hipGetLastError());
     }
-    // staging buffer: as many segments per chunk as fit ~1 GiB (at least one)
+    // staging buffer: as many segments per chunk as fit ~4 GiB (at least one): enough workgroups per launch that
+    // the last partial round of the grid over 256 CUs stays a small fraction
     const size_t esz = (p->output == SPYHIP_OUT_FOURIER) ? 8 : 4;
     const size_t per_seg = (size_t)p->nscales * p->nchan * p->nsig * esz;
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nseg, ((size_t)1 << 30) / std::max<size_t>(per_seg, 1)));
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nseg, ((size_t)4 << 30) / std::max<size_t>(per_seg, 1)));
     if (chunk > p->chunk) {
         if (p->stage.p) { (void)hipFree(p->stage.p); p->stage.p = nullptr; }
         if (p->stage.alloc(per_seg * chunk)) return -2;
@@ -197,8 +225,6 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
     }
     chunk = p->chunk;
     a.stage = p->stage.p;
-    const long long nunit = p->log2n <= 13 ? (p->nchan + 1) / 2 : p->nchan;   // channel pairs / channels
-    const long long ngrp = (nunit + p->G - 1) / p->G;
     for (int s0 = 0; s0 < nseg; s0 += chunk) {
         const int ns = std::min(chunk, nseg - s0);
         CwtArgs c = a;
@@ -208,19 +234,29 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         c.trial_hi = a.trial_hi + s0;
         if (a.trend) c.trend = a.trend + (size_t)s0 * p->nchan * 2;
         c.nseg = ns;
-        const long long grid = (long long)ns * ngrp * p->nblocks;
-        if (grid > 0x7fffffffLL || p->nscales > 65535 || ns > 65535) { spy::set_error("cwt_exec: grid too large"); return -1; }
-        const unsigned g = (unsigned)grid;
-        int rc;
-        switch (p->log2n) {
-            case 10: rc = launch_cwt2_out<10, 4>(p, c, g); break;
-            case 11: rc = launch_cwt2_out<11, 2>(p, c, g); break;
-            case 12: rc = launch_cwt2_out<12, 1>(p, c, g); break;
-            case 13: rc = launch_cwt2_out<13, 1>(p, c, g); break;
-            case 14: rc = launch_cwt_out<14, 1>(p, c, g); break;
-            default: spy::set_error("cwt_exec: unsupported block length 2^%d", p->log2n); return -1;
+        if (p->nscales > 65535 || ns > 65535) { spy::set_error("cwt_exec: grid too large"); return -1; }
+        for (const CwtGroup* gr : p->groups) {           // one launch per block length
+            CwtArgs k = c;
+            k.nscales = gr->nscales;
+            k.sidx = gr->sidx.p;
+            k.tw = gr->tw.p; k.hspec = gr->hspec.p; k.cshift = gr->cshift.p;
+            k.V = gr->V; k.halo = gr->halo; k.nblocks = gr->nblocks;
+            const long long nunit = gr->log2n <= 13 ? (p->nchan + 1) / 2 : p->nchan;   // channel pairs / channels
+            const long long ngrp = (nunit + gr->G - 1) / gr->G;
+            const long long grid = (long long)ns * ngrp * gr->nblocks;
+            if (grid > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
+            const unsigned g = (unsigned)grid;
+            int rc;
+            switch (gr->log2n) {
+                case 10: rc = launch_cwt2_out<10, 4>(p, k, g); break;
+                case 11: rc = launch_cwt2_out<11, 2>(p, k, g); break;
+                case 12: rc = launch_cwt2_out<12, 1>(p, k, g); break;
+                case 13: rc = launch_cwt2_out<13, 1>(p, k, g); break;
+                case 14: rc = launch_cwt_out<14, 1>(p, k, g); break;
+                default: spy::set_error("cwt_exec: unsupported block length 2^%d", gr->log2n); return -1;
+            }
+            if (rc) return rc;
         }
-        if (rc) return rc;
         const dim3 sg((p->nsig + 63) / 64, p->nscales, accumulate == 2 ? 1 : ns);
         if (esz == 8) hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float2>, sg, dim3(256), 0, p->ctx->stream, c);
         else hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float>, sg, dim3(256), 0, p->ctx->stream, c);

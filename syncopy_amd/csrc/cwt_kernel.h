@@ -42,6 +42,8 @@ struct CwtArgs {
     void* stage;                  // (chunk segments, nscales, nchan, nsig): time-contiguous staging of the
                                   // converted values; cwt_scatter_kernel transposes it into `out`
     int seg0;                     // first segment of the chunk being processed
+    const int* sidx;              // scale s of this launch -> scale index of the plan (nullptr = identity): scales
+    int nscales_total;            // are grouped by the block length their kernel support needs (0 = nscales)
 };
 
 // per (segment, channel): mean and least-squares slope over the trial rows [lo, hi), in two
@@ -157,7 +159,8 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) cwt_kernel(CwtArgs 
         for (int e = 0; e < 16; ++e) v[e] = cmul(Z[e], ldg<float2>(H, (unsigned)(j + T * e) * 8u));
         fft_inverse<LOG2N, G>(v, lds, j, h, a.tw);
         const int sh = a.cshift[s];
-        const size_t rowo = (((size_t)b * a.nscales + s) * a.nchan + c) * (size_t)a.nsig;
+        const size_t rowo = (((size_t)b * (a.nscales_total ? a.nscales_total : a.nscales) + (a.sidx ? a.sidx[s] : s)) * a.nchan + c) *
+                            (size_t)a.nsig;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int n = j + T * e - sh + o0;
@@ -236,7 +239,8 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArg
         for (int e = 0; e < 16; ++e) v[e] = cmul_s(Z[e], ldg<float2>(H, (unsigned)(j + T * e) * 8u));
         fft2_inverse<LOG2N, G>(v, lds, j, h, a.tw);
         const int sh = a.cshift[s];
-        const size_t rowo = (((size_t)b * a.nscales + s) * a.nchan + c0) * (size_t)a.nsig;
+        const size_t rowo = (((size_t)b * (a.nscales_total ? a.nscales_total : a.nscales) + (a.sidx ? a.sidx[s] : s)) * a.nchan + c0) *
+                            (size_t)a.nsig;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int n = j + T * e - sh + o0;
@@ -264,23 +268,42 @@ __global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
     // read-modify-write of the output per chunk); otherwise blockIdx.z = segment of the chunk
     const bool sum_segs = a.accumulate == 2;
     const int bl0 = sum_segs ? 0 : blockIdx.z, bl1 = sum_segs ? a.nseg : bl0 + 1;
-    const size_t seg_stride = (size_t)a.nscales * a.nchan * (size_t)a.nsig;
+    const size_t seg_stride = (size_t)a.nscales * a.nchan * (size_t)a.nsig;     // (launched with nscales = plan total)
     const V* const st0 = reinterpret_cast<const V*>(a.stage) + (size_t)s * a.nchan * (size_t)a.nsig;
     V* const out = reinterpret_cast<V*>(a.out);
     const int oseg = sum_segs ? 0 : a.seg0 + bl0;
     const int n = n0 + tx;
     for (int c0 = 0; c0 < a.nchan; c0 += 64) {
         if (c0) __syncthreads();
-#pragma unroll 4
-        for (int r = ty; r < 64; r += 4) {
-            if (c0 + r < a.nchan && n < a.nsig) {
-                V acc = st0[(size_t)bl0 * seg_stride + (size_t)(c0 + r) * a.nsig + n];
-                for (int bl = bl0 + 1; bl < bl1; ++bl) {
-                    const V x = st0[(size_t)bl * seg_stride + (size_t)(c0 + r) * a.nsig + n];
-                    if constexpr (sizeof(V) == 8) acc = cadd(acc, x);
-                    else acc = acc + x;
+        if (sizeof(V) == 4 && (a.nsig & 3) == 0) {
+            // 16-byte loads: 16 lanes cover the 64 samples of one channel row, a wave covers 4 rows
+            const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;          // rr in [0, 16)
+            const int nq = n0 + 4 * q;
+#pragma unroll
+            for (int r = rr; r < 64; r += 16) {
+                if (c0 + r < a.nchan && nq < a.nsig) {
+                    const float* src = reinterpret_cast<const float*>(st0) + (size_t)(c0 + r) * a.nsig + nq;
+                    float4 acc = *reinterpret_cast<const float4*>(src + (size_t)bl0 * seg_stride);
+                    for (int bl = bl0 + 1; bl < bl1; ++bl) {
+                        const float4 x = *reinterpret_cast<const float4*>(src + (size_t)bl * seg_stride);
+                        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+                    }
+                    float* t = reinterpret_cast<float*>(&tile[r][4 * q]);
+                    t[0] = acc.x; t[1] = acc.y; t[2] = acc.z; t[3] = acc.w;
                 }
-                tile[r][tx] = acc;
+            }
+        } else {
+#pragma unroll 4
+            for (int r = ty; r < 64; r += 4) {
+                if (c0 + r < a.nchan && n < a.nsig) {
+                    V acc = st0[(size_t)bl0 * seg_stride + (size_t)(c0 + r) * a.nsig + n];
+                    for (int bl = bl0 + 1; bl < bl1; ++bl) {
+                        const V x = st0[(size_t)bl * seg_stride + (size_t)(c0 + r) * a.nsig + n];
+                        if constexpr (sizeof(V) == 8) acc = cadd(acc, x);
+                        else acc = acc + x;
+                    }
+                    tile[r][tx] = acc;
+                }
             }
         }
         __syncthreads();
