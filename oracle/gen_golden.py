@@ -127,6 +127,32 @@ gg = spy.connectivityanalysis(spec5g, method="granger")
 kw["chain_granger"] = gg.data[()]
 save("chain", data=np.stack(trials_of(n5j)), samplerate=n5j.samplerate, **kw)
 
+# ---------------------------------------------------------------- channelcmb, ppc, corr (connectivity_analysis.py:335-381,501-529,
+# 551-566,624-663,681-733,760-763; ST_compRoutines.py:159-233,466-584; AV_compRoutines.py:166-228)
+kw = {}
+for tag, cmb in (("idx", [[3, 0], [1, 2]]), ("str", [["channel2", "channel4"], ["channel4", "channel1"]])):
+    for meth in ("coh", "csd", "ppc"):
+        r = spy.connectivityanalysis(spec5, method=meth, channelcmb=cmb)
+        kw[f"cmb_{tag}_{meth}"] = r.data[()]
+        kw[f"cmb_{tag}_{meth}_channel_i"] = np.array(r.channel_i, dtype="U")
+        kw[f"cmb_{tag}_{meth}_channel_j"] = np.array(r.channel_j, dtype="U")
+    r = spy.connectivityanalysis(spec5g, method="granger", channelcmb=cmb)
+    kw[f"cmb_{tag}_granger"] = r.data[()]
+    kw[f"cmb_{tag}_granger_channel_i"] = np.array(r.channel_i, dtype="U")
+    kw[f"cmb_{tag}_granger_channel_j"] = np.array(r.channel_j, dtype="U")
+kw["ppc_spec"] = ca(spec5, method="ppc")
+kw["ppc_analog"] = ca(n5j, method="ppc", tapsmofrq=3, foilim=[0, 60])
+kw["ppc_analog_hann"] = ca(n5j, method="ppc", taper="hann", pad="nextpow2")
+cc = spy.connectivityanalysis(n5j, method="corr")
+kw["corr"] = cc.data[()]
+kw["corr_time"] = np.array(cc.time[0])
+kw["corr_poly1"] = ca(n5j, method="corr", polyremoval=1)
+kw["corr_keeptrials_first3"] = ca(n5j, slice(0, 3 * 500), method="corr", keeptrials=True)
+n5odd = n5j.selectdata(latency=[-1, 3.99 - 1])            # odd number of samples per trial (lags: nSamples // 2 + 1)
+kw["corr_odd_nsamples"] = np.array([np.diff(n5odd.sampleinfo)[0, 0]])
+kw["corr_odd"] = ca(n5odd, method="corr")
+save("conn_next", data=np.stack(trials_of(n5j)), samplerate=n5j.samplerate, **kw)
+
 # ---------------------------------------------------------------- mtmfft option sweep (incl. unequal trial lengths + selections)
 rng = np.random.default_rng(2024)
 lens = [1500, 2000, 1800, 2000]

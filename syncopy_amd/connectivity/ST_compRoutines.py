@@ -77,19 +77,41 @@ def spectral_dyadic_product_cF(specs, send_idx=None, send_N=None, rec_idx=None, 
     """Single-trial cross spectra straight from complex spectra (nTime, nTaper, nFreq, N): the outer product
     over channels, averaged over tapers (syncopy/connectivity/ST_compRoutines.py:30-117) - the MFMA kernel with
     the tapers of one time sample as rows.  Returns (nTime, nFreq, N, N) complex64."""
-    if send_idx is not None:
-        raise NotImplementedError("channelcmb (rectangular sender/receiver blocks) is listed as 'next' in SURVEY.md 8f")
     nTime, nTaper, nFreq, nChannels = specs.shape
-    outShape = (nTime, nFreq, nChannels, nChannels)
+    sub = _cmb_union(send_idx, rec_idx)
+    outShape = (nTime, nFreq, nChannels, nChannels) if sub is None else (nTime, nFreq, len(sub[1]), len(sub[2]))
     if noCompute:
         return outShape, spectralDTypes["fourier"]
     backend.require_gpu()
+    if sub is not None:
+        specs = np.asarray(specs)[..., sub[0]]
     dev = torch.from_numpy(np.ascontiguousarray(specs, dtype=np.complex64)).cuda()
-    acc = torch.zeros(outShape, dtype=torch.complex64, device=dev.device)
+    n = dev.shape[-1]
+    acc = torch.zeros((nTime, nFreq, n, n), dtype=torch.complex64, device=dev.device)
     for t in range(nTime):
         backend.csd_accumulate(dev[t].contiguous(), acc[t])
         backend.csd_finalize(acc[t], 1.0 / nTaper)
+    if sub is not None:
+        acc = _cmb_block(acc, sub)
     return backend.to_host(acc)
+
+
+def _cmb_union(send_idx, rec_idx):
+    """`channelcmb` (connectivity_analysis.py:501-529): the rectangular sender x receiver block is cut out of the
+    Hermitian product of the channels that occur at all - (channels of the union, senders' and receivers' positions
+    in it), or None without `channelcmb`."""
+    if send_idx is None:
+        return None
+    send, rec = np.asarray(send_idx, dtype=int).ravel(), np.asarray(rec_idx, dtype=int).ravel()
+    union = np.unique(np.concatenate((send, rec)))
+    return union, np.searchsorted(union, send), np.searchsorted(union, rec)
+
+
+def _cmb_block(acc, sub):
+    """acc[..., senders, receivers] on the device."""
+    si = torch.as_tensor(sub[1], device=acc.device)
+    ri = torch.as_tensor(sub[2], device=acc.device)
+    return acc.index_select(-2, si).index_select(-1, ri).contiguous()
 
 
 class SpectralDyadicProduct(ComputationalRoutine):
@@ -106,14 +128,18 @@ class SpectralDyadicProduct(ComputationalRoutine):
         T = self.numTrials
         mine = self.my_trials()
         host = np.asarray(data.data)
+        sub = _cmb_union(self.cfg.get("send_idx"), self.cfg.get("rec_idx"))
+        if sub is not None:
+            chans = list(sub[0])                       # a channel selection next to channelcmb is ruled out upstream
         if chans is not None:
             host = host[..., chans]
-        F, C = self.targetShapes[0][1], self.targetShapes[0][2]
+        F, C = self.targetShapes[0][1], host.shape[-1]
         K = host.shape[1]
         lens = {rows[k][1] - rows[k][0] for k in range(T)}
         if self.keeptrials or lens != {1}:
             # time-resolved spectra or kept trials: per-trial compute function (one launch per time sample)
-            parts = [torch.from_numpy(self.computeFunction(host[rows[k][0]:rows[k][1]])).cuda() for k in mine]
+            kw = {} if sub is None else dict(send_idx=sub[1], rec_idx=sub[2])
+            parts = [torch.from_numpy(self.computeFunction(host[rows[k][0]:rows[k][1]], **kw)).cuda() for k in mine]
             from ..specest.compRoutines import _store_trials
             _store_trials(self, out, parts)
             return
@@ -124,12 +150,18 @@ class SpectralDyadicProduct(ComputationalRoutine):
             backend.csd_accumulate(dev, acc)            # rows = trials x tapers
         backend.csd_allreduce_(acc)
         backend.csd_finalize(acc, 1.0 / (K * T))
+        if sub is not None:
+            acc = _cmb_block(acc, sub)
         out._dev = acc.reshape(self.outputShape)
         out.data = backend.to_host(out._dev)
 
     def process_metadata(self, data, out):
         time_axis = bool(np.any(np.diff(data.trialdefinition)[:, 0] != 1))
         propagate_properties(data, out, self.keeptrials, time_axis)
+        if self.cfg.get("send_idx") is not None:          # ST_compRoutines.py:151-155
+            names = np.array(data.channel)
+            out.channel_i = names[np.asarray(self.cfg["send_idx"], dtype=int)]
+            out.channel_j = names[np.asarray(self.cfg["rec_idx"], dtype=int)]
         out.freq = data.freq
 
 

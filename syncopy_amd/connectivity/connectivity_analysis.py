@@ -20,7 +20,7 @@ from .ST_compRoutines import CrossSpectra, SpectralDyadicProduct
 
 def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi=None, foilim=None, pad="maxperlen",
                          polyremoval=0, tapsmofrq=None, nTaper=None, taper="hann", taper_opt=None, jackknife=False,
-                         select=None, compute_method=None, routine_classes=None, **kwargs):
+                         channelcmb=None, select=None, compute_method=None, routine_classes=None, **kwargs):
     """Cross-spectral connectivity of AnalogData on MI355X (arguments as spy.connectivityanalysis,
     connectivity_analysis.py:51-67)."""
     if not isinstance(data, (AnalogData, SpectralData)) or data.data is None:
@@ -44,10 +44,45 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     classes.update(routine_classes or {})
     data.selectdata(select)
     try:
+        cmb = _parse_channelcmb(data, channelcmb)
         return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
-                             nTaper, taper, taper_opt, compute_method, jackknife)
+                             nTaper, taper, taper_opt, compute_method, jackknife, cmb)
     finally:
         data.selection = None
+
+
+def _parse_channelcmb(data, channelcmb):
+    """[senders, receivers] -> two lists of channel indices, validated as in connectivity_analysis.py:335-381."""
+    if channelcmb is None:
+        return None
+    if not isinstance(data, SpectralData):
+        raise SPYTypeError(data, "data", expected="SpectralData, `channelcmb` not supported for other data types, ")
+    if not isinstance(channelcmb, list):
+        raise SPYTypeError(channelcmb, "channelcmb", expected="list")
+    if len(channelcmb) != 2:
+        raise SPYValueError(legal="list with exactly two elements: [senders, receivers]", varname="channelcmb",
+                            actual=f"length of {len(channelcmb)}")
+    if selected_channels(data) is not None and list(selected_channels(data)) != list(range(len(data.channel))):
+        raise SPYValueError("either channel selection or use channelcmb", "select/channelcmb", "both")
+    senders, receivers = channelcmb
+    for seq, name in ((senders, "channelcmb[senders,"), (receivers, "channelcmb[,receivers]")):
+        if isinstance(seq, (str, bytes)) or not hasattr(seq, "__len__") or len(seq) == 0:
+            raise SPYTypeError(seq, name, expected="sequence of channel names or indices")
+    if isinstance(senders[0], (bool, np.bool_)) or not isinstance(senders[0], (str, int, np.integer)):
+        raise SPYTypeError(senders[0], "channelcmb[senders,", "either `int` or `str`")
+    by_name = isinstance(senders[0], str)
+    names = [str(c) for c in data.channel]
+    out = []
+    for seq, name in ((senders, "channelcmb[senders,"), (receivers, "channelcmb[,receivers]")):
+        idx = []
+        for chan in seq:
+            if isinstance(chan, str) != by_name or (not by_name and not isinstance(chan, (int, np.integer))):
+                raise SPYTypeError(chan, name, expected="str" if by_name else "int")
+            if (by_name and chan not in names) or (not by_name and not 0 <= chan < len(names)):
+                raise SPYValueError("names or indices of existing channels", "channelcmb", chan)
+            idx.append(names.index(chan) if by_name else int(chan))
+        out.append(idx)
+    return out
 
 
 def _trial_average(x):
@@ -72,7 +107,47 @@ def _as_single_trials(template, arr):
     return obj
 
 
-def _connectivity_from_spectra(data, classes, method, keeptrials, output, compute_method, jackknife):
+def _post_select(out, send, rec):
+    """out[..., senders, receivers] with the labels - coherence with `channelcmb` (connectivity_analysis.py:760-763)."""
+    sel = CrossSpectralData(dimord=out.dimord)
+    sel.data = np.ascontiguousarray(np.asarray(out.data)[..., send, :][..., rec])
+    sel.samplerate, sel.trialdefinition, sel.freq = out.samplerate, out.trialdefinition, out.freq
+    sel.channel_i, sel.channel_j = np.array(out.channel_i)[send], np.array(out.channel_j)[rec]
+    sel.cfg = out.cfg
+    return sel
+
+
+def _pairwise_granger(data, classes, st, compute_method, log_dict, send, rec):
+    """Granger with `channelcmb` (connectivity_analysis.py:681-733): one bivariate factorisation per
+    (sender, receiver) pair on the 2 x 2 sub-block of the trial-averaged cross spectra; only the direction
+    sender -> receiver is kept."""
+    st_out = CrossSpectralData(dimord=CrossSpectra.dimord)
+    st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=False)
+    st.compute(data, st_out, parallel=False, log_dict=log_dict, method=compute_method)
+    S = np.asarray(st_out.data)
+    res = np.empty((1, S.shape[1], len(send), len(rec)), dtype=np.float32)
+    pair_out = None
+    for i1, ch1 in enumerate(send):
+        for i2, ch2 in enumerate(rec):
+            pair = _as_single_trials(st_out, S[..., [ch1, ch2], :][..., [ch1, ch2]])
+            pair.channel_i = pair.channel_j = np.array(st_out.channel_i)[[ch1, ch2]]
+            pair.trialdefinition = np.array([[0, 1.0, 0]])
+            av = classes["granger"](rtol=5e-6, nIter=100, cond_max=1e4)
+            pair_out = CrossSpectralData(dimord=st_out.dimord)
+            av.initialize(pair, pair_out._stackingDim, chan_per_worker=None, keeptrials=False)
+            av.pre_check()
+            av.compute(pair, pair_out, parallel=False, log_dict=log_dict, method=compute_method)
+            res[0, :, i1, i2] = np.asarray(pair_out.data)[0, :, 0, 1]
+    out = CrossSpectralData(dimord=st_out.dimord)
+    out.data = res
+    out.samplerate, out.freq = st_out.samplerate, st_out.freq
+    out.channel_i, out.channel_j = np.array(data.channel)[send], np.array(data.channel)[rec]
+    out.trialdefinition = np.array([[0, 1.0, 0]])
+    out.cfg = dict(log_dict or {})
+    return out
+
+
+def _connectivity_from_spectra(data, classes, method, keeptrials, output, compute_method, jackknife, cmb=None):
     """SpectralData input (connectivity_analysis.py:475-538): the spectra exist already, the ST stage is the dyadic
     product; everything about tapers / padding / frequencies was decided in freqanalysis."""
     if not np.issubdtype(np.asarray(data.data).dtype, np.complexfloating):
@@ -81,12 +156,29 @@ def _connectivity_from_spectra(data, classes, method, keeptrials, output, comput
     if method == "granger" and data.data.shape[data.dimord.index("time")] != len(data.sampleinfo):
         raise NotImplementedError("Time resolved Granger causality from tf-spectra not available atm")
     log_dict = {"method": method, "output": output, "keeptrials": keeptrials}
-    st = classes["dyadic"]()
-    return _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
+    if cmb is not None and method == "csd":
+        # truly rectangular products (connectivity_analysis.py:503-529)
+        st = classes["dyadic"](send_idx=cmb[0], send_N=len(cmb[0]), rec_idx=cmb[1], rec_N=len(cmb[1]))
+    else:
+        st = classes["dyadic"]()
+    if cmb is not None and method == "granger":
+        if "granger" not in classes:
+            raise NotImplementedError("Wilson/Granger kernels are not part of this build")
+        if jackknife:
+            SPYWarning("jackknife estimates are not computed for pairwise (channelcmb) Granger causality")
+        return _pairwise_granger(data, classes, st, compute_method, log_dict, *cmb)
+    out = _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
+    if cmb is not None and method == "coh":
+        jack = {k: getattr(out, k, None) for k in ("jack_var", "jack_bias")}
+        out = _post_select(out, *cmb)
+        for k, v in jack.items():
+            if v is not None:
+                setattr(out, k, np.ascontiguousarray(np.asarray(v)[..., cmb[0], :][..., cmb[1]]))
+    return out
 
 
 def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq, nTaper, taper,
-                  taper_opt, compute_method, jackknife=False):
+                  taper_opt, compute_method, jackknife=False, cmb=None):
     fs = data.samplerate
     timeAxis = data.dimord.index("time")
     trl = selected_trialdefinition(data)
@@ -99,7 +191,7 @@ def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, p
         raise SPYValueError(f"False, trial averaging needed for method {method}!", varname="keeptrials",
                             actual=keeptrials)
     if isinstance(data, SpectralData):
-        return _connectivity_from_spectra(data, classes, method, keeptrials, output, compute_method, jackknife)
+        return _connectivity_from_spectra(data, classes, method, keeptrials, output, compute_method, jackknife, cmb)
     nSamples = process_padding(pad, lenTrials, fs)
     foi, foilim = process_foi(foi, foilim, fs)
     if method == "granger":

@@ -48,7 +48,8 @@ class OracleCrossSpectra(CrossSpectra):
 
 def _dyadic_cF(specs, send_idx=None, send_N=None, rec_idx=None, rec_N=None, chunkShape=None, noCompute=False):
     if noCompute:
-        return (specs.shape[0], specs.shape[2], specs.shape[3], specs.shape[3]), np.complex64
+        ni, nj = (specs.shape[3], specs.shape[3]) if send_idx is None else (len(send_idx), len(rec_idx))
+        return (specs.shape[0], specs.shape[2], ni, nj), np.complex64
     return O.spectral_dyadic_product(np.asarray(specs), send_idx, rec_idx)
 
 

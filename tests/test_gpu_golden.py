@@ -8,7 +8,8 @@ import pytest
 import syncopy_amd as spy
 from oracle_routines import ORACLE_CONN, ORACLE_FREQ
 from parity import assert_parity
-from test_oracle_golden import JACK_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, chain_checks, check_jackknife
+from test_oracle_golden import (JACK_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, chain_checks, check_jackknife,
+                                cmb_checks)
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +69,14 @@ def test_chained_spectraldata_input(golden_dir, how):
     chain_checks(_load(golden_dir, "chain"),
                  lambda d, **kw: spy.freqanalysis(d, compute_method=how, **kw),
                  lambda d, **kw: spy.connectivityanalysis(d, compute_method=how, **kw))
+
+
+@pytest.mark.parametrize("how", ["hip", "sequential"])
+def test_channelcmb(golden_dir, how):
+    """channelcmb=[senders, receivers]: rectangular csd, post-selected coherence, pairwise bivariate Granger."""
+    cmb_checks(_load(golden_dir, "conn_next"),
+               lambda d, **kw: spy.freqanalysis(d, compute_method=how, **kw),
+               lambda d, **kw: spy.connectivityanalysis(d, compute_method=how, **kw))
 
 
 @pytest.mark.parametrize("name", sorted(JACK_VARIANTS))

@@ -130,6 +130,58 @@ def test_chained_spectraldata_input(golden_dir):
     chain_checks(_load(golden_dir, "chain"), fa, ca)
 
 
+CMBS = {"idx": [[3, 0], [1, 2]], "str": [["channel2", "channel4"], ["channel4", "channel1"]]}
+
+
+def _n5_data(z):
+    return spy.AnalogData(np.concatenate(list(z["data"])), samplerate=float(z["samplerate"]),
+                          trialdefinition=np.stack([np.arange(20) * 1000, np.arange(1, 21) * 1000,
+                                                    np.zeros(20)], axis=1))
+
+
+def cmb_checks(z, freq, conn, methods=("coh", "csd", "granger")):
+    """`channelcmb=[senders, receivers]` on SpectralData input (SURVEY 8f 'next' row 2) against the reference's
+    results: rectangular, labelled in the order given; equal to the post-selection of the full result
+    (tests/test_connectivity.py:184-229,475-512,651-679)."""
+    data = _n5_data(z)
+    spec = freq(data, method="mtmfft", tapsmofrq=3, output="fourier", keeptapers=True, foilim=[0, 60])
+    specg = freq(data, method="mtmfft", tapsmofrq=3, output="fourier", keeptapers=True, demean_taper=True)
+    for tag, cmb in CMBS.items():
+        for meth in methods:
+            src = specg if meth == "granger" else spec
+            out = conn(src, method=meth, channelcmb=cmb)
+            want = z[f"cmb_{tag}_{meth}"]
+            assert out.data.shape == want.shape and out.data.dtype == want.dtype
+            assert list(out.channel_i) == list(z[f"cmb_{tag}_{meth}_channel_i"])
+            assert list(out.channel_j) == list(z[f"cmb_{tag}_{meth}_channel_j"])
+            full = np.asarray(conn(src, method=meth).data)
+            names = [str(c) for c in src.channel]
+            si = [names.index(c) if isinstance(c, str) else c for c in cmb[0]]
+            ri = [names.index(c) if isinstance(c, str) else c for c in cmb[1]]
+            post = full[..., si, :][..., ri]
+            if meth == "granger":
+                # a channel paired with itself is a singular 2 x 2 problem: whatever comes out is not compared
+                ok = np.array([[a != b for b in ri] for a in si])
+                got, ref = np.asarray(out.data)[:, 2:][..., ok], want[:, 2:][..., ok]
+                np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-3)
+                np.testing.assert_allclose(got, post[:, 2:][..., ok], atol=1e-2)     # test_connectivity.py:229
+            else:
+                assert_parity(out.data, want, what=f"channelcmb {tag} {meth}")
+                assert_parity(out.data, post, what=f"channelcmb {tag} {meth} vs post-selection")
+    with pytest.raises(Exception):
+        conn(data, method="coh", channelcmb=CMBS["idx"])            # AnalogData input is rejected (:337-339)
+    with pytest.raises(Exception):
+        conn(spec, method="coh", channelcmb=[[0, 1]])               # needs [senders, receivers] (:344-347)
+    with pytest.raises(Exception):
+        conn(spec, method="coh", channelcmb=[[0, 7], [1]])          # unknown channel (:371-381)
+    with pytest.raises(Exception):
+        conn(spec, method="coh", channelcmb=[[0, "channel2"], [1]])  # mixed names / indices (:365)
+
+
+def test_channelcmb(golden_dir):
+    cmb_checks(_load(golden_dir, "conn_next"), fa, ca)
+
+
 JACK_VARIANTS = {
     "coh_abs": dict(method="coh", tapsmofrq=3),
     "coh_complex": dict(method="coh", tapsmofrq=3, output="complex", foilim=[5, 60]),
