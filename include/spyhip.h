@@ -146,6 +146,24 @@ int spyhip_coh_normalize(spyhip_ctx* ctx, const void* csd_d, int nfreq, int ncha
 int spyhip_coh_from_accumulator(spyhip_ctx* ctx, const void* acc_d, int nfreq, int nchan, double scale, int output,
                                 void* out_d);
 
+/* ---- K7: pairwise phase consistency -----------------------------------------
+ * Replaces ppc_column_cF (connectivity/ST_compRoutines.py:159-233) and the loop over all trial pairs with its
+ * weighted average (connectivity/connectivity_analysis.py:624-663):
+ *   ppc[f,i,j] = 2/(T(T-1)) sum_{a<b} cos(arg(S_a[f,i,j] conj(S_b[f,i,j])))  =  (|sum_t u_t|^2 - T) / (T(T-1)),
+ *   u_t = S_t/|S_t| (1 where S_t = 0, as np.angle(0) = 0),  S_t = taper mean of X conj(X)^T of trial t.
+ * spyhip_ppc_accumulate: acc[f,i,j] += sum_t u_t straight from the tapered spectra of spyhip_fft_exec
+ *   (spec_d complex64 (ntrials*ntaper, nfreq, nchan), the ntaper rows of a trial adjacent); acc_d complex64
+ *   (nfreq, nchan, nchan), maintained on the lower triangle (32x32 tile granularity).
+ * spyhip_ppc_accumulate_csd: the same sum from single-trial cross spectra that exist already
+ *   (csd_d complex64 (ntrials, nelem), acc_d complex64 (nelem): any block shape, e.g. channelcmb rectangles).
+ * spyhip_ppc_finalize: out float32 (nfreq, ni, nj) from the accumulator and the total number of trials;
+ *   lower_only = 1 for accumulators of spyhip_ppc_accumulate (the upper triangle is mirrored). */
+int spyhip_ppc_accumulate(spyhip_ctx* ctx, const void* spec_d, int ntrials, int ntaper, int nfreq, int nchan,
+                          void* acc_d);
+int spyhip_ppc_accumulate_csd(spyhip_ctx* ctx, const void* csd_d, int ntrials, int64_t nelem, void* acc_d);
+int spyhip_ppc_finalize(spyhip_ctx* ctx, const void* acc_d, int nfreq, int ni, int nj, int lower_only,
+                        int64_t ntrials, void* out_d);
+
 /* ---- K3: Morlet continuous wavelet transform ------------------------------
  * Replaces cwt_time (specest/wavelets/transform.py:88-108) with Morlet.time
  * (specest/wavelets/wavelets.py:27-86) and the tail of wavelet_cF

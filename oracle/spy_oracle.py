@@ -426,6 +426,33 @@ def spectral_dyadic_product(specs, send_idx=None, rec_idx=None):
     return p.mean(axis=1)
 
 
+def trial_mean(x):
+    """spy.mean(dim="trials") (statistics/summary_stats.py:321-400): sequential sum in the data dtype, one division."""
+    acc = np.zeros(x.shape[1:], dtype=x.dtype)
+    for t in range(x.shape[0]):
+        acc += x[t]
+    acc /= x.shape[0]
+    return acc
+
+
+def ppc_column(cs1, cs2):
+    """connectivity/ST_compRoutines.py:159-233: cosine of the angular distance of two single-trial cross spectra."""
+    return np.cos(np.angle(cs1 * cs2.conj()))
+
+
+def ppc(st_csd):
+    """connectivity/connectivity_analysis.py:624-663: all T(T-1)/2 trial pairs, column by column of the upper
+    triangle of the trial x trial matrix, float32 accumulator.  st_csd: (T, F, Ni, Nj) complex64 -> (1, F, Ni, Nj)."""
+    T = st_csd.shape[0]
+    acc = np.zeros(st_csd.shape[1:], dtype=np.float32)
+    weights = np.arange(1, T) / (T - 1)
+    for k in range(1, T):
+        pairs = np.stack([ppc_column(st_csd[j], st_csd[k]) for j in range(k)])      # the k pairs (j < k, k)
+        acc += trial_mean(pairs) * weights[k - 1]
+    acc *= 2 / T
+    return acc[np.newaxis]
+
+
 # --------------------------------------------------------------------------
 # G1-G3: Wilson spectral factorisation and Granger causality
 # --------------------------------------------------------------------------

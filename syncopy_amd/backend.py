@@ -323,6 +323,41 @@ def coh_from_accumulator(acc, scale, output="abs"):
     return out
 
 
+def ppc_accumulate(spec, ntaper, acc):
+    """acc (F, C, C) complex64 += sum over trials of the unit phasors of the single-trial cross spectra, straight
+    from tapered spectra spec (ntrials * ntaper, F, C) complex64 (K7; lower triangle maintained)."""
+    assert spec.is_cuda and spec.dtype == torch.complex64 and spec.is_contiguous() and spec.dim() == 3
+    assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous()
+    R, F, Cn = spec.shape
+    assert R % ntaper == 0 and tuple(acc.shape) == (F, Cn, Cn)
+    ctx = context(spec.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_ppc_accumulate(ctx.handle, _ptr(spec), R // ntaper, int(ntaper), F, Cn, _ptr(acc)),
+          "spyhip_ppc_accumulate")
+
+
+def ppc_accumulate_csd(csd, acc):
+    """acc (...) complex64 += unit phasors of the single-trial cross spectra csd (ntrials, ...) complex64."""
+    assert csd.is_cuda and csd.dtype == torch.complex64 and csd.is_contiguous()
+    assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and tuple(csd.shape[1:]) == tuple(acc.shape)
+    ctx = context(csd.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_ppc_accumulate_csd(ctx.handle, _ptr(csd), csd.shape[0], acc.numel(), _ptr(acc)),
+          "spyhip_ppc_accumulate_csd")
+
+
+def ppc_finalize(acc, ntrials, lower_only):
+    """Pairwise phase consistency (F, ni, nj) float32 from the accumulated phasor sums of `ntrials` trials."""
+    assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and acc.dim() == 3
+    F, ni, nj = acc.shape
+    out = torch.empty((F, ni, nj), dtype=torch.float32, device=acc.device)
+    ctx = context(acc.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_ppc_finalize(ctx.handle, _ptr(acc), F, ni, nj, int(bool(lower_only)), int(ntrials),
+                                      _ptr(out)), "spyhip_ppc_finalize")
+    return out
+
+
 def granger(csd, rtol=5e-6, niter=100, cond_max=1e4, eps_max=1e-1, want_factors=False):
     """Wilson spectral factorisation + Granger causality of a trial-averaged CSD (F, C, C) complex64.
     Returns (granger float32 (F,C,C), info dict[, H complex128 (F,C,C), Sigma complex128 (C,C)])."""

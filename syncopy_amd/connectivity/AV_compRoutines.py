@@ -21,6 +21,22 @@ def normalize_csd_cF(csd_av_dat, output="abs", chunkShape=None, noCompute=False)
     return backend.to_host(torch.stack(res, dim=0))
 
 
+def pairwise_phase_consistency(st_csd):
+    """PPC of kept single-trial cross spectra (T, F, Ni, Nj) complex64 -> (1, F, Ni, Nj) float32: what the loop over
+    PPC_column routines and its weighted average amount to (connectivity_analysis.py:624-663;
+    ST_compRoutines.py:159-233), through K7's closed form - unit phasors summed over trials, then
+    (|U|^2 - T)/(T(T-1))."""
+    backend.require_gpu()
+    st_csd = np.asarray(st_csd)
+    T = st_csd.shape[0]
+    acc = torch.zeros(st_csd.shape[1:], dtype=torch.complex64, device="cuda")
+    per = max(1, int((1 << 30) // max(1, acc.numel() * 8)))
+    for t0 in range(0, T, per):
+        dev = torch.from_numpy(np.ascontiguousarray(st_csd[t0:t0 + per], dtype=np.complex64)).cuda()
+        backend.ppc_accumulate_csd(dev, acc)
+    return backend.to_host(backend.ppc_finalize(acc, T, lower_only=False))[np.newaxis]
+
+
 class _AverageRoutine(ComputationalRoutine):
     dimord = ["time", "freq", "channel_i", "channel_j"]
 

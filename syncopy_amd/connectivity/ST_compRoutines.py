@@ -155,6 +155,30 @@ class SpectralDyadicProduct(ComputationalRoutine):
         out._dev = acc.reshape(self.outputShape)
         out.data = backend.to_host(out._dev)
 
+    def ppc_hip(self, data):
+        """Pairwise phase consistency of spectra that exist already (one time sample per trial): K7 on the uploaded
+        (trials x tapers, F, C) block; `channelcmb` rectangles are cut out of the channels that occur at all."""
+        rows, chans = trial_rows(data), selected_channels(data)
+        T = self.numTrials
+        if {rows[k][1] - rows[k][0] for k in range(T)} != {1}:
+            raise NotImplementedError("pairwise phase consistency of time-resolved spectra")
+        host = np.asarray(data.data)
+        sub = _cmb_union(self.cfg.get("send_idx"), self.cfg.get("rec_idx"))
+        if sub is not None:
+            chans = list(sub[0])
+        if chans is not None:
+            host = host[..., chans]
+        K, F, C = host.shape[1:]
+        U = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+        mine = self.my_trials()
+        if len(mine):
+            sel = np.array([rows[k][0] for k in mine])
+            dev = torch.from_numpy(np.ascontiguousarray(host[sel], dtype=np.complex64)).cuda()
+            backend.ppc_accumulate(dev.reshape(-1, F, C), K, U)
+        parallel.allreduce_sum_(U)
+        res = backend.ppc_finalize(U, T, lower_only=True)
+        return res if sub is None else _cmb_block(res, sub)
+
     def process_metadata(self, data, out):
         time_axis = bool(np.any(np.diff(data.trialdefinition)[:, 0] != 1))
         propagate_properties(data, out, self.keeptrials, time_axis)
@@ -216,6 +240,29 @@ class CrossSpectra(ComputationalRoutine):
             out._acc_raw, out._acc_scale = acc, scale
             out._dev_thunk = device_csd
             out.set_pending(lambda: backend.to_host(device_csd()), shape, np.complex64)
+
+    def ppc_hip(self, data):
+        """Pairwise phase consistency with the kernels (connectivity_analysis.py:624-663, ST_compRoutines.py:159-233):
+        the tapered spectra of each batch of trials go straight into K7, which forms every trial's taper-averaged
+        cross spectrum, normalises it to a unit phasor and sums over trials in registers; one sum over ranks, then
+        ppc = (|U|^2 - T)/(T(T-1)).  No single-trial cross spectrum is ever stored (the reference keeps all T of them
+        and visits T(T-1)/2 pairs).  Returns the (F, C, C) float32 device tensor."""
+        cfg = self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
+        freqs, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
+        pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
+        F, C = self.targetShapes[0][1], self.targetShapes[0][2]
+        T = self.numTrials
+        mine = [rows[k] for k in self.my_trials()]
+        U = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
+        for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
+                                             cfg["demean_taper"], False, pr, freq_idx, "fourier", True, reuse=True):
+            backend.ppc_accumulate(spec.reshape(-1, F, C), spec.shape[1], U)
+        parallel.allreduce_sum_(U)
+        self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T
+        return backend.ppc_finalize(U, T, lower_only=True)
 
     def jackknife_hip(self, data, evaluate):
         """Streaming jackknife on the device (connectivity_analysis.py:601-606,736-757; statistics/jackknifing.py):

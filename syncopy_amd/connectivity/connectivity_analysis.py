@@ -14,7 +14,7 @@ from ..shared.const_def import connectivity_outputs, connectivityMethods
 from ..shared.errors import SPYTypeError, SPYValueError, SPYWarning
 from ..shared.input_processors import process_foi, process_padding, process_taper
 from ..shared.tools import best_match
-from .AV_compRoutines import NormalizeCrossSpectra
+from .AV_compRoutines import NormalizeCrossSpectra, pairwise_phase_consistency
 from .ST_compRoutines import CrossSpectra, SpectralDyadicProduct
 
 
@@ -35,7 +35,8 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     if polyremoval is not None:
         if not isinstance(polyremoval, numbers.Number) or polyremoval not in (0, 1):
             raise SPYValueError("0, 1 or None", varname="polyremoval", actual=polyremoval)
-    classes = {"csd": CrossSpectra, "coh": NormalizeCrossSpectra, "dyadic": SpectralDyadicProduct}
+    classes = {"csd": CrossSpectra, "coh": NormalizeCrossSpectra, "dyadic": SpectralDyadicProduct,
+               "ppc": pairwise_phase_consistency}
     try:
         from .AV_compRoutines import GrangerCausality
         classes["granger"] = GrangerCausality
@@ -156,7 +157,7 @@ def _connectivity_from_spectra(data, classes, method, keeptrials, output, comput
     if method == "granger" and data.data.shape[data.dimord.index("time")] != len(data.sampleinfo):
         raise NotImplementedError("Time resolved Granger causality from tf-spectra not available atm")
     log_dict = {"method": method, "output": output, "keeptrials": keeptrials}
-    if cmb is not None and method == "csd":
+    if cmb is not None and method in ("csd", "ppc"):
         # truly rectangular products (connectivity_analysis.py:503-529)
         st = classes["dyadic"](send_idx=cmb[0], send_N=len(cmb[0]), rec_idx=cmb[1], rec_N=len(cmb[1]))
     else:
@@ -187,7 +188,7 @@ def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, p
     if nTrials == 1:
         raise SPYValueError("multi-trial input data, spectral connectivity measures critically depend on trial "
                             "averaging!", "data", "only one trial")
-    if keeptrials is not False and method in ("coh", "granger"):
+    if keeptrials is not False and method in ("coh", "ppc", "granger"):
         raise SPYValueError(f"False, trial averaging needed for method {method}!", varname="keeptrials",
                             actual=keeptrials)
     if isinstance(data, SpectralData):
@@ -241,8 +242,33 @@ def _jackknife_on_device(data, st, av, st_out, log_dict):
     return out
 
 
+def _ppc(data, classes, st, compute_method, log_dict):
+    """Pairwise phase consistency (connectivity_analysis.py:551-562,590,624-663): all trial pairs of the single-trial
+    cross spectra.  With the kernels nothing is kept (K7 streams the trials); the per-trial engine path keeps the
+    single-trial cross spectra as the reference does and hands them to classes["ppc"]."""
+    from .. import backend
+    out = CrossSpectralData(dimord=CrossSpectra.dimord)
+    if compute_method in (None, "hip") and hasattr(st, "ppc_hip"):
+        st.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=False)
+        out._dev = st.ppc_hip(data).unsqueeze(0)
+        out.data = backend.to_host(out._dev)
+        st.process_metadata(data, out)
+    else:
+        st_out = CrossSpectralData(dimord=CrossSpectra.dimord)
+        st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=True)
+        st.compute(data, st_out, parallel=False, log_dict=log_dict, method=compute_method)
+        out.data = np.ascontiguousarray(classes["ppc"](np.asarray(st_out.data)), dtype=np.float32)
+        out.samplerate, out.freq = st_out.samplerate, st_out.freq
+        out.channel_i, out.channel_j = st_out.channel_i, st_out.channel_j
+        out.trialdefinition = np.array([[0, 1.0, 0]])
+    out.cfg = dict(log_dict or {})
+    return out
+
+
 def _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict):
     """ST stage (single-trial cross spectra, trial-averaged unless kept) -> AV stage, plus the jackknife."""
+    if method == "ppc":
+        return _ppc(data, classes, st, compute_method, log_dict)
     if method == "coh":
         if output not in connectivity_outputs:
             raise SPYValueError(f"one of {sorted(connectivity_outputs)}", varname="output", actual=output)

@@ -204,6 +204,28 @@ def csd_finalize(acc, scale):
     lib().emu_csd_finalize(acc.ctypes.data_as(C.c_void_p), C.c_int(F), C.c_int(Cn), C.c_float(scale))
 
 
+def ppc_accumulate(spec, ntaper, acc):
+    """Emulated spyhip_ppc_accumulate: spec (T * ntaper, F, C) complex64, acc (F, C, C) complex64 in place."""
+    spec = np.ascontiguousarray(spec, dtype=np.complex64)
+    R, F, Cn = spec.shape
+    lib().emu_ppc_accumulate(spec.ctypes.data_as(C.c_void_p), C.c_int(R // ntaper), C.c_int(ntaper), C.c_int(F),
+                             C.c_int(Cn), acc.ctypes.data_as(C.c_void_p))
+
+
+def ppc_accumulate_csd(csd, acc):
+    csd = np.ascontiguousarray(csd, dtype=np.complex64)
+    lib().emu_ppc_accumulate_csd(csd.ctypes.data_as(C.c_void_p), C.c_int(csd.shape[0]), C.c_longlong(acc.size),
+                                 acc.ctypes.data_as(C.c_void_p))
+
+
+def ppc_finalize(acc, ntrials, lower_only):
+    F, ni, nj = acc.shape
+    out = np.empty((F, ni, nj), dtype=np.float32)
+    lib().emu_ppc_finalize(acc.ctypes.data_as(C.c_void_p), C.c_int(F), C.c_int(ni), C.c_int(nj),
+                           C.c_int(int(lower_only)), C.c_longlong(ntrials), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def coh_from_accumulator(acc, scale, output="abs"):
     """Emulated spyhip_coh_from_accumulator (raw lower-triangle accumulator -> coherence)."""
     F, Cn, _ = acc.shape

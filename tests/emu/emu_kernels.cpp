@@ -16,6 +16,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
 #include "../../syncopy_amd/csrc/csd_kernel.h"
+#include "../../syncopy_amd/csrc/ppc_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_long.h"
@@ -324,6 +325,30 @@ void emu_coh_normalize(const float* csd, int F, int C, int kind, void* out) {
         emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::coh_normalize_kernel<true>(reinterpret_cast<const float2*>(csd), F, C, kind, out); });
     else
         emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::coh_normalize_kernel<false>(reinterpret_cast<const float2*>(csd), F, C, kind, out); });
+}
+
+// K7 (mirrors ppc.hip)
+void emu_ppc_accumulate(const float* spec, int ntrials, int ntaper, int F, int C, float* acc) {
+    spyppc::PpcArgs a{};
+    a.spec = reinterpret_cast<const float2*>(spec);
+    a.ntrials = ntrials; a.ntaper = ntaper; a.F = F; a.C = C;
+    a.acc = reinterpret_cast<float2*>(acc);
+    const int nt = (C + 31) / 32;
+    const size_t lds = 2 * (size_t)2 * ntaper * 32 * sizeof(float2);
+    emu::launch(dim3((unsigned)(F * (nt * (nt + 1) / 2))), dim3(256), lds, [&] { spyppc::ppc_accum_kernel(a); });
+}
+
+void emu_ppc_accumulate_csd(const float* csd, int ntrials, long long n, float* acc) {
+    emu::launch(dim3((unsigned)((n + 255) / 256)), dim3(256), 0, [&] {
+        spyppc::ppc_accum_csd_kernel(reinterpret_cast<const float2*>(csd), n, ntrials, reinterpret_cast<float2*>(acc));
+    });
+}
+
+void emu_ppc_finalize(const float* acc, int F, int ni, int nj, int lower_only, long long T, float* out) {
+    const long long n = (long long)F * ni * nj;
+    emu::launch(dim3((unsigned)((n + 255) / 256)), dim3(256), 0, [&] {
+        spyppc::ppc_finalize_kernel(reinterpret_cast<const float2*>(acc), F, ni, nj, lower_only, (double)T, out);
+    });
 }
 
 // CWT: plan tables (kernel spectra, shifts) are built by the Python mirror of cwt.hip.

@@ -94,6 +94,8 @@ static inline T __shfl_xor(T v, int mask) {
 // D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for r in [0,16)   (cdna_hip_programming.md section 3)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
     double* s = emu::wave_scratch();
     float* A = reinterpret_cast<float*>(s);        // [2][32]

@@ -80,4 +80,4 @@ class OracleGrangerCausality(_AverageRoutine):
 ORACLE_FREQ = {"mtmfft": OracleMultiTaperFFT, "mtmconvol": OracleMultiTaperFFTConvol,
                "wavelet": OracleWaveletTransform}
 ORACLE_CONN = {"csd": OracleCrossSpectra, "coh": OracleNormalizeCrossSpectra, "granger": OracleGrangerCausality,
-               "dyadic": OracleSpectralDyadicProduct}
+               "dyadic": OracleSpectralDyadicProduct, "ppc": O.ppc}

@@ -155,6 +155,26 @@ def test_csd_mfma_kernel(C, F, R, tpw):
         assert_parity(E.coh_normalize(acc, output), O.normalize_csd(acc, output), what=output)
 
 
+@pytest.mark.parametrize("C,F,T,K", [(5, 4, 6, 3), (40, 2, 7, 1), (70, 1, 5, 7)])
+def test_ppc_kernel(C, F, T, K):
+    """K7's kernel source on the CPU: phasor sums + closed form = the oracle's walk over all trial pairs."""
+    rng = np.random.default_rng(C)
+    spec = (rng.normal(size=(T, K, F, C)) + 1j * rng.normal(size=(T, K, F, C))).astype(np.complex64)
+    spec += (2.0 * rng.normal(size=(1, K, F, C))).astype(np.complex64)
+    spec[..., C - 1] = 0                                # np.angle(0) = 0: consistent with everything
+    st = O.spectral_dyadic_product(spec)
+    ref = O.ppc(st)[0]
+    U = np.zeros((F, C, C), np.complex64)
+    E.ppc_accumulate(spec[:2].reshape(-1, F, C), K, U)
+    E.ppc_accumulate(spec[2:].reshape(-1, F, C), K, U)
+    got = E.ppc_finalize(U, T, True)
+    assert_parity(got, ref, what="ppc", rtol=1e-4, atol_rel=2e-5)
+    assert np.array_equal(got, got.transpose(0, 2, 1)) and np.allclose(got[:, C - 1], 1, atol=1e-6)
+    U2 = np.zeros((F, C, C), np.complex64)
+    E.ppc_accumulate_csd(st, U2)
+    assert_parity(E.ppc_finalize(U2, T, False), ref, what="ppc from csd", rtol=1e-4, atol_rel=2e-5)
+
+
 @pytest.mark.parametrize("nsig,scales,detrend,output", [
     (700, [0.05, 0.02, 0.004], 0, "pow"),            # kernels of 500/200/40 taps, one block
     (3000, [0.03, 0.006], 1, "fourier"),             # several overlap-save blocks

@@ -9,7 +9,7 @@ import syncopy_amd as spy
 from oracle_routines import ORACLE_CONN, ORACLE_FREQ
 from parity import assert_parity
 from test_oracle_golden import (JACK_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, chain_checks, check_jackknife,
-                                cmb_checks)
+                                cmb_checks, ppc_checks)
 
 pytestmark = pytest.mark.gpu
 
@@ -77,6 +77,19 @@ def test_channelcmb(golden_dir, how):
     cmb_checks(_load(golden_dir, "conn_next"),
                lambda d, **kw: spy.freqanalysis(d, compute_method=how, **kw),
                lambda d, **kw: spy.connectivityanalysis(d, compute_method=how, **kw))
+
+
+@pytest.mark.parametrize("how", ["hip", "sequential"])
+def test_ppc(golden_dir, how):
+    """method='ppc': K7 streams the trials (hip) / kept single-trial cross spectra through the same closed form
+    (sequential) - against the reference's all-pairs result."""
+    z = _load(golden_dir, "conn_next")
+    f = lambda d, **kw: spy.freqanalysis(d, compute_method=how, **kw)              # noqa: E731
+    c = lambda d, **kw: spy.connectivityanalysis(d, compute_method=how, **kw)      # noqa: E731
+    # the reference's own float32 walk over the pairs (cos(angle()) per pair, running means) carries ~1e-6 of
+    # absolute error on an estimate of magnitude <= 1; the closed form does not: the floor is widened to 5e-6
+    ppc_checks(z, f, c, atol_rel=5e-6)
+    cmb_checks(z, f, c, methods=("ppc",), atol_rel=5e-6)
 
 
 @pytest.mark.parametrize("name", sorted(JACK_VARIANTS))

@@ -243,6 +243,32 @@ def test_csd_accumulate_vs_oracle(be, C, F, R):
             assert_parity(coh, cref, what=f"coh {output}")
 
 
+@pytest.mark.parametrize("C,F,T,K", [(5, 33, 6, 3), (40, 17, 9, 1), (70, 9, 12, 7), (256, 3, 40, 7)])
+def test_ppc_vs_oracle(be, C, F, T, K):
+    """K7 (phasor sums + closed form) against the oracle's walk over all trial pairs; both entry points; accumulation
+    across launches; an all-zero channel has ppc = 1 with everything (np.angle(0) = 0 in the reference)."""
+    rng = np.random.default_rng(C + T)
+    spec = (rng.normal(size=(T, K, F, C)) + 1j * rng.normal(size=(T, K, F, C))).astype(np.complex64)
+    spec += (2.0 * rng.normal(size=(1, K, F, C))).astype(np.complex64)          # common part: non-trivial consistency
+    spec[..., C - 1] = 0
+    st = O.spectral_dyadic_product(spec)                                       # (T, F, C, C) complex64
+    ref = O.ppc(st)[0]
+    s = torch.from_numpy(spec).cuda().reshape(T * K, F, C)
+    U = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    half = (T // 2) * K
+    be.ppc_accumulate(s[:half].contiguous(), K, U)
+    be.ppc_accumulate(s[half:].contiguous(), K, U)
+    got = be.ppc_finalize(U, T, lower_only=True).cpu().numpy()
+    # the phase of a single-trial cross spectrum is only as good as |S| against the rounding of its K products
+    assert_parity(got, ref, what="ppc", rtol=1e-4, atol_rel=2e-5)
+    assert np.array_equal(got, got.transpose(0, 2, 1))
+    assert np.allclose(got[:, C - 1, :], 1, atol=1e-6) and np.allclose(got[:, np.arange(C), np.arange(C)], 1, atol=1e-6)
+    U2 = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    be.ppc_accumulate_csd(torch.from_numpy(st).cuda(), U2)
+    got2 = be.ppc_finalize(U2, T, lower_only=False).cpu().numpy()
+    assert_parity(got2, ref, what="ppc from csd", rtol=1e-4, atol_rel=2e-5)
+
+
 def test_cwt_trial_sum_mode(be):
     """accumulate=2 (out[0] += sum over segments, the keeptrials=False path) equals the sum of the per-segment
     outputs of the plain mode; 5 channels exercise the padded channel pair of the packed kernel."""

@@ -139,7 +139,7 @@ def _n5_data(z):
                                                     np.zeros(20)], axis=1))
 
 
-def cmb_checks(z, freq, conn, methods=("coh", "csd", "granger")):
+def cmb_checks(z, freq, conn, methods=("coh", "csd", "granger"), **tol):
     """`channelcmb=[senders, receivers]` on SpectralData input (SURVEY 8f 'next' row 2) against the reference's
     results: rectangular, labelled in the order given; equal to the post-selection of the full result
     (tests/test_connectivity.py:184-229,475-512,651-679)."""
@@ -166,8 +166,8 @@ def cmb_checks(z, freq, conn, methods=("coh", "csd", "granger")):
                 np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-3)
                 np.testing.assert_allclose(got, post[:, 2:][..., ok], atol=1e-2)     # test_connectivity.py:229
             else:
-                assert_parity(out.data, want, what=f"channelcmb {tag} {meth}")
-                assert_parity(out.data, post, what=f"channelcmb {tag} {meth} vs post-selection")
+                assert_parity(out.data, want, what=f"channelcmb {tag} {meth}", **tol)
+                assert_parity(out.data, post, what=f"channelcmb {tag} {meth} vs post-selection", **tol)
     with pytest.raises(Exception):
         conn(data, method="coh", channelcmb=CMBS["idx"])            # AnalogData input is rejected (:337-339)
     with pytest.raises(Exception):
@@ -180,6 +180,29 @@ def cmb_checks(z, freq, conn, methods=("coh", "csd", "granger")):
 
 def test_channelcmb(golden_dir):
     cmb_checks(_load(golden_dir, "conn_next"), fa, ca)
+
+
+def ppc_checks(z, freq, conn, **tol):
+    """method='ppc' (SURVEY 8f 'next' row 4) on SpectralData and AnalogData input against the reference's results."""
+    data = _n5_data(z)
+    spec = freq(data, method="mtmfft", tapsmofrq=3, output="fourier", keeptapers=True, foilim=[0, 60])
+    out = conn(spec, method="ppc")
+    assert out.data.dtype == np.float32 and list(out.channel_i) == [f"channel{i}" for i in range(1, 6)]
+    assert_parity(out.data, z["ppc_spec"], what="ppc (SpectralData)", **tol)
+    np.testing.assert_allclose(out.freq, spec.freq)
+    assert np.array_equal(out.trialdefinition, [[0, 1, 0]])
+    assert_parity(conn(data, method="ppc", tapsmofrq=3, foilim=[0, 60]).data, z["ppc_analog"], what="ppc (AnalogData)",
+                  **tol)
+    assert_parity(conn(data, method="ppc", taper="hann", pad="nextpow2").data, z["ppc_analog_hann"],
+                  what="ppc (hann, nextpow2)", **tol)
+    with pytest.raises(Exception):
+        conn(data, method="ppc", keeptrials=True)                  # trial pairs are the estimate (:448-451)
+
+
+def test_ppc(golden_dir):
+    z = _load(golden_dir, "conn_next")
+    ppc_checks(z, fa, ca)
+    cmb_checks(z, fa, ca, methods=("ppc",))
 
 
 JACK_VARIANTS = {

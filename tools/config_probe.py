@@ -25,7 +25,7 @@ def sync_time(fn, n=3):
 
 
 res = {}
-which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "frontend", "jack", "h2d", "granger"]
+which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "frontend", "jack", "h2d", "granger", "ppc"]
 
 if "c2" in which:
     C, N, T, K = 256, 4096, 1000, 7
@@ -39,6 +39,20 @@ if "c2" in which:
                             "kernel": plan.kernel_name}
     print("c2", res["c2_mtmfft_pow"], flush=True)
     del data, out
+
+if "ppc" in which:
+    # K7 alone on the headline shape: spectra of 100 trials x 7 tapers resident, phasor sums over them
+    C, F, T, K = 256, 2049, 100, 7
+    g = torch.Generator(device="cuda").manual_seed(5)
+    spec = torch.view_as_complex(torch.randn((T * K, F, C, 2), device="cuda", generator=g))
+    U = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    dt = sync_time(lambda: be.ppc_accumulate(spec, K, U), n=3)
+    pairs = F * (C // 32) * (C // 32 + 1) // 2 * 1024
+    res["ppc_accumulate"] = {"trials_per_s": T / dt, "us_per_trial": 1e6 * dt / T,
+                             "Gpairs_per_s": pairs * T / dt / 1e9,
+                             "GFLOPs": pairs * T * (8 * K + 12) / dt / 1e9}
+    print("ppc", res["ppc_accumulate"], flush=True)
+    del spec, U
 
 if "conv" in which:
     C, N, T = 128, 16384, 100
