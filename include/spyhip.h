@@ -164,6 +164,27 @@ int spyhip_ppc_accumulate_csd(spyhip_ctx* ctx, const void* csd_d, int ntrials, i
 int spyhip_ppc_finalize(spyhip_ctx* ctx, const void* acc_d, int nfreq, int ni, int nj, int lower_only,
                         int64_t ntrials, void* out_d);
 
+/* ---- K8: cross-covariance / cross-correlation -------------------------------
+ * Replaces cross_covariance_cF (connectivity/ST_compRoutines.py:466-584: one fftconvolve per channel pair and
+ * trial, lags 0 .. N/2 divided by the overlap N - lag, norm=True: divided by the products of np.std), the trial
+ * average, and normalize_ccov_cF (connectivity/AV_compRoutines.py:166-228).
+ * The trial sum is taken on the cross spectra: feed spyhip_csd_accumulate with the spectra of the trials
+ * zero-padded to nfft = spyhip_ccov_nfft(nsamples) points (spyhip_fft_exec, boxcar, FOURIER; 1 row per trial),
+ * then ONE inverse transform per channel pair:
+ *   out[l,a,b] = scale * R_ab(l) / (N - l)         a >= b,   R_ab(tau) = sum_n x_a[n] x_b[n - tau]
+ *   out[l,a,b] = scale * R_ab(l + q) / (N - l)     a <  b,   q = 1 for even N, 0 for odd N (the reference's
+ *                                                            reversed "same" crop), l = 0 .. ceil(N/2) - 1
+ * acc_d: raw lower-triangle accumulator (nfft/2 + 1, nchan, nchan) complex64; out_d float32 (ceil(N/2), nchan,
+ * nchan); scale = 1 / (ntrials * fft_scale^2) (the 1/nfft of the inverse transform is applied inside).  norm: 0 none; 1 divide by sqrt(out[0,a,a] out[0,b,b])
+ * (normalize_ccov_cF); 2 divide by np.std(x_a) np.std(x_b) of the ONE trial in acc_d (cross_covariance_cF norm=True).
+ * spyhip_ccov_nfft: transform length for trials of nsamples (power of two >= N + ceil(N/2), 1024 .. 8192), or -1. */
+int spyhip_ccov_nfft(int nsamples);
+int spyhip_ccov_from_accumulator(spyhip_ctx* ctx, const void* acc_d, int nfft, int nchan, int nsamples, double scale,
+                                 int norm, void* out_d);
+/* normalize_ccov_cF alone, in place on a cross-covariance cc_d float32 (nlag, nchan, nchan):
+ * cc[l,a,b] /= sqrt(cc[0,a,a] cc[0,b,b]). */
+int spyhip_ccov_normalize(spyhip_ctx* ctx, void* cc_d, int nlag, int nchan);
+
 /* ---- K3: Morlet continuous wavelet transform ------------------------------
  * Replaces cwt_time (specest/wavelets/transform.py:88-108) with Morlet.time
  * (specest/wavelets/wavelets.py:27-86) and the tail of wavelet_cF

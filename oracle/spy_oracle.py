@@ -453,6 +453,55 @@ def ppc(st_csd):
     return acc[np.newaxis]
 
 
+def cross_covariance(x, samplerate=1, polyremoval=0, norm=False):
+    """connectivity/ST_compRoutines.py:466-584, line by line: (N, C) -> ((nLags, 1, C, C) float64, lags).
+    Note the reversed "same" crop of the upper triangle: for an even number of samples it starts one lag late."""
+    from scipy.signal import detrend as sp_detrend, fftconvolve
+    dat = np.array(x)
+    n, c = dat.shape
+    lags = np.arange(0, n // 2) if n % 2 == 0 else np.arange(0, n // 2 + 1)
+    if polyremoval == 0:
+        dat = sp_detrend(dat, type="constant", axis=0)
+    elif polyremoval == 1:
+        dat = sp_detrend(dat, type="linear", axis=0)
+    norm_overlap = np.arange(n, n // 2, step=-1)
+    CC = np.empty((len(lags), 1, c, c))
+    for i in range(c):
+        for j in range(i + 1):
+            cc12 = fftconvolve(dat[:, i], dat[::-1, j], mode="same")
+            CC[:, 0, i, j] = cc12[n // 2:] / norm_overlap
+            if i != j:
+                CC[:, 0, j, i] = cc12[::-1][n // 2:] / norm_overlap
+    if norm:
+        stds = np.std(dat, axis=0)
+        CC = CC / (stds[:, None] * stds[None, :])
+    return CC, lags / samplerate
+
+
+def cross_covariance_cF(trl, samplerate=1, polyremoval=0, timeAxis=0, norm=False, fullOutput=False,
+                        chunkShape=None, noCompute=False):
+    dat = trl.T if timeAxis != 0 else trl
+    n, c = dat.shape
+    nlag = n // 2 + (n & 1)
+    if noCompute:
+        return (nlag, 1, c, c), np.float32
+    CC, lags = cross_covariance(dat, samplerate, polyremoval, norm)
+    return (CC, lags) if fullOutput else CC
+
+
+def normalize_ccov(trl_av):
+    """connectivity/AV_compRoutines.py:166-228: (nLags, 1, C, C) cross-covariance -> cross-correlation."""
+    cc = trl_av[:, 0, ...]
+    diag = trl_av[0, 0, ...].diagonal()
+    return (cc / np.sqrt(diag[:, None] * diag[None, :]).T)[:, None, ...]
+
+
+def normalize_ccov_cF(trl_av, chunkShape=None, noCompute=False):
+    if noCompute:
+        return trl_av.shape, np.float32
+    return normalize_ccov(trl_av)
+
+
 # --------------------------------------------------------------------------
 # G1-G3: Wilson spectral factorisation and Granger causality
 # --------------------------------------------------------------------------

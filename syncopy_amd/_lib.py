@@ -37,6 +37,9 @@ SIGNATURES = {
     "spyhip_ppc_accumulate": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "spyhip_ppc_accumulate_csd": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp]),
     "spyhip_ppc_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    "spyhip_ccov_nfft": (C.c_int, [C.c_int]),
+    "spyhip_ccov_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "spyhip_ccov_from_accumulator": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]),
     "spyhip_csd_tril_pack": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "spyhip_csd_tril_unpack": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "spyhip_csd_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double]),

@@ -358,6 +358,38 @@ def ppc_finalize(acc, ntrials, lower_only):
     return out
 
 
+def ccov_nfft(nsamples):
+    """Transform length K8 needs for trials of `nsamples` samples (no GPU involved)."""
+    from ._lib import load
+    n = load().spyhip_ccov_nfft(int(nsamples))
+    if n < 0:
+        raise ValueError(f"cross-covariance: trials of {nsamples} samples exceed the supported 5461")
+    return n
+
+
+def ccov_from_accumulator(acc, nsamples, scale, norm=0):
+    """Cross-covariance lags (nlag, C, C) float32 from the raw accumulator (nfft/2+1, C, C) of csd_accumulate over
+    the spectra of zero-padded trials (K8).  norm: 0 none, 1 zero-lag auto-covariances, 2 np.std products."""
+    assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and acc.dim() == 3
+    F, Cn, _ = acc.shape
+    nlag = nsamples // 2 + (nsamples & 1)
+    out = torch.empty((nlag, Cn, Cn), dtype=torch.float32, device=acc.device)
+    ctx = context(acc.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_ccov_from_accumulator(ctx.handle, _ptr(acc), 2 * (F - 1), Cn, int(nsamples), float(scale),
+                                               int(norm), _ptr(out)), "spyhip_ccov_from_accumulator")
+    return out
+
+
+def ccov_normalize_(cc):
+    """In place: cc (nlag, C, C) float32 /= sqrt(cc[0,a,a] cc[0,b,b]) (normalize_ccov_cF)."""
+    assert cc.is_cuda and cc.dtype == torch.float32 and cc.is_contiguous() and cc.dim() == 3
+    ctx = context(cc.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_ccov_normalize(ctx.handle, _ptr(cc), cc.shape[0], cc.shape[1]), "spyhip_ccov_normalize")
+    return cc
+
+
 def granger(csd, rtol=5e-6, niter=100, cond_max=1e4, eps_max=1e-1, want_factors=False):
     """Wilson spectral factorisation + Granger causality of a trial-averaged CSD (F, C, C) complex64.
     Returns (granger float32 (F,C,C), info dict[, H complex128 (F,C,C), Sigma complex128 (C,C)])."""

@@ -139,3 +139,28 @@ class GrangerCausality(_AverageRoutine):
         for key, value in (self.metadata[0] or {}).items():
             label, cast = key.split("--")
             out.info[label] = bool(value) if cast == "bool" else float(value)
+
+
+def normalize_ccov_cF(trl_av_dat, chunkShape=None, noCompute=False):
+    """Cross-correlation from the trial-averaged cross-covariance (nLags, 1, N, N): divided by the square roots of
+    the zero-lag auto-covariances (AV_compRoutines.py:166-228)."""
+    outShape = trl_av_dat.shape
+    if noCompute:
+        return outShape, spectralDTypes["abs"]
+    backend.require_gpu()
+    dev = torch.from_numpy(np.ascontiguousarray(trl_av_dat, dtype=np.float32)).cuda()
+    return backend.to_host(backend.ccov_normalize_(dev[:, 0].contiguous()))[:, np.newaxis]
+
+
+class NormalizeCrossCov(_AverageRoutine):
+    computeFunction = staticmethod(normalize_ccov_cF)
+    method = ""
+    valid_kws = []
+
+    def compute_hip(self, data, out):
+        dev = getattr(data, "_dev", None)
+        if dev is None:
+            dev = torch.from_numpy(np.ascontiguousarray(data.data, dtype=np.float32)).cuda()
+        res = backend.ccov_normalize_(dev[:, 0].contiguous().clone()).unsqueeze(1)
+        out._dev = res
+        out.data = backend.to_host(res)

@@ -1,5 +1,6 @@
-"""Single-trial cross-spectra on MI355X (signatures of syncopy/connectivity/ST_compRoutines.py:
-cross_spectra_cF:269 / CrossSpectra:427, spectral_dyadic_product_cF:30)."""
+"""Single-trial cross-spectra and cross-covariances on MI355X (signatures of
+syncopy/connectivity/ST_compRoutines.py: cross_spectra_cF:269 / CrossSpectra:427, spectral_dyadic_product_cF:30,
+cross_covariance_cF:466 / CrossCovariance:587)."""
 from hashlib import blake2b
 
 import numpy as np
@@ -324,3 +325,102 @@ class CrossSpectra(ComputationalRoutine):
     def process_metadata(self, data, out):
         propagate_properties(data, out, self.keeptrials)
         out.freq = self.cfg["foi"]
+
+
+def _padded_spectra(dev, rows, chans, n, polyremoval, max_bytes=8 << 30):
+    """Batches (B, F, C) of plain DFT spectra (boxcar, no normalisation) of the equally long trials `rows`,
+    zero-padded to the length K8 needs for n samples."""
+    L = backend.ccov_nfft(n)
+    nchan = dev.shape[1] if chans is None else len(chans)
+    ci = None if chans is None else torch.tensor(np.asarray(chans), dtype=torch.int32, device=dev.device)
+    plan = hs.get_plan(n, L, nchan, "boxcar", None, n, 1.0, polyremoval, False, None, "fourier", True, dev.device)
+    per_trial = (L // 2 + 1) * nchan * 8
+    bmax = max(1, int(max_bytes // per_trial))
+    for i in range(0, len(rows), bmax):
+        starts = torch.tensor([r[0] for r in rows[i:i + bmax]], dtype=torch.int64, device=dev.device)
+        buf = backend.handover_buffer(plan.out_shape(len(starts)), dev.device)
+        spec = plan.execute(dev, starts, chan_idx=ci, out=buf)
+        yield spec.reshape(len(starts), L // 2 + 1, nchan)
+
+
+def _ccov_trials(dev, rows, chans, polyremoval, scale, norm):
+    """K8 on the trials `rows` (equal length): cross spectra of the zero-padded trials summed by the MFMA kernel,
+    one inverse transform per channel pair.  Returns ((nlag, C, C) float32 device tensor, raw accumulator)."""
+    n = rows[0][1] - rows[0][0]
+    L = backend.ccov_nfft(n)
+    nchan = dev.shape[1] if chans is None else len(chans)
+    acc = torch.zeros((L // 2 + 1, nchan, nchan), dtype=torch.complex64, device=dev.device)
+    for spec in _padded_spectra(dev, rows, chans, n, polyremoval):
+        backend.csd_accumulate(spec, acc)
+    return acc, n
+
+
+def cross_covariance_cF(trl_dat, samplerate=1, polyremoval=0, timeAxis=0, norm=False, fullOutput=False,
+                        chunkShape=None, noCompute=False):
+    """Single-trial cross-covariance (`norm=True`: cross-correlation) between all channels for the lags
+    0 .. N/2; returns (nLags, 1, N, N) float32 [and the lags in s]."""
+    dat = trl_dat.T if timeAxis != 0 else trl_dat
+    nSamples, nChannels = dat.shape
+    nlag = nSamples // 2 + (nSamples & 1)
+    outShape = (nlag, 1, nChannels, nChannels)
+    if noCompute:
+        return outShape, spectralDTypes["abs"]
+    backend.require_gpu()
+    dev = torch.from_numpy(np.ascontiguousarray(dat, dtype=np.float32)).cuda()
+    pr = polyremoval if polyremoval in (0, 1) and polyremoval is not False else None
+    acc, n = _ccov_trials(dev, [(0, nSamples)], None, pr, 1.0, norm)
+    CC = backend.to_host(backend.ccov_from_accumulator(acc, n, 1.0, 2 if norm else 0))[:, np.newaxis]
+    if fullOutput:
+        return CC, np.arange(nlag) / samplerate
+    return CC
+
+
+class CrossCovariance(ComputationalRoutine):
+    dimord = ["time", "freq", "channel_i", "channel_j"]
+    computeFunction = staticmethod(cross_covariance_cF)
+    valid_kws = ["samplerate", "polyremoval", "timeAxis", "norm", "fullOutput"]
+
+    def compute_hip(self, data, out):
+        """All trials of this rank at once.  Trial average (keeptrials=False): the cross spectra of the zero-padded
+        trials are summed by the MFMA kernel and over ranks, then ONE inverse transform per channel pair - the
+        reference's per-trial, per-pair convolutions never happen.  Kept trials: the same per trial."""
+        cfg = self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
+        T = self.numTrials
+        mine = [rows[k] for k in self.my_trials()]
+        if self.keeptrials:
+            parts = []
+            for r in mine:
+                acc, n = _ccov_trials(dev, [r], chans, pr, 1.0, cfg["norm"])
+                parts.append(backend.ccov_from_accumulator(acc, n, 1.0, 2 if cfg["norm"] else 0).unsqueeze(1))
+            from ..specest.compRoutines import _store_trials
+            _store_trials(self, out, parts)
+            return
+        lens = {r[1] - r[0] for r in rows}
+        if len(lens) != 1:
+            raise ValueError("trial averaging of cross-covariances needs trials of equal length")
+        n = lens.pop()
+        L = backend.ccov_nfft(n)
+        nchan = self.targetShapes[0][2]
+        acc = torch.zeros((L // 2 + 1, nchan, nchan), dtype=torch.complex64, device=dev.device)
+        for spec in _padded_spectra(dev, mine, chans, n, pr):
+            backend.csd_accumulate(spec, acc)
+        backend.csd_allreduce_(acc)
+        res = backend.ccov_from_accumulator(acc, n, 1.0 / T, 2 if cfg["norm"] else 0)
+        out._dev = res.unsqueeze(1)
+        out.data = backend.to_host(out._dev)
+
+    def process_metadata(self, data, out):
+        # lags live on the time axis, offset 0 (ST_compRoutines.py:610-640)
+        from ..datatype import selected_trialdefinition
+        chans = selected_channels(data)
+        names = np.array(data.channel) if chans is None else np.array(data.channel)[chans]
+        old = selected_trialdefinition(data)
+        sizes = np.ceil(np.diff(old[:, :2], axis=1)[:, 0] / 2)
+        si = np.r_[0, np.cumsum(sizes)]
+        trl = np.column_stack([si[:-1], si[1:], np.zeros(len(sizes))])
+        out.trialdefinition = trl if self.keeptrials else trl[[0], :]
+        out.samplerate = data.samplerate
+        out.channel_i, out.channel_j = names, names.copy()

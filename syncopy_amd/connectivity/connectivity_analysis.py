@@ -1,4 +1,4 @@
-"""`connectivityanalysis` metafunction for method = 'csd' | 'coh' | 'granger' on AnalogData.
+"""`connectivityanalysis` metafunction: method = 'csd' | 'coh' | 'granger' | 'ppc' | 'corr'.
 
 Two-stage pipeline of syncopy/connectivity/connectivity_analysis.py: single-trial
 cross-spectra accumulated over trials (ST stage, :587-599), then one evaluation on the
@@ -14,8 +14,8 @@ from ..shared.const_def import connectivity_outputs, connectivityMethods
 from ..shared.errors import SPYTypeError, SPYValueError, SPYWarning
 from ..shared.input_processors import process_foi, process_padding, process_taper
 from ..shared.tools import best_match
-from .AV_compRoutines import NormalizeCrossSpectra, pairwise_phase_consistency
-from .ST_compRoutines import CrossSpectra, SpectralDyadicProduct
+from .AV_compRoutines import NormalizeCrossCov, NormalizeCrossSpectra, pairwise_phase_consistency
+from .ST_compRoutines import CrossCovariance, CrossSpectra, SpectralDyadicProduct
 
 
 def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi=None, foilim=None, pad="maxperlen",
@@ -36,7 +36,7 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
         if not isinstance(polyremoval, numbers.Number) or polyremoval not in (0, 1):
             raise SPYValueError("0, 1 or None", varname="polyremoval", actual=polyremoval)
     classes = {"csd": CrossSpectra, "coh": NormalizeCrossSpectra, "dyadic": SpectralDyadicProduct,
-               "ppc": pairwise_phase_consistency}
+               "ppc": pairwise_phase_consistency, "ccov": CrossCovariance, "ccov_norm": NormalizeCrossCov}
     try:
         from .AV_compRoutines import GrangerCausality
         classes["granger"] = GrangerCausality
@@ -178,6 +178,32 @@ def _connectivity_from_spectra(data, classes, method, keeptrials, output, comput
     return out
 
 
+def _cross_correlation(data, classes, keeptrials, foi, foilim, pad, polyremoval, compute_method):
+    """method='corr' (connectivity_analysis.py:383-386,408-437): single-trial cross-covariances over the lags
+    0 .. N/2, trial-averaged and normalised to cross-correlations - or, with keeptrials, normalised per trial."""
+    if not isinstance(data, AnalogData):
+        raise SPYValueError("AnalogData instance as input for method corr", "data", data.__class__.__name__)
+    if pad != "maxperlen":
+        raise SPYValueError("'maxperlen', no padding needed/allowed for cross-correlations", varname="pad",
+                            actual=f"{pad}")
+    if foi is not None or foilim is not None:
+        SPYWarning("Parameter `foi` has no effect for method `corr`")
+    log_dict = {"method": "corr", "keeptrials": keeptrials, "polyremoval": polyremoval, "pad": pad}
+    st = classes["ccov"](samplerate=data.samplerate, polyremoval=polyremoval, timeAxis=data.dimord.index("time"),
+                         norm=bool(keeptrials))
+    st_out = CrossSpectralData(dimord=CrossCovariance.dimord)
+    st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=bool(keeptrials))
+    st.compute(data, st_out, parallel=False, log_dict=log_dict, method=compute_method)
+    if keeptrials:
+        return st_out
+    av = classes["ccov_norm"]()
+    out = CrossSpectralData(dimord=st_out.dimord)
+    av.initialize(st_out, out._stackingDim, chan_per_worker=None, keeptrials=False)
+    av.pre_check()
+    av.compute(st_out, out, parallel=False, log_dict=log_dict, method=compute_method)
+    return out
+
+
 def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq, nTaper, taper,
                   taper_opt, compute_method, jackknife=False, cmb=None):
     fs = data.samplerate
@@ -185,12 +211,14 @@ def _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, p
     trl = selected_trialdefinition(data)
     lenTrials = np.diff(trl[:, :2]).squeeze(axis=1)
     nTrials = lenTrials.size
-    if nTrials == 1:
+    if nTrials == 1 and method != "corr":
         raise SPYValueError("multi-trial input data, spectral connectivity measures critically depend on trial "
                             "averaging!", "data", "only one trial")
     if keeptrials is not False and method in ("coh", "ppc", "granger"):
         raise SPYValueError(f"False, trial averaging needed for method {method}!", varname="keeptrials",
                             actual=keeptrials)
+    if method == "corr":
+        return _cross_correlation(data, classes, keeptrials, foi, foilim, pad, polyremoval, compute_method)
     if isinstance(data, SpectralData):
         return _connectivity_from_spectra(data, classes, method, keeptrials, output, compute_method, jackknife, cmb)
     nSamples = process_padding(pad, lenTrials, fs)

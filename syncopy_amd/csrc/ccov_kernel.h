@@ -1,0 +1,116 @@
+// K8: cross-covariance / cross-correlation lags from the accumulated cross spectra of zero-padded trials.
+//
+// The reference convolves every channel pair of every trial in the time domain order
+// (connectivity/ST_compRoutines.py:466-584: fftconvolve(x_i, x_j[::-1], "same"), cropped to the lags
+// 0 .. N/2 and divided by the overlap N - lag), then averages over trials and normalises
+// (AV_compRoutines.py:166-228).  The trial average commutes with the inverse transform: the cross spectra
+// X_a conj(X_b) of the zero-padded trials are summed over trials by the MFMA kernel (K4), and ONE inverse
+// transform per channel pair yields the trial-averaged R_ab(tau) = sum_n x_a[n] x_b[n - tau] for all lags.
+//
+// Index conventions of the reference, kept bit for bit in meaning:
+//   out[l, a, b] = R_ab(l) / (N - l)                      a >= b
+//   out[l, a, b] = R_ab(l + q) / (N - l),  a < b          q = 1 for an even number of samples (the reversed
+//                                                         "same" crop starts one sample late), 0 for odd.
+#pragma once
+#include "spy_common.h"
+#include "fft2_device.h"
+
+namespace spyfft {
+
+struct CcovArgs {
+    const float2* acc;    // (L/2 + 1, C, C) complex64: sum over trials of X_a conj(X_b), lower triangle valid
+    const float2* tw;     // exp(-2 pi i m / L), m < L
+    int C, nsamples, nlag, q;
+    long long npairs;     // C (C + 1) / 2
+    float scale;          // 1 / (L * ntrials * fft_scale^2)
+    float* out;           // (nlag, C, C)
+};
+
+__device__ __forceinline__ void pair_of(long long p, int& a, int& b) {
+    long long r = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > p) --r;
+    while ((r + 1) * (r + 2) / 2 <= p) ++r;
+    a = (int)r;
+    b = (int)(p - r * (r + 1) / 2);
+}
+
+// Workgroup = G thread sets; a set transforms TWO channel pairs (the halves of the packed registers) of the lower
+// triangle: Hermitian extension on load (index k > L/2 reads conj(acc[L - k])), inverse transform in LDS, real part
+// = R_ab(tau) at tau = k (lags >= 0) and tau = k - L (lags < 0, which are the mirrored element's lags).
+template <int LOG2N, int G>
+__global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) ccov_lags_kernel(CcovArgs a) {
+    using C = Cfg2<LOG2N, G>;
+    constexpr int L = C::N, T = C::T;
+    SPY_DYN_SMEM(v2f, lds);
+    const int tid = threadIdx.x;
+    const int h = tid % G, j = tid / G;
+    const long long p0 = ((long long)blockIdx.x * G + h) * 2;
+    int ca[2] = {0, 0}, cb[2] = {0, 0};
+    bool has[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        has[i] = p0 + i < a.npairs;
+        if (has[i]) pair_of(p0 + i, ca[i], cb[i]);
+    }
+    const size_t cc = (size_t)a.C * a.C;
+    C2 v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = j + T * e;
+        const bool mir = k > L / 2;
+        const size_t row = (size_t)(mir ? L - k : k) * cc;
+        float2 s[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            s[i] = make_float2(0.f, 0.f);
+            if (has[i]) s[i] = a.acc[row + (size_t)ca[i] * a.C + cb[i]];
+            if (mir) s[i].y = -s[i].y;
+        }
+        v[e].r = v2f{s[0].x, s[1].x};
+        v[e].i = v2f{s[0].y, s[1].y};
+    }
+    fft2_inverse<LOG2N, G>(v, lds, j, h, a.tw);
+    const size_t Cn = (size_t)a.C;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int tau = j + T * e;
+        // lags >= 0: the element itself
+        if (tau < a.nlag) {
+            const float w = a.scale / (float)(a.nsamples - tau);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (has[i]) a.out[((size_t)tau * Cn + ca[i]) * Cn + cb[i]] = v[e].r[i] * w;
+        }
+        // lags < 0 (tau - L): R_ba(l + q) of the mirrored element with l + q = L - tau
+        const int l = (a.q == 0 && tau == 0) ? 0 : L - tau - a.q;
+        if (l >= 0 && l < a.nlag) {
+            const float w = a.scale / (float)(a.nsamples - l);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (has[i] && ca[i] != cb[i]) a.out[((size_t)l * Cn + cb[i]) * Cn + ca[i]] = v[e].r[i] * w;
+        }
+    }
+}
+
+// d[a]: what the normalisation divides by, per channel (before the square root of the product of two):
+//   mode 1  CC[0,a,a]                                  zero-lag auto-covariance of the trial average
+//                                                       (normalize_ccov_cF, AV_compRoutines.py:215-225)
+//   mode 2  CC[0,a,a] - mean_a^2 = np.std(x_a)^2        single trials, cross_covariance_cF(norm=True)
+//                                                       (ST_compRoutines.py:575-579); mean_a^2 = |X_a(0)|^2 / N^2
+__global__ void __launch_bounds__(256) ccov_diag_kernel(const float* out, const float2* acc, int Cn, int mode,
+                                                        float dc_scale, float* d) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cn) return;
+    float v = out[(size_t)c * Cn + c];
+    if (mode == 2) v -= acc[(size_t)c * Cn + c].x * dc_scale;
+    d[c] = v;
+}
+
+__global__ void __launch_bounds__(256) ccov_normalize_kernel(float* out, long long n, int Cn, const float* d) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int b = (int)(idx % Cn), a = (int)((idx / Cn) % Cn);
+    out[idx] = out[idx] / sqrtf(d[a] * d[b]);
+}
+
+}  // namespace spyfft

@@ -10,5 +10,5 @@ spectralDTypes = {
 availableTapers = [w for w in windows.__all__ if w not in ("get_window", "exponential", "dpss")]
 availablePaddingOpt = ["maxperlen", "nextpow2"]
 availableMethods = ("mtmfft", "mtmconvol", "wavelet", "welch")
-connectivityMethods = ("coh", "csd", "granger", "ppc")
+connectivityMethods = ("coh", "corr", "csd", "granger", "ppc")
 connectivity_outputs = {"abs", "pow", "complex", "fourier", "angle", "real", "imag"}

@@ -226,6 +226,20 @@ def ppc_finalize(acc, ntrials, lower_only):
     return out
 
 
+def ccov_from_accumulator(acc, nsamples, scale, norm=0):
+    """Emulated spyhip_ccov_from_accumulator: acc (nfft/2+1, C, C) complex64 -> (nlag, C, C) float32."""
+    acc = np.ascontiguousarray(acc, dtype=np.complex64)
+    F, Cn, _ = acc.shape
+    L = 2 * (F - 1)
+    tw = np.exp(-2j * np.pi * np.arange(L) / L).astype(np.complex64)
+    nlag = nsamples // 2 + (nsamples & 1)
+    out = np.zeros((nlag, Cn, Cn), dtype=np.float32)
+    rc = lib().emu_ccov(acc.ctypes.data_as(C.c_void_p), tw.ctypes.data_as(C.c_void_p), C.c_int(L), C.c_int(Cn),
+                        C.c_int(nsamples), C.c_double(scale), C.c_int(norm), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return out
+
+
 def coh_from_accumulator(acc, scale, output="abs"):
     """Emulated spyhip_coh_from_accumulator (raw lower-triangle accumulator -> coherence)."""
     F, Cn, _ = acc.shape

@@ -17,6 +17,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
 #include "../../syncopy_amd/csrc/csd_kernel.h"
 #include "../../syncopy_amd/csrc/ppc_kernel.h"
+#include "../../syncopy_amd/csrc/ccov_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_long.h"
@@ -105,6 +106,13 @@ int run_long(const spyfft::LongArgs& a, int l, int stage, long long items) {
 }  // namespace
 
 static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD entry points
+
+template <int LOG2N, int G>
+static void emu_launch_ccov(const spyfft::CcovArgs& a) {
+    using C = spyfft::Cfg2<LOG2N, G>;
+    const long long grid = (a.npairs + 2 * G - 1) / (2 * G);
+    emu::launch(dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::ccov_lags_kernel<LOG2N, G>(a); });
+}
 
 extern "C" {
 
@@ -349,6 +357,36 @@ void emu_ppc_finalize(const float* acc, int F, int ni, int nj, int lower_only, l
     emu::launch(dim3((unsigned)((n + 255) / 256)), dim3(256), 0, [&] {
         spyppc::ppc_finalize_kernel(reinterpret_cast<const float2*>(acc), F, ni, nj, lower_only, (double)T, out);
     });
+}
+
+// K8 (mirrors ccov.hip): tw = exp(-2 pi i m / L) from the caller; norm as spyhip_ccov_from_accumulator
+int emu_ccov(const float* acc, const float* tw, int nfft, int nchan, int nsamples, double scale, int norm, float* out) {
+    spyfft::CcovArgs a{};
+    a.acc = reinterpret_cast<const float2*>(acc);
+    a.tw = reinterpret_cast<const float2*>(tw);
+    a.C = nchan; a.nsamples = nsamples;
+    a.nlag = nsamples / 2 + (nsamples & 1);
+    a.q = (nsamples & 1) ? 0 : 1;
+    a.npairs = (long long)nchan * (nchan + 1) / 2;
+    a.scale = (float)(scale / (double)nfft);
+    a.out = out;
+    switch (nfft) {
+        case 1024: emu_launch_ccov<10, 4>(a); break;
+        case 2048: emu_launch_ccov<11, 2>(a); break;
+        case 4096: emu_launch_ccov<12, 1>(a); break;
+        case 8192: emu_launch_ccov<13, 1>(a); break;
+        default: return -1;
+    }
+    if (norm) {
+        std::vector<float> d(nchan);
+        const float dc = (float)(scale / ((double)nsamples * (double)nsamples));
+        emu::launch(dim3((nchan + 255) / 256), dim3(256), 0,
+                    [&] { spyfft::ccov_diag_kernel(out, a.acc, nchan, norm, dc, d.data()); });
+        const long long n = (long long)a.nlag * nchan * nchan;
+        emu::launch(dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                    [&] { spyfft::ccov_normalize_kernel(out, n, nchan, d.data()); });
+    }
+    return 0;
 }
 
 // CWT: plan tables (kernel spectra, shifts) are built by the Python mirror of cwt.hip.

@@ -7,8 +7,8 @@ mapping, and (b) GPU tests can compare product vs oracle on arbitrary inputs."""
 import numpy as np
 
 from oracle import spy_oracle as O
-from syncopy_amd.connectivity.AV_compRoutines import NormalizeCrossSpectra, _AverageRoutine
-from syncopy_amd.connectivity.ST_compRoutines import CrossSpectra, SpectralDyadicProduct
+from syncopy_amd.connectivity.AV_compRoutines import NormalizeCrossCov, NormalizeCrossSpectra, _AverageRoutine
+from syncopy_amd.connectivity.ST_compRoutines import CrossCovariance, CrossSpectra, SpectralDyadicProduct
 from syncopy_amd.specest.compRoutines import MultiTaperFFT, MultiTaperFFTConvol, _make_trialdef
 from syncopy_amd.shared.computational_routine import ComputationalRoutine, propagate_properties
 
@@ -77,7 +77,16 @@ class OracleGrangerCausality(_AverageRoutine):
             out.info[label] = bool(value) if cast == "bool" else float(value)
 
 
+class OracleCrossCovariance(CrossCovariance):
+    computeFunction = staticmethod(O.cross_covariance_cF)
+
+
+class OracleNormalizeCrossCov(NormalizeCrossCov):
+    computeFunction = staticmethod(O.normalize_ccov_cF)
+
+
 ORACLE_FREQ = {"mtmfft": OracleMultiTaperFFT, "mtmconvol": OracleMultiTaperFFTConvol,
                "wavelet": OracleWaveletTransform}
 ORACLE_CONN = {"csd": OracleCrossSpectra, "coh": OracleNormalizeCrossSpectra, "granger": OracleGrangerCausality,
-               "dyadic": OracleSpectralDyadicProduct, "ppc": O.ppc}
+               "dyadic": OracleSpectralDyadicProduct, "ppc": O.ppc,
+               "ccov": OracleCrossCovariance, "ccov_norm": OracleNormalizeCrossCov}

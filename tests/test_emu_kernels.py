@@ -175,6 +175,28 @@ def test_ppc_kernel(C, F, T, K):
     assert_parity(E.ppc_finalize(U2, T, False), ref, what="ppc from csd", rtol=1e-4, atol_rel=2e-5)
 
 
+@pytest.mark.parametrize("C,N,norm", [(5, 600, 0), (6, 301, 1), (3, 1400, 2)])
+def test_ccov_kernel(C, N, norm):
+    """K8's kernel source on the CPU: lags from accumulated cross spectra of zero-padded trials = the oracle's
+    per-pair fftconvolve walk (even N: the upper triangle one lag late, as in the reference)."""
+    rng = np.random.default_rng(N)
+    T = 1 if norm == 2 else 3
+    x = rng.normal(size=(T, N, C))
+    x[:, 2:, 1] += 0.7 * x[:, :-2, 0]
+    x = (x - x.mean(axis=1, keepdims=True)).astype(np.float32)
+    nlag = N // 2 + (N & 1)
+    L = 1024
+    while L < N + nlag:
+        L *= 2
+    X = np.fft.rfft(x.astype(np.float64), n=L, axis=1).astype(np.complex64)          # (T, F, C)
+    acc = np.einsum("tfa,tfb->fab", X, X.conj()).astype(np.complex64)
+    got = E.ccov_from_accumulator(acc, N, 1.0 / T, norm)
+    ref = np.mean([O.cross_covariance(t, 1.0, None, norm == 2)[0] for t in x], axis=0)
+    if norm == 1:
+        ref = O.normalize_ccov(ref)
+    assert_parity(got, ref[:, 0].astype(np.float32), what=f"ccov norm={norm}", atol_rel=1e-5)
+
+
 @pytest.mark.parametrize("nsig,scales,detrend,output", [
     (700, [0.05, 0.02, 0.004], 0, "pow"),            # kernels of 500/200/40 taps, one block
     (3000, [0.03, 0.006], 1, "fourier"),             # several overlap-save blocks

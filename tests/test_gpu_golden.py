@@ -9,7 +9,7 @@ import syncopy_amd as spy
 from oracle_routines import ORACLE_CONN, ORACLE_FREQ
 from parity import assert_parity
 from test_oracle_golden import (JACK_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, chain_checks, check_jackknife,
-                                cmb_checks, ppc_checks)
+                                cmb_checks, corr_checks, ppc_checks)
 
 pytestmark = pytest.mark.gpu
 
@@ -90,6 +90,15 @@ def test_ppc(golden_dir, how):
     # absolute error on an estimate of magnitude <= 1; the closed form does not: the floor is widened to 5e-6
     ppc_checks(z, f, c, atol_rel=5e-6)
     cmb_checks(z, f, c, methods=("ppc",), atol_rel=5e-6)
+
+
+@pytest.mark.parametrize("how", ["hip", "sequential"])
+def test_corr(golden_dir, how):
+    """method='corr': K8 (trial sum on the cross spectra of the zero-padded trials, one inverse transform per
+    channel pair) against the reference's per-trial, per-pair fftconvolve.  Both sides transform in float32: the
+    floor is 1e-5 of the largest value (the zero-lag auto-correlation 1)."""
+    corr_checks(_load(golden_dir, "conn_next"), lambda d, **kw: spy.connectivityanalysis(d, compute_method=how, **kw),
+                atol_rel=1e-5)
 
 
 @pytest.mark.parametrize("name", sorted(JACK_VARIANTS))

@@ -269,6 +269,34 @@ def test_ppc_vs_oracle(be, C, F, T, K):
     assert_parity(got2, ref, what="ppc from csd", rtol=1e-4, atol_rel=2e-5)
 
 
+@pytest.mark.parametrize("C,N,T,pr", [(5, 700, 3, 0), (40, 1365, 2, 1), (70, 301, 4, None), (12, 4096, 2, 0),
+                                      (33, 5461, 1, 0)])
+def test_ccov_vs_oracle(be, C, N, T, pr):
+    """K8 against the oracle's literal walk over channel pairs (even / odd N incl. the reference's one-lag-late upper
+    triangle for even N, every transform length 1024..8192, all normalisations)."""
+    import syncopy_amd.connectivity.ST_compRoutines as ST
+    rng = np.random.default_rng(C + N)
+    x = rng.normal(size=(T, N, C)).astype(np.float32)
+    x[:, 1:] += 0.6 * x[:, :-1]
+    x[:, 3:, 1] += 0.5 * x[:, :-3, 0]                       # a lagged coupling: asymmetric in the lag
+    x += rng.normal(size=(1, 1, C)).astype(np.float32)      # channel offsets (matter for polyremoval=None)
+    ref = np.mean([O.cross_covariance(t, 1.0, pr, False)[0] for t in x], axis=0)[:, 0]
+    dev = torch.from_numpy(x.reshape(T * N, C)).cuda()
+    rows = [(t * N, (t + 1) * N) for t in range(T)]
+    acc, n = ST._ccov_trials(dev, rows, None, pr, 1.0, False)
+    got = be.ccov_from_accumulator(acc, N, 1.0 / T, 0).cpu().numpy()
+    assert got.shape == ref.shape
+    assert_parity(got, ref.astype(np.float32), what="ccov", atol_rel=1e-5)
+    assert_parity(be.ccov_from_accumulator(acc, N, 1.0 / T, 1).cpu().numpy(),
+                  O.normalize_ccov(ref[:, None])[:, 0].astype(np.float32), what="ccov normalised", atol_rel=1e-5)
+    assert_parity(be.ccov_normalize_(torch.from_numpy(got).cuda()).cpu().numpy(),
+                  O.normalize_ccov(ref[:, None])[:, 0].astype(np.float32), what="ccov_normalize", atol_rel=1e-5)
+    acc1, _ = ST._ccov_trials(dev, rows[:1], None, pr, 1.0, True)
+    ref1 = O.cross_covariance(x[0], 1.0, pr, True)[0][:, 0]
+    assert_parity(be.ccov_from_accumulator(acc1, N, 1.0, 2).cpu().numpy(), ref1.astype(np.float32),
+                  what="single-trial cross-correlation (np.std products)", atol_rel=1e-5)
+
+
 def test_cwt_trial_sum_mode(be):
     """accumulate=2 (out[0] += sum over segments, the keeptrials=False path) equals the sum of the per-segment
     outputs of the plain mode; 5 channels exercise the padded channel pair of the packed kernel."""

@@ -205,6 +205,32 @@ def test_ppc(golden_dir):
     cmb_checks(z, fa, ca, methods=("ppc",))
 
 
+def corr_checks(z, conn, **tol):
+    """method='corr' (SURVEY 8f 'next' row 4) against the reference: trial-averaged cross-correlation over the lags
+    0 .. N/2 (even and odd numbers of samples, polyremoval 0 / 1) and per-trial normalisation with keeptrials."""
+    data = _n5_data(z)
+    out = conn(data, method="corr")
+    assert out.data.dtype == np.float32 and out.data.shape == (500, 1, 5, 5)
+    assert_parity(out.data, z["corr"], what="corr", **tol)
+    np.testing.assert_allclose(out.time[0], z["corr_time"])
+    assert list(out.channel_i) == [f"channel{i}" for i in range(1, 6)]
+    assert_parity(conn(data, method="corr", polyremoval=1).data, z["corr_poly1"], what="corr polyremoval=1", **tol)
+    kept = conn(data, method="corr", keeptrials=True)
+    assert kept.data.shape == (20 * 500, 1, 5, 5) and len(kept.trials) == 20
+    assert_parity(kept.data[:1500], z["corr_keeptrials_first3"], what="corr keeptrials", **tol)
+    n_odd = int(z["corr_odd_nsamples"][0])
+    odd = spy.AnalogData(np.concatenate([t[:n_odd] for t in z["data"]]), samplerate=float(z["samplerate"]),
+                         trialdefinition=np.stack([np.arange(20) * n_odd, np.arange(1, 21) * n_odd,
+                                                   np.zeros(20)], axis=1))
+    assert_parity(conn(odd, method="corr").data, z["corr_odd"], what="corr odd nSamples", **tol)
+    with pytest.raises(Exception):
+        conn(data, method="corr", pad="nextpow2")                   # connectivity_analysis.py:383-386
+
+
+def test_corr(golden_dir):
+    corr_checks(_load(golden_dir, "conn_next"), ca)
+
+
 JACK_VARIANTS = {
     "coh_abs": dict(method="coh", tapsmofrq=3),
     "coh_complex": dict(method="coh", tapsmofrq=3, output="complex", foilim=[5, 60]),

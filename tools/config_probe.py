@@ -25,7 +25,7 @@ def sync_time(fn, n=3):
 
 
 res = {}
-which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "frontend", "jack", "h2d", "granger", "ppc"]
+which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "frontend", "jack", "h2d", "granger", "ppc", "corr"]
 
 if "c2" in which:
     C, N, T, K = 256, 4096, 1000, 7
@@ -53,6 +53,23 @@ if "ppc" in which:
                              "GFLOPs": pairs * T * (8 * K + 12) / dt / 1e9}
     print("ppc", res["ppc_accumulate"], flush=True)
     del spec, U
+
+if "corr" in which:
+    # K8 on the headline shape: cross-correlation of 256 channels x 4096 samples, 200 trials, 2048 lags
+    import syncopy_amd.connectivity.ST_compRoutines as ST
+    C, N, T = 256, 4096, 200
+    data = synthdata.ar2_uncoupled_fast(C, N, T, seed=6)
+    rows = [(t * N, (t + 1) * N) for t in range(T)]
+    state = {}
+
+    def accumulate():
+        state["acc"], _ = ST._ccov_trials(data, rows, None, 0, 1.0, False)
+    dt_acc = sync_time(accumulate, n=2)
+    dt_lag = sync_time(lambda: be.ccov_from_accumulator(state["acc"], N, 1.0 / T, 1), n=3)
+    res["corr"] = {"accumulate_us_per_trial": 1e6 * dt_acc / T, "lags_ms": 1e3 * dt_lag,
+                   "out_GB": 2048 * C * C * 4 / 1e9, "trials_per_s_incl_lags": T / (dt_acc + dt_lag)}
+    print("corr", res["corr"], flush=True)
+    del data, state
 
 if "conv" in which:
     C, N, T = 128, 16384, 100
