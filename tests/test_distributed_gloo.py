@@ -36,8 +36,13 @@ def _run(kind):
     if kind == "pow_avg":
         return spy.freqanalysis(d, method="mtmfft", tapsmofrq=4, keeptrials=False, compute_method="sequential",
                                 routine_classes=ORACLE_FREQ).data
+    if kind in ("ppc", "corr"):
+        return spy.connectivityanalysis(d, method=kind, compute_method="sequential", routine_classes=ORACLE_CONN).data
     return spy.connectivityanalysis(d, method="coh", tapsmofrq=4, compute_method="sequential",
                                     routine_classes=ORACLE_CONN).data
+
+
+KINDS = ("pow", "pow_avg", "coh", "ppc", "corr")
 
 
 def _worker(rank, world, port, tmp):
@@ -46,7 +51,7 @@ def _worker(rank, world, port, tmp):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         assert parallel.world() == (rank, world)
-        res = {k: _run(k) for k in ("pow", "pow_avg", "coh")}
+        res = {k: _run(k) for k in KINDS}
         np.savez(os.path.join(tmp, f"rank{rank}.npz"), **res)
     finally:
         dist.destroy_process_group()
@@ -61,13 +66,15 @@ def test_shard_bounds():
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_two_ranks_match_single_process(tmp_path, world):
-    ref = {k: _run(k) for k in ("pow", "pow_avg", "coh")}
+    ref = {k: _run(k) for k in KINDS}
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(z["pow"], ref["pow"])                 # stacked: bit-identical, rank order kept
         assert_parity(z["pow_avg"], ref["pow_avg"], what="trial mean")
         assert_parity(z["coh"], ref["coh"], what="coherence")
+        assert_parity(z["ppc"], ref["ppc"], what="ppc")             # kept single trials gathered, then all pairs
+        assert_parity(z["corr"], ref["corr"], what="corr")          # trial mean of cross-covariances, normalised
         if r > 0:                                                   # every rank holds the same reduced result
             z0 = np.load(tmp_path / "rank0.npz")
             assert np.array_equal(z["coh"], z0["coh"]) and np.array_equal(z["pow_avg"], z0["pow_avg"])
