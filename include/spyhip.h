@@ -146,6 +146,25 @@ int spyhip_coh_normalize(spyhip_ctx* ctx, const void* csd_d, int nfreq, int ncha
 int spyhip_coh_from_accumulator(spyhip_ctx* ctx, const void* acc_d, int nfreq, int nchan, double scale, int output,
                                 void* out_d);
 
+/* ---- K3s: superlets ----------------------------------------------------------
+ * spyhip_cwt_plan_create_sl: a CWT plan (same exec / destroy as above) whose kernels are the superlet formulation
+ *   MorletSL (specest/superlet.py:268-292) sampled as cwtSL does (:311-375): support 10*s*cycles/dt samples, norm
+ *   sqrt(dt)/(4 pi), k_sd standard deviations of the Gaussian envelope (the reference uses 5).
+ * spyhip_slt_combine: one factor of the geometric mean of multiplicativeSLT / FASLT (superlet.py:97-211):
+ *   acc[r, s0+q, c] = (init ? 1 : acc[r, s0+q, c]) * spec[r, q, c] ^ expo[q]     principal branch, 0^e = 0 (e > 0)
+ *   acc_d complex64 (nrows, nscales, nchan); spec_d complex64 (nrows, nsub, nchan) = FOURIER output of one order's
+ *   plan over the scales [s0, s0+nsub); expo = nsub host doubles (0 leaves the element as it is); modulus_only = 1
+ *   folds |spec|^expo instead (all that the POW / ABS outputs need: no phase arithmetic); modulus_only = 2: acc_d and
+ *   spec_d are float32 arrays of moduli (ABS output of the plan), half the traffic; | 4: the product is squared on
+ *   store (last factor of a POW output).
+ * spyhip_spec_convert: spectralConversions (shared/const_def.py:25-33) of n complex64 values to a real output kind. */
+int spyhip_cwt_plan_create_sl(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales, double dt,
+                              double cycles, double k_sd, int detrend, int output, const int32_t* tpos, int ntime_out,
+                              spyhip_cwt_plan** out);
+int spyhip_slt_combine(spyhip_ctx* ctx, void* acc_d, const void* spec_d, int64_t nrows, int nscales, int nsub, int s0,
+                       int nchan, const double* expo, int init, int modulus_only);
+int spyhip_spec_convert(spyhip_ctx* ctx, const void* in_d, int64_t n, int output, void* out_d);
+
 /* ---- K7: pairwise phase consistency -----------------------------------------
  * Replaces ppc_column_cF (connectivity/ST_compRoutines.py:159-233) and the loop over all trial pairs with its
  * weighted average (connectivity/connectivity_analysis.py:624-663):

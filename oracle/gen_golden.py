@@ -227,6 +227,18 @@ tfa("welch_dpss_avg", method="welch", tapsmofrq=4, t_ftimwin=0.4, toi=0.25, foil
 tfa("welch_pow2_nooverlap", method="welch", taper="hann", t_ftimwin=0.256, toi=0.0, polyremoval=1)
 save("welch_variants", **kw)
 
+# ---------------------------------------------------------------- superlets (specest/superlet.py, compRoutines.py:655-805,
+# freqanalysis.py:910-965): multiplicative and fractional adaptive, every output the path converts to
+kw = {"data": np.stack(trials_of(tf)), "samplerate": tf.samplerate, "trialdefinition": tf.trialdefinition}
+tfa("slt_mult", method="superlet", order_max=3, foi=np.arange(20, 90, 10), toi="all")
+tfa("slt_mult_c5_toi", method="superlet", order_max=4, order_min=2, c_1=5, foi=np.array([30.0, 60.0]),
+    toi=np.arange(-0.5, 0.5, 0.05), output="abs", polyremoval=1)
+tfa("slt_adaptive", method="superlet", order_max=6, order_min=1, c_1=3, adaptive=True, foilim=[10, 60], toi="all",
+    keeptrials=False)
+tfa("slt_adaptive_fourier", method="superlet", order_max=4, adaptive=True, foi=np.arange(15, 75, 5), toi="all",
+    output="fourier")
+save("superlet_variants", **kw)
+
 # ---------------------------------------------------------------- backend-level vectors
 kw = {}
 # harmonic known-answer signal (tests/backend/test_timefreq.py:351-404)

@@ -374,6 +374,83 @@ def wavelet_cF(trl, preselect, postselect, toi=None, timeAxis=0, polyremoval=Non
 
 
 # --------------------------------------------------------------------------
+# S6: superlet transform (Moca et al. 2021)
+# --------------------------------------------------------------------------
+def morlet_sl(t, s, c_i, k_sd=5):
+    """specest/superlet.py:268-292 (MorletSL.time): Morlet with c_i cycles inside the Gaussian envelope."""
+    ts = t / s
+    out = k_sd / (s * c_i * (2 * np.pi) ** 1.5) * np.exp(1j * ts)
+    out *= np.exp(-0.5 * (k_sd * ts / (2 * np.pi * c_i)) ** 2)
+    return out
+
+
+def sl_scale_from_period(period):
+    """specest/superlet.py:306-308."""
+    return period / (2 * np.pi)
+
+
+def cwt_sl(x, c_i, scales, dt):
+    """specest/superlet.py:311-363 (cwtSL): support 10*s*c_i/dt samples, norm sqrt(dt)/(4 pi), stored complex64."""
+    out = np.zeros((len(scales),) + x.shape, dtype=np.complex64)
+    for i, s in enumerate(scales):
+        M = 10 * s * c_i / dt
+        t = np.arange((-M + 1) / 2.0, (M + 1) / 2.0) * dt
+        ker = dt ** 0.5 / (4 * np.pi) * morlet_sl(t, s, c_i)
+        out[i] = sps.fftconvolve(x, ker[:, None], mode="same")
+    return out
+
+
+def adaptive_order(freq, order_min, order_max):
+    """specest/superlet.py:378-395: linear map of the frequencies onto [order_min, order_max]."""
+    return order_min + (order_max - order_min) * (freq - freq[0]) / (freq[-1] - freq[0])
+
+
+def superlet(x, samplerate, scales, order_max, order_min=1, c_1=3, adaptive=False):
+    """specest/superlet.py:13-211: geometric mean of the Morlet transforms of the superlet set; multiplicative
+    (same set for all scales) or fractional adaptive (order grows linearly with frequency).  -> (nScales, N, C)."""
+    dt = 1 / samplerate
+    if not adaptive:
+        cycles = c_1 * np.arange(order_min, order_max + 1)
+        n_ord = order_max + 1 - order_min
+        g = np.power(cwt_sl(x, cycles[0], scales, dt), 1 / n_ord)
+        for c in cycles[1:]:
+            g *= np.power(cwt_sl(x, c, scales, dt), 1 / n_ord)
+        return g
+    fois = 1 / (2 * np.pi * scales)
+    orders = adaptive_order(fois, order_min, order_max)
+    orders_int = np.int32(np.floor(orders))
+    cycles = c_1 * np.unique(orders_int)
+    exponents = 1 / (orders - order_min + 1)
+    jumps = np.where(np.diff(orders_int))[0]
+    assert len(cycles) == len(jumps) + 1
+    alphas = orders % orders_int
+    g = np.power(cwt_sl(x, cycles[0], scales, dt).T, exponents).T
+    last = 1
+    for i, jump in enumerate(jumps):
+        nxt = cwt_sl(x, cycles[i + 1], scales[last:], dt)
+        span = slice(last, jump + 1)
+        g[span, :] *= np.power(nxt[:jump - last + 1].T, alphas[span] * exponents[span]).T
+        g[jump + 1:] *= np.power(nxt[jump - last + 1:].T, exponents[jump + 1:]).T
+        last = jump + 1
+    return g
+
+
+def superlet_cF(trl, preselect, postselect, toi=None, timeAxis=0, polyremoval=0, output="pow",
+                noCompute=False, chunkShape=None, method_kwargs=None):
+    """specest/compRoutines.py:655-764; method_kwargs = {samplerate, scales, order_max, order_min, c_1, adaptive}."""
+    dat = trl.T if timeAxis != 0 else trl
+    n_time = toi.size if isinstance(toi, np.ndarray) else dat.shape[0]
+    scales = method_kwargs["scales"]
+    shape = (n_time, 1, scales.size, dat.shape[1])
+    if noCompute:
+        return shape, OUT_DTYPE[output]
+    dat = detrend(dat, polyremoval)
+    spec = superlet(dat[preselect, :], **method_kwargs)
+    spec = spec.transpose(1, 0, 2)[postselect]
+    return convert_output(spec[:, None, :, :], output)
+
+
+# --------------------------------------------------------------------------
 # X1-X5: cross-spectral densities and coherence
 # --------------------------------------------------------------------------
 def csd(x, fs=1, n_fft=None, taper="hann", taper_opt=None, demean_taper=False, faithful=True):

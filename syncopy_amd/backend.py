@@ -76,12 +76,12 @@ def to_host(t):
 _handover = {}
 
 
-def handover_buffer(shape, device):
-    key = (tuple(shape), str(device))
+def handover_buffer(shape, device, dtype=torch.complex64):
+    key = (tuple(shape), str(device), dtype)
     buf = _handover.get(key)
     if buf is None:
         _handover.clear()                       # keep at most one (they are large)
-        buf = torch.empty(shape, dtype=torch.complex64, device=device)
+        buf = torch.empty(shape, dtype=dtype, device=device)
         _handover[key] = buf
     return buf
 
@@ -177,7 +177,9 @@ class CWTPlan:
     """spyhip_cwt_plan: Morlet CWT (overlap-save FFT convolution) of segments of the trial matrix."""
 
     def __init__(self, nsig, nchan, scales, dt, w0=6.0, detrend=None, output="pow", tpos=None, ntime_out=None,
-                 device=None):
+                 device=None, sl_cycles=None, k_sd=5.0):
+        """`sl_cycles`: superlet formulation MorletSL with that many cycles (spyhip_cwt_plan_create_sl) instead of
+        Morlet(w0)."""
         self.ctx = context(device)
         scales = np.ascontiguousarray(scales, dtype=np.float64)
         self.nsig, self.nchan, self.nscales = int(nsig), int(nchan), int(scales.size)
@@ -190,9 +192,15 @@ class CWTPlan:
             tp, self.ntime_out = tpa.ctypes.data_as(_lib.c_i32p), int(ntime_out)
         h = C.c_void_p()
         self.ctx.bind_stream()
-        check(self.ctx.lib.spyhip_cwt_plan_create(
-            self.ctx.handle, self.nsig, self.nchan, self.nscales, scales.ctypes.data_as(_lib.c_f64p), float(dt),
-            float(w0), DETREND[detrend], self.kind, tp, self.ntime_out, C.byref(h)), "spyhip_cwt_plan_create")
+        if sl_cycles is not None:
+            check(self.ctx.lib.spyhip_cwt_plan_create_sl(
+                self.ctx.handle, self.nsig, self.nchan, self.nscales, scales.ctypes.data_as(_lib.c_f64p), float(dt),
+                float(sl_cycles), float(k_sd), DETREND[detrend], self.kind, tp, self.ntime_out, C.byref(h)),
+                "spyhip_cwt_plan_create_sl")
+        else:
+            check(self.ctx.lib.spyhip_cwt_plan_create(
+                self.ctx.handle, self.nsig, self.nchan, self.nscales, scales.ctypes.data_as(_lib.c_f64p), float(dt),
+                float(w0), DETREND[detrend], self.kind, tp, self.ntime_out, C.byref(h)), "spyhip_cwt_plan_create")
         self.handle = h
         self.out_dtype = torch.complex64 if self.kind == 2 else torch.float32
 
@@ -388,6 +396,40 @@ def ccov_normalize_(cc):
     ctx.bind_stream()
     check(ctx.lib.spyhip_ccov_normalize(ctx.handle, _ptr(cc), cc.shape[0], cc.shape[1]), "spyhip_ccov_normalize")
     return cc
+
+
+def slt_combine(acc, spec, s0, expo, init, modulus_only=False, square=False):
+    """One factor of the superlet geometric mean: acc[..., s0+q, :] = (init ? 1 : acc) * spec[..., q, :] ** expo[q].
+    acc (nseg, ntime, nscales, C), spec (nseg, ntime, nsub, C) on the device, complex64 - or float32 moduli (ABS output
+    of the plan; `square` stores the squared product: last factor of a POW output); expo: nsub host floats;
+    modulus_only (complex arrays): fold |spec| ** expo."""
+    real = acc.dtype == torch.float32
+    assert acc.is_cuda and acc.is_contiguous() and acc.dim() == 4 and acc.dtype in (torch.complex64, torch.float32)
+    assert spec.is_cuda and spec.dtype == acc.dtype and spec.is_contiguous() and spec.dim() == 4
+    assert acc.shape[:2] == spec.shape[:2] and acc.shape[3] == spec.shape[3]
+    assert real or not square
+    expo = np.ascontiguousarray(expo, dtype=np.float64)
+    assert expo.size == spec.shape[2] and s0 + expo.size <= acc.shape[2]
+    mode = (2 | (4 if square else 0)) if real else int(bool(modulus_only))
+    ctx = context(acc.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_slt_combine(ctx.handle, _ptr(acc), _ptr(spec), acc.shape[0] * acc.shape[1], acc.shape[2],
+                                     spec.shape[2], int(s0), acc.shape[3], expo.ctypes.data_as(_lib.c_f64p),
+                                     int(bool(init)), mode), "spyhip_slt_combine")
+    return acc
+
+
+def spec_convert(spec, output):
+    """spectralConversions of a complex64 device tensor: real kinds -> float32 tensor, 'fourier'/'complex' -> itself."""
+    kind = OUTPUT_KIND[output]
+    if kind == 2:
+        return spec
+    assert spec.is_cuda and spec.dtype == torch.complex64 and spec.is_contiguous()
+    out = torch.empty(spec.shape, dtype=torch.float32, device=spec.device)
+    ctx = context(spec.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_spec_convert(ctx.handle, _ptr(spec), spec.numel(), kind, _ptr(out)), "spyhip_spec_convert")
+    return out
 
 
 def granger(csd, rtol=5e-6, niter=100, cond_max=1e4, eps_max=1e-1, want_factors=False):

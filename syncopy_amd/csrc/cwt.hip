@@ -71,9 +71,30 @@ int launch_cwt_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
 }
 }  // namespace
 
+// family 0: Morlet(w0 = p0) as Morlet.time / cwt_time sample it; family 1: the superlet formulation MorletSL with
+// p0 = c_i cycles inside the Gaussian envelope of p1 = k_sd standard deviations (specest/superlet.py:268-363)
+static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales, double dt,
+                                int family, double p0, double p1, int detrend, int output, const int32_t* tpos,
+                                int ntime_out, spyhip_cwt_plan** out);
+
 extern "C" int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
                                       double dt, double w0, int detrend, int output, const int32_t* tpos,
                                       int ntime_out, spyhip_cwt_plan** out) {
+    return cwt_plan_create_impl(ctx, nsig, nchan, nscales, scales, dt, 0, w0, 0.0, detrend, output, tpos, ntime_out, out);
+}
+
+extern "C" int spyhip_cwt_plan_create_sl(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
+                                         double dt, double cycles, double k_sd, int detrend, int output,
+                                         const int32_t* tpos, int ntime_out, spyhip_cwt_plan** out) {
+    if (!(cycles > 0) || !(k_sd > 0)) { spy::set_error("cwt_plan_create_sl: cycles and k_sd must be positive"); return -1; }
+    return cwt_plan_create_impl(ctx, nsig, nchan, nscales, scales, dt, 1, cycles, k_sd, detrend, output, tpos,
+                                ntime_out, out);
+}
+
+static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales, double dt,
+                                int family, double p0, double p1, int detrend, int output, const int32_t* tpos,
+                                int ntime_out, spyhip_cwt_plan** out) {
+    const double w0 = p0;
     if (!ctx || !scales || !out) { spy::set_error("cwt_plan_create: null argument"); return -1; }
     if (nsig < 1 || nchan < 1 || nscales < 1 || dt <= 0) { spy::set_error("cwt_plan_create: bad shape"); return -1; }
     if (output < SPYHIP_OUT_POW || output > SPYHIP_OUT_ABSIMAG) { spy::set_error("bad output kind %d", output); return -1; }
@@ -84,7 +105,7 @@ extern "C" int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int 
     std::vector<Ker> kers(nscales);
     for (int s = 0; s < nscales; ++s) {
         const double sc = scales[s];
-        const double M = 10.0 * sc / dt;
+        const double M = family == 1 ? 10.0 * sc * p0 / dt : 10.0 * sc / dt;       // superlet.py:366-375
         const double t0 = (-M + 1.0) / 2.0, t1 = (M + 1.0) / 2.0;
         long long L = (long long)std::ceil(t1 - t0);               // len(np.arange(t0, t1))
         if (L < 1) L = 1;
@@ -96,10 +117,19 @@ extern "C" int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int 
         k.c = (int)(c - m0);
         const double norm = std::sqrt(dt) / (sc * 8.0 * PI) * std::pow(PI, -0.25);
         const double corr = std::exp(-0.5 * w0 * w0);
+        // MorletSL: sqrt(dt)/(4 pi) * k_sd / (s c (2 pi)^1.5) * exp(i t/s) * exp(-(k_sd t/s / (2 pi c))^2 / 2)
+        const double norm_sl = std::sqrt(dt) / (4.0 * PI) * p1 / (sc * p0 * std::pow(2.0 * PI, 1.5));
         k.re.resize(m1 - m0);
         k.im.resize(m1 - m0);
         for (long long m = m0; m < m1; ++m) {
             const double x = (t0 + (double)m) * dt / sc;            // t / s
+            if (family == 1) {
+                const double u = p1 * x / (2.0 * PI * p0);
+                const double g = norm_sl * std::exp(-0.5 * u * u);
+                k.re[m - m0] = g * std::cos(x);
+                k.im[m - m0] = g * std::sin(x);
+                continue;
+            }
             const double g = norm * std::exp(-0.5 * x * x);
             k.re[m - m0] = g * (std::cos(w0 * x) - corr);
             k.im[m - m0] = g * std::sin(w0 * x);
@@ -262,5 +292,47 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         else hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float>, sg, dim3(256), 0, p->ctx->stream, c);
         SPY_HIP_CHECK(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" int spyhip_slt_combine(spyhip_ctx* ctx, void* acc_d, const void* spec_d, int64_t nrows, int nscales,
+                                  int nsub, int s0, int nchan, const double* expo, int init, int modulus_only) {
+    if (!ctx || !acc_d || !spec_d || !expo) { spy::set_error("slt_combine: null argument"); return -1; }
+    if (nrows < 0 || nscales < 1 || nsub < 1 || s0 < 0 || s0 + nsub > nscales || nchan < 1) {
+        spy::set_error("slt_combine: bad shape");
+        return -1;
+    }
+    if (nrows == 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    // the kernel takes <= SLT_MAX_SCALES exponents by value: wider scale sets go in slices
+    for (int q0 = 0; q0 < nsub; q0 += spyfft::SLT_MAX_SCALES) {
+        const int nq = std::min(spyfft::SLT_MAX_SCALES, nsub - q0);
+        spyfft::SltArgs a{};
+        a.acc = reinterpret_cast<float2*>(acc_d);
+        a.spec = reinterpret_cast<const float2*>(spec_d);
+        a.nrows = nrows; a.nscales = nscales; a.nsub = nq; a.s0 = s0 + q0; a.nchan = nchan; a.init = init;
+        a.nsub_total = nsub; a.q0 = q0; a.modulus_only = modulus_only & 3; a.square = (modulus_only >> 2) & 1;
+        for (int q = 0; q < nq; ++q) a.expo[q] = expo[q0 + q];
+        const long long blocks = ((long long)nrows * nq * nchan + 255) / 256;
+        if (blocks > 0x7fffffffLL) { spy::set_error("slt_combine: grid too large"); return -1; }
+        hipLaunchKernelGGL(spyfft::slt_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+    }
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int spyhip_spec_convert(spyhip_ctx* ctx, const void* in_d, int64_t n, int output, void* out_d) {
+    if (!ctx || !in_d || !out_d) { spy::set_error("spec_convert: null argument"); return -1; }
+    if (output < SPYHIP_OUT_POW || output > SPYHIP_OUT_ABSIMAG || output == SPYHIP_OUT_FOURIER) {
+        spy::set_error("spec_convert: %d is not a real output kind", output);
+        return -1;
+    }
+    if (n <= 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) { spy::set_error("spec_convert: grid too large"); return -1; }
+    hipLaunchKernelGGL(spyfft::spec_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const float2*>(in_d), (long long)n, output, reinterpret_cast<float*>(out_d));
+    SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }

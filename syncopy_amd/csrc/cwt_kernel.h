@@ -326,4 +326,92 @@ __global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
     }
 }
 
+// ---- superlets (specest/superlet.py:97-211): geometric mean over the wavelet set, one order at a time ----------
+// acc[r, s0+q, c] = (init ? 1 : acc[...]) * spec[r, q, c] ^ expo[q]   (principal branch, 0^e = 0 for e > 0).
+// The modulus goes through a split log2 / exp2 (see below) so that its error does not scale with log|z|; the phase
+// (atan2f, sincosf) is skipped altogether for outputs that only need the modulus.
+constexpr int SLT_MAX_SCALES = 128;
+struct SltArgs {
+    float2* acc;
+    const float2* spec;
+    long long nrows;
+    int nscales, nsub, s0, nchan, init;
+    int nsub_total, q0;          // this launch covers the scales [q0, q0 + nsub) of spec's nsub_total
+    int modulus_only;            // 1: |spec|^expo instead of spec^expo (no phase work); 2: acc and spec are REAL
+                                 // float32 arrays holding moduli (ABS output of the plan) - half the traffic
+    int square;                  // modulus_only == 2: store the square of the product (last factor, POW output)
+    double expo[SLT_MAX_SCALES];
+};
+
+__global__ void __launch_bounds__(256) slt_combine_kernel(SltArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = a.nrows * a.nsub * a.nchan;
+    if (idx >= n) return;
+    const int c = (int)(idx % a.nchan), q = (int)((idx / a.nchan) % a.nsub);
+    const long long r = idx / ((long long)a.nchan * a.nsub);
+    const double e = a.expo[q];
+    const size_t di = ((size_t)r * a.nscales + a.s0 + q) * a.nchan + c;
+    const size_t si = ((size_t)r * a.nsub_total + a.q0 + q) * a.nchan + c;
+    if (a.modulus_only == 2) {
+        float* const dst = reinterpret_cast<float*>(a.acc) + di;
+        if (e == 0.0 && !a.init && !a.square) return;
+        const float m = reinterpret_cast<const float*>(a.spec)[si];
+        float p = 1.f;
+        if (e != 0.0) {
+            p = 0.f;
+            if (m > 0.f) {
+                int ex;
+                const float mant = frexpf(m, &ex);
+                const double t = e * ((double)ex + (double)__log2f(mant));
+                const double ti = floor(t);
+                p = ldexpf(exp2f((float)(t - ti)), (int)ti);
+            }
+        }
+        float g = a.init ? p : *dst * p;
+        if (a.square) g *= g;
+        *dst = g;
+        return;
+    }
+    float2* dst = a.acc + di;
+    if (e == 0.0 && !a.init) return;                    // z^0 = 1
+    const float2 z = a.spec[si];
+    float px = 1.f, py = 0.f;
+    if (e != 0.0) {
+        const double m2 = (double)z.x * z.x + (double)z.y * z.y;
+        if (m2 > 0.0) {
+            // |z|^e = 2^(e/2 * log2 |z|^2): exponent and mantissa of |z|^2 apart (log2f of [1,2) is good to 1e-7
+            // absolute whatever the magnitude), the product with e/2 and the split into integer + fraction in fp64,
+            // 2^fraction in fp32, the integer part by ldexp
+            int ex;
+            const float mant = frexpf((float)m2, &ex);                      // (float)m2 never flushes: |z| is fp32
+            const double t = 0.5 * e * ((double)ex + (double)__log2f(mant));
+            const double ti = floor(t);
+            const float mag = ldexpf(exp2f((float)(t - ti)), (int)ti);
+            if (a.modulus_only) {
+                px = mag;
+            } else {
+                float sn, cs;
+                sincosf((float)(e * (double)atan2f(z.y, z.x)), &sn, &cs);
+                px = mag * cs;
+                py = mag * sn;
+            }
+        } else {
+            px = 0.f;
+        }
+    }
+    if (a.init) {
+        *dst = make_float2(px, py);
+    } else {
+        const float2 g = *dst;
+        *dst = make_float2(g.x * px - g.y * py, g.x * py + g.y * px);
+    }
+}
+
+// spectralConversions (shared/const_def.py:25-33) of a complex64 array: any real output kind -> float32
+__global__ void __launch_bounds__(256) spec_convert_kernel(const float2* in, long long n, int kind, float* out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    out[idx] = convert_real_slow(in[idx], kind);
+}
+
 }  // namespace spyfft

@@ -9,6 +9,6 @@ spectralDTypes = {
 
 availableTapers = [w for w in windows.__all__ if w not in ("get_window", "exponential", "dpss")]
 availablePaddingOpt = ["maxperlen", "nextpow2"]
-availableMethods = ("mtmfft", "mtmconvol", "wavelet", "welch")
+availableMethods = ("mtmfft", "mtmconvol", "wavelet", "superlet", "welch")
 connectivityMethods = ("coh", "corr", "csd", "granger", "ppc")
 connectivity_outputs = {"abs", "pow", "complex", "fourier", "angle", "real", "imag"}

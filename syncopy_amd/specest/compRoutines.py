@@ -301,6 +301,106 @@ class WaveletTransform(ComputationalRoutine):
         out.freq = getattr(self, "_foi", None)
 
 
+def _superlet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwargs):
+    """Superlet spectra of trials `rows` with per-trial pre/post-selections: one CWT plan per order of the set
+    (MorletSL kernels, complex output), each folded into the geometric mean by spyhip_slt_combine, converted at the
+    end.  Returns a list of (nTime, 1, nScales, C) device tensors."""
+    from .wavelet_tools import superlet_steps
+    device = dev.device
+    nchan = dev.shape[1] if chans is None else len(chans)
+    ci = None if chans is None else torch.tensor(np.asarray(chans), dtype=torch.int32, device=device)
+    scales = np.asarray(method_kwargs["scales"], dtype=np.float64)
+    dt = 1.0 / method_kwargs["samplerate"]
+    steps = superlet_steps(scales, method_kwargs["order_max"], method_kwargs.get("order_min", 1),
+                           method_kwargs.get("c_1", 3), method_kwargs.get("adaptive", False))
+    results = [None] * len(rows)
+    groups = {}
+    for k, ((a, b), ps, qs) in enumerate(zip(rows, pre, post)):
+        s0, s1, _ = ps.indices(b - a)
+        nsig = max(s1 - s0, 0)
+        tpos, nuniq, gather = _postselect_map(nsig, qs)
+        key = (nsig, None if tpos is None else tpos.tobytes(), None if gather is None else gather.tobytes())
+        groups.setdefault(key, (nsig, tpos, nuniq, gather, []))[4].append((k, a + s0, a, b))
+    for nsig, tpos, nuniq, gather, members in groups.values():
+        ntime = nsig if tpos is None else nuniq
+        # bound the two complex work arrays (product and one order's transform) to ~8 GiB
+        per_trial = ntime * scales.size * nchan * 8 * 2
+        bmax = max(1, int((8 << 30) // max(per_trial, 1)))
+        for i0 in range(0, len(members), bmax):
+            part = members[i0:i0 + bmax]
+            starts = torch.tensor([m[1] for m in part], dtype=torch.int64, device=device)
+            lo = torch.tensor([m[2] for m in part], dtype=torch.int64, device=device)
+            hi = torch.tensor([m[3] for m in part], dtype=torch.int64, device=device)
+            # pow / abs need moduli only: the plans deliver |W| as float32 and the product stays real (half the
+            # traffic, no phase arithmetic); every other output folds the complex transforms
+            real = output in ("pow", "abs")
+            wdt = torch.float32 if real else torch.complex64
+            acc = torch.empty((len(part), ntime, scales.size, nchan), dtype=wdt, device=device)
+            for n, (cycles, sc0, expo) in enumerate(steps):
+                pkey = ("sl", nsig, nchan, scales[sc0:].tobytes(), dt, cycles, polyremoval, real,
+                        None if tpos is None else tpos.tobytes(), str(device))
+                if pkey not in _cwt_plans:
+                    _cwt_plans[pkey] = hs.backend.CWTPlan(nsig, nchan, scales[sc0:], dt, detrend=polyremoval,
+                                                          output="abs" if real else "fourier", tpos=tpos,
+                                                          ntime_out=nuniq, device=device, sl_cycles=cycles)
+                plan = _cwt_plans[pkey]
+                buf = hs.backend.handover_buffer(plan.out_shape(len(part)), device, dtype=wdt)
+                spec = plan.execute(dev, starts, lo, hi, chan_idx=ci, out=buf)
+                # POW: the product is squared on its way out - with the last factor if that one covers every scale
+                # (multiplicative set), else in one more pass (adaptive set: later orders cover fewer scales)
+                fused_sq = real and output == "pow" and n == len(steps) - 1 and sc0 == 0
+                hs.backend.slt_combine(acc, spec, sc0, expo, init=(n == 0), square=fused_sq)
+            if real and output == "pow" and not fused_sq:
+                hs.backend.slt_combine(acc, acc, 0, np.zeros(scales.size), init=False, square=True)
+            res = acc if real else hs.backend.spec_convert(acc, output)
+            for i, m in enumerate(part):
+                r = res[i]
+                if gather is not None:
+                    r = r.index_select(0, torch.from_numpy(gather).to(device))
+                results[m[0]] = r.unsqueeze(1)
+    return results
+
+
+def superlet_cF(trl_dat, preselect, postselect, toi=None, timeAxis=0, polyremoval=0, output="pow", noCompute=False,
+                chunkShape=None, method_kwargs=None):
+    """Superlet transform of one trial (signature of specest/compRoutines.py:655-764); returns
+    (nTime, 1, nScales, nChannel)."""
+    dat = trl_dat.T if timeAxis != 0 else trl_dat
+    nChannels = dat.shape[1]
+    nTime = toi.size if isinstance(toi, np.ndarray) else dat.shape[0]
+    nScales = method_kwargs["scales"].size
+    outShape = (nTime, 1, nScales, nChannels)
+    if noCompute:
+        return outShape, spectralDTypes[output]
+    dev = _as_device_trial(trl_dat, timeAxis)
+    res = _superlet_device(dev, [(0, dev.shape[0])], [preselect], [postselect], None, polyremoval, output,
+                           method_kwargs)[0]
+    return hs.backend.to_host(res)
+
+
+class SuperletTransform(ComputationalRoutine):
+    computeFunction = staticmethod(superlet_cF)
+    valid_kws = ["preselect", "postselect", "toi", "timeAxis", "polyremoval", "output", "method_kwargs", "samplerate",
+                 "scales", "order_max", "order_min", "c_1", "adaptive"]
+
+    def compute_hip(self, data, out):
+        cfg = self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        mine = list(self.my_trials())
+        pre = [self._argv(k)[0] for k in mine]
+        post = [self._argv(k)[1] for k in mine]
+        parts = _superlet_device(dev, [rows[k] for k in mine], pre, post, chans, cfg["polyremoval"], cfg["output"],
+                                 cfg["method_kwargs"])
+        _store_trials(self, out, parts)
+
+    def process_metadata(self, data, out):
+        propagate_properties(data, out, self.keeptrials, time_axis=True)
+        out.trialdefinition, out.samplerate = _make_trialdef(self.cfg, out.trialdefinition.copy(), data.samplerate)
+        out.taper = np.array(["None"])
+        out.freq = getattr(self, "_foi", None)
+
+
 def _store_trials(cr, out, parts, stack=False):
     """Results of this rank's trials -> `out.data`: concatenated along the stacking axis in rank order
     (keeptrials) or summed sequentially in the output dtype, all-reduced once and divided by the global

@@ -1,4 +1,4 @@
-"""`freqanalysis` metafunction: parameter resolution for mtmfft / mtmconvol / wavelet.
+"""`freqanalysis` metafunction: parameter resolution for mtmfft / mtmconvol / welch / wavelet / superlet.
 
 Reproduces the parameter -> kernel-argument mapping of syncopy/specest/freqanalysis.py
 (padding :459-461, foi :600-612, tapers :622-632, sliding windows :670-820,
@@ -28,8 +28,9 @@ def _scalar(value, varname, lims):
 
 def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None, foilim=None, pad="maxperlen",
                  polyremoval=0, taper="hann", demean_taper=False, taper_opt=None, tapsmofrq=None, nTaper=None,
-                 keeptapers=False, toi="all", t_ftimwin=None, wavelet="Morlet", width=6, order=None, ft_compat=False,
-                 select=None, compute_method=None, routine_classes=None, **kwargs):
+                 keeptapers=False, toi="all", t_ftimwin=None, wavelet="Morlet", width=6, order=None, order_max=None,
+                 order_min=1, c_1=3, adaptive=False, ft_compat=False, select=None, compute_method=None,
+                 routine_classes=None, **kwargs):
     """Spectral estimation of AnalogData on MI355X.  Arguments as spy.freqanalysis
     (freqanalysis.py:62-90).  `compute_method`: None/'hip' (batched from the in-HBM trial
     queue) or 'sequential' (the reference's per-trial loop over the same kernels).
@@ -38,8 +39,9 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
         raise SPYTypeError(data, varname="data", expected="non-empty AnalogData")
     classes = {"mtmfft": MultiTaperFFT, "mtmconvol": MultiTaperFFTConvol}
     try:
-        from .compRoutines import WaveletTransform
+        from .compRoutines import SuperletTransform, WaveletTransform
         classes["wavelet"] = WaveletTransform
+        classes["superlet"] = SuperletTransform
     except ImportError:
         pass
     classes.update(routine_classes or {})
@@ -61,14 +63,14 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
     try:
         return _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
                              demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin, wavelet, width,
-                             ft_compat, compute_method)
+                             ft_compat, compute_method, (order_max, order_min, c_1, adaptive))
     finally:
         data.selection = None
 
 
 def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
                   demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin, wavelet, width, ft_compat,
-                  compute_method):
+                  compute_method, slt=(None, 1, 3, False)):
     fs = data.samplerate
     trl = selected_trialdefinition(data)
     sinfo = trl[:, :2]
@@ -193,27 +195,7 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
         # `order` branch at :861-864 then replaces it by a default-constructed Morlet(), so
         # `width` never reaches the transform and w0 is always 6.
         width = 6.0
-        preSelect, postSelect = [slice(None)] * numTrials, [slice(None)] * numTrials
-        if isinstance(toi, str):
-            if toi != "all":
-                raise SPYValueError("`toi = 'all'` to center wavelets on all time-points", varname="toi", actual=toi)
-        else:
-            toi = np.array(toi, dtype=float)
-            if toi.ndim != 1 or toi.size == 0:
-                raise SPYValueError("1d array of time-points", varname="toi", actual=str(toi.shape))
-            if toi.min() < tStart.min() or toi.max() > tEnd.max():
-                raise SPYValueError(f"all array elements to be bounded by {tStart.min()} and {tEnd.max()}",
-                                    varname="toi", actual=f"array with range {toi.min()} to {toi.max()}")
-            if toi.size > 2 and not np.allclose(np.diff(toi, 2), np.zeros(len(toi) - 2)):
-                raise SPYValueError("array of equidistant time-points or 'all' for wavelet based methods",
-                                    varname="toi", actual=toi)
-            preSelect, postSelect = [], []
-            for tk in range(numTrials):
-                start = int(fs * (toi[0] - tStart[tk]))
-                stop = int(fs * (toi[-1] - tStart[tk]) + 1)
-                preSelect.append(slice(max(0, start), max(stop, stop - start)))
-                smpIdx = np.minimum(lenTrials[tk] - 1, fs * (toi - tStart[tk]) - start)
-                postSelect.append(smpIdx.astype(np.intp))
+        toi, preSelect, postSelect = _wavelet_toi(toi, numTrials, tStart, tEnd, lenTrials, fs)
         if foi is None and foilim is None:
             scales = optimal_wavelet_scales(int(minTrialLength * fs), dt, w0=width)
             foi = 1 / (4 * np.pi * scales / (width + np.sqrt(2 + width ** 2)))
@@ -228,12 +210,80 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
                                 output=output, method_kwargs=method_kwargs)
         cr._foi = foi
 
+    elif method == "superlet":
+        if "superlet" not in classes:
+            raise NotImplementedError("superlet transform kernels are not part of this build")
+        from .wavelet_tools import optimal_wavelet_scales
+        order_max, order_min, c_1, adaptive = slt
+        if order_max is None:
+            raise SPYValueError("Positive integer needed for order_max", varname="order_max", actual=None)
+        _int_like(order_max, "order_max", 1, np.inf)
+        _int_like(order_min, "order_min", 1, order_max)
+        _int_like(c_1, "c_1", 1, np.inf)
+        toi, preSelect, postSelect = _wavelet_toi(toi, numTrials, tStart, tEnd, lenTrials, fs)
+        if foi is None and foilim is None:
+            # scale_from_period(p) = p / (2 pi), fourier_period(s) = 2 pi s (superlet.py:295-308)
+            scales = optimal_wavelet_scales(int(minTrialLength * fs), dt, scale_from_period=lambda p: p / (2 * np.pi))
+            foi = 1 / (2 * np.pi * scales)
+        else:
+            if foilim is not None:
+                foi = np.arange(foilim[0], foilim[1] + 1, dtype=float)
+            foi = np.asarray(foi, dtype=float).copy()
+            foi[foi < 0.01] = 0.01
+            scales = (1.0 / foi) / (2 * np.pi)
+        if adaptive:
+            if len(scales) < 2:
+                raise SPYValueError("A range of frequencies", varname="foi", actual="Single frequency")
+            if np.any(np.diff(scales) > 0):
+                SPYWarning("Sorting frequencies low to high for adaptive SLT..")
+                scales = np.sort(scales)[::-1]
+        method_kwargs = {"samplerate": fs, "scales": scales, "order_max": int(order_max), "order_min": int(order_min),
+                         "c_1": int(c_1), "adaptive": bool(adaptive)}
+        cr = classes["superlet"](preSelect, postSelect, toi=toi, timeAxis=timeAxis, polyremoval=polyremoval,
+                                 output=output, method_kwargs=method_kwargs)
+        cr._foi = foi
+
     out = SpectralData(dimord=SpectralData._defaultDimord)
     cr.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=keeptrials)
     cr.compute(data, out, parallel=False, log_dict=log_dct, method=compute_method)
     if method == "welch":
         out = _time_mean(out)
     return out
+
+
+def _wavelet_toi(toi, numTrials, tStart, tEnd, lenTrials, fs):
+    """`toi` of the wavelet based methods (freqanalysis.py:511-560): 'all' or equidistant time-points -> per-trial
+    pre-selection (interval to transform) and post-selection (samples to keep)."""
+    preSelect, postSelect = [slice(None)] * numTrials, [slice(None)] * numTrials
+    if isinstance(toi, str):
+        if toi != "all":
+            raise SPYValueError("`toi = 'all'` to center wavelets on all time-points", varname="toi", actual=toi)
+    else:
+        toi = np.array(toi, dtype=float)
+        if toi.ndim != 1 or toi.size == 0:
+            raise SPYValueError("1d array of time-points", varname="toi", actual=str(toi.shape))
+        if toi.min() < tStart.min() or toi.max() > tEnd.max():
+            raise SPYValueError(f"all array elements to be bounded by {tStart.min()} and {tEnd.max()}",
+                                varname="toi", actual=f"array with range {toi.min()} to {toi.max()}")
+        if toi.size > 2 and not np.allclose(np.diff(toi, 2), np.zeros(len(toi) - 2)):
+            raise SPYValueError("array of equidistant time-points or 'all' for wavelet based methods",
+                                varname="toi", actual=toi)
+        preSelect, postSelect = [], []
+        for tk in range(numTrials):
+            start = int(fs * (toi[0] - tStart[tk]))
+            stop = int(fs * (toi[-1] - tStart[tk]) + 1)
+            preSelect.append(slice(max(0, start), max(stop, stop - start)))
+            smpIdx = np.minimum(lenTrials[tk] - 1, fs * (toi - tStart[tk]) - start)
+            postSelect.append(smpIdx.astype(np.intp))
+    return toi, preSelect, postSelect
+
+
+def _int_like(val, name, lo, hi):
+    """scalar_parser(..., ntype="int_like") (shared/parsers.py:133-222)."""
+    if isinstance(val, bool) or not isinstance(val, numbers.Number) or not np.isfinite(val) or int(val) != val:
+        raise SPYTypeError(val, varname=name, expected="int_like scalar")
+    if not lo <= val <= hi:
+        raise SPYValueError(f"value to be greater or equals {lo} and less or equals {hi}", varname=name, actual=val)
 
 
 def _time_mean(spec):

@@ -36,6 +36,16 @@ class OracleWaveletTransform(ComputationalRoutine):
         out.freq = getattr(self, "_foi", None)
 
 
+def _superlet_cF(trl, preselect, postselect, toi=None, timeAxis=0, polyremoval=None, output="pow", noCompute=False,
+                 chunkShape=None, method_kwargs=None):
+    return O.superlet_cF(trl, preselect, postselect, toi, timeAxis, polyremoval, output, noCompute, chunkShape,
+                         method_kwargs)
+
+
+class OracleSuperletTransform(OracleWaveletTransform):
+    computeFunction = staticmethod(_superlet_cF)
+
+
 def _cross_spectra_cF(trl, samplerate=1, nSamples=None, foi=None, taper="hann", taper_opt=None, demean_taper=False,
                       polyremoval=False, timeAxis=0, chunkShape=None, noCompute=False):
     return O.cross_spectra_cF(trl, samplerate, nSamples, foi, taper, taper_opt, demean_taper, polyremoval, timeAxis,
@@ -86,7 +96,7 @@ class OracleNormalizeCrossCov(NormalizeCrossCov):
 
 
 ORACLE_FREQ = {"mtmfft": OracleMultiTaperFFT, "mtmconvol": OracleMultiTaperFFTConvol,
-               "wavelet": OracleWaveletTransform}
+               "wavelet": OracleWaveletTransform, "superlet": OracleSuperletTransform}
 ORACLE_CONN = {"csd": OracleCrossSpectra, "coh": OracleNormalizeCrossSpectra, "granger": OracleGrangerCausality,
                "dyadic": OracleSpectralDyadicProduct, "ppc": O.ppc,
                "ccov": OracleCrossCovariance, "ccov_norm": OracleNormalizeCrossCov}

@@ -8,8 +8,8 @@ import pytest
 import syncopy_amd as spy
 from oracle_routines import ORACLE_CONN, ORACLE_FREQ
 from parity import assert_parity
-from test_oracle_golden import (JACK_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, chain_checks, check_jackknife,
-                                cmb_checks, corr_checks, ppc_checks)
+from test_oracle_golden import (JACK_VARIANTS, SLT_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, chain_checks,
+                                check_jackknife, check_superlet, cmb_checks, corr_checks, ppc_checks)
 
 pytestmark = pytest.mark.gpu
 
@@ -99,6 +99,19 @@ def test_corr(golden_dir, how):
     floor is 1e-5 of the largest value (the zero-lag auto-correlation 1)."""
     corr_checks(_load(golden_dir, "conn_next"), lambda d, **kw: spy.connectivityanalysis(d, compute_method=how, **kw),
                 atol_rel=1e-5)
+
+
+@pytest.mark.parametrize("how", ["hip", "sequential"])
+@pytest.mark.parametrize("name", sorted(SLT_VARIANTS))
+def test_superlet_variants(golden_dir, name, how):
+    """method='superlet': one MorletSL CWT per order of the set (K3 with the superlet kernel family), folded into
+    the geometric mean on the device - against the reference's multiplicative / fractional adaptive transforms."""
+    z = _load(golden_dir, "superlet_variants")
+    data = spy.AnalogData(np.concatenate(list(z["data"])), samplerate=float(z["samplerate"]),
+                          trialdefinition=z["trialdefinition"])
+    # a root of a small modulus amplifies the fp32 transform's ABSOLUTE error (d|z|^e = e |z|^(e-1) d|z|): the floor is
+    # widened from 1e-6 to 5e-6 of the largest value
+    check_superlet(spy.freqanalysis(data, compute_method=how, **SLT_VARIANTS[name]), z, name, atol_rel=5e-6)
 
 
 @pytest.mark.parametrize("name", sorted(JACK_VARIANTS))

@@ -297,6 +297,44 @@ def test_ccov_vs_oracle(be, C, N, T, pr):
                   what="single-trial cross-correlation (np.std products)", atol_rel=1e-5)
 
 
+def test_slt_combine_and_convert(be):
+    """One factor of the superlet geometric mean (principal-branch complex power, 0^e = 0, exponent 0 = untouched,
+    scale offset, > 128 scales per call) and the real conversions, against NumPy."""
+    rng = np.random.default_rng(8)
+    nseg, nt, ns, nsub, s0, C = 2, 37, 150, 140, 10, 3
+    acc = (rng.normal(size=(nseg, nt, ns, C)) + 1j * rng.normal(size=(nseg, nt, ns, C))).astype(np.complex64)
+    spec = (rng.normal(size=(nseg, nt, nsub, C)) + 1j * rng.normal(size=(nseg, nt, nsub, C))).astype(np.complex64)
+    spec[0, 0, 0, 0] = 0
+    spec[0, 1, 1, 0] = -2.0                              # on the branch cut: arg = +pi
+    expo = rng.uniform(0.1, 1.0, size=nsub)
+    expo[5] = 0.0
+    ref = acc.astype(np.complex128)
+    ref[:, :, s0:] *= np.power(spec.astype(np.complex128).transpose(0, 1, 3, 2), expo).transpose(0, 1, 3, 2)
+    d_acc, d_spec = torch.from_numpy(acc).cuda(), torch.from_numpy(spec).cuda()
+    got = be.slt_combine(d_acc, d_spec, s0, expo, init=False).cpu().numpy()
+    assert_parity(got, ref.astype(np.complex64), what="slt_combine")
+    assert np.array_equal(got[:, :, :s0], acc[:, :, :s0]) and np.array_equal(got[:, :, s0 + 5], acc[:, :, s0 + 5])
+    init = be.slt_combine(torch.from_numpy(acc).cuda(), d_spec, s0, expo, init=True).cpu().numpy()
+    want = np.power(spec.astype(np.complex128).transpose(0, 1, 3, 2), expo).transpose(0, 1, 3, 2)
+    assert_parity(init[:, :, s0:], want.astype(np.complex64), what="slt_combine init")
+    assert init[0, 0, s0, 0] == 0 and np.all(init[:, :, s0 + 5] == 1)
+    mod = be.slt_combine(torch.from_numpy(np.abs(acc).astype(np.complex64)).cuda(), d_spec, s0, expo, init=False,
+                         modulus_only=True).cpu().numpy()
+    assert_parity(mod.real[:, :, s0:], np.abs(ref[:, :, s0:]).astype(np.float32), what="slt_combine modulus")
+    assert np.all(mod.imag == 0)
+    racc = torch.from_numpy(np.abs(acc)).cuda()
+    rspec = torch.from_numpy(np.abs(spec)).cuda()
+    rgot = be.slt_combine(racc.clone(), rspec, s0, expo, init=False).cpu().numpy()
+    assert_parity(rgot[:, :, s0:], np.abs(ref[:, :, s0:]).astype(np.float32), what="slt_combine real")
+    rsq = be.slt_combine(racc.clone(), rspec, s0, expo, init=False, square=True).cpu().numpy()
+    assert_parity(rsq[:, :, s0:], (np.abs(ref[:, :, s0:]) ** 2).astype(np.float32), what="slt_combine real squared")
+    assert np.array_equal(rsq[:, :, :s0], np.abs(acc)[:, :, :s0])
+    for kind, fn in (("pow", lambda z: np.abs(z) ** 2), ("abs", np.abs), ("real", np.real), ("imag", np.imag)):
+        assert_parity(be.spec_convert(d_spec, kind).cpu().numpy(), fn(spec.astype(np.complex128)).astype(np.float32),
+                      what=kind)
+    assert be.spec_convert(d_spec, "fourier") is d_spec
+
+
 def test_cwt_trial_sum_mode(be):
     """accumulate=2 (out[0] += sum over segments, the keeptrials=False path) equals the sum of the per-segment
     outputs of the plain mode; 5 channels exercise the padded channel pair of the packed kernel."""

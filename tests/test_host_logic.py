@@ -120,3 +120,27 @@ def test_empty_and_ragged_inputs():
     d = _uneq()
     with pytest.raises(SPYValueError):
         spy.freqanalysis(d, method="mtmfft", foilim=[600, 700])                 # outside Nyquist
+
+
+@pytest.mark.parametrize("adaptive,order_max,order_min,c_1", [(False, 3, 1, 3), (False, 4, 2, 5), (True, 6, 1, 3),
+                                                             (True, 4, 2, 4)])
+def test_superlet_steps_reproduce_the_geometric_mean(adaptive, order_max, order_min, c_1):
+    """The (cycles, first scale, exponents) steps the device path folds one by one = the oracle's restatement of
+    multiplicativeSLT / FASLT (specest/superlet.py:97-182), including fractional orders."""
+    from oracle import spy_oracle as O
+    from syncopy_amd.specest.wavelet_tools import superlet_steps
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(400, 2)).astype(np.float32)
+    foi = np.arange(12, 48, 3.0)
+    scales = (1 / foi) / (2 * np.pi)
+    ref = O.superlet(x, 200.0, scales, order_max, order_min, c_1, adaptive)
+    acc = None
+    for n, (cycles, s0, expo) in enumerate(superlet_steps(scales, order_max, order_min, c_1, adaptive)):
+        spec = O.cwt_sl(x, cycles, scales[s0:], 1 / 200.0).astype(np.complex128)
+        fac = np.power(spec.T, expo).T
+        if n == 0:
+            assert s0 == 0
+            acc = fac
+        else:
+            acc[s0:] *= fac
+    np.testing.assert_allclose(np.abs(acc), np.abs(ref), rtol=1e-5, atol=1e-7 * np.abs(ref).max())

@@ -25,7 +25,7 @@ def sync_time(fn, n=3):
 
 
 res = {}
-which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "frontend", "jack", "h2d", "granger", "ppc", "corr"]
+which = sys.argv[1:] or ["c2", "conv", "conv500", "wav", "frontend", "jack", "h2d", "granger", "ppc", "corr", "slt"]
 
 if "c2" in which:
     C, N, T, K = 256, 4096, 1000, 7
@@ -70,6 +70,24 @@ if "corr" in which:
                    "out_GB": 2048 * C * C * 4 / 1e9, "trials_per_s_incl_lags": T / (dt_acc + dt_lag)}
     print("corr", res["corr"], flush=True)
     del data, state
+
+if "slt" in which:
+    # superlets on the c4 shape: 128 ch x 16384 samples, 25 frequencies 4..100 Hz, orders 1..5 (c_1 = 3), pow
+    from syncopy_amd.specest import compRoutines as CR
+    C, N, T = 128, 16384, 8
+    data = synthdata.ar2_uncoupled_fast(C, N, T, seed=7)
+    foi = np.arange(4, 104, 4, dtype=float)
+    mk = {"samplerate": 1000.0, "scales": (1 / foi) / (2 * np.pi), "order_max": 5, "order_min": 1, "c_1": 3,
+          "adaptive": False}
+    rows = [(t * N, (t + 1) * N) for t in range(T)]
+    sl = [slice(None)] * T
+
+    def run():
+        return CR._superlet_device(data, rows, sl, sl, None, 0, "pow", mk)
+    dt = sync_time(run, n=2)
+    res["c4_superlet"] = {"trials_per_s": T / dt, "ms_per_trial": 1e3 * dt / T, "orders": 5}
+    print("slt", res["c4_superlet"], flush=True)
+    del data
 
 if "conv" in which:
     C, N, T = 128, 16384, 100
