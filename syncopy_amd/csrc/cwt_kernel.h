@@ -330,6 +330,11 @@ __global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
 // acc[r, s0+q, c] = (init ? 1 : acc[...]) * spec[r, q, c] ^ expo[q]   (principal branch, 0^e = 0 for e > 0).
 // The modulus goes through a split log2 / exp2 (see below) so that its error does not scale with log|z|; the phase
 // (atan2f, sincosf) is skipped altogether for outputs that only need the modulus.
+#ifdef SPY_HOST_EMU
+#define spy_log2f log2f
+#else
+#define spy_log2f __log2f          // v_log_f32: the argument is a mantissa in [0.5, 1)
+#endif
 constexpr int SLT_MAX_SCALES = 128;
 struct SltArgs {
     float2* acc;
@@ -362,7 +367,7 @@ __global__ void __launch_bounds__(256) slt_combine_kernel(SltArgs a) {
             if (m > 0.f) {
                 int ex;
                 const float mant = frexpf(m, &ex);
-                const double t = e * ((double)ex + (double)__log2f(mant));
+                const double t = e * ((double)ex + (double)spy_log2f(mant));
                 const double ti = floor(t);
                 p = ldexpf(exp2f((float)(t - ti)), (int)ti);
             }
@@ -384,7 +389,7 @@ __global__ void __launch_bounds__(256) slt_combine_kernel(SltArgs a) {
             // 2^fraction in fp32, the integer part by ldexp
             int ex;
             const float mant = frexpf((float)m2, &ex);                      // (float)m2 never flushes: |z| is fp32
-            const double t = 0.5 * e * ((double)ex + (double)__log2f(mant));
+            const double t = 0.5 * e * ((double)ex + (double)spy_log2f(mant));
             const double ti = floor(t);
             const float mag = ldexpf(exp2f((float)(t - ti)), (int)ti);
             if (a.modulus_only) {
