@@ -183,6 +183,19 @@ int spyhip_ppc_accumulate_csd(spyhip_ctx* ctx, const void* csd_d, int ntrials, i
 int spyhip_ppc_finalize(spyhip_ctx* ctx, const void* acc_d, int nfreq, int ni, int nj, int lower_only,
                         int64_t ntrials, void* out_d);
 
+/* ---- K9: streaming jackknife of the coherence --------------------------------
+ * Replaces, for method='coh' with jackknife=True, the T leave-one-out trial averages (statistics/jackknifing.py:14-108),
+ * the AV stage on every replicate (connectivity_analysis.py:736-745) and the sums behind bias_var (:111-184):
+ *   for every trial t of the batch:  S_t = taper mean of X conj(X)^T,  loo = (T*S - S_t)/(T-1)  (complex64),
+ *   c_t = conv(loo_ij / sqrt(loo_ii loo_jj)),  d_t = c_t - direct;   sum_d += d_t,  sum_d2 += |d_t|^2   (float64)
+ * spec_d complex64 (ntrials*ntaper, nfreq, nchan) as for spyhip_ppc_accumulate; csd_d complex64 (nfreq, nchan, nchan)
+ * = the finalised trial average S; direct_d = spyhip_coh_normalize(S) in the same output kind (float32, or complex64
+ * for FOURIER); sum_d float64 (nfreq, nchan, nchan) - or complex128 for FOURIER -, sum_d2 float64; T = ntrials_total.
+ * bias = (T-1) sum_d / T,  var = (T-1) (sum_d2 - |sum_d|^2 / T). */
+int spyhip_jack_coh_accumulate(spyhip_ctx* ctx, const void* spec_d, int ntrials, int ntaper, int nfreq, int nchan,
+                               const void* csd_d, const void* direct_d, int output, int64_t ntrials_total,
+                               void* sum_d, void* sum_d2);
+
 /* ---- K8: cross-covariance / cross-correlation -------------------------------
  * Replaces cross_covariance_cF (connectivity/ST_compRoutines.py:466-584: one fftconvolve per channel pair and
  * trial, lags 0 .. N/2 divided by the overlap N - lag, norm=True: divided by the products of np.std), the trial

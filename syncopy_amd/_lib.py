@@ -37,6 +37,8 @@ SIGNATURES = {
     "spyhip_ppc_accumulate": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "spyhip_ppc_accumulate_csd": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp]),
     "spyhip_ppc_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    "spyhip_jack_coh_accumulate": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int64,
+                                             vp, vp]),
     "spyhip_ccov_nfft": (C.c_int, [C.c_int]),
     "spyhip_ccov_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "spyhip_ccov_from_accumulator": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]),

@@ -366,6 +366,25 @@ def ppc_finalize(acc, ntrials, lower_only):
     return out
 
 
+def jack_coh_accumulate(spec, ntaper, csd, direct, output, ntrials_total, sum_d, sum_d2):
+    """Streaming jackknife of the coherence (K9): for every trial of spec (ntrials * ntaper, F, C) the leave-one-out
+    coherence replicate minus `direct` is summed into sum_d (float64 / complex128) and its squared modulus into
+    sum_d2 (float64); csd = finalised trial average (F, C, C) complex64."""
+    assert spec.is_cuda and spec.dtype == torch.complex64 and spec.is_contiguous() and spec.dim() == 3
+    R, F, Cn = spec.shape
+    kind = OUTPUT_KIND[output]
+    assert R % ntaper == 0 and tuple(csd.shape) == (F, Cn, Cn) and csd.dtype == torch.complex64 and csd.is_contiguous()
+    assert tuple(direct.shape) == (F, Cn, Cn) and direct.is_contiguous()
+    assert direct.dtype == (torch.complex64 if kind == 2 else torch.float32)
+    assert sum_d.dtype == (torch.complex128 if kind == 2 else torch.float64) and sum_d.is_contiguous()
+    assert sum_d2.dtype == torch.float64 and sum_d2.is_contiguous() and tuple(sum_d2.shape) == (F, Cn, Cn)
+    ctx = context(spec.device)
+    ctx.bind_stream()
+    check(ctx.lib.spyhip_jack_coh_accumulate(ctx.handle, _ptr(spec), R // ntaper, int(ntaper), F, Cn, _ptr(csd),
+                                             _ptr(direct), kind, int(ntrials_total), _ptr(sum_d), _ptr(sum_d2)),
+          "spyhip_jack_coh_accumulate")
+
+
 def ccov_nfft(nsamples):
     """Transform length K8 needs for trials of `nsamples` samples (no GPU involved)."""
     from ._lib import load

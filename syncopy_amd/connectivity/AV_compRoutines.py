@@ -71,6 +71,12 @@ class NormalizeCrossSpectra(_AverageRoutine):
         """AV stage on one device CSD (F, C, C) -> (F, C, C); used by the streaming jackknife."""
         return backend.coh_normalize(csd.contiguous(), self.cfg["output"])
 
+    def jackknife_accumulate(self, spec, ntaper, csd, direct, ntrials_total, sum_d, sum_d2):
+        """Pass 2 of the streaming jackknife for a batch of trials in ONE kernel (K9): single-trial cross spectra,
+        leave-one-out averages, their coherence and the sums of d_t / |d_t|^2 never leave the registers."""
+        backend.jack_coh_accumulate(spec, ntaper, csd.contiguous(), direct.contiguous(), self.cfg["output"],
+                                    ntrials_total, sum_d, sum_d2)
+
     def compute_hip(self, data, out):
         raw = getattr(data, "_acc_raw", None)
         if raw is not None:

@@ -265,7 +265,7 @@ class CrossSpectra(ComputationalRoutine):
         self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T
         return backend.ppc_finalize(U, T, lower_only=True)
 
-    def jackknife_hip(self, data, evaluate):
+    def jackknife_hip(self, data, evaluate, fused=None):
         """Streaming jackknife on the device (connectivity_analysis.py:601-606,736-757; statistics/jackknifing.py):
         never more than a handful of (F, C, C) arrays live at once instead of the reference's T single-trial CSDs.
         Pass 1 accumulates the trial-averaged CSD S (one all-reduce); pass 2 re-computes every trial's own CSD S_t,
@@ -273,7 +273,9 @@ class CrossSpectra(ComputationalRoutine):
         AV stage on it (`evaluate`: (F, C, C) complex64 Hermitian -> (F, C, C) tensor) and keeps only the float64 sums
         of d_t = replicate_t - direct and |d_t|^2.  Returns (S, direct, jack_bias, jack_var) device tensors:
             bias = (T-1) * mean_t d_t,   var = (T-1) * (sum_t |d_t|^2 - |sum_t d_t|^2 / T)
-        (= the reference's (T-1) (jack_avg - direct) and (T-1) sum |jack_avg - replicate_t|^2)."""
+        (= the reference's (T-1) (jack_avg - direct) and (T-1) sum |jack_avg - replicate_t|^2).
+        `fused(spec, ntaper, S, direct, T, sum_d, sum_d2)`: optional single-kernel form of pass 2 for a batch of
+        trials (NormalizeCrossSpectra.jackknife_accumulate)."""
         cfg = self.cfg
         dev = data.device_data()
         rows, chans = trial_rows(data), selected_channels(data)
@@ -303,8 +305,12 @@ class CrossSpectra(ComputationalRoutine):
         cplx = direct.is_complex()
         sum_d = torch.zeros(direct.shape, dtype=torch.complex128 if cplx else torch.float64, device=dev.device)
         sum_d2 = torch.zeros(direct.shape, dtype=torch.float64, device=dev.device)
-        St = torch.empty_like(S)
+        St = None if fused is not None else torch.empty_like(S)
         for _, spec in batches(mine):
+            if fused is not None:
+                # the AV stage offers the whole pass 2 as one kernel (coherence: K9): replicates never exist in HBM
+                fused(spec.reshape(-1, F, C), spec.shape[1], S, direct, T, sum_d, sum_d2)
+                continue
             for t in range(spec.shape[0]):
                 St.zero_()
                 backend.csd_accumulate(spec[t], St)

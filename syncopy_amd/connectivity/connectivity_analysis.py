@@ -255,7 +255,7 @@ def _jackknife_on_device(data, st, av, st_out, log_dict):
     from .. import backend
     st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=False)
     av.metadata = []
-    S, direct, bias, var = st.jackknife_hip(data, av.evaluate_device)
+    S, direct, bias, var = st.jackknife_hip(data, av.evaluate_device, fused=getattr(av, "jackknife_accumulate", None))
     st_out._dev = S.reshape(st.outputShape)
     st_out.set_pending(lambda: backend.to_host(st_out._dev), st.outputShape, np.complex64)
     st.process_metadata(data, st_out)

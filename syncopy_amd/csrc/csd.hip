@@ -191,3 +191,38 @@ extern "C" int spyhip_coh_normalize(spyhip_ctx* ctx, const void* csd_d, int nfre
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+#include "jack_kernel.h"
+
+extern "C" int spyhip_jack_coh_accumulate(spyhip_ctx* ctx, const void* spec_d, int ntrials, int ntaper, int nfreq,
+                                          int nchan, const void* csd_d, const void* direct_d, int output,
+                                          int64_t ntrials_total, void* sum_d, void* sum_d2) {
+    if (!ctx || !spec_d || !csd_d || !direct_d || !sum_d || !sum_d2) { spy::set_error("jack_coh_accumulate: null argument"); return -1; }
+    if (ntrials < 0 || ntaper < 1 || nfreq < 1 || nchan < 1 || ntrials_total < 2) { spy::set_error("jack_coh_accumulate: bad shape"); return -1; }
+    if (output < SPYHIP_OUT_POW || output > SPYHIP_OUT_ABSIMAG) { spy::set_error("bad output kind %d", output); return -1; }
+    if (ntrials == 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    spycsd::JackArgs a{};
+    a.spec = reinterpret_cast<const float2*>(spec_d);
+    a.S = reinterpret_cast<const float2*>(csd_d);
+    a.direct = direct_d;
+    a.ntrials = ntrials; a.K = ntaper; a.F = nfreq; a.C = nchan; a.kind = output;
+    a.T = (float)ntrials_total;
+    a.sum_d = reinterpret_cast<double*>(sum_d);
+    a.sum_d2 = reinterpret_cast<double*>(sum_d2);
+    const long long nt = (nchan + 31) / 32, blocks = (long long)nfreq * (nt * (nt + 1) / 2);
+    if (blocks > 0x7fffffffLL) { spy::set_error("jack_coh_accumulate: grid too large"); return -1; }
+    const size_t lds = 2 * (size_t)2 * ntaper * 32 * sizeof(float2);
+    if (lds > ctx->lds_per_block) { spy::set_error("jack_coh_accumulate: %d tapers do not fit the LDS staging buffer", ntaper); return -3; }
+    if (output == SPYHIP_OUT_FOURIER) {
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spycsd::jack_coh_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(spycsd::jack_coh_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+    } else {
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spycsd::jack_coh_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(spycsd::jack_coh_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+    }
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}

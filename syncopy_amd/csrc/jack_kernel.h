@@ -1,0 +1,154 @@
+// K9: streaming leave-one-out (jackknife) replicates of the coherence.
+//
+// Reference (connectivity_analysis.py:601-606,736-757; statistics/jackknifing.py:14-184): keep all T single-trial
+// cross spectra, form T leave-one-out averages (T*S - S_t)/(T-1), run normalize_csd on each, then bias and variance
+// from the replicates.  Here one pass over the tapered spectra of a batch of trials does all of it per (frequency,
+// channel pair): S_t from the trial's K tapers, the replicate, its coherence, d_t = replicate - direct, and the
+// float64 sums of d_t and |d_t|^2 stay in registers; one read-modify-write of the two sum arrays per launch.
+#pragma once
+#include "spy_common.h"
+#include "csd_kernel.h"
+
+namespace spycsd {
+
+struct JackArgs {
+    const float2* spec;   // (ntrials * K, F, C) complex64 tapered spectra, the K rows of a trial adjacent
+    const float2* S;      // (F, C, C) complex64: trial- and taper-averaged cross spectra, full Hermitian array
+    const void* direct;   // (F, C, C) float32 (real kinds) or complex64: coherence of S in the requested output kind
+    int ntrials, K, F, C, kind;
+    float T;              // total number of trials of the estimate
+    double* sum_d;        // (F, C, C) float64, or (F, C, C, 2) for the complex kind: += sum_t d_t
+    double* sum_d2;       // (F, C, C) float64: += sum_t |d_t|^2
+};
+
+__device__ __forceinline__ float fast_rsqrt(float x) {
+#ifdef SPY_HOST_EMU
+    return 1.0f / sqrtf(x);
+#else
+    return __builtin_amdgcn_rsqf(x);
+#endif
+}
+__device__ __forceinline__ float fast_sqrt(float x) {
+#ifdef SPY_HOST_EMU
+    return sqrtf(x);
+#else
+    return __builtin_amdgcn_sqrtf(x);
+#endif
+}
+
+// Workgroup = (frequency, 32 x 32 tile of the lower triangle of the channel square), 256 threads: thread (ti, tq) owns the pairs
+// (i = ti, j = 4 tq .. 4 tq + 3).  Staging as in K7 (ntaper x 64 spectra per trial through LDS, double-buffered).
+template <bool CPLX>
+__global__ void __launch_bounds__(256) jack_coh_kernel(JackArgs a) {
+    SPY_DYN_SMEM(float2, jk_lds);
+    const int tid = threadIdx.x, ti = tid & 31, tq = tid >> 5;
+    const int nt = (a.C + 31) / 32, ntl = nt * (nt + 1) / 2;
+    const int f = blockIdx.x / ntl;
+    int bi, bj;
+    tile_of(blockIdx.x % ntl, bi, bj);                  // bi >= bj: the upper triangle is mirrored on the way out
+    const int K = a.K, per = 2 * K * 32;
+    float2* buf[2] = {jk_lds, jk_lds + per};
+
+    auto stage = [&](int t, float2* dst) {
+        for (int e = tid; e < per; e += 256) {
+            const int side = e / (K * 32), k = (e - side * K * 32) >> 5, c = e & 31;
+            const int ch = (side ? bj : bi) * 32 + c;
+            float2 v = make_float2(0.f, 0.f);
+            if (ch < a.C) v = a.spec[((size_t)((size_t)t * K + k) * a.F + f) * a.C + ch];
+            dst[e] = v;
+        }
+    };
+
+    const int i = bi * 32 + ti, ic = i < a.C ? i : a.C - 1;
+    const size_t fb = (size_t)f * a.C * a.C;
+    const float Sii = a.S[fb + (size_t)ic * a.C + ic].x;
+    float2 Sij[4], dir[4];
+    float Sjj[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = bj * 32 + tq * 4 + q, jc = j < a.C ? j : a.C - 1;
+        Sij[q] = a.S[fb + (size_t)ic * a.C + jc];
+        Sjj[q] = a.S[fb + (size_t)jc * a.C + jc].x;
+        if (CPLX) dir[q] = reinterpret_cast<const float2*>(a.direct)[fb + (size_t)ic * a.C + jc];
+        else dir[q] = make_float2(reinterpret_cast<const float*>(a.direct)[fb + (size_t)ic * a.C + jc], 0.f);
+    }
+    const float invK = 1.0f / (float)K, T = a.T, invT1 = 1.0f / (a.T - 1.0f);
+    double sd[4], sdi[4], sd2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sd[q] = sdi[q] = sd2[q] = 0.0;
+
+    stage(0, buf[0]);
+    __syncthreads();
+    for (int t = 0; t < a.ntrials; ++t) {
+        const float2* b = buf[t & 1];
+        if (t + 1 < a.ntrials) stage(t + 1, buf[(t + 1) & 1]);
+        float2 s[4];
+        float pj[4], pi = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[q] = make_float2(0.f, 0.f);
+            pj[q] = 0.f;
+        }
+        for (int k = 0; k < K; ++k) {
+            const float2 xi = b[k * 32 + ti];
+            const float4* p4 = reinterpret_cast<const float4*>(b + (K + k) * 32 + tq * 4);
+            const float4 j01 = p4[0], j23 = p4[1];
+            const float2 xj[4] = {make_float2(j01.x, j01.y), make_float2(j01.z, j01.w), make_float2(j23.x, j23.y),
+                                  make_float2(j23.z, j23.w)};
+            pi += xi.x * xi.x + xi.y * xi.y;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[q].x += xi.x * xj[q].x + xi.y * xj[q].y;
+                s[q].y += xi.y * xj[q].x - xi.x * xj[q].y;
+                pj[q] += xj[q].x * xj[q].x + xj[q].y * xj[q].y;
+            }
+        }
+        // leave-one-out average in complex64 as the reference forms it: (T * S - S_t) / (T - 1)
+        const float lii = (T * Sii - pi * invK) * invT1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float lx = (T * Sij[q].x - s[q].x * invK) * invT1;
+            const float ly = (T * Sij[q].y - s[q].y * invK) * invT1;
+            const float ljj = (T * Sjj[q] - pj[q] * invK) * invT1;
+            const float rden = fast_rsqrt(lii * ljj);                // 1 ulp: d_t itself is good to ~1e-7 |c| only
+            const float2 c = make_float2(lx * rden, ly * rden);
+            if (CPLX) {
+                const float dx = c.x - dir[q].x, dy = c.y - dir[q].y;
+                sd[q] += (double)dx;
+                sdi[q] += (double)dy;
+                sd2[q] += (double)dx * dx + (double)dy * dy;
+            } else {
+                const float d = (a.kind == SPYHIP_OUT_ABS ? fast_sqrt(c.x * c.x + c.y * c.y) : coh_convert(c, a.kind)) - dir[q].x;
+                sd[q] += (double)d;
+                sd2[q] += (double)d * d;
+            }
+        }
+        __syncthreads();
+    }
+    if (i >= a.C) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = bj * 32 + tq * 4 + q;
+        if (j >= a.C) continue;
+        const size_t o = fb + (size_t)i * a.C + j;
+        if (CPLX) {
+            a.sum_d[2 * o] += sd[q];
+            a.sum_d[2 * o + 1] += sdi[q];
+        } else {
+            a.sum_d[o] += sd[q];
+        }
+        a.sum_d2[o] += sd2[q];
+        if (bi == bj) continue;                          // diagonal tiles hold both triangles themselves
+        // mirror (j, i): the coherency is Hermitian - imaginary part and phase change sign, the rest is symmetric
+        const size_t m = fb + (size_t)j * a.C + i;
+        if (CPLX) {
+            a.sum_d[2 * m] += sd[q];
+            a.sum_d[2 * m + 1] -= sdi[q];
+        } else {
+            a.sum_d[m] += (a.kind == SPYHIP_OUT_IMAG || a.kind == SPYHIP_OUT_ANGLE) ? -sd[q] : sd[q];
+        }
+        a.sum_d2[m] += sd2[q];
+    }
+}
+
+}  // namespace spycsd
