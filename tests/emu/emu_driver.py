@@ -204,6 +204,17 @@ def csd_finalize(acc, scale):
     lib().emu_csd_finalize(acc.ctypes.data_as(C.c_void_p), C.c_int(F), C.c_int(Cn), C.c_float(scale))
 
 
+def jack_coh_accumulate(spec, ntaper, S, direct, output, ntrials_total, sum_d, sum_d2):
+    """Emulated spyhip_jack_coh_accumulate (sum_d / sum_d2 float64 in place; sum_d complex128 for 'complex')."""
+    spec = np.ascontiguousarray(spec, dtype=np.complex64)
+    R, F, Cn = spec.shape
+    S = np.ascontiguousarray(S, dtype=np.complex64)
+    direct = np.ascontiguousarray(direct)
+    lib().emu_jack_coh(spec.ctypes.data_as(C.c_void_p), C.c_int(R // ntaper), C.c_int(ntaper), C.c_int(F), C.c_int(Cn),
+                       S.ctypes.data_as(C.c_void_p), direct.ctypes.data_as(C.c_void_p), C.c_int(OUT_KINDS[output]),
+                       C.c_longlong(ntrials_total), sum_d.ctypes.data_as(C.c_void_p), sum_d2.ctypes.data_as(C.c_void_p))
+
+
 def ppc_accumulate(spec, ntaper, acc):
     """Emulated spyhip_ppc_accumulate: spec (T * ntaper, F, C) complex64, acc (F, C, C) complex64 in place."""
     spec = np.ascontiguousarray(spec, dtype=np.complex64)

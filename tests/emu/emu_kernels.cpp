@@ -18,6 +18,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/csd_kernel.h"
 #include "../../syncopy_amd/csrc/ppc_kernel.h"
 #include "../../syncopy_amd/csrc/ccov_kernel.h"
+#include "../../syncopy_amd/csrc/jack_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_long.h"
@@ -333,6 +334,23 @@ void emu_coh_normalize(const float* csd, int F, int C, int kind, void* out) {
         emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::coh_normalize_kernel<true>(reinterpret_cast<const float2*>(csd), F, C, kind, out); });
     else
         emu::launch(dim3(4), dim3(256), 0, [&] { spycsd::coh_normalize_kernel<false>(reinterpret_cast<const float2*>(csd), F, C, kind, out); });
+}
+
+// K9 (mirrors spyhip_jack_coh_accumulate)
+void emu_jack_coh(const float* spec, int ntrials, int K, int F, int C, const float* S, const void* direct, int kind,
+                  long long T, double* sum_d, double* sum_d2) {
+    spycsd::JackArgs a{};
+    a.spec = reinterpret_cast<const float2*>(spec);
+    a.S = reinterpret_cast<const float2*>(S);
+    a.direct = direct;
+    a.ntrials = ntrials; a.K = K; a.F = F; a.C = C; a.kind = kind;
+    a.T = (float)T;
+    a.sum_d = sum_d; a.sum_d2 = sum_d2;
+    const int nt = (C + 31) / 32;
+    const size_t lds = 2 * (size_t)2 * K * 32 * sizeof(float2);
+    const dim3 grid((unsigned)(F * (nt * (nt + 1) / 2)));
+    if (kind == SPYHIP_OUT_FOURIER) emu::launch(grid, dim3(256), lds, [&] { spycsd::jack_coh_kernel<true>(a); });
+    else emu::launch(grid, dim3(256), lds, [&] { spycsd::jack_coh_kernel<false>(a); });
 }
 
 // K7 (mirrors ppc.hip)

@@ -175,6 +175,30 @@ def test_ppc_kernel(C, F, T, K):
     assert_parity(E.ppc_finalize(U2, T, False), ref, what="ppc from csd", rtol=1e-4, atol_rel=2e-5)
 
 
+@pytest.mark.parametrize("C,F,T,K,output", [(5, 3, 6, 3, "abs"), (40, 2, 5, 2, "complex"), (33, 1, 4, 1, "imag")])
+def test_jackknife_coherence_kernel(C, F, T, K, output):
+    """K9's kernel source on the CPU: sums of (leave-one-out coherence - direct) and of its squared modulus against a
+    NumPy walk over the replicates (statistics/jackknifing.py:14-108 + csd.py:118-172)."""
+    rng = np.random.default_rng(C)
+    spec = (rng.normal(size=(T, K, F, C)) + 1j * rng.normal(size=(T, K, F, C))).astype(np.complex64)
+    spec += (1.5 * rng.normal(size=(1, K, F, C))).astype(np.complex64)
+    st = O.spectral_dyadic_product(spec).astype(np.complex128)                  # (T, F, C, C)
+    S = st.mean(axis=0)
+    direct = O.normalize_csd(S.astype(np.complex64)[None], output)[0]
+    sum_d = np.zeros((F, C, C), np.complex128 if output == "complex" else np.float64)
+    sum_d2 = np.zeros((F, C, C), np.float64)
+    E.jack_coh_accumulate(spec[:2].reshape(-1, F, C), K, S, direct, output, T, sum_d, sum_d2)
+    E.jack_coh_accumulate(spec[2:].reshape(-1, F, C), K, S, direct, output, T, sum_d, sum_d2)
+    rd, rd2 = np.zeros_like(sum_d), np.zeros_like(sum_d2)
+    for t in range(T):
+        loo = ((T * S - st[t]) / (T - 1)).astype(np.complex64)
+        d = O.normalize_csd(loo[None], output)[0].astype(sum_d.dtype) - direct
+        rd += d
+        rd2 += np.abs(d) ** 2
+    np.testing.assert_allclose(sum_d, rd, rtol=1e-3, atol=2e-6 * T)
+    np.testing.assert_allclose(sum_d2, rd2, rtol=2e-3, atol=1e-9)
+
+
 @pytest.mark.parametrize("C,N,norm", [(5, 600, 0), (6, 301, 1), (3, 1400, 2)])
 def test_ccov_kernel(C, N, norm):
     """K8's kernel source on the CPU: lags from accumulated cross spectra of zero-padded trials = the oracle's
