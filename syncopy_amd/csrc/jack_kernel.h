@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) jack_coh_kernel(JackArgs a) {
     int bi, bj;
     tile_of(blockIdx.x % ntl, bi, bj);                  // bi >= bj: the upper triangle is mirrored on the way out
     const int K = a.K, per = 2 * K * 32;
-    float2* buf[2] = {jk_lds, jk_lds + per};
+    // (buffers addressed as jk_lds + n * per: a pointer array would decay to flat addressing)
 
     auto stage = [&](int t, float2* dst) {
         for (int e = tid; e < per; e += 256) {
@@ -77,11 +77,11 @@ __global__ void __launch_bounds__(256) jack_coh_kernel(JackArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) sd[q] = sdi[q] = sd2[q] = 0.0;
 
-    stage(0, buf[0]);
+    stage(0, jk_lds);
     __syncthreads();
     for (int t = 0; t < a.ntrials; ++t) {
-        const float2* b = buf[t & 1];
-        if (t + 1 < a.ntrials) stage(t + 1, buf[(t + 1) & 1]);
+        const float2* b = jk_lds + (t & 1) * per;
+        if (t + 1 < a.ntrials) stage(t + 1, jk_lds + ((t + 1) & 1) * per);
         float2 s[4];
         float pj[4], pi = 0.f;
 #pragma unroll

@@ -20,12 +20,13 @@ struct PpcArgs {
 
 // unit phasor of s (scaled first: |s|^2 of small spectra underflows in fp32)
 __device__ __forceinline__ float2 unit_phasor(float2 s) {
+    // branch-free: m = 0 -> r = inf, x = y = NaN, selected away at the end
     const float m = fmaxf(fabsf(s.x), fabsf(s.y));
-    if (!(m > 0.f)) return make_float2(1.f, 0.f);
     const float r = __builtin_amdgcn_rcpf(m);
     const float x = s.x * r, y = s.y * r;
     const float inv = __builtin_amdgcn_rsqf(x * x + y * y);
-    return make_float2(x * inv, y * inv);
+    const bool ok = m > 0.f;
+    return make_float2(ok ? x * inv : 1.f, ok ? y * inv : 0.f);
 }
 
 // Workgroup = (frequency, 32 x 32 tile of the lower triangle), 256 threads: thread (ti, tq) owns the pairs
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(256) ppc_accum_kernel(PpcArgs a) {
     while (rem >= bi + 1) { rem -= bi + 1; ++bi; }
     const int bj = rem;
     const int K = a.ntaper, per = 2 * K * 32;
-    float2* buf[2] = {ppc_lds, ppc_lds + per};
+    // (buffers addressed as ppc_lds + n * per: a pointer array would decay to flat addressing)
 
     auto stage = [&](int t, float2* dst) {
         for (int e = tid; e < per; e += 256) {
@@ -56,29 +57,33 @@ __global__ void __launch_bounds__(256) ppc_accum_kernel(PpcArgs a) {
     float2 u[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) u[q] = make_float2(0.f, 0.f);
-    stage(0, buf[0]);
+    stage(0, ppc_lds);
     __syncthreads();
     for (int t = 0; t < a.ntrials; ++t) {
-        const float2* b = buf[t & 1];
-        if (t + 1 < a.ntrials) stage(t + 1, buf[(t + 1) & 1]);
-        float2 s[4];
+        const float2* b = ppc_lds + (t & 1) * per;
+        if (t + 1 < a.ntrials) stage(t + 1, ppc_lds + ((t + 1) & 1) * per);
+        // xi * conj(xj) = xi * xj.re + (xi.im, -xi.re) * xj.im: two packed FMAs per pair and taper
+        typedef float pk2 __attribute__((ext_vector_type(2)));
+        pk2 s[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] = make_float2(0.f, 0.f);
+        for (int q = 0; q < 4; ++q) s[q] = pk2{0.f, 0.f};
         for (int k = 0; k < K; ++k) {
-            const float2 xi = b[k * 32 + ti];
+            const float2 xi2 = b[k * 32 + ti];
             const float4* pj = reinterpret_cast<const float4*>(b + (K + k) * 32 + tq * 4);
             const float4 j01 = pj[0], j23 = pj[1];
-            const float2 xj[4] = {make_float2(j01.x, j01.y), make_float2(j01.z, j01.w), make_float2(j23.x, j23.y),
-                                  make_float2(j23.z, j23.w)};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {          // xi * conj(xj)
-                s[q].x += xi.x * xj[q].x + xi.y * xj[q].y;
-                s[q].y += xi.y * xj[q].x - xi.x * xj[q].y;
-            }
+            const pk2 xi = pk2{xi2.x, xi2.y}, xs = pk2{xi2.y, -xi2.x};
+            s[0] = xi * pk2{j01.x, j01.x} + s[0];
+            s[1] = xi * pk2{j01.z, j01.z} + s[1];
+            s[2] = xi * pk2{j23.x, j23.x} + s[2];
+            s[3] = xi * pk2{j23.z, j23.z} + s[3];
+            s[0] = xs * pk2{j01.y, j01.y} + s[0];
+            s[1] = xs * pk2{j01.w, j01.w} + s[1];
+            s[2] = xs * pk2{j23.y, j23.y} + s[2];
+            s[3] = xs * pk2{j23.w, j23.w} + s[3];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float2 p = unit_phasor(s[q]);
+            const float2 p = unit_phasor(make_float2(s[q].x, s[q].y));
             u[q].x += p.x;
             u[q].y += p.y;
         }

@@ -191,12 +191,27 @@ if "jack" in which:
     data = spy.AnalogData(host, samplerate=1000.0, trialdefinition=trl)
     spy.connectivityanalysis(data, method="coh", tapsmofrq=1, polyremoval=0)        # upload + plans
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    coh = spy.connectivityanalysis(data, method="coh", tapsmofrq=1, polyremoval=0, jackknife=True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(3):                                   # best of three: the first call allocates pinned result buffers
+        t0 = time.perf_counter()
+        coh = spy.connectivityanalysis(data, method="coh", tapsmofrq=1, polyremoval=0, jackknife=True)
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
+    # K9 alone: leave-one-out replicates of 100 resident trials
+    F, K = N // 2 + 1, 7
+    g = torch.Generator(device="cuda").manual_seed(9)
+    spec = torch.view_as_complex(torch.randn((100 * K, F, C, 2), device="cuda", generator=g))
+    S = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    be.csd_accumulate(spec, S)
+    be.csd_finalize(S, 1.0 / (100 * K))
+    direct = be.coh_normalize(S, "abs")
+    sd = torch.zeros((F, C, C), dtype=torch.float64, device="cuda")
+    sd2 = torch.zeros_like(sd)
+    dk = sync_time(lambda: be.jack_coh_accumulate(spec, K, S, direct, "abs", 100, sd, sd2), n=3)
     res["jackknife_coh"] = {"trials": T, "seconds": dt, "ms_per_replicate": 1e3 * dt / T,
+                            "kernel_us_per_replicate": 1e6 * dk / 100,
                             "var_max": float(coh.jack_var.max()), "finite": bool(np.isfinite(coh.jack_var).all())}
+    del spec, S, direct, sd, sd2
     print("jack", res["jackknife_coh"], flush=True)
     del data, host, coh
 
