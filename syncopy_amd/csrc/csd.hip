@@ -9,7 +9,7 @@ using spycsd::CsdArgs;
 
 namespace {
 
-template <int TA, int TB, bool FAST = false>
+template <int TA, int TB, int FAST = 0>
 int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item_end, int nsplit = 1) {
     auto kern = spycsd::csd_accum_kernel<TA, TB, FAST>;
     const int per = 4 * (TA + TB);
@@ -22,20 +22,22 @@ int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item
     const size_t chunk_max = (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2);
     int kb = 32;
     while (kb > 4 && (size_t)kb * rowbytes > chunk_max) kb -= 4;
-    if ((size_t)kb * rowbytes > chunk_max || 3 * (size_t)kb * rowbytes > ctx->lds_per_block) {
+    if (!FAST && ((size_t)kb * rowbytes > chunk_max || 3 * (size_t)kb * rowbytes > ctx->lds_per_block)) {
         spy::set_error("csd_accumulate: %d channels do not fit the LDS staging buffer", a.C);
         return -3;
     }
     const long long rows_wg = nsplit > 1 ? a.rows_per_split : a.nrows;
     if (kb > rows_wg && !FAST) kb = (int)((rows_wg + 3) & ~3LL);
-    if (FAST && kb != 16) { spy::set_error("csd_accumulate: internal error (fast path needs 16-row chunks)"); return -1; }
+    if (FAST) kb = 16;                                   // three 32 KiB buffers of 16 rows x 256 elements
     a.kb = kb;
     a.item_base = item_base;
     a.item_end = item_end;
-    const size_t lds = 3 * (size_t)kb * rowbytes;
+    // FAST: + one row of slack - a tile's columns past the last frequency of a row are read (and never stored)
+    const size_t lds = FAST ? 3 * (size_t)16 * 256 * sizeof(float2) + 512 : 3 * (size_t)kb * rowbytes;
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long long grid = (item_end - item_base + per - 1) / per;
+    const long long wg_items = FAST ? a.fast_per : per;
+    const long long grid = (item_end - item_base + wg_items - 1) / wg_items;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nsplit), dim3(spycsd::CSD_THREADS), lds, ctx->stream, a);
@@ -73,17 +75,27 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
     a.nitems = (long long)nfreq * a.ntiles;
     a.cpad = a.nt * 32;
     a.blocked = blocked;
+    // The instruction-lean path: even C <= 256, row-major spectra.  A 256-element LDS row holds nfb consecutive
+    // frequencies (1 for C > 128, 2 for C = 128, 4 for C = 64, ...) and a workgroup owns their nfb * ntiles <= 40 tiles.
+    const bool fast = !blocked && (nchan % 2 == 0) && nchan <= 256;
+    if (fast) {
+        int nfb = 256 / nchan;
+        while (nfb > 1 && nfb * a.ntiles > 40) --nfb;
+        if (nfb > nfreq) nfb = nfreq;
+        a.fast_per = nfb * a.ntiles;
+    }
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
-    if (a.ntiles >= 21) {
+    if (fast || a.ntiles >= 21) {
         // One workgroup per CU: F = 2049 frequencies on 256 CUs would leave a 9th, almost empty round.
         // The workgroups beyond the last full round are re-cut into 1-tile-per-wave workgroups
         // (4.5x more, each 5x shorter), so the tail costs ~1/5 of a round and stays deterministic.
-        const long long per = 36, nwg = (a.nitems + per - 1) / per;
+        const long long per = fast ? a.fast_per : 36, nwg = (a.nitems + per - 1) / per;
         const long long full = (nwg / ctx->num_cu) * ctx->num_cu, rem = nwg - full;
         if (full > 0 && rem > 0 && rem * 4 <= ctx->num_cu) {
-            // C = 256, row-major spectra: the specialised instruction-lean path
-            int rc = (nchan == 256 && !blocked) ? launch_accum<5, 4, true>(ctx, a, 0, full * per)
-                                                : launch_accum<5, 4>(ctx, a, 0, full * per);
+            // 36 tiles in every workgroup (C = 256): the variant without per-tile guards
+            int rc = !fast ? launch_accum<5, 4>(ctx, a, 0, full * per)
+                           : (a.ntiles == 36 ? launch_accum<5, 4, 1>(ctx, a, 0, full * per)
+                                             : launch_accum<5, 4, 2>(ctx, a, 0, full * per));
             if (rc) return rc;
             // tail: 1 tile per wave AND the rows split over blockIdx.y, so that its rem*4.5*nsplit short
             // workgroups fill the chip once; splits > 0 leave partial sums in library scratch that a
@@ -115,8 +127,8 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
             }
             return 0;
         }
-        return (nchan == 256 && !blocked) ? launch_accum<5, 4, true>(ctx, a, 0, a.nitems)
-                                          : launch_accum<5, 4>(ctx, a, 0, a.nitems);
+        if (!fast) return launch_accum<5, 4>(ctx, a, 0, a.nitems);
+        return a.ntiles == 36 ? launch_accum<5, 4, 1>(ctx, a, 0, a.nitems) : launch_accum<5, 4, 2>(ctx, a, 0, a.nitems);
     }
     if (a.ntiles >= 6) return launch_accum<3, 2>(ctx, a, 0, a.nitems);
     return launch_accum<1, 1>(ctx, a, 0, a.nitems);

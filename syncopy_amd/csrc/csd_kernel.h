@@ -42,6 +42,7 @@ struct CsdArgs {
     float2* part;
     int part_f0, part_nf;
     int blocked;                // spec = (nrows, ceil(C/4), F, 4): channel quads contiguous in frequency
+    int fast_per;               // FAST path: items per workgroup = (frequencies per 256-element LDS row) * ntiles
 };
 
 __device__ __forceinline__ void tile_of(int tt, int& ti, int& tj) {
@@ -76,13 +77,17 @@ constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chu
 // One chunk of kb rows is fetched into registers (all loads in flight together) while the
 // previous chunk is being multiplied, then written to LDS.
 //
-// FAST (host-selected: C = cpad = 256, one frequency per workgroup, kb = 16, row-major spectra): the matrix pipe
+// FAST (host-selected: even C <= 256, row-major spectra, kb = 16; a 256-element LDS row holds nfb = 256 / C
+// consecutive frequencies - one for C in (128, 256], two for C = 128, four for C = 64 ... - and the workgroup owns
+// their nfb * ntiles <= 40 tiles, dealt round-robin to the waves): the matrix pipe
 // and every other instruction of a SIMD's two waves share one issue port, so what is not an MFMA costs matrix
 // time (ablations: staging instructions -12 %, loop overhead -12 %).  The fast path keeps the non-MFMA count
 // minimal: 16-byte staging loads/stores addressed by a scalar base + one lane offset (4 + 4 instructions per
 // chunk instead of ~250), the row-pair loop fully unrolled with every LDS fragment address = one register per
 // tile + an immediate, the three LDS buffers reached by bumping those registers once per chunk.
-template <int TA, int TB, bool FAST = false>
+// FAST: 0 generic path, 1 instruction-lean path with 36 tiles in every workgroup (C = 256: every wave has 4 or 5
+// tiles, no per-tile guards in the loop), 2 instruction-lean path with any tile count per wave
+template <int TA, int TB, int FAST = 0>
 __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     SPY_DYN_SMEM(float2, X);   // 2 x [kb][rowlen]
     constexpr int PER = 4 * (TA + TB);
@@ -97,8 +102,12 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     // waves {0,2,5,7} own TA tiles, {1,3,4,6} own TB: every SIMD carries TA+TB tiles whether the hardware places
     // waves w and w+4 or waves 2s and 2s+1 of a workgroup on the same SIMD
     constexpr unsigned BIG = FAST ? 0xA5u : 0x0Fu;   // (generic path: waves 0-3, one live register less)
-    const int ntile_w = ((BIG >> wave) & 1u) ? TA : TB;                      // wave-uniform
+    int ntile_w = ((BIG >> wave) & 1u) ? TA : TB;                            // wave-uniform
     const int first_w = wave * TB + __builtin_popcount(BIG & ((1u << wave) - 1u)) * (TA - TB);
+    // FAST: tile v of the workgroup goes to the wave at position v % 8 of the order (0, 2, 5, 7, 1, 3, 4, 6) - the
+    // waves that take one tile more when the count is not a multiple of 8 are spread over the four SIMDs
+    const int wpos = ((BIG >> wave) & 1u) ? __builtin_popcount(BIG & ((1u << wave) - 1u))
+                                          : 4 + __builtin_popcount(~BIG & ((1u << wave) - 1u));
 
     const int split = a.rows_per_split > 0 ? (int)blockIdx.y : 0;
     const long long row_lo = (long long)split * a.rows_per_split;
@@ -113,10 +122,17 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         const long long g32 = ((long long)gridDim.x >> 5) << 5;
         if (wg < g32) wg = (wg & ~31LL) + 4 * (wg & 7) + ((wg & 31) >> 3);
     }
-    const long long item0 = a.item_base + wg * PER;
-    long long last = item0 + PER;
+    const int per_wg = FAST ? a.fast_per : PER;
+    const long long item0 = a.item_base + wg * per_wg;
+    long long last = item0 + per_wg;
     if (last > a.item_end) last = a.item_end;
     if (item0 >= a.item_end) return;
+    if constexpr (FAST) {
+        const int nv = (int)(last - item0);
+        ntile_w = nv > wpos ? (nv - wpos + 7) >> 3 : 0;
+    }
+    // item index of this wave's tile t
+    auto item_of = [&](int t) { return FAST ? item0 + wpos + 8 * t : item0 + first_w + t; };
     const int f_lo = (int)(item0 / a.ntiles);
     const int nfb = (int)((last - 1) / a.ntiles) - f_lo + 1;
     const int rowlen = nfb * a.cpad;
@@ -125,14 +141,17 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     f32x16 accr[TA], acci[TA];
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
-        const long long item = item0 + first_w + t;
+        const long long item = item_of(t);
         int f = f_lo, ti = 0, tj = 0;
         if (t < ntile_w && item < a.item_end) {
             f = (int)(item / a.ntiles);
             tile_of((int)(item % a.ntiles), ti, tj);
         }
-        aoff[t] = (f - f_lo) * a.cpad + ti * 32 + l31;
-        boff[t] = (f - f_lo) * a.cpad + tj * 32 + l31;
+        // FAST packs the frequencies of a row at their distance in memory (C, not the padded tile width): a tile's
+        // columns beyond C belong to the next frequency and only feed accumulator entries that are never stored
+        const int fstride = FAST ? a.C : a.cpad;
+        aoff[t] = (f - f_lo) * fstride + ti * 32 + l31;
+        boff[t] = (f - f_lo) * fstride + tj * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             accr[t][r] = 0.f;
@@ -148,7 +167,11 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         const unsigned rowbytes = (unsigned)rowstride * 8u;
         const char* const fb = reinterpret_cast<const char*>(a.spec + (size_t)row_lo * rowstride + (size_t)f_lo * a.C);
         const int srow = tid >> 7;                                  // this thread stages rows srow + 4v, v < 4
-        const unsigned coff = (unsigned)(tid & 127) * 16u;          // ... columns 2*(tid&127), +1 (16 bytes)
+        // ... columns 2*(tid&127), +1 (16 bytes) of the row = the (up to 256) elements of this workgroup's
+        // frequencies; columns past them are zero-filled (their load is redirected to column 0)
+        const int nf_wg = (int)((last - 1) / a.ntiles) - f_lo + 1;
+        const bool colok = 2 * (tid & 127) < nf_wg * a.C;
+        const unsigned coff = colok ? (unsigned)(tid & 127) * 16u : 0u;
         const long long nchunk = (nrows + KB - 1) / KB;
         float4 pf[4];
         unsigned okmask = 0;
@@ -163,7 +186,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
                 const int row = srow + 4 * v;
                 const int rc = row < rleft ? row : rleft - 1;       // clamped: the load is unconditional
                 pf[v] = *reinterpret_cast<const float4*>(base + ((unsigned)rc * rowbytes + coff));
-                okmask |= (row < rleft) ? (1u << v) : 0u;
+                okmask |= (row < rleft && colok) ? (1u << v) : 0u;
             }
         };
         auto put = [&](int buf) {
@@ -224,7 +247,8 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
                 }
                 sched_fence_csd();
 #pragma unroll
-                for (int t = 0; t < NPRE; ++t) mfma4(t, av[t], bv[t]);
+                for (int t = 0; t < NPRE; ++t)
+                    if (FAST == 1 || t < ntile_w) mfma4(t, av[t], bv[t]);
                 sched_fence_csd();
                 if (st + 1 < KB / 2) {
 #pragma unroll
@@ -252,7 +276,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
                 sched_fence_csd();
 #pragma unroll
                 for (int t = NPRE; t < TA; ++t) {
-                    if (t >= TB && t >= ntile_w) break;
+                    if ((FAST != 1 || t >= TB) && t >= ntile_w) break;
                     mfma4(t, av[t], bv[t]);
                 }
             }
@@ -403,7 +427,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     // ---- acc += tile (each (f, tile) is owned by exactly one wave: plain read-modify-write)
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
-        const long long item = item0 + first_w + t;
+        const long long item = item_of(t);
         if (t >= ntile_w || item >= a.item_end) continue;
         const int f = (int)(item / a.ntiles);
         int ti, tj;

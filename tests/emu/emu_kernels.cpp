@@ -287,30 +287,42 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     a.nitems = (long long)F * a.ntiles;
     a.cpad = a.nt * 32;
     a.blocked = g_blocked;
+    // as csd.hip: even C <= 256, row-major spectra -> the instruction-lean path (force_tpw != 0 picks a generic kernel)
+    const bool fast = force_tpw == 0 && !g_blocked && (C % 2 == 0) && C <= 256;
     int ta = 1, tb = 1;
-    if (a.ntiles >= 21) { ta = 5; tb = 4; }
+    if (fast || a.ntiles >= 21) { ta = 5; tb = 4; }
     else if (a.ntiles >= 6) { ta = 3; tb = 2; }
     if (force_tpw == 1) { ta = 1; tb = 1; }
     if (force_tpw == 3) { ta = 3; tb = 2; }
     if (force_tpw == 5) { ta = 5; tb = 4; }
-    const int per = 4 * (ta + tb);
+    int per = 4 * (ta + tb);
     int nfb = (per + a.ntiles - 1) / a.ntiles;
     if (per % a.ntiles != 0 && a.ntiles > 1) nfb += 1;
     if (nfb > F) nfb = F;
     const size_t rowbytes = (size_t)nfb * a.cpad * sizeof(float2);
     int kb = 32;
     while (kb > 4 && (size_t)kb * rowbytes > (size_t)spycsd::CSD_THREADS * spycsd::CSD_PF * sizeof(float2)) kb -= 4;
-    const bool fast = (ta == 5 && C == 256 && !g_blocked);     // as csd.hip: the instruction-lean path
     if (kb > nrows && !fast) kb = (int)((nrows + 3) & ~3LL);
+    size_t lds = 3 * (size_t)kb * rowbytes;
+    if (fast) {
+        int nf = 256 / C;
+        while (nf > 1 && nf * a.ntiles > 40) --nf;
+        if (nf > F) nf = F;
+        a.fast_per = nf * a.ntiles;
+        per = a.fast_per;
+        kb = 16;
+        lds = 3 * (size_t)16 * 256 * sizeof(float2) + 512;
+    }
     a.kb = kb;
     a.item_base = 0; a.item_end = a.nitems;
-    const size_t lds = 3 * (size_t)kb * rowbytes;
     const unsigned grid = (unsigned)((a.nitems + per - 1) / per);
     const unsigned T = spycsd::CSD_THREADS;
-    if (ta == 5 && fast) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, true>(a); });
+    if (fast && a.ntiles == 36) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });
+    else if (fast) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 2>(a); });
     else if (ta == 5) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4>(a); });
     else if (ta == 3) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<3, 2>(a); });
     else emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<1, 1>(a); });
+    if (fast) return 6;
     return ta;
 }
 
