@@ -13,3 +13,4 @@ from .datatype import AnalogData, CrossSpectralData, SpectralData  # noqa: F401
 from .specest.freqanalysis import freqanalysis  # noqa: F401
 from .connectivity.connectivity_analysis import connectivityanalysis  # noqa: F401
 from . import synthdata  # noqa: F401
+from .shared.kwarg_decorators import StructDict, get_defaults  # noqa: F401

@@ -12,12 +12,14 @@ import numpy as np
 from ..datatype import AnalogData, CrossSpectralData, SpectralData, selected_channels, selected_trialdefinition
 from ..shared.const_def import connectivity_outputs, connectivityMethods
 from ..shared.errors import SPYTypeError, SPYValueError, SPYWarning
+from ..shared.kwarg_decorators import unwrap_cfg
 from ..shared.input_processors import process_foi, process_padding, process_taper
 from ..shared.tools import best_match
 from .AV_compRoutines import NormalizeCrossCov, NormalizeCrossSpectra, pairwise_phase_consistency
 from .ST_compRoutines import CrossCovariance, CrossSpectra, SpectralDyadicProduct
 
 
+@unwrap_cfg
 def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi=None, foilim=None, pad="maxperlen",
                          polyremoval=0, tapsmofrq=None, nTaper=None, taper="hann", taper_opt=None, jackknife=False,
                          channelcmb=None, select=None, compute_method=None, routine_classes=None, **kwargs):

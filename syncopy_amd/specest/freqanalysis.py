@@ -11,6 +11,7 @@ import numpy as np
 from ..datatype import AnalogData, SpectralData, selected_trialdefinition
 from ..shared.const_def import availableMethods, spectralDTypes
 from ..shared.errors import SPYInfo, SPYTypeError, SPYValueError, SPYWarning
+from ..shared.kwarg_decorators import unwrap_cfg
 from ..shared.input_processors import process_foi, process_padding, process_taper
 from ..shared.tools import best_match
 from .compRoutines import MultiTaperFFT, MultiTaperFFTConvol
@@ -26,6 +27,7 @@ def _scalar(value, varname, lims):
                             actual=f"{value}")
 
 
+@unwrap_cfg
 def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None, foilim=None, pad="maxperlen",
                  polyremoval=0, taper="hann", demean_taper=False, taper_opt=None, tapsmofrq=None, nTaper=None,
                  keeptapers=False, toi="all", t_ftimwin=None, wavelet="Morlet", width=6, order=None, order_max=None,

@@ -144,3 +144,34 @@ def test_superlet_steps_reproduce_the_geometric_mean(adaptive, order_max, order_
         else:
             acc[s0:] *= fac
     np.testing.assert_allclose(np.abs(acc), np.abs(ref), rtol=1e-5, atol=1e-7 * np.abs(ref).max())
+
+
+def test_cfg_style_calls_and_replay():
+    """FieldTrip-style `cfg` calls (shared/kwarg_decorators.py:32-300): every supported signature gives the result of
+    the keyword call, conflicts are rejected, and `out.cfg` replays a chained freqanalysis -> connectivityanalysis
+    (tests/test_connectivity.py:684-693: two entries after the chain)."""
+    from oracle_routines import ORACLE_CONN, ORACLE_FREQ
+    d = spy.synthdata.ar2_network(AdjMat=np.zeros((3, 3)), nSamples=300, nTrials=4, seed=1)
+    ex = dict(compute_method="sequential", routine_classes=ORACLE_FREQ)
+    ref = spy.freqanalysis(d, method="mtmfft", tapsmofrq=3, keeptrials=False, **ex)
+    cfg = spy.StructDict()
+    cfg.method, cfg.tapsmofrq, cfg.keeptrials = "mtmfft", 3, "no"
+    for call in (lambda: spy.freqanalysis(cfg, d, **ex), lambda: spy.freqanalysis(d, cfg, **ex),
+                 lambda: spy.freqanalysis(d, cfg=cfg, **ex), lambda: spy.freqanalysis(dict(cfg, data=d), **ex),
+                 lambda: spy.freqanalysis(cfg=dict(cfg, dataset=d), **ex)):
+        assert np.array_equal(call().data, ref.data)
+    assert "data" not in cfg and cfg.keeptrials == "no"                  # the user's cfg is left alone
+    for bad in (lambda: spy.freqanalysis(d, cfg, tapsmofrq=2, **ex),      # parameter in cfg AND as keyword
+                lambda: spy.freqanalysis(d, cfg, {}, **ex),               # two dicts
+                lambda: spy.freqanalysis(d, cfg, cfg=cfg, **ex),          # positional and keyword cfg
+                lambda: spy.freqanalysis(dict(cfg, data=d), d, **ex),     # data twice
+                lambda: spy.freqanalysis(cfg, **ex)):                     # no data at all
+        with pytest.raises(Exception):
+            bad()
+    spec = spy.freqanalysis(d, method="mtmfft", tapsmofrq=3, output="fourier", keeptapers=True, **ex)
+    assert set(spec.cfg) == {"freqanalysis"} and spec.cfg["freqanalysis"]["tapsmofrq"] == 3
+    coh = spy.connectivityanalysis(spec, method="coh", compute_method="sequential", routine_classes=ORACLE_CONN)
+    assert set(coh.cfg) == {"freqanalysis", "connectivityanalysis"}
+    again = spy.freqanalysis(d, spec.cfg, **ex)                           # replay from the record
+    assert np.array_equal(again.data, spec.data)
+    assert spy.get_defaults(spy.connectivityanalysis).method == "coh"
