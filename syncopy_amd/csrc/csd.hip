@@ -37,7 +37,8 @@ int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long wg_items = FAST ? a.fast_per : per;
-    const long long grid = (item_end - item_base + wg_items - 1) / wg_items;
+    long long grid = (item_end - item_base + wg_items - 1) / wg_items;
+    if (FAST == 3) grid = ((item_end - item_base) / a.ntiles) * a.fast_nwgf;     // whole frequencies x workgroups each
     if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nsplit), dim3(spycsd::CSD_THREADS), lds, ctx->stream, a);
@@ -83,6 +84,19 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
         while (nfb > 1 && nfb * a.ntiles > 40) --nfb;
         if (nfb > nfreq) nfb = nfreq;
         a.fast_per = nfb * a.ntiles;
+    }
+    // Even C in (256, 512]: the same path with 512-element rows; the tiles of a frequency are shared by
+    // ceil(ntiles / 40) workgroups (512 channels: 4 x 34 tiles), each staging the whole row.
+    if (!blocked && (nchan % 2 == 0) && nchan > 256 && nchan <= 512) {
+        a.fast_nwgf = (a.ntiles + 39) / 40;
+        a.fast_per = (a.ntiles + a.fast_nwgf - 1) / a.fast_nwgf;
+        const long long nwg = (long long)nfreq * a.fast_nwgf;
+        long long f_main = nfreq;
+        const long long rem = nwg % ctx->num_cu;
+        if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) f_main = ((nwg - rem) / a.fast_nwgf);
+        int rc = launch_accum<5, 4, 3>(ctx, a, 0, f_main * a.ntiles);
+        if (rc || f_main == nfreq) return rc;
+        return launch_accum<1, 1>(ctx, a, f_main * a.ntiles, a.nitems);     // the last partial round, re-cut
     }
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
     if (fast || a.ntiles >= 21) {

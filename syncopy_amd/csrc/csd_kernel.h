@@ -43,6 +43,7 @@ struct CsdArgs {
     int part_f0, part_nf;
     int blocked;                // spec = (nrows, ceil(C/4), F, 4): channel quads contiguous in frequency
     int fast_per;               // FAST path: items per workgroup = (frequencies per 256-element LDS row) * ntiles
+    int fast_nwgf;              // FAST == 3: workgroups per frequency (each owns <= fast_per of its ntiles tiles)
 };
 
 __device__ __forceinline__ void tile_of(int tt, int& ti, int& tj) {
@@ -86,7 +87,8 @@ constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chu
 // chunk instead of ~250), the row-pair loop fully unrolled with every LDS fragment address = one register per
 // tile + an immediate, the three LDS buffers reached by bumping those registers once per chunk.
 // FAST: 0 generic path, 1 instruction-lean path with 36 tiles in every workgroup (C = 256: every wave has 4 or 5
-// tiles, no per-tile guards in the loop), 2 instruction-lean path with any tile count per wave
+// tiles, no per-tile guards in the loop), 2 instruction-lean path with any tile count per wave, 3 the same for even
+// C in (256, 512]: 512-element LDS rows (8 rows per chunk), fast_nwgf workgroups share the tiles of one frequency
 template <int TA, int TB, int FAST = 0>
 __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     SPY_DYN_SMEM(float2, X);   // 2 x [kb][rowlen]
@@ -123,10 +125,17 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         if (wg < g32) wg = (wg & ~31LL) + 4 * (wg & 7) + ((wg & 31) >> 3);
     }
     const int per_wg = FAST ? a.fast_per : PER;
-    const long long item0 = a.item_base + wg * per_wg;
+    long long item0 = a.item_base + wg * per_wg;
     long long last = item0 + per_wg;
+    if constexpr (FAST == 3) {
+        // workgroup (f, k): tiles [k * per, (k + 1) * per) of frequency f, never across a frequency boundary
+        const long long fq = a.item_base / a.ntiles + wg / a.fast_nwgf;
+        item0 = fq * a.ntiles + (wg % a.fast_nwgf) * per_wg;
+        last = item0 + per_wg;
+        if (last > (fq + 1) * a.ntiles) last = (fq + 1) * a.ntiles;
+    }
     if (last > a.item_end) last = a.item_end;
-    if (item0 >= a.item_end) return;
+    if (item0 >= last) return;
     if constexpr (FAST) {
         const int nv = (int)(last - item0);
         ntile_w = nv > wpos ? (nv - wpos + 7) >> 3 : 0;
@@ -160,18 +169,19 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     }
 
     if constexpr (FAST) {
-        constexpr int ROWLEN = 256, KB = 16, CHUNK = KB * ROWLEN;   // float2 elements per LDS buffer (32 KiB)
+        constexpr int ROWLEN = FAST == 3 ? 512 : 256, KB = 4096 / ROWLEN, CHUNK = KB * ROWLEN;   // 32 KiB per LDS buffer
+        constexpr int TPR = ROWLEN / 2, RSTEP = CSD_THREADS / TPR;  // threads per row (16 bytes each), rows per pass
         constexpr int NPRE = 2;
         float4* const X4 = reinterpret_cast<float4*>(X);
         const size_t rowstride = (size_t)a.F * a.C;                 // float2 elements between rows
         const unsigned rowbytes = (unsigned)rowstride * 8u;
         const char* const fb = reinterpret_cast<const char*>(a.spec + (size_t)row_lo * rowstride + (size_t)f_lo * a.C);
-        const int srow = tid >> 7;                                  // this thread stages rows srow + 4v, v < 4
-        // ... columns 2*(tid&127), +1 (16 bytes) of the row = the (up to 256) elements of this workgroup's
+        const int srow = tid / TPR;                                 // this thread stages rows srow + RSTEP v, v < 4
+        // ... columns 2*(tid % TPR), +1 (16 bytes) of the row = the (up to ROWLEN) elements of this workgroup's
         // frequencies; columns past them are zero-filled (their load is redirected to column 0)
         const int nf_wg = (int)((last - 1) / a.ntiles) - f_lo + 1;
-        const bool colok = 2 * (tid & 127) < nf_wg * a.C;
-        const unsigned coff = colok ? (unsigned)(tid & 127) * 16u : 0u;
+        const bool colok = 2 * (tid % TPR) < nf_wg * a.C;
+        const unsigned coff = colok ? (unsigned)(tid % TPR) * 16u : 0u;
         const long long nchunk = (nrows + KB - 1) / KB;
         float4 pf[4];
         unsigned okmask = 0;
@@ -183,7 +193,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
             okmask = 0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int row = srow + 4 * v;
+                const int row = srow + RSTEP * v;
                 const int rc = row < rleft ? row : rleft - 1;       // clamped: the load is unconditional
                 pf[v] = *reinterpret_cast<const float4*>(base + ((unsigned)rc * rowbytes + coff));
                 okmask |= (row < rleft && colok) ? (1u << v) : 0u;

@@ -315,8 +315,17 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     }
     a.kb = kb;
     a.item_base = 0; a.item_end = a.nitems;
-    const unsigned grid = (unsigned)((a.nitems + per - 1) / per);
+    unsigned grid = (unsigned)((a.nitems + per - 1) / per);
     const unsigned T = spycsd::CSD_THREADS;
+    if (force_tpw == 0 && !g_blocked && (C % 2 == 0) && C > 256 && C <= 512) {      // as csd.hip: the wide variant
+        a.fast_nwgf = (a.ntiles + 39) / 40;
+        a.fast_per = (a.ntiles + a.fast_nwgf - 1) / a.fast_nwgf;
+        a.kb = 8;
+        grid = (unsigned)(F * a.fast_nwgf);
+        emu::launch(dim3(grid), dim3(T), 3 * (size_t)16 * 256 * sizeof(float2) + 512,
+                    [&] { spycsd::csd_accum_kernel<5, 4, 3>(a); });
+        return 7;
+    }
     if (fast && a.ntiles == 36) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });
     else if (fast) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 2>(a); });
     else if (ta == 5) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4>(a); });

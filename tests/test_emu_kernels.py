@@ -141,7 +141,9 @@ def test_fp32_fft_error_level():
                                        # the instruction-lean path away from 256 channels: 2 / 4 / 8 frequencies per
                                        # LDS row (incl. a last, partial group), tiles crossing into the next frequency
                                        (128, 5, 6, 0), (64, 7, 5, 0), (32, 11, 4, 0), (6, 50, 3, 0), (192, 2, 5, 0),
-                                       (100, 3, 5, 3), (40, 5, 7, 1)])
+                                       (100, 3, 5, 3), (40, 5, 7, 1),
+                                       # the wide variant (512-element rows, several workgroups per frequency)
+                                       (320, 2, 5, 0), (384, 1, 9, 0)])
 def test_csd_mfma_kernel(C, F, R, tpw):
     rng = np.random.default_rng(C)
     spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)
