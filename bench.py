@@ -233,8 +233,8 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": ("spycsd::csd_accum_kernel<5, 4, %d>" % (1 if C == 256 else 2) if C % 2 == 0 and C <= 256 and not blocked
-                           else "spycsd::csd_accum_kernel<TA, TB, 0>") + " (+ row-split <1, 1> tail and its reduction)",
+                "kernel": ("spycsd::csd_accum_kernel<5, 4, %d>" % (1 if C == 256 else 2 if C < 256 else 3) if C <= 512 and not blocked
+                           else "spycsd::csd_accum_kernel<5, 4, 0>") + " (+ row-split <1, 1> tail and its reduction)",
                 "achieved": achieved,
                 "peak": PEAK_MFMA_F32_TFLOPS,
                 "unit": "TFLOP/s",

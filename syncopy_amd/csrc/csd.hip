@@ -76,18 +76,18 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
     a.nitems = (long long)nfreq * a.ntiles;
     a.cpad = a.nt * 32;
     a.blocked = blocked;
-    // The instruction-lean path: even C <= 256, row-major spectra.  A 256-element LDS row holds nfb consecutive
+    // The instruction-lean path: C <= 256, row-major spectra.  A 256-element LDS row holds nfb consecutive
     // frequencies (1 for C > 128, 2 for C = 128, 4 for C = 64, ...) and a workgroup owns their nfb * ntiles <= 40 tiles.
-    const bool fast = !blocked && (nchan % 2 == 0) && nchan <= 256;
+    const bool fast = !blocked && nchan <= 256;            // (odd C: 8-byte staging loads instead of 16-byte ones)
     if (fast) {
         int nfb = 256 / nchan;
         while (nfb > 1 && nfb * a.ntiles > 40) --nfb;
         if (nfb > nfreq) nfb = nfreq;
         a.fast_per = nfb * a.ntiles;
     }
-    // Even C in (256, 512]: the same path with 512-element rows; the tiles of a frequency are shared by
+    // C in (256, 512]: the same path with 512-element rows; the tiles of a frequency are shared by
     // ceil(ntiles / 40) workgroups (512 channels: 4 x 34 tiles), each staging the whole row.
-    if (!blocked && (nchan % 2 == 0) && nchan > 256 && nchan <= 512) {
+    if (!blocked && nchan > 256 && nchan <= 512) {
         a.fast_nwgf = (a.ntiles + 39) / 40;
         a.fast_per = (a.ntiles + a.fast_nwgf - 1) / a.fast_nwgf;
         const long long nwg = (long long)nfreq * a.fast_nwgf;

@@ -182,6 +182,11 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         const int nf_wg = (int)((last - 1) / a.ntiles) - f_lo + 1;
         const bool colok = 2 * (tid % TPR) < nf_wg * a.C;
         const unsigned coff = colok ? (unsigned)(tid % TPR) * 16u : 0u;
+        // odd C: rows are 8-byte aligned only and the last pair of an odd-length row has no second element - the
+        // pair is fetched as two 8-byte loads, the missing element redirected to column 0 and zeroed
+        const bool odd = FAST != 1 && (a.C & 1);
+        const bool hiok = 2 * (tid % TPR) + 1 < nf_wg * a.C;
+        const unsigned coff_hi = hiok ? coff + 8u : 0u;
         const long long nchunk = (nrows + KB - 1) / KB;
         float4 pf[4];
         unsigned okmask = 0;
@@ -195,7 +200,14 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
             for (int v = 0; v < 4; ++v) {
                 const int row = srow + RSTEP * v;
                 const int rc = row < rleft ? row : rleft - 1;       // clamped: the load is unconditional
-                pf[v] = *reinterpret_cast<const float4*>(base + ((unsigned)rc * rowbytes + coff));
+                if (odd) {
+                    const float2 lo = *reinterpret_cast<const float2*>(base + ((unsigned)rc * rowbytes + coff));
+                    float2 hi = *reinterpret_cast<const float2*>(base + ((unsigned)rc * rowbytes + coff_hi));
+                    if (!hiok) hi = make_float2(0.f, 0.f);
+                    pf[v] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    pf[v] = *reinterpret_cast<const float4*>(base + ((unsigned)rc * rowbytes + coff));
+                }
                 okmask |= (row < rleft && colok) ? (1u << v) : 0u;
             }
         };

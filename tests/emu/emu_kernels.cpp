@@ -288,7 +288,7 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     a.cpad = a.nt * 32;
     a.blocked = g_blocked;
     // as csd.hip: even C <= 256, row-major spectra -> the instruction-lean path (force_tpw != 0 picks a generic kernel)
-    const bool fast = force_tpw == 0 && !g_blocked && (C % 2 == 0) && C <= 256;
+    const bool fast = force_tpw == 0 && !g_blocked && C <= 256;
     int ta = 1, tb = 1;
     if (fast || a.ntiles >= 21) { ta = 5; tb = 4; }
     else if (a.ntiles >= 6) { ta = 3; tb = 2; }
@@ -317,7 +317,7 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     a.item_base = 0; a.item_end = a.nitems;
     unsigned grid = (unsigned)((a.nitems + per - 1) / per);
     const unsigned T = spycsd::CSD_THREADS;
-    if (force_tpw == 0 && !g_blocked && (C % 2 == 0) && C > 256 && C <= 512) {      // as csd.hip: the wide variant
+    if (force_tpw == 0 && !g_blocked && C > 256 && C <= 512) {      // as csd.hip: the wide variant
         a.fast_nwgf = (a.ntiles + 39) / 40;
         a.fast_per = (a.ntiles + a.fast_nwgf - 1) / a.fast_nwgf;
         a.kb = 8;

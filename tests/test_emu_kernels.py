@@ -143,7 +143,9 @@ def test_fp32_fft_error_level():
                                        (128, 5, 6, 0), (64, 7, 5, 0), (32, 11, 4, 0), (6, 50, 3, 0), (192, 2, 5, 0),
                                        (100, 3, 5, 3), (40, 5, 7, 1),
                                        # the wide variant (512-element rows, several workgroups per frequency)
-                                       (320, 2, 5, 0), (384, 1, 9, 0)])
+                                       (320, 2, 5, 0), (384, 1, 9, 0), (257, 1, 3, 0),
+                                       # odd channel counts on the lean path: 8-byte staging loads, odd row lengths
+                                       (5, 9, 6, 5), (33, 4, 5, 3), (63, 5, 6, 0), (255, 2, 4, 0)])
 def test_csd_mfma_kernel(C, F, R, tpw):
     rng = np.random.default_rng(C)
     spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)

@@ -221,7 +221,8 @@ def test_csd_tail_row_split(be):
 @pytest.mark.parametrize("C,F,R", [(5, 33, 14), (16, 101, 140), (40, 17, 35), (70, 9, 64), (256, 5, 70),
                                    (256, 259, 10),     # 259 workgroups on 256 CUs: exercises the re-cut tail
                                    (128, 131, 20), (64, 1027, 9), (192, 300, 12),   # lean path, several f per row
-                                   (384, 7, 40), (512, 65, 20), (300, 130, 10)])    # wide variant (+ its tail)
+                                   (384, 7, 40), (512, 65, 20), (300, 130, 10),     # wide variant (+ its tail)
+                                   (255, 270, 9), (63, 33, 14), (127, 3, 40), (301, 5, 12)])   # odd channel counts
 def test_csd_accumulate_vs_oracle(be, C, F, R):
     rng = np.random.default_rng(C + F)
     spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)
