@@ -281,7 +281,7 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
                       p->log2n, p->G, mode);
         p->kernel_name = buf;
-    } else if (nfft >= 8 && 2 * nfft - 1 <= 8192 && !std::getenv("SPYHIP_FORCE_GENERIC")) {
+    } else if (nfft >= 2 && 2 * nfft - 1 <= 8192 && !std::getenv("SPYHIP_FORCE_GENERIC")) {
         // Bluestein on the packed power-of-two engine: M = 2^log2n >= 2 nfft - 1 (at least 256)
         int M = 256;
         while (M < 2 * nfft - 1) M <<= 1;

@@ -122,7 +122,7 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
             out.ctypes.data_as(C.c_void_p))
         assert rc == 0
         return out
-    if 2 * nfft - 1 <= 8192 and nfft >= 8 and not force_generic:
+    if 2 * nfft - 1 <= 8192 and nfft >= 2 and not force_generic:
         # Bluestein on the packed power-of-two engine (mirror of spyhip_fft_plan_create)
         M = 256
         while M < 2 * nfft - 1:

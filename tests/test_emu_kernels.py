@@ -97,6 +97,9 @@ def test_bluestein_kernel_modes():
     _fft_case(500, 500, 5, 3, "abs", False, 1)
     _fft_case(300, 360, 6, 2, "fourier", False, -1)
     _fft_case(77, 77, 4, 2, "real", True, 0, freq_idx=np.array([3, 0, 38, 20]), chan_idx=[3, 3, 0, 1])
+    for n in (3, 5, 7, 13):                                        # trials of a handful of samples
+        _fft_case(n, n, 3, 1, "fourier", True, 0, nseg=2)
+    _fft_case(3, 8, 2, 1, "pow", False, -1, nseg=1)
 
 
 def test_generic_kernel_matches_pow2_kernel():

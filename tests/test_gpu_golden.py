@@ -291,3 +291,26 @@ def test_jackknife_fused_kernel_matches_replicate_loop(output):
     if output == "angle":                                 # the phase of a near-zero coherence is not a stable quantity
         return
     np.testing.assert_allclose(fused.jack_bias, loop.jack_bias, rtol=2e-3, atol=1e-4 * np.abs(loop.jack_bias).max())
+
+
+@pytest.mark.parametrize("C,N,T", [(1, 50, 2), (2, 7, 3), (3, 256, 2), (7, 33, 5), (33, 100, 2), (65, 64, 3)])
+def test_edge_shapes_against_oracle(C, N, T):
+    """Degenerate shapes through the whole product path against the oracle-bound engine: one channel, a handful of
+    samples (Bluestein / tiny transforms), channel counts around the tile edges, two trials."""
+    rng = np.random.default_rng(C * 1000 + N)
+    x = rng.normal(size=(T * N, C)).astype(np.float32)
+    trl = np.stack([np.arange(T) * N, np.arange(1, T + 1) * N, np.zeros(T)], axis=1)
+    data = spy.AnalogData(x, samplerate=100.0, trialdefinition=trl)
+    okw = dict(compute_method="sequential")
+    for kw in (dict(method="mtmfft", taper="hann"), dict(method="mtmfft", taper="hann", output="fourier"),
+               dict(method="mtmfft", tapsmofrq=8 if N >= 30 else 30, keeptapers=False, keeptrials=False)):
+        got = spy.freqanalysis(data, **kw)
+        ref = spy.freqanalysis(data, routine_classes=ORACLE_FREQ, **okw, **kw)
+        assert got.data.shape == ref.data.shape
+        assert_parity(got.data, ref.data, what=f"mtmfft {kw}", atol_rel=3e-6)
+    for kw in (dict(method="csd", taper="hann"), dict(method="coh", taper="hann", output="pow"),
+               dict(method="corr")):
+        got = spy.connectivityanalysis(data, **kw)
+        ref = spy.connectivityanalysis(data, routine_classes=ORACLE_CONN, **okw, **kw)
+        assert got.data.shape == ref.data.shape
+        assert_parity(got.data, ref.data, what=f"connectivity {kw}", atol_rel=1e-5)
