@@ -108,7 +108,7 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
         if (full > 0 && rem > 0 && rem * 4 <= ctx->num_cu) {
             // 36 tiles in every workgroup (C = 256): the variant without per-tile guards
             int rc = !fast ? launch_accum<5, 4>(ctx, a, 0, full * per)
-                           : (a.ntiles == 36 ? launch_accum<5, 4, 1>(ctx, a, 0, full * per)
+                           : (nchan == 256 ? launch_accum<5, 4, 1>(ctx, a, 0, full * per)
                                              : launch_accum<5, 4, 2>(ctx, a, 0, full * per));
             if (rc) return rc;
             // tail: 1 tile per wave AND the rows split over blockIdx.y, so that its rem*4.5*nsplit short
@@ -142,7 +142,7 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
             return 0;
         }
         if (!fast) return launch_accum<5, 4>(ctx, a, 0, a.nitems);
-        return a.ntiles == 36 ? launch_accum<5, 4, 1>(ctx, a, 0, a.nitems) : launch_accum<5, 4, 2>(ctx, a, 0, a.nitems);
+        return nchan == 256 ? launch_accum<5, 4, 1>(ctx, a, 0, a.nitems) : launch_accum<5, 4, 2>(ctx, a, 0, a.nitems);
     }
     if (a.ntiles >= 6) return launch_accum<3, 2>(ctx, a, 0, a.nitems);
     return launch_accum<1, 1>(ctx, a, 0, a.nitems);

@@ -18,6 +18,7 @@
 
 #ifndef SPY_HOST_EMU
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 namespace spycsd {
@@ -86,6 +87,32 @@ constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chu
 // minimal: 16-byte staging loads/stores addressed by a scalar base + one lane offset (4 + 4 instructions per
 // chunk instead of ~250), the row-pair loop fully unrolled with every LDS fragment address = one register per
 // tile + an immediate, the three LDS buffers reached by bumping those registers once per chunk.
+// FAST == 1 tile ownership (C = 256: 8 channel blocks, 36 lower-triangle tiles per frequency): every wave owns ONE
+// diagonal tile, always in slot 3, plus three off-diagonal tiles (slots 0-2) and - waves 0, 2, 5, 7 - a fifth one
+// (slot 4).  The diagonal tile is Hermitian: only its 16 x 16 sub-blocks (0,0), (1,0), (1,1) are computed, with
+// v_mfma_f32_16x16x4_f32 on four rows at a time (3/4 of the matrix work of a full 32 x 32 tile; the consumers of the
+// accumulator only ever read elements with i >= j).  Entry = five (ti, tj) pairs, 3 bits each, slot t at bits 6t.
+constexpr unsigned fast_pack(int a0, int b0, int a1, int b1, int a2, int b2, int a3, int b3, int a4, int b4) {
+    return (unsigned)(a0 | (b0 << 3)) | ((unsigned)(a1 | (b1 << 3)) << 6) | ((unsigned)(a2 | (b2 << 3)) << 12) |
+           ((unsigned)(a3 | (b3 << 3)) << 18) | ((unsigned)(a4 | (b4 << 3)) << 24);
+}
+__device__ __forceinline__ void fast_tile(int wave, int t, int& ti, int& tj) {
+    unsigned e;
+    switch (wave) {
+        case 0: e = fast_pack(4, 2, 4, 0, 2, 0, 0, 0, 1, 0); break;
+        case 1: e = fast_pack(6, 2, 6, 1, 2, 1, 1, 1, 0, 0); break;
+        case 2: e = fast_pack(7, 3, 7, 0, 3, 0, 3, 3, 3, 2); break;
+        case 3: e = fast_pack(5, 3, 5, 1, 3, 1, 5, 5, 0, 0); break;
+        case 4: e = fast_pack(7, 4, 7, 1, 4, 1, 7, 7, 0, 0); break;
+        case 5: e = fast_pack(6, 4, 6, 3, 4, 3, 4, 4, 5, 4); break;
+        case 6: e = fast_pack(6, 5, 6, 0, 5, 0, 6, 6, 0, 0); break;
+        default: e = fast_pack(7, 5, 7, 2, 5, 2, 2, 2, 7, 6); break;
+    }
+    e >>= 6 * t;
+    ti = (int)(e & 7u);
+    tj = (int)((e >> 3) & 7u);
+}
+
 // FAST: 0 generic path, 1 instruction-lean path with 36 tiles in every workgroup (C = 256: every wave has 4 or 5
 // tiles, no per-tile guards in the loop), 2 instruction-lean path with any tile count per wave, 3 the same for even
 // C in (256, 512]: 512-element LDS rows (8 rows per chunk), fast_nwgf workgroups share the tiles of one frequency
@@ -152,7 +179,9 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     for (int t = 0; t < TA; ++t) {
         const long long item = item_of(t);
         int f = f_lo, ti = 0, tj = 0;
-        if (t < ntile_w && item < a.item_end) {
+        if constexpr (FAST == 1) {
+            fast_tile(wave, t, ti, tj);
+        } else if (t < ntile_w && item < a.item_end) {
             f = (int)(item / a.ntiles);
             tile_of((int)(item % a.ntiles), ti, tj);
         }
@@ -234,6 +263,24 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
         }
         const char* const Xb = reinterpret_cast<const char*>(X);
         auto lds2 = [&](unsigned addr, int imm) { return *reinterpret_cast<const float2*>(Xb + addr + imm); };
+        // FAST == 1: the diagonal tile (slot 3) in 16 x 16 x 4 fragments - lane l holds channel (l & 15) of sub-block
+        // 0 / 1 of the block and row (l >> 4) of a group of four rows
+        constexpr int DG = 3;
+        unsigned dA = (unsigned)((lane >> 4) * ROWLEN + (aoff[DG] - l31) + (lane & 15)) * 8u;
+        f32x4 dre[3], dim[3];                                        // sub-blocks (0,0), (1,0), (1,1)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dre[q][r] = 0.f;
+                dim[q][r] = 0.f;
+            }
+        auto mfma4d = [&](int q, float2 av, float2 bv) {
+            dre[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, dre[q], 0, 0, 0);
+            dim[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.x, dim[q], 0, 0, 0);
+            dre[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, dre[q], 0, 0, 0);
+            dim[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av.x, bv.y, dim[q], 0, 0, 0);
+        };
         auto mfma4 = [&](int t, float2 av, float2 bv) {
             accr[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accr[t], 0, 0, 0);
             acci[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acci[t], 0, 0, 0);
@@ -264,8 +311,14 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
                 }
 #pragma unroll
                 for (int t = NPRE; t < TA; ++t) {
+                    if (FAST == 1 && t == DG) continue;
                     av[t] = lds2(aA[t], st * RP);
                     bv[t] = lds2(aB[t], st * RP);
+                }
+                float2 d0 = make_float2(0.f, 0.f), d1 = d0;
+                if (FAST == 1 && (st & 1)) {                        // rows 2 (st - 1) .. 2 st + 1 of the chunk
+                    d0 = lds2(dA, (st - 1) * RP);
+                    d1 = lds2(dA, (st - 1) * RP + 128);
                 }
                 sched_fence_csd();
 #pragma unroll
@@ -287,6 +340,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
                         aA[t] += (unsigned)delta;
                         aB[t] += (unsigned)delta;
                     }
+                    dA += (unsigned)delta;
                     if (c + 1 < nchunk) {
 #pragma unroll
                         for (int t = 0; t < NPRE; ++t) {
@@ -299,11 +353,32 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
 #pragma unroll
                 for (int t = NPRE; t < TA; ++t) {
                     if ((FAST != 1 || t >= TB) && t >= ntile_w) break;
+                    if (FAST == 1 && t == DG) continue;
                     mfma4(t, av[t], bv[t]);
+                }
+                if (FAST == 1 && (st & 1)) {
+                    mfma4d(0, d0, d0);
+                    mfma4d(1, d1, d0);
+                    mfma4d(2, d1, d1);
                 }
             }
             __syncthreads();
             b0 = b0 == 2 ? 0 : b0 + 1;
+        }
+        if constexpr (FAST == 1) {
+            // diagonal tile: lane l holds column (l & 15) and rows 4 (l >> 4) + r of each 16 x 16 sub-block
+            float2* const base = a.acc + (size_t)f_lo * a.C * a.C;
+            const int g0 = aoff[DG] - l31;                           // first channel of the diagonal block
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ia = (q >= 1) ? 16 : 0, jb = (q == 2) ? 16 : 0;
+                float2* const pb = base + (size_t)(g0 + ia + 4 * (lane >> 4)) * a.C + (g0 + jb + (lane & 15));
+                float2 old[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[r] = pb[(size_t)r * a.C];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[(size_t)r * a.C] = make_float2(old[r].x + dre[q][r], old[r].y + dim[q][r]);
+            }
         }
     } else {
     // element i of this thread = LDS slot u = tid + 512*i = (row kr, column cc) of the chunk
@@ -450,10 +525,15 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
         const long long item = item_of(t);
-        if (t >= ntile_w || item >= a.item_end) continue;
-        const int f = (int)(item / a.ntiles);
-        int ti, tj;
-        tile_of((int)(item % a.ntiles), ti, tj);
+        if (t >= ntile_w || (FAST != 1 && item >= a.item_end)) continue;
+        if (FAST == 1 && t == 3) continue;                          // the diagonal tile was written above
+        int f = f_lo, ti, tj;
+        if constexpr (FAST == 1) {
+            fast_tile(wave, t, ti, tj);
+        } else {
+            f = (int)(item / a.ntiles);
+            tile_of((int)(item % a.ntiles), ti, tj);
+        }
         const int j = tj * 32 + l31;
         // read-modify-write of the 16 rows this lane holds: all loads first (clamped, branch-free), then stores
         const int jc = j < a.C ? j : a.C - 1;

@@ -326,7 +326,7 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
                     [&] { spycsd::csd_accum_kernel<5, 4, 3>(a); });
         return 7;
     }
-    if (fast && a.ntiles == 36) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });
+    if (fast && C == 256) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });
     else if (fast) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 2>(a); });
     else if (ta == 5) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4>(a); });
     else if (ta == 3) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<3, 2>(a); });

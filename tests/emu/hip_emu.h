@@ -117,6 +117,27 @@ static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x
     return d;
 }
 
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D[row=4*(l>>4)+r][col=l&15] for r in [0,4)
+static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
+    double* s = emu::wave_scratch();
+    float* A = reinterpret_cast<float*>(s);        // [4][16]
+    float* B = A + 64;                             // [4][16]
+    unsigned l = emu::lane();
+    emu::wave_sync();
+    A[(l >> 4) * 16 + (l & 15)] = a;
+    B[(l >> 4) * 16 + (l & 15)] = b;
+    emu::wave_sync();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r, col = l & 15;
+        float acc = d[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(A[k * 16 + row], B[k * 16 + col], acc);
+        d[r] = acc;
+    }
+    emu::wave_sync();
+    return d;
+}
+
 // v_mfma_f64_16x16x4_f64: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D[row=(l>>4)+4*r][col=l&15]
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 static inline f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, f64x4 c, int, int, int) {

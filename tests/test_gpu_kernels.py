@@ -128,8 +128,9 @@ def test_fft_zero_extended_segments(be):
 
 @pytest.mark.parametrize("C,N,B,K", [(256, 4096, 3, 2), (6, 512, 5, 3), (37, 1024, 4, 1), (8, 8192, 2, 2)])
 def test_blocked_handover_layout_is_bit_identical(be, C, N, B, K):
-    """FFT -> CSD through the channel-blocked hand-over layout (coalesced stores) gives exactly the accumulator of
-    the (B, K, F, C) path, and the blocked spectra are a pure re-ordering of the standard ones."""
+    """FFT -> CSD through the channel-blocked hand-over layout (coalesced stores) gives the accumulator of the
+    (B, K, F, C) path (bit for bit where both layouts run the same kernel), and the blocked spectra are a pure
+    re-ordering of the standard ones."""
     rng = np.random.default_rng(C)
     data = torch.from_numpy(rng.normal(size=(B * N, C)).astype(np.float32)).cuda()
     starts = torch.arange(B, device="cuda", dtype=torch.int64) * N
@@ -150,7 +151,15 @@ def test_blocked_handover_layout_is_bit_identical(be, C, N, B, K):
     a_blk = torch.zeros_like(a_std)
     be.csd_accumulate(s_std, a_std)
     be.csd_accumulate(s_blk, a_blk, blocked=True)
-    assert torch.equal(torch.view_as_real(a_std), torch.view_as_real(a_blk))
+    # what consumers read is the lower triangle (the rest of a diagonal tile is never looked at)
+    be.csd_finalize(a_std, 1.0)
+    be.csd_finalize(a_blk, 1.0)
+    if C == 256:
+        # 256 channels: the standard layout takes the variant whose diagonal tiles are summed four rows at a time on
+        # 16 x 16 x 4 matrix instructions - same products, different order of the float32 additions
+        assert_parity(a_std.cpu().numpy(), a_blk.cpu().numpy(), what="blocked vs standard layout")
+    else:
+        assert torch.equal(torch.view_as_real(a_std), torch.view_as_real(a_blk))
     assert not be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, False, None, "pow", True).set_blocked(True)
 
 
