@@ -82,27 +82,33 @@ __global__ void __launch_bounds__(256) jack_coh_kernel(JackArgs a) {
     for (int t = 0; t < a.ntrials; ++t) {
         const float2* b = jk_lds + (t & 1) * per;
         if (t + 1 < a.ntrials) stage(t + 1, jk_lds + ((t + 1) & 1) * per);
-        float2 s[4];
-        float pj[4], pi = 0.f;
+        // xi * conj(xj) = xi * xj.re + (xi.im, -xi.re) * xj.im: two packed FMAs per pair and taper; the powers of the
+        // four column channels as two packed FMA chains over (re^2 + im^2)
+        typedef float pk2 __attribute__((ext_vector_type(2)));
+        pk2 s[4], pj01 = pk2{0.f, 0.f}, pj23 = pk2{0.f, 0.f};
+        float pi = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            s[q] = make_float2(0.f, 0.f);
-            pj[q] = 0.f;
-        }
+        for (int q = 0; q < 4; ++q) s[q] = pk2{0.f, 0.f};
         for (int k = 0; k < K; ++k) {
-            const float2 xi = b[k * 32 + ti];
+            const float2 xi2 = b[k * 32 + ti];
             const float4* p4 = reinterpret_cast<const float4*>(b + (K + k) * 32 + tq * 4);
             const float4 j01 = p4[0], j23 = p4[1];
-            const float2 xj[4] = {make_float2(j01.x, j01.y), make_float2(j01.z, j01.w), make_float2(j23.x, j23.y),
-                                  make_float2(j23.z, j23.w)};
-            pi += xi.x * xi.x + xi.y * xi.y;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s[q].x += xi.x * xj[q].x + xi.y * xj[q].y;
-                s[q].y += xi.y * xj[q].x - xi.x * xj[q].y;
-                pj[q] += xj[q].x * xj[q].x + xj[q].y * xj[q].y;
-            }
+            const pk2 xi = pk2{xi2.x, xi2.y}, xs = pk2{xi2.y, -xi2.x};
+            pi += xi2.x * xi2.x + xi2.y * xi2.y;
+            s[0] = xi * pk2{j01.x, j01.x} + s[0];
+            s[1] = xi * pk2{j01.z, j01.z} + s[1];
+            s[2] = xi * pk2{j23.x, j23.x} + s[2];
+            s[3] = xi * pk2{j23.z, j23.z} + s[3];
+            s[0] = xs * pk2{j01.y, j01.y} + s[0];
+            s[1] = xs * pk2{j01.w, j01.w} + s[1];
+            s[2] = xs * pk2{j23.y, j23.y} + s[2];
+            s[3] = xs * pk2{j23.w, j23.w} + s[3];
+            pj01 = pk2{j01.x, j01.z} * pk2{j01.x, j01.z} + pj01;
+            pj01 = pk2{j01.y, j01.w} * pk2{j01.y, j01.w} + pj01;
+            pj23 = pk2{j23.x, j23.z} * pk2{j23.x, j23.z} + pj23;
+            pj23 = pk2{j23.y, j23.w} * pk2{j23.y, j23.w} + pj23;
         }
+        const float pj[4] = {pj01.x, pj01.y, pj23.x, pj23.y};
         // leave-one-out average in complex64 as the reference forms it: (T * S - S_t) / (T - 1)
         const float lii = (T * Sii - pi * invK) * invT1;
 #pragma unroll
