@@ -49,7 +49,30 @@ __global__ void __launch_bounds__(256) jack_coh_kernel(JackArgs a) {
     const int K = a.K, per = 2 * K * 32;
     // (buffers addressed as jk_lds + n * per: a pointer array would decay to flat addressing)
 
+    // staging offsets inside a trial are the same for every trial: computed once (as in K7)
+    constexpr int NST = 4;
+    unsigned soff[NST];
+    bool sok[NST];
+#pragma unroll
+    for (int n = 0; n < NST; ++n) {
+        const int e = tid + 256 * n;
+        const int side = e / (K * 32), k = (e - side * K * 32) >> 5, c = e & 31;
+        const int ch = (side ? bj : bi) * 32 + c;
+        sok[n] = e < per && ch < a.C;
+        soff[n] = sok[n] ? (unsigned)(((size_t)k * a.F + f) * a.C + ch) : 0u;
+    }
+    const size_t tstride = (size_t)K * a.F * a.C;
+    const bool small = per <= 256 * NST && tstride < (1ull << 31);
     auto stage = [&](int t, float2* dst) {
+        if (small) {
+            const float2* base = a.spec + (size_t)t * tstride;
+#pragma unroll
+            for (int n = 0; n < NST; ++n) {
+                const int e = tid + 256 * n;
+                if (256 * n < per && e < per) dst[e] = sok[n] ? base[soff[n]] : make_float2(0.f, 0.f);
+            }
+            return;
+        }
         for (int e = tid; e < per; e += 256) {
             const int side = e / (K * 32), k = (e - side * K * 32) >> 5, c = e & 31;
             const int ch = (side ? bj : bi) * 32 + c;
