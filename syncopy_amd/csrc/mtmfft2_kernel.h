@@ -32,12 +32,15 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
 
     // XCD-aware block -> (segment, quad group): the S workgroups that share 128-byte lines of the
     // (time x channel) rows get ids congruent mod 8 (same XCD / L2) and adjacent in dispatch order.
+    // Each XCD walks a contiguous run of clusters: consecutive segments (overlapping sliding-window frames share half
+    // of their rows) then find those rows in the L2 they were just fetched into.
     const long long id = blockIdx.x;
     const int xcd = (int)(id & 7);
     const long long y = id >> 3;
-    const long long cidx = (y / a.S) * 8 + xcd;
+    const long long nclt = (long long)a.nseg * a.ncl, chunk = (nclt + 7) >> 3;
+    const long long cidx = (long long)xcd * chunk + y / a.S;
     const int q = (int)(y % a.S);
-    if (cidx >= (long long)a.nseg * a.ncl) return;
+    if (cidx >= nclt) return;
     const int b = (int)(cidx / a.ncl);
     const int pg = (int)(cidx % a.ncl) * a.S + q;
     if (pg >= a.npg) return;
