@@ -100,9 +100,11 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmfft
     const long long id = blockIdx.x;
     const int xcd = (int)(id & 7);
     const long long y = id >> 3;
-    const long long cidx = (y / a.S) * 8 + xcd;
+    // each XCD walks a contiguous run of clusters (see mtmfft2_kernel.h): the rows of a spectrum meet in one L2
+    const long long nclt = (long long)a.nseg * a.ncl, chunk = (nclt + 7) >> 3;
+    const long long cidx = (long long)xcd * chunk + y / a.S;
     const int q = (int)(y % a.S);
-    if (cidx >= (long long)a.nseg * a.ncl) return;
+    if (cidx >= nclt) return;
     const int b = (int)(cidx / a.ncl);
     const int pg = (int)(cidx % a.ncl) * a.S + q;
     if (pg >= a.npg) return;
