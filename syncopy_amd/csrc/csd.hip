@@ -236,7 +236,7 @@ extern "C" int spyhip_jack_coh_accumulate(spyhip_ctx* ctx, const void* spec_d, i
     a.T = (float)ntrials_total;
     a.sum_d = reinterpret_cast<double*>(sum_d);
     a.sum_d2 = reinterpret_cast<double*>(sum_d2);
-    const long long nt = (nchan + 31) / 32, blocks = (long long)nfreq * (nt * (nt + 1) / 2);
+    const long long nt = (nchan + 31) / 32, blocks = 8LL * ((nfreq + 7) / 8) * (nt * (nt + 1) / 2);
     if (blocks > 0x7fffffffLL) { spy::set_error("jack_coh_accumulate: grid too large"); return -1; }
     const size_t lds = 2 * (size_t)2 * ntaper * 32 * sizeof(float2);
     if (lds > ctx->lds_per_block) { spy::set_error("jack_coh_accumulate: %d tapers do not fit the LDS staging buffer", ntaper); return -3; }

@@ -43,9 +43,13 @@ __global__ void __launch_bounds__(256) jack_coh_kernel(JackArgs a) {
     SPY_DYN_SMEM(float2, jk_lds);
     const int tid = threadIdx.x, ti = tid & 31, tq = tid >> 5;
     const int nt = (a.C + 31) / 32, ntl = nt * (nt + 1) / 2;
-    const int f = blockIdx.x / ntl;
+    // all tiles of a frequency on ONE XCD, one after the other (as K7)
+    const int fchunk = (a.F + 7) >> 3;
+    const unsigned yid = blockIdx.x >> 3;
+    const int f = (int)(blockIdx.x & 7u) * fchunk + (int)(yid / ntl);
+    if ((int)(yid / ntl) >= fchunk || f >= a.F) return;
     int bi, bj;
-    tile_of(blockIdx.x % ntl, bi, bj);                  // bi >= bj: the upper triangle is mirrored on the way out
+    tile_of((int)(yid % ntl), bi, bj);                  // bi >= bj: the upper triangle is mirrored on the way out
     const int K = a.K, per = 2 * K * 32;
     // (buffers addressed as jk_lds + n * per: a pointer array would decay to flat addressing)
 

@@ -13,7 +13,7 @@ extern "C" int spyhip_ppc_accumulate(spyhip_ctx* ctx, const void* spec_d, int nt
     a.spec = reinterpret_cast<const float2*>(spec_d);
     a.ntrials = ntrials; a.ntaper = ntaper; a.F = nfreq; a.C = nchan;
     a.acc = reinterpret_cast<float2*>(acc_d);
-    const long long nt = (nchan + 31) / 32, blocks = (long long)nfreq * (nt * (nt + 1) / 2);
+    const long long nt = (nchan + 31) / 32, blocks = 8LL * ((nfreq + 7) / 8) * (nt * (nt + 1) / 2);   // 8 XCDs x frequencies each
     if (blocks > 0x7fffffffLL) { spy::set_error("ppc_accumulate: grid too large"); return -1; }
     const size_t lds = 2 * (size_t)2 * ntaper * 32 * sizeof(float2);
     if (lds > ctx->lds_per_block) { spy::set_error("ppc_accumulate: %d tapers do not fit the LDS staging buffer", ntaper); return -3; }

@@ -37,8 +37,13 @@ __global__ void __launch_bounds__(256) ppc_accum_kernel(PpcArgs a) {
     SPY_DYN_SMEM(float2, ppc_lds);
     const int tid = threadIdx.x, ti = tid & 31, tq = tid >> 5;
     const int nt = (a.C + 31) / 32, ntl = nt * (nt + 1) / 2;
-    const int f = blockIdx.x / ntl;
-    int rem = blockIdx.x % ntl, bi = 0;
+    // all tiles of a frequency run on ONE XCD (ids congruent mod 8), one after the other: the frequency's rows are
+    // fetched from HBM into that L2 once instead of into all eight
+    const int fchunk = (a.F + 7) >> 3;
+    const unsigned yid = blockIdx.x >> 3;
+    const int f = (int)(blockIdx.x & 7u) * fchunk + (int)(yid / ntl);
+    if ((int)(yid / ntl) >= fchunk || f >= a.F) return;
+    int rem = (int)(yid % ntl), bi = 0;
     while (rem >= bi + 1) { rem -= bi + 1; ++bi; }
     const int bj = rem;
     const int K = a.ntaper, per = 2 * K * 32;

@@ -369,7 +369,7 @@ void emu_jack_coh(const float* spec, int ntrials, int K, int F, int C, const flo
     a.sum_d = sum_d; a.sum_d2 = sum_d2;
     const int nt = (C + 31) / 32;
     const size_t lds = 2 * (size_t)2 * K * 32 * sizeof(float2);
-    const dim3 grid((unsigned)(F * (nt * (nt + 1) / 2)));
+    const dim3 grid((unsigned)(8 * ((F + 7) / 8) * (nt * (nt + 1) / 2)));
     if (kind == SPYHIP_OUT_FOURIER) emu::launch(grid, dim3(256), lds, [&] { spycsd::jack_coh_kernel<true>(a); });
     else emu::launch(grid, dim3(256), lds, [&] { spycsd::jack_coh_kernel<false>(a); });
 }
@@ -382,7 +382,7 @@ void emu_ppc_accumulate(const float* spec, int ntrials, int ntaper, int F, int C
     a.acc = reinterpret_cast<float2*>(acc);
     const int nt = (C + 31) / 32;
     const size_t lds = 2 * (size_t)2 * ntaper * 32 * sizeof(float2);
-    emu::launch(dim3((unsigned)(F * (nt * (nt + 1) / 2))), dim3(256), lds, [&] { spyppc::ppc_accum_kernel(a); });
+    emu::launch(dim3((unsigned)(8 * ((F + 7) / 8) * (nt * (nt + 1) / 2))), dim3(256), lds, [&] { spyppc::ppc_accum_kernel(a); });
 }
 
 void emu_ppc_accumulate_csd(const float* csd, int ntrials, long long n, float* acc) {
