@@ -36,7 +36,7 @@ int launch_lags(spyhip_ctx* ctx, const spyfft::CcovArgs& a) {
     auto kern = spyfft::ccov_lags_kernel<LOG2N, G>;
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-    const long long grid = (a.npairs + 2 * G - 1) / (2 * G);
+    const long long grid = 8 * (((a.npairs + 2 * G - 1) / (2 * G) + 7) / 8);     // 8 XCDs x pair blocks each
     if (grid > 0x7fffffffLL) { spy::set_error("ccov: grid too large"); return -1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, ctx->stream, a);
     SPY_HIP_CHECK(hipGetLastError());

@@ -44,7 +44,12 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) ccov_lags_kernel(C
     SPY_DYN_SMEM(v2f, lds);
     const int tid = threadIdx.x;
     const int h = tid % G, j = tid / G;
-    const long long p0 = ((long long)blockIdx.x * G + h) * 2;
+    // neighbouring channel pairs share 128-byte lines of every accumulator row: each XCD takes a contiguous run of
+    // pair blocks (ids congruent mod 8 run on one XCD, one after the other), so a line is fetched into one L2 only
+    const long long nblk = (a.npairs + 2 * G - 1) / (2 * G), chunk = (nblk + 7) >> 3;
+    const long long blk = (long long)(blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= chunk || blk >= nblk) return;
+    const long long p0 = (blk * G + h) * 2;
     int ca[2] = {0, 0}, cb[2] = {0, 0};
     bool has[2];
 #pragma unroll

@@ -111,7 +111,7 @@ static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD
 template <int LOG2N, int G>
 static void emu_launch_ccov(const spyfft::CcovArgs& a) {
     using C = spyfft::Cfg2<LOG2N, G>;
-    const long long grid = (a.npairs + 2 * G - 1) / (2 * G);
+    const long long grid = 8 * (((a.npairs + 2 * G - 1) / (2 * G) + 7) / 8);
     emu::launch(dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::ccov_lags_kernel<LOG2N, G>(a); });
 }
 
