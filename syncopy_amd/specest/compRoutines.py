@@ -232,8 +232,8 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
         pkey = (nsig, nchan, scales.tobytes(), dt, w0, polyremoval, output, None if tpos is None else tpos.tobytes(),
                 str(device))
         if pkey not in _cwt_plans:
-            _cwt_plans[pkey] = hs.backend.CWTPlan(nsig, nchan, scales, dt, w0, polyremoval, output, tpos, nuniq,
-                                                  device=device)
+            hs._bounded_put(_cwt_plans, pkey, hs.backend.CWTPlan(nsig, nchan, scales, dt, w0, polyremoval, output,
+                                                                 tpos, nuniq, device=device))
         plan = _cwt_plans[pkey]
         starts = torch.tensor([m[1] for m in members], dtype=torch.int64, device=device)
         lo = torch.tensor([m[2] for m in members], dtype=torch.int64, device=device)
@@ -340,9 +340,10 @@ def _superlet_device(dev, rows, pre, post, chans, polyremoval, output, method_kw
                 pkey = ("sl", nsig, nchan, scales[sc0:].tobytes(), dt, cycles, polyremoval, real,
                         None if tpos is None else tpos.tobytes(), str(device))
                 if pkey not in _cwt_plans:
-                    _cwt_plans[pkey] = hs.backend.CWTPlan(nsig, nchan, scales[sc0:], dt, detrend=polyremoval,
-                                                          output="abs" if real else "fourier", tpos=tpos,
-                                                          ntime_out=nuniq, device=device, sl_cycles=cycles)
+                    hs._bounded_put(_cwt_plans, pkey,
+                                    hs.backend.CWTPlan(nsig, nchan, scales[sc0:], dt, detrend=polyremoval,
+                                                       output="abs" if real else "fourier", tpos=tpos,
+                                                       ntime_out=nuniq, device=device, sl_cycles=cycles))
                 plan = _cwt_plans[pkey]
                 buf = hs.backend.handover_buffer(plan.out_shape(len(part)), device, dtype=wdt)
                 spec = plan.execute(dev, starts, lo, hi, chan_idx=ci, out=buf)

@@ -12,6 +12,15 @@ from .. import backend
 
 _plan_cache = {}
 _taper_cache = {}
+MAX_CACHED_PLANS = 64
+
+
+def _bounded_put(cache, key, value):
+    """Insert into a plan cache that keeps the most recent MAX_CACHED_PLANS entries (plans own device tables:
+    a long session over many shapes must not accumulate them)."""
+    while len(cache) >= MAX_CACHED_PLANS:
+        cache.pop(next(iter(cache)))
+    cache[key] = value
 
 
 def taper_table(taper, nsig, nnorm, taper_opt=None):
@@ -53,7 +62,7 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
                                keeptapers, device=device)
         if blocked:
             plan.set_blocked(True)
-        _plan_cache[key] = plan
+        _bounded_put(_plan_cache, key, plan)
     return _plan_cache[key]
 
 
