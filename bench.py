@@ -12,7 +12,10 @@ Trials shard across ranks with no other exchange (weak scaling: 1000 trials per 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  At N = 1 the line also carries `secondary` (the other SURVEY 8(d) numbers: c2
+mtmfft power, c4 sliding-window FFT and Morlet wavelets, c5 Wilson/Granger AV stage - each with its dominant kernel
+and its fraction of the bound it is priced against) and `cpu_baseline` (the reference's CPU path as restated by the
+oracle: one core, and one process per core).
 """
 import argparse
 import json
@@ -26,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F64_TFLOPS = 78.6          # MI355X_MICROARCH.md: FP64 vector / matrix
 PEAK_HBM_GBS = 8000.0
 
 
@@ -41,39 +45,101 @@ def parse():
     ap.add_argument("--blocked", action="store_true",
                     help="FFT -> CSD hand-over in the channel-blocked layout (faster FFT stores, slower CSD fetch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c2 / c4 / c5 secondary measurements")
     return ap.parse_args()
 
 
-def cpu_baseline(nchan, nsamp, budget_s=30.0):
-    """Reference-faithful CPU path (oracle = port of the reference's NumPy/SciPy calls) timed on
-    the host: single-trial cross spectra exactly as csd.py:94-102 does them (incl. the
-    (K,F,C,C) temporary), the per-trial cost of the reference's compute_sequential loop."""
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (= port of the reference's NumPy/SciPy calls) timed on the host cores
+# ----------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_worker(args):
+    """One process of the one-process-per-core baseline: `n` trials of cross_spectra_cF, BLAS/FFT threads = 1."""
+    nchan, nsamp, n, faithful, seed = args
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
     from oracle import spy_oracle as O
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     x = rng.normal(size=(nsamp, nchan)).astype(np.float32)
     topt = {"NW": 1.0 * nsamp / 1000.0, "Kmax": 7}
-    n = 0
+    acc = None
     t0 = time.perf_counter()
-    while True:
-        O.cross_spectra_cF(x.copy(), samplerate=1000.0, nSamples=nsamp, foi=None, taper="dpss", taper_opt=topt,
-                           polyremoval=0, faithful=True)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s / 2 or n >= 8:
-            break
-    return {"value": n / el, "unit": "trials/s", "cores": 1, "kind": "port",
-            "sample": f"{n} trial(s) of {nchan} ch x {nsamp} samples, cross_spectra_cF (mtmfft + (K,F,C,C) outer "
-                      f"product + taper mean, as csd.py:94-102), {el:.1f} s on one host core"}
+    for _ in range(n):
+        r, _ = O.cross_spectra_cF(x.copy(), samplerate=1000.0, nSamples=nsamp, foi=None, taper="dpss", taper_opt=topt,
+                                  polyremoval=0, faithful=faithful)
+        acc = r if acc is None else acc.__iadd__(r)      # the trial sum of compute_sequential (:1022-1032)
+    return time.perf_counter() - t0
 
 
+def cpu_baseline(nchan, nsamp):
+    """BASELINE.md section 4.2 on the GPU box's host: the reference's per-trial coherence ST stage
+    (mtmfft + outer product + taper mean, csd.py:94-102) as restated by the oracle,
+      (a) one process, one trial at a time = compute_sequential (computational_routine.py:944), "reference-faithful"
+          (materialises the (K,F,C,C) product like csd.py:98) and "best-effort CPU" (einsum accumulation);
+      (b) one process per core over disjoint trials = the Dask LocalCluster trial map (:926), BLAS threads = 1 -
+          best-effort variant only (the faithful one needs 8.6 GB per process).
+    `value` is (a)-faithful: the reference's own code path on one core."""
+    import multiprocessing as mp
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or 1
+        avail = psutil.virtual_memory().available
+    except Exception:
+        phys, avail = os.cpu_count() or 1, 64 << 30
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else phys
+    ncore = max(1, min(phys, usable))
+    t_f = _cpu_worker((nchan, nsamp, 1, True, 0))
+    t_e = _cpu_worker((nchan, nsamp, 2, False, 0)) / 2
+    # one process per core: each holds a (F,C,C) complex64 result + accumulator (~2.2 GB at 256 x 4096)
+    per_proc = 3 * (nsamp // 2 + 1) * nchan * nchan * 8
+    nproc = int(max(1, min(ncore, (avail // 2) // max(per_proc, 1))))
+    per = 2
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(nproc) as pool:
+        pool.map(_cpu_worker, [(nchan, nsamp, per, False, 100 + i) for i in range(nproc)])
+    t_all = time.perf_counter() - t0
+    return {
+        "value": 1.0 / t_f, "unit": "trials/s", "cores": 1, "kind": "port",
+        "sample": f"1 trial of {nchan} ch x {nsamp} samples, cross_spectra_cF reference-faithful (mtmfft + (K,F,C,C) outer "
+                  f"product + taper mean, as csd.py:94-102), {t_f:.1f} s on one host core",
+        "cpu_model": _cpu_model(), "physical_cores": phys, "usable_cores": usable,
+        "variants": {
+            "faithful_1core": {"value": 1.0 / t_f, "cores": 1, "s_per_trial": t_f},
+            "best_effort_einsum_1core": {"value": 1.0 / t_e, "cores": 1, "s_per_trial": t_e},
+            "best_effort_einsum_process_per_core": {
+                "value": nproc * per / t_all, "cores": nproc, "trials": nproc * per, "wall_s": t_all,
+                "note": "one process per core (spawn, pool start-up included), BLAS threads = 1, inputs in RAM; "
+                        "processes limited to half the free memory"},
+        },
+    }
+
+
+# ----------------------------------------------------------------------------------------------------------------
 def pmc_traffic(nrows, nfreq, nchan):
-    """HBM bytes per CSD launch from the committed counter passes (profiles/r1_pmc_counters_final.txt:
+    """HBM bytes per CSD launch from the committed counter passes (profiles/r*_pmc_counters_final.txt:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/pmc_harness.cpp, same launch
     shape).  Units are KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM) prescribes for 16-byte
     per-lane streaming reads on gfx950.  Counters are only valid for the shape they were taken on
     (first line of the file)."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_counters_final.txt")
-    if not os.path.exists(path):
+    for name in ("r2_pmc_counters_final.txt", "r1_pmc_counters_final.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
         return None
     total, cur = 0.0, None
     for ln in open(path):
@@ -109,6 +175,105 @@ class _QuietStdout:
         sys.stdout.flush()
         os.dup2(self.saved, 1)
         os.close(self.saved)
+
+
+def _event_ms(torch, fn, reps=3):
+    """Average duration of fn() in ms between events on torch's current stream (= the library's stream)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def secondary(torch, be, synthdata, data, N, C, T):
+    """The other SURVEY 8(d) numbers, inputs resident in HBM, each priced against the bound SURVEY 8(d) names:
+    frac = max(bytes / 8 TB/s, flops / peak) / measured time."""
+    from scipy.signal import windows
+    out = []
+    K = 7
+    F = N // 2 + 1
+    # ---- c2: mtmfft power spectra, 7 tapers, taper mean (configs[1])
+    tapers = windows.dpss(N, 1.0 * N / 1000.0, K) * np.sqrt(N)
+    plan = be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, False, None, "pow", False)
+    starts = torch.arange(T, device="cuda", dtype=torch.int64) * N
+    buf = torch.empty(plan.out_shape(T), dtype=torch.float32, device="cuda")
+    ms = _event_ms(torch, lambda: plan.execute(data, starts, out=buf))
+    byt, flop = N * C * 4 + F * C * 4, K * C * 2.5 * N * np.log2(N)
+    bound_us = max(byt / (PEAK_HBM_GBS * 1e9), flop / (PEAK_MFMA_F32_TFLOPS * 1e12)) * 1e6
+    out.append({"name": "c2 mtmfft power (BASELINE configs[1]): %d ch x %d samp x %d trials, 7 DPSS tapers, taper mean" % (C, N, T),
+                "value": T / (ms * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms / T,
+                "channel_samples_per_s": T / (ms * 1e-3) * N * C, "kernel": plan.kernel_name,
+                "bound": "fft-flop (fp32 vector peak) vs hbm, whichever is larger", "bound_us_per_trial": bound_us,
+                "bytes_per_trial": byt, "flop_per_trial": flop, "frac": bound_us / (1e3 * ms / T),
+                "hbm_GBps": byt * T / (ms * 1e-3) / 1e9})
+    del buf, plan
+    # ---- c4: 128 ch x 16384 samples (configs[3]); (i) 512-sample Hann windows, 50 % overlap
+    C4, N4, T4 = 128, 16384, 200
+    d4 = synthdata.ar2_uncoupled_fast(C4, N4, T4, seed=77)
+    nperseg, step = 512, 256
+    w = windows.hann(nperseg)
+    w = w * np.sqrt(4 / 3) * np.sqrt(nperseg / w.sum())
+    plan = be.FFTPlan(nperseg, nperseg, C4, w[None], np.sqrt(2) / nperseg, 0, False, None, "pow", False)
+    nT = int(np.ceil(N4 / step))
+    fr = torch.arange(nT, device="cuda", dtype=torch.int64) * step - nperseg // 2
+    tr = torch.arange(T4, device="cuda", dtype=torch.int64) * N4
+    st = (tr[:, None] + fr[None, :]).reshape(-1).contiguous()
+    lo = tr[:, None].expand(T4, nT).reshape(-1).contiguous()
+    hi = (lo + N4).contiguous()
+    buf = torch.empty(plan.out_shape(T4 * nT), dtype=torch.float32, device="cuda")
+    ms = _event_ms(torch, lambda: plan.execute(d4, st, lo, hi, out=buf))
+    byt = N4 * C4 * 4 + nT * (nperseg // 2 + 1) * C4 * 4
+    out.append({"name": "c4 mtmconvol (BASELINE configs[3] i): %d ch x %d samp x %d trials, hann nperseg 512, 50 %% overlap, pow" % (C4, N4, T4),
+                "value": T4 / (ms * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms / T4, "kernel": plan.kernel_name,
+                "bound": "hbm", "bytes_per_trial": byt, "bound_us_per_trial": byt / (PEAK_HBM_GBS * 1e9) * 1e6,
+                "frac": byt / (PEAK_HBM_GBS * 1e9) / (1e-3 * ms / T4), "hbm_GBps": byt * T4 / (ms * 1e-3) / 1e9})
+    del buf, plan
+    # ---- c4 (ii): Morlet wavelets, 25 scales 4 .. 100 Hz, every sample, trial average accumulated on the device
+    foi = np.arange(4, 104, 4, dtype=float)
+    scales = (1 / foi) * (6 + np.sqrt(38)) / (4 * np.pi)
+    plan = be.CWTPlan(N4, C4, scales, 1e-3, 6.0, 0, "pow")
+    res = torch.zeros(plan.out_shape(1), dtype=torch.float32, device="cuda")
+    ms = _event_ms(torch, lambda: plan.execute(d4, tr, tr, tr + N4, out=res, accumulate=2), reps=2)
+    byt = N4 * C4 * 4 + N4 * 25 * C4 * 4          # keeptrials=True accounting of SURVEY 8(d)
+    flop_lo = 26 * C4 * 5 * 18816 * np.log2(18816)
+    bound_us = max(byt / (PEAK_HBM_GBS * 1e9), flop_lo / (PEAK_MFMA_F32_TFLOPS * 1e12)) * 1e6
+    out.append({"name": "c4 wavelet (BASELINE configs[3] ii): %d ch x %d samp x %d trials, Morlet w0=6, 25 scales 4..100 Hz, toi=all, pow, trial average" % (C4, N4, T4),
+                "value": T4 / (ms * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms / T4,
+                "kernel": "spycwt::cwt2_kernel (4 block groups) + cwt_scatter_kernel",
+                "bound": "max(hbm at keeptrials accounting, fft-flop lower estimate)", "bytes_per_trial": byt,
+                "flop_per_trial": flop_lo, "bound_us_per_trial": bound_us, "frac": bound_us / (1e3 * ms / T4)})
+    del res, plan, d4
+    # ---- c5: Wilson / Granger AV stage on the CSD of the resident trials (demean_taper as method='granger' sets it)
+    plan = be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, True, None, "fourier", True)
+    acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    Tg = min(T, 400)
+    for b0 in range(0, Tg, 100):
+        be.csd_accumulate(plan.execute(data, starts[b0:b0 + 100]), acc)
+    be.csd_finalize(acc, 1.0 / (K * Tg))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    G, meta = be.granger(acc, niter=100)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = be.granger_stats() if hasattr(be, "granger_stats") else {}
+    iters = stats.get("iterations")
+    flop_it = 2 * (F - 1) * 8.0 * C ** 3 * 6            # SURVEY 8(d): inverse + 4 GEMMs on the 2(F-1) lag-domain bins
+    entry = {"name": "c5 Granger AV stage (BASELINE configs[4], one GPU): regularize_csd + wilson_sf + granger on %d x %d x %d" % (F, C, C),
+             "value": dt, "unit": "s", "higher_is_better": False, "converged": meta["converged"],
+             "max_rel_err": meta["max rel. err"], "cond0": meta["initial cond. num"], "iterations": iters,
+             "kernel": "spywil::zgemm_mfma_kernel / zinv_blocked_kernel", "bound": "fp64 %.1f TFLOP/s" % PEAK_F64_TFLOPS,
+             "flop_per_iteration": flop_it}
+    if iters:
+        entry["frac"] = iters * flop_it / (PEAK_F64_TFLOPS * 1e12) / dt
+    entry.update({k: v for k, v in stats.items() if k != "iterations"})
+    out.append(entry)
+    assert bool(torch.isfinite(G).all()), "non-finite Granger values"
+    return out
 
 
 def main():
@@ -151,7 +316,7 @@ def main():
     B = min(args.batch, T)
     spec = torch.empty(plan.out_shape(B), dtype=torch.complex64, device="cuda")
     acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
-    ev_csd, ev_fft = [], []
+    ev_csd, ev_fft, ev_coll = [], [], []
 
     def step(timed):
         acc.zero_()
@@ -171,9 +336,15 @@ def main():
                 ev_csd.append((e1, e2, nb))
         if dist_on:
             # the accumulator carries its lower triangle only: pack -> all-reduce -> unpack (0.54 GB instead of 1.07)
+            if timed:
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
             packed = be.csd_tril_pack(acc)
             dist.all_reduce(torch.view_as_real(packed))
             be.csd_tril_unpack(packed, acc)
+            if timed:
+                c1.record()
+                ev_coll.append((c0, c1, packed.numel() * 8))
         # K5 fused: scale + coherency + |.| + Hermitian mirror straight from the raw accumulator
         return be.coh_from_accumulator(acc, 1.0 / (K * T * world), "abs")
 
@@ -207,6 +378,9 @@ def main():
         achieved = sum(flops) / (sum(csd_ms) * 1e-3) / 1e12
         fft_bytes = sum(nb * (N * C * 4 + K * F * C * 8) for _, _, nb in ev_fft)
         value = world * T * args.steps / el
+        coll = {"executed": bool(dist_on), "backend": "nccl (RCCL)" if dist_on else None}
+        if ev_coll:
+            coll.update({"bytes": ev_coll[0][2], "pack_allreduce_unpack_ms": float(np.mean([a.elapsed_time(b) for a, b, _ in ev_coll]))})
         line = {
             "metric": "trials/sec for mtmfft+coherence (256 ch x 4096 samples, 7 DPSS tapers, full CSD)",
             "value": value,
@@ -230,11 +404,11 @@ def main():
                 "fft_ms_per_trial": sum(fft_ms) / (T * args.steps),
                 "fft_stream_GBps": fft_bytes / (sum(fft_ms) * 1e-3) / 1e9,
                 "csd_ms_per_trial": sum(csd_ms) / (T * args.steps),
+                "collective": coll,
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": ("spycsd::csd_accum_kernel<5, 4, %d>" % (1 if C == 256 else 2 if C < 256 else 3) if C <= 512 and not blocked
-                           else "spycsd::csd_accum_kernel<5, 4, 0>") + " (+ row-split <1, 1> tail and its reduction)",
+                "kernel": be.csd_kernel_name(C, blocked) + " (+ row-split <1, 1> tail and its reduction)",
                 "achieved": achieved,
                 "peak": PEAK_MFMA_F32_TFLOPS,
                 "unit": "TFLOP/s",
@@ -245,6 +419,9 @@ def main():
                 "traffic": pmc_traffic(rows[0], F, C),
             },
         }
+        if world == 1 and not args.no_secondary:
+            del spec
+            line["secondary"] = secondary(torch, be, synthdata, data, N, C, T)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(C, N)
         print(json.dumps(line), flush=True)

@@ -17,6 +17,8 @@ OUTPUT_KIND = {"pow": 0, "abs": 1, "fourier": 2, "complex": 2, "real": 3, "imag"
 DETREND = {None: -1, False: -1, 0: 0, 1: 1}
 
 _contexts = {}
+_NP_DTYPE = {torch.float32: np.float32, torch.float64: np.float64, torch.complex64: np.complex64,
+             torch.complex128: np.complex128, torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8}
 
 
 def require_gpu():
@@ -59,16 +61,41 @@ def _ptr(t):
     return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
 
 
+_PIN_BYTES = 256 << 20
+_pin = {}
+
+
 def to_host(t):
-    """Device tensor -> NumPy array through a pinned staging buffer (pageable D2H copies run at ~6 GB/s, pinned
-    ones at ~57 GB/s on this platform); small results take the plain path."""
-    if not t.is_cuda or t.numel() * t.element_size() < (8 << 20):
+    """Device tensor -> NumPy array in ordinary pageable memory.  Large results are staged through ONE reusable
+    pinned buffer of 256 MiB per dtype family (pageable D2H copies run at ~6 GB/s, pinned ones at ~57 GB/s on this
+    platform) and copied out chunk by chunk, so a result the user holds on to never keeps page-locked memory
+    alive; small results take the plain path."""
+    nbytes = t.numel() * t.element_size()
+    if not t.is_cuda or nbytes < (8 << 20):
         return t.cpu().numpy()
     t = t.contiguous()
-    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    host.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
-    return host.numpy()
+    flat = t.view(-1).view(torch.uint8) if not t.is_complex() else torch.view_as_real(t).view(-1).view(torch.uint8)
+    out = np.empty(t.shape, dtype=_NP_DTYPE[t.dtype])
+    dst = out.reshape(-1).view(np.uint8)
+    stage = _pin.get("buf")
+    if stage is None:
+        stage = _pin["buf"] = (torch.empty(_PIN_BYTES, dtype=torch.uint8, pin_memory=True),
+                               torch.empty(_PIN_BYTES, dtype=torch.uint8, pin_memory=True))
+    stream = torch.cuda.current_stream(t.device)
+    pending = None                                   # (event, staging buffer, offset, length) of the copy in flight
+    for k, off in enumerate(range(0, nbytes, _PIN_BYTES)):
+        n = min(_PIN_BYTES, nbytes - off)
+        buf = stage[k & 1]
+        buf[:n].copy_(flat[off:off + n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        if pending is not None:                      # drain the previous chunk while this one is on the bus
+            pending[0].synchronize()
+            dst[pending[2]:pending[2] + pending[3]] = pending[1][:pending[3]].numpy()
+        pending = (ev, buf, off, n)
+    pending[0].synchronize()
+    dst[pending[2]:pending[2] + pending[3]] = pending[1][:pending[3]].numpy()
+    return out
 
 
 # reusable (rows, F, C) spectra buffers of the coherence path, one per (shape, device): the FFT -> CSD hand-over
@@ -258,12 +285,26 @@ def csd_accumulate(spec, acc, blocked=False):
     return acc
 
 
+def csd_kernel_name(nchan, blocked=False):
+    """Name of the csd_accum_kernel instance spyhip_csd_accumulate launches for `nchan` channels (launch policy of
+    csrc/csd.hip), for matching rocprofv3 rows."""
+    nt = (nchan + 31) // 32
+    ntiles = nt * (nt + 1) // 2
+    if not blocked and nchan <= 256:
+        return "spycsd::csd_accum_kernel<5, 4, %d>" % (1 if nchan == 256 else 2)
+    if not blocked and nchan <= 512:
+        return "spycsd::csd_accum_kernel<5, 4, 3>"
+    if ntiles >= 21:
+        return "spycsd::csd_accum_kernel<5, 4, 0>"
+    return "spycsd::csd_accum_kernel<3, 2, 0>" if ntiles >= 6 else "spycsd::csd_accum_kernel<1, 1, 0>"
+
+
 def csd_allreduce_(acc):
     """Sum the (lower-triangle) CSD accumulator over all ranks in place: the ONE collective of the coherence path.
     Only the lower triangle carries data before csd_finalize, so it is packed to (F, C(C+1)/2), all-reduced over
     RCCL and unpacked (half the bytes on xGMI).  No-op for a single process."""
     from . import parallel
-    if parallel.world()[1] == 1:
+    if not parallel.collective_active():
         return acc
     assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and acc.dim() == 3
     F, Cn, _ = acc.shape

@@ -12,7 +12,7 @@ import numpy as np
 from ..datatype import AnalogData, CrossSpectralData, SpectralData, selected_channels, selected_trialdefinition
 from ..shared.const_def import connectivity_outputs, connectivityMethods
 from ..shared.errors import SPYTypeError, SPYValueError, SPYWarning
-from ..shared.kwarg_decorators import unwrap_cfg
+from ..shared.kwarg_decorators import attached_selection, unwrap_cfg
 from ..shared.input_processors import process_foi, process_padding, process_taper
 from ..shared.tools import best_match
 from .AV_compRoutines import NormalizeCrossCov, NormalizeCrossSpectra, pairwise_phase_consistency
@@ -45,13 +45,10 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     except ImportError:
         pass
     classes.update(routine_classes or {})
-    data.selectdata(select)
-    try:
+    with attached_selection(data, select):
         cmb = _parse_channelcmb(data, channelcmb)
         return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
                              nTaper, taper, taper_opt, compute_method, jackknife, cmb)
-    finally:
-        data.selection = None
 
 
 def _parse_channelcmb(data, channelcmb):

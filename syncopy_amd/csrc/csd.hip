@@ -118,7 +118,10 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
             long long nsplit = ctx->num_cu / tail_wg;
             const long long max_split = (nrows + 63) / 64;          // at least 64 rows per split
             if (nsplit > max_split) nsplit = max_split;
-            if (nsplit < 2) return launch_accum<1, 1>(ctx, a, full * per, a.nitems);
+            // the partial sums of the splits are reduced per whole frequency from f0 on: the tail must start on a
+            // frequency boundary (always true on the fast path, whose `per` is a multiple of ntiles; the (5,4)
+            // path of the blocked layout has per = 36 whatever ntiles is)
+            if (nsplit < 2 || (full * per) % a.ntiles != 0) return launch_accum<1, 1>(ctx, a, full * per, a.nitems);
             const int f0 = (int)(full * per / a.ntiles), nf = nfreq - f0;
             const size_t need = (size_t)(nsplit - 1) * nf * nchan * nchan * sizeof(float2);
             if (need > ctx->scratch_bytes) {

@@ -22,6 +22,8 @@ class _Base:
     def __init__(self, data=None, samplerate=None, trialdefinition=None, dimord=None):
         self.dimord = list(dimord) if dimord is not None else list(self._defaultDimord)
         self.samplerate = None if samplerate is None else float(samplerate)
+        self._device = None
+        self._device_key = None
         self._data = None
         self._pending = None          # (thunk, shape, dtype): host array produced on first access (results that
                                       # may never leave the device, e.g. the CSD between the ST and the AV stage)
@@ -49,6 +51,13 @@ class _Base:
     def data(self, value):
         self._data = value
         self._pending = None
+        self.invalidate()
+
+    def invalidate(self):
+        """Forget device copies of `.data`.  Assigning `.data` does this by itself; after editing the host array IN
+        PLACE (`obj.data[...] = ...`) call it explicitly - in-place edits cannot be seen from here."""
+        self._device = None
+        self._device_key = None
 
     def set_pending(self, thunk, shape, dtype):
         """The host array is `thunk()` - evaluated only if somebody reads `.data`."""
@@ -129,7 +138,6 @@ class AnalogData(_Base):
         if channel is None:
             channel = ["channel" + str(i + 1).zfill(len(str(nchan))) for i in range(nchan)]
         self.channel = np.array(channel)
-        self._device = None
 
     def device_data(self, device=None):
         """The (time x channel) float32 matrix in HBM (uploaded once, C-order, channel fastest)."""
@@ -139,10 +147,13 @@ class AnalogData(_Base):
         dev = torch.device("cuda" if device is None else device)
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
-        if self._device is None or self._device.device != dev:
+        # the copy belongs to one host array in one orientation: a new array object, shape or dimord uploads again
+        key = (id(self._data), self._data.shape, tuple(self.dimord), str(dev))
+        if self._device is None or self._device_key != key:
             host = self.data if self.dimord.index("time") == 0 else self.data.T
             host = np.ascontiguousarray(host, dtype=np.float32)
             self._device = torch.from_numpy(host).to(dev)
+            self._device_key = key
         return self._device
 
     def selectdata(self, select=None):

@@ -19,6 +19,16 @@ def world():
     return 0, 1
 
 
+def collective_active():
+    """True when sums over ranks have to run: more than one rank - or a process group of ONE rank with
+    SPY_FORCE_COLLECTIVE=1, which lets the pack -> all-reduce -> unpack path be executed (and bit-compared with the
+    group-less result) on a 1-GPU box."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or bool(os.environ.get("SPY_FORCE_COLLECTIVE"))
+
+
 def shard_bounds(n, size):
     """Contiguous ranges [lo, hi) of n trials for `size` ranks, remainder to the low ranks."""
     base, rem = divmod(n, size)
@@ -38,8 +48,7 @@ def my_shard(n):
 def allreduce_sum_(t):
     """In-place sum over ranks of a torch tensor (complex tensors go as interleaved floats);
     fixed reduction algorithm of the backend => identical result on every rank."""
-    _, size = world()
-    if size > 1:
+    if collective_active():
         dist.all_reduce(torch.view_as_real(t) if t.is_complex() else t, op=dist.ReduceOp.SUM)
     return t
 

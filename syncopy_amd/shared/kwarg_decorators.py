@@ -1,8 +1,9 @@
 """FieldTrip-style `cfg` calls of the metafunctions (contract of syncopy/shared/kwarg_decorators.py:32-300,
 `unwrap_cfg`; `StructDict` as syncopy/shared/tools.py:27-68)."""
+import contextlib
 import functools
 
-from .errors import SPYTypeError, SPYValueError
+from .errors import SPYError, SPYTypeError, SPYValueError
 
 
 class StructDict(dict):
@@ -19,6 +20,25 @@ class StructDict(dict):
 
     def __delattr__(self, name):
         del self[name]
+
+
+@contextlib.contextmanager
+def attached_selection(data, select):
+    """`select=` of a metafunction call (shared/kwarg_decorators.py:302-415, `unwrap_select`): the selection is attached
+    for the duration of the call and removed afterwards - only if this call attached it.  A selection the user made
+    in place beforehand (`data.selectdata(...)`) is honoured and left alone; giving both is an error."""
+    mine = False
+    if select is not None:
+        if data.selection is not None:
+            raise SPYError(f"Selection found both in kwarg 'select' ({select}) and in passed Syncopy Data object of "
+                           f"type '{type(data).__name__}'")
+        data.selectdata(select)
+        mine = True
+    try:
+        yield data
+    finally:
+        if mine:
+            data.selection = None
 
 
 def get_defaults(func):

@@ -5,6 +5,7 @@ syncopy/specest/compRoutines.py (mtmfft_cF:60, mtmconvol_cF:245, wavelet_cF:483;
 MultiTaperFFT:194, MultiTaperFFTConvol:417, WaveletTransform:598) so the classes can
 be bound under spy.freqanalysis unchanged; all arithmetic runs in libspyhip.
 """
+import numbers
 from hashlib import blake2b
 
 import numpy as np
@@ -231,10 +232,10 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
     for nsig, tpos, nuniq, gather, members in groups.values():
         pkey = (nsig, nchan, scales.tobytes(), dt, w0, polyremoval, output, None if tpos is None else tpos.tobytes(),
                 str(device))
-        if pkey not in _cwt_plans:
-            hs._bounded_put(_cwt_plans, pkey, hs.backend.CWTPlan(nsig, nchan, scales, dt, w0, polyremoval, output,
-                                                                 tpos, nuniq, device=device))
-        plan = _cwt_plans[pkey]
+        plan = hs._cache_hit(_cwt_plans, pkey)
+        if plan is None:
+            plan = hs.backend.CWTPlan(nsig, nchan, scales, dt, w0, polyremoval, output, tpos, nuniq, device=device)
+            hs._bounded_put(_cwt_plans, pkey, plan)
         starts = torch.tensor([m[1] for m in members], dtype=torch.int64, device=device)
         lo = torch.tensor([m[2] for m in members], dtype=torch.int64, device=device)
         hi = torch.tensor([m[3] for m in members], dtype=torch.int64, device=device)
@@ -339,12 +340,12 @@ def _superlet_device(dev, rows, pre, post, chans, polyremoval, output, method_kw
             for n, (cycles, sc0, expo) in enumerate(steps):
                 pkey = ("sl", nsig, nchan, scales[sc0:].tobytes(), dt, cycles, polyremoval, real,
                         None if tpos is None else tpos.tobytes(), str(device))
-                if pkey not in _cwt_plans:
-                    hs._bounded_put(_cwt_plans, pkey,
-                                    hs.backend.CWTPlan(nsig, nchan, scales[sc0:], dt, detrend=polyremoval,
-                                                       output="abs" if real else "fourier", tpos=tpos,
-                                                       ntime_out=nuniq, device=device, sl_cycles=cycles))
-                plan = _cwt_plans[pkey]
+                plan = hs._cache_hit(_cwt_plans, pkey)
+                if plan is None:
+                    plan = hs.backend.CWTPlan(nsig, nchan, scales[sc0:], dt, detrend=polyremoval,
+                                              output="abs" if real else "fourier", tpos=tpos,
+                                              ntime_out=nuniq, device=device, sl_cycles=cycles)
+                    hs._bounded_put(_cwt_plans, pkey, plan)
                 buf = hs.backend.handover_buffer(plan.out_shape(len(part)), device, dtype=wdt)
                 spec = plan.execute(dev, starts, lo, hi, chan_idx=ci, out=buf)
                 # POW: the product is squared on its way out - with the last factor if that one covers every scale
@@ -433,31 +434,29 @@ def _store_trials(cr, out, parts, stack=False):
 
 
 def _make_trialdef(cfg, trialdefinition, samplerate):
-    """Timing of time-frequency outputs (rules of specest/compRoutines.py:813-900)."""
+    """Timing of time-frequency outputs (what specest/compRoutines.py:813-900 arrives at): the number of time points
+    every trial contributes, their stacking positions, trigger offsets and the output sampling rate.
+      `toi` array   : toi.size points per trial; rate 1/step for evenly spaced points (else 1.0), offset toi[0] * rate
+      `toi` fraction: one point per hop of the sliding window; offsets and rate divided by the hop
+      `toi` 'all'   : one point per input sample; the first trial keeps its original start sample"""
+    trl = np.array(trialdefinition, dtype=float)
+    n_in = trl[:, 1] - trl[:, 0]
     toi = cfg["toi"]
+    origin = 0.0
     if isinstance(toi, np.ndarray):
-        nToi = toi.size
-        time = np.cumsum([nToi] * trialdefinition.shape[0])
-        trialdefinition[:, 0] = time - nToi
-        trialdefinition[:, 1] = time
-        tSteps = np.diff(toi)
-        if tSteps.size and np.allclose(tSteps, [tSteps[0]] * tSteps.size):
-            samplerate = 1 / (toi[1] - toi[0])
-        else:
-            samplerate = 1.0
-            trialdefinition[:, 2] = 0
-        trialdefinition[:, 2] = toi[0] * samplerate
-    elif np.issubdtype(type(toi), np.number):
-        mKw = cfg["method_kwargs"]
-        winSize = mKw["nperseg"] - mKw["noverlap"]
-        lens = np.ceil(np.diff(trialdefinition[:, :2]) / winSize)
-        sumLens = np.cumsum(lens).reshape(lens.shape)
-        trialdefinition[:, 0] = np.ravel(sumLens - lens)
-        trialdefinition[:, 1] = sumLens.ravel()
-        trialdefinition[:, 2] = trialdefinition[:, 2] / winSize
-        samplerate = np.round(samplerate / winSize, 2)
+        n_out = np.full(trl.shape[0], float(toi.size))
+        steps = np.diff(toi)
+        samplerate = 1 / (toi[1] - toi[0]) if steps.size and np.allclose(steps, steps[0]) else 1.0
+        trl[:, 2] = toi[0] * samplerate
+    elif isinstance(toi, numbers.Number):
+        hop = cfg["method_kwargs"]["nperseg"] - cfg["method_kwargs"]["noverlap"]
+        n_out = np.ceil(n_in / hop)
+        trl[:, 2] /= hop
+        samplerate = np.round(samplerate / hop, 2)
     else:
-        bounds = np.cumsum(np.diff(trialdefinition[:, :2]))
-        trialdefinition[1:, 0] = bounds[:-1]
-        trialdefinition[:, 1] = bounds
-    return trialdefinition, samplerate
+        n_out, origin = n_in, trl[0, 0]
+    stop = np.cumsum(n_out)
+    trl[:, 0] = stop - n_out
+    trl[:, 1] = stop
+    trl[0, 0] += origin
+    return trl, samplerate

@@ -11,7 +11,7 @@ import numpy as np
 from ..datatype import AnalogData, SpectralData, selected_trialdefinition
 from ..shared.const_def import availableMethods, spectralDTypes
 from ..shared.errors import SPYInfo, SPYTypeError, SPYValueError, SPYWarning
-from ..shared.kwarg_decorators import unwrap_cfg
+from ..shared.kwarg_decorators import attached_selection, unwrap_cfg
 from ..shared.input_processors import process_foi, process_padding, process_taper
 from ..shared.tools import best_match
 from .compRoutines import MultiTaperFFT, MultiTaperFFTConvol
@@ -61,13 +61,10 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
             raise SPYValueError("0, 1 or None", varname="polyremoval", actual=polyremoval)
         polyremoval = int(polyremoval)
 
-    data.selectdata(select)
-    try:
+    with attached_selection(data, select):
         return _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
                              demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin, wavelet, width,
                              ft_compat, compute_method, (order_max, order_min, c_1, adaptive))
-    finally:
-        data.selection = None
 
 
 def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
@@ -154,32 +151,12 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
                 SPYWarning(f"`toi` selection too fine, max. time resolution is {dt}s")
             equidistant = bool(np.allclose(tSteps, [tSteps[0]] * tSteps.size)) if tSteps.size else True
         nperseg = int(t_ftimwin * fs)
-        halfWin = int(nperseg / 2)
-        postSelect = slice(None)
+        # hop of the sliding window: a fraction of the window for `toi` in [0, 1], one sample otherwise
         noverlap = min(nperseg - 1, int(overlap * nperseg)) if 0 <= overlap <= 1 else nperseg - 1
         if overlap < 0:
-            offStart = ((toi[0] - tStart) * fs).astype(np.intp)
-            padBegin = halfWin - offStart
-            padBegin = ((padBegin > 0) * padBegin).astype(np.intp)
-            if tSteps.size and tSteps.max() * fs > halfWin and equidistant:
-                equidistant = False
-            soi = []
-            if equidistant:
-                for tk in range(numTrials):
-                    start = max(0, int(round(fs * (toi[0] - tStart[tk]) - halfWin)))
-                    stop = int(round(fs * (toi[-1] - tStart[tk]) + halfWin + 1))
-                    soi.append(slice(start, max(stop, stop - start)))
-                delta_idx = int(round((soi[0].stop - soi[0].start) / toi.size))
-                delta_idx = delta_idx if delta_idx > 1 else 1
-                postSelect = slice(None, None, delta_idx)
-            else:
-                for tk in range(numTrials):
-                    starts = (fs * (toi - tStart[tk]) - halfWin).astype(np.intp) + padBegin[tk]
-                    stops = (fs * (toi - tStart[tk]) + halfWin + 1).astype(np.intp) + padBegin[tk]
-                    stops = np.maximum(stops, stops - starts)
-                    soi.append([slice(int(a), int(b)) for a, b in zip(starts, stops)])
+            soi, postSelect, equidistant = _windows_at(toi, equidistant, nperseg, fs, tStart)
         else:
-            soi = [slice(None)] * numTrials
+            soi, postSelect = [slice(None)] * numTrials, slice(None)
         method_kwargs = {"samplerate": fs, "nperseg": nperseg, "noverlap": noverlap, "taper": taper,
                          "taper_opt": taper_opt}
         cr = classes["mtmconvol"](soi, [postSelect] * numTrials, equidistant=equidistant, toi=toi, foi=foi,
@@ -251,6 +228,31 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
     if method == "welch":
         out = _time_mean(out)
     return out
+
+
+def _windows_at(toi, even, nperseg, fs, tStart):
+    """Which samples of every trial the sliding-window analysis reads when `toi` lists explicit time points, and
+    which of the resulting frames are kept (integers as freqanalysis.py:752-793 produces them).
+
+    `centre[k, i]` is the (fractional) sample of trial k on which window i is centred.
+      * closely spaced, evenly spaced points (largest step <= half a window): ONE stretch per trial from half a window
+        before the first to half a window after the last point, transformed with hop 1; every `stride`-th frame is a
+        requested point.  Returns (stretches, slice(None, None, stride), True).
+      * anything else: one window per point, [centre - half, centre + half], shifted right by the part of the first
+        window that would start before the trial.  Returns (lists of windows, slice(None), False)."""
+    half = nperseg // 2
+    centre = fs * (toi[None, :] - np.asarray(tStart)[:, None])
+    steps = np.diff(toi)
+    if even and not (steps.size and steps.max() * fs > half):
+        first = np.maximum(0, np.rint(centre[:, 0] - half).astype(np.intp))
+        last = np.rint(centre[:, -1] + half + 1).astype(np.intp)
+        stride = max(1, int(np.rint((last[0] - first[0]) / toi.size)))
+        return [slice(int(a), int(b)) for a, b in zip(first, last)], slice(None, None, stride), True
+    lead = np.maximum(0, half - np.trunc(centre[:, 0]).astype(np.intp))[:, None]
+    lo = np.trunc(centre - half).astype(np.intp) + lead
+    hi = np.trunc(centre + half + 1).astype(np.intp) + lead
+    hi = np.maximum(hi, hi - lo)                      # a window that starts before sample 0 keeps its length
+    return [[slice(int(a), int(b)) for a, b in zip(r0, r1)] for r0, r1 in zip(lo, hi)], slice(None), False
 
 
 def _wavelet_toi(toi, numTrials, tStart, tEnd, lenTrials, fs):

@@ -16,11 +16,19 @@ MAX_CACHED_PLANS = 64
 
 
 def _bounded_put(cache, key, value):
-    """Insert into a plan cache that keeps the most recent MAX_CACHED_PLANS entries (plans own device tables:
-    a long session over many shapes must not accumulate them)."""
+    """Insert into a plan cache that keeps the MAX_CACHED_PLANS most recently USED entries (plans own device tables:
+    a long session over many shapes must not accumulate them); `_cache_hit` keeps the order up to date."""
     while len(cache) >= MAX_CACHED_PLANS:
-        cache.pop(next(iter(cache)))
+        cache.pop(next(iter(cache)))            # dicts iterate in insertion order: the first key is the least recent
     cache[key] = value
+
+
+def _cache_hit(cache, key):
+    """Look up `key`; a hit moves the entry to the most-recent end."""
+    value = cache.get(key)
+    if value is not None:
+        cache[key] = cache.pop(key)
+    return value
 
 
 def taper_table(taper, nsig, nnorm, taper_opt=None):
@@ -56,14 +64,15 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
     fkey = None if freq_idx is None else np.asarray(freq_idx, dtype=np.int32).tobytes()
     key = (int(nsig), int(nfft), int(nchan), taper, tuple(sorted((taper_opt or {}).items())), int(nnorm),
            float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device), bool(blocked))
-    if key not in _plan_cache:
+    plan = _cache_hit(_plan_cache, key)
+    if plan is None:
         tp = taper_table(taper, nsig, nnorm, taper_opt)
         plan = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
                                keeptapers, device=device)
         if blocked:
             plan.set_blocked(True)
         _bounded_put(_plan_cache, key, plan)
-    return _plan_cache[key]
+    return plan
 
 
 def full_freq_idx(freq_idx, nfft):

@@ -1,0 +1,59 @@
+"""Worker of tests/test_gpu_nccl.py (launched by torch.distributed.run, one rank per visible GPU): the product's
+coherence path under an initialised "nccl" (= RCCL) process group.  With SPY_FORCE_COLLECTIVE=1 a group of ONE rank
+still runs csd_tril_pack -> all_reduce -> csd_tril_unpack, so the collective leg executes on a 1-GPU box."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(out_path):
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    try:
+        import syncopy_amd as spy
+        from syncopy_amd import backend as be
+        from syncopy_amd import parallel
+        assert parallel.collective_active()
+        adj = np.zeros((37, 37))
+        adj[0, 1] = adj[5, 30] = 0.3
+        data = spy.synthdata.ar2_network(AdjMat=adj, nSamples=1024, nTrials=11, seed=3, samplerate=500)
+        res = {}
+        res["coh"] = spy.connectivityanalysis(data, method="coh", tapsmofrq=3).data
+        res["csd"] = spy.connectivityanalysis(data, method="csd", tapsmofrq=3).data
+        res["ppc"] = spy.connectivityanalysis(data, method="ppc", tapsmofrq=3).data
+        res["corr"] = spy.connectivityanalysis(data, method="corr").data
+        res["pow_avg"] = spy.freqanalysis(data, method="mtmfft", tapsmofrq=3, keeptrials=False).data
+        res["pow"] = spy.freqanalysis(data, method="mtmfft", tapsmofrq=3).data
+        # bench.py's own sequence on a raw accumulator, bit-compared with the untouched lower triangle
+        g = torch.Generator(device="cuda").manual_seed(1)
+        spec = torch.view_as_complex(torch.randn((21, 130, 256, 2), generator=g, device="cuda"))
+        acc = torch.zeros((130, 256, 256), dtype=torch.complex64, device="cuda")
+        be.csd_accumulate(spec, acc)
+        before = acc.clone()
+        packed = be.csd_tril_pack(acc)
+        dist.all_reduce(torch.view_as_real(packed))
+        acc.fill_(7.0)
+        be.csd_tril_unpack(packed, acc)
+        ii, jj = np.tril_indices(256)
+        world = dist.get_world_size()
+        same = torch.equal(torch.view_as_real(acc[:, ii, jj].contiguous()),
+                           torch.view_as_real((before[:, ii, jj] * world).contiguous()))
+        res["pack_allreduce_unpack_bit_exact"] = np.array(same)
+        res["world"] = np.array(world)
+        torch.cuda.synchronize()
+        if dist.get_rank() == 0:
+            np.savez(out_path, **res)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

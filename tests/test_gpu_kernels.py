@@ -362,3 +362,29 @@ def test_cwt_trial_sum_mode(be):
     plan.execute(data, st[4:].contiguous(), st[4:].contiguous(), (st[4:] + nsig).contiguous(), out=total, accumulate=2)
     ref = each.double().sum(dim=0, keepdim=True).float()
     assert_parity(total.cpu().numpy(), ref.cpu().numpy(), what="cwt trial sum")
+
+
+def test_blocked_tail_starts_inside_a_frequency(be):
+    """the (5,4) path of the blocked hand-over layout cuts work into 36-tile items whatever ntiles is, so
+    the re-cut tail can start in the middle of a frequency (C = 192: 21 tiles).  The row-split reduction only covers
+    whole frequencies - such tails must run unsplit.  The library scratch is dirtied first by a launch that does
+    split (C = 256)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    spec = torch.view_as_complex(torch.randn((300, 259, 256, 2), generator=g, device="cuda"))
+    acc = torch.zeros((259, 256, 256), dtype=torch.complex64, device="cuda")
+    be.csd_accumulate(spec, acc)                                  # leaves partial sums in ctx->scratch
+    del spec, acc
+    C, F, R = 192, 1001, 128
+    spec = torch.view_as_complex(torch.randn((R, F, C, 2), generator=g, device="cuda"))
+    blk = spec.reshape(R, F, C // 4, 4).permute(0, 2, 1, 3).contiguous()
+    a_std = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    a_blk = torch.zeros_like(a_std)
+    be.csd_accumulate(spec, a_std)
+    be.csd_accumulate(blk, a_blk, blocked=True)
+    be.csd_finalize(a_std, 1.0 / R)
+    be.csd_finalize(a_blk, 1.0 / R)
+    assert_parity(a_blk.cpu().numpy(), a_std.cpu().numpy(), what="blocked tail")
+    for f in (0, 500, 989, 990, 991, 1000):
+        x = spec[:, f, :].to(torch.complex128)
+        ref = (x.T @ x.conj() / R).cpu().numpy()
+        assert_parity(a_blk[f].cpu().numpy(), ref.astype(np.complex64), what=f"blocked csd f={f}")

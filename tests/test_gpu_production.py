@@ -1,0 +1,199 @@
+"""Parity at the BASELINE.json production shapes ("Next round" item 1): the kernels that serve
+c2/c3 (256 ch x 4096, K1 <12,...> + K4 <5,4,1>), c4 (128 ch x 16384: every CWT block group, the 512-sample sliding
+window) and c5 (Wilson / Granger with the 16x16 blocked inverse, the fp64-MFMA zgemm tiles and the condition-number
+iteration at C >= 16 ... 256) are compared with the oracle at the sizes they are benchmarked on - through the front
+ends and the C ABI, a few trials each so the CPU oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+import syncopy_amd as spy
+from oracle import spy_oracle as O
+from oracle_routines import ORACLE_FREQ
+from parity import assert_parity, excess
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from syncopy_amd import backend
+    backend.require_gpu()
+
+
+# ------------------------------------------------------------------------------------------------ c2 / c3
+@pytest.fixture(scope="module")
+def c3_data():
+    """4 trials of 256 ch x 4096 samples, AR(2) with a handful of couplings (so that coherence is not flat) and one
+    channel with an offset + a 50 Hz line (dynamic range the AR(2) spectra do not have; the offset makes the bins next
+    to DC depend on the ORDER of the float32 mean - the reference sums the rows sequentially)."""
+    adj = np.zeros((256, 256))
+    for i, j in ((0, 1), (10, 200), (255, 3), (128, 129)):
+        adj[i, j] = 0.25
+    data = spy.synthdata.ar2_network(AdjMat=adj, nSamples=4096, nTrials=4, seed=21)
+    t = np.arange(4096 * 4) / 1000.0
+    data.data[:, 7] += (3.0 + 5.0 * np.sin(2 * np.pi * 50.0 * t)).astype(np.float32)
+    return data
+
+
+def _trials(data):
+    td = np.asarray(data.trialdefinition)
+    return [np.array(data.data[int(a):int(b)]) for a, b in td[:, :2]]
+
+
+def test_c2_mtmfft_pow_256x4096(c3_data):
+    """BASELINE configs[1] shape through spy.freqanalysis: K1 <12,1,0,true> at 256 channels vs the oracle's float64
+    taper + rfft (mtmfft.py:96-127, compRoutines.py:169-189)."""
+    out = spy.freqanalysis(c3_data, method="mtmfft", tapsmofrq=1)
+    assert out.data.shape == (4, 1, 2049, 256) and out.data.dtype == np.float32
+    mk = dict(samplerate=1000.0, taper="dpss", taper_opt={"NW": 4.096, "Kmax": 7}, nSamples=4096, demean_taper=False)
+    for t, trl in enumerate(_trials(c3_data)):
+        ref, _ = O.mtmfft_cF(trl, foi=np.fft.rfftfreq(4096, 1e-3), keeptapers=False, polyremoval=0, output="pow",
+                             method_kwargs=mk)
+        assert_parity(out.data[t], ref[0], what=f"c2 pow trial {t}")
+
+
+def test_c2_fourier_keeptapers_256x4096(c3_data):
+    """The coherence front half (complex spectra of every taper, K1 <12,2,2,false>) at 256 channels."""
+    out = spy.freqanalysis(c3_data, method="mtmfft", tapsmofrq=1, output="fourier", keeptapers=True,
+                           select={"trials": [0, 3]})
+    assert out.data.shape == (2, 7, 2049, 256) and out.data.dtype == np.complex64
+    mk = dict(samplerate=1000.0, taper="dpss", taper_opt={"NW": 4.096, "Kmax": 7}, nSamples=4096, demean_taper=False)
+    trials = _trials(c3_data)
+    for k, t in enumerate((0, 3)):
+        ref, _ = O.mtmfft_cF(trials[t], foi=np.fft.rfftfreq(4096, 1e-3), keeptapers=True, polyremoval=0,
+                             output="fourier", method_kwargs=mk)
+        assert_parity(out.data[k], ref[0], what=f"c2 fourier trial {t}")
+
+
+def test_c3_coherence_256x4096(c3_data):
+    """BASELINE configs[2] shape through spy.connectivityanalysis: K1 + K4 <5,4,1> (+ tail) + fused K5 vs the
+    oracle's per-trial csd (einsum form of csd.py:94-102, complex64 products), the sequential complex64 trial sum
+    (computational_routine.py:1022-1032) and normalize_csd (csd.py:118-172)."""
+    coh = spy.connectivityanalysis(c3_data, method="coh", tapsmofrq=1)
+    csd = spy.connectivityanalysis(c3_data, method="csd", tapsmofrq=1)
+    assert coh.data.shape == (1, 2049, 256, 256) and coh.data.dtype == np.float32
+    acc = np.zeros((2049, 256, 256), dtype=np.complex64)
+    for trl in _trials(c3_data):
+        specs, _ = O.mtmfft(O.detrend(trl, 0), 1000.0, 4096, "dpss", {"NW": 4.096, "Kmax": 7})
+        for f0 in range(0, 2049, 64):            # O.csd(faithful=False), 64 frequencies at a time (cache-sized)
+            s = specs[:, f0:f0 + 64]
+            acc[f0:f0 + 64] += (np.einsum("kfi,kfj->fij", s, s.conj()) / 7).astype(np.complex64)
+    acc /= 4
+    assert_parity(csd.data[0], acc, what="c3 csd")
+    sub = np.r_[0:2049:8, 2047, 2048]            # NumPy's complex64 sqrt takes ~10 s per 1000 bins: every 8th bin
+    assert_parity(coh.data[0][sub], O.normalize_csd(acc[sub], "abs"), what="c3 coherence")
+    assert np.array_equal(coh.data[0], coh.data[0].transpose(0, 2, 1))
+    assert np.all(np.abs(coh.data[0][:, np.arange(256), np.arange(256)] - 1) < 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ c4
+@pytest.fixture(scope="module")
+def c4_data():
+    return spy.synthdata.ar2_network(AdjMat=np.zeros((128, 128)), nSamples=16384, nTrials=1, seed=4)
+
+
+def test_c4_mtmconvol_128x16384(c4_data):
+    """BASELINE configs[3] (i): 512-sample Hann windows, 50 % overlap (K2 at N = 512, 128 channels)."""
+    kw = dict(method="mtmconvol", taper="hann", t_ftimwin=0.512, toi=0.5, output="pow")
+    got = spy.freqanalysis(c4_data, **kw)
+    ref = spy.freqanalysis(c4_data, compute_method="sequential", routine_classes=ORACLE_FREQ, **kw)
+    assert got.data.shape == ref.data.shape == (64, 1, 257, 128)
+    assert_parity(got.data, ref.data, what="c4 mtmconvol")
+
+
+def test_c4_wavelet_128x16384(c4_data):
+    """BASELINE configs[3] (ii): Morlet, 25 scales 4 ... 100 Hz, toi='all' - hits every CWT block group
+    (1024 / 2048 / 4096 / 8192-point blocks) at 128 channels (transform.py:88-108)."""
+    kw = dict(method="wavelet", wavelet="Morlet", width=6, foi=np.arange(4, 104, 4), toi="all", output="pow")
+    got = spy.freqanalysis(c4_data, **kw)
+    ref = spy.freqanalysis(c4_data, compute_method="sequential", routine_classes=ORACLE_FREQ, **kw)
+    assert got.data.shape == ref.data.shape == (16384, 1, 25, 128)
+    assert_parity(got.data, ref.data, what="c4 wavelet")
+
+
+# ------------------------------------------------------------------------------------------------ c5
+def _var_csd(C, F, seed, floor=0.05):
+    """Spectral matrix of a random stable VAR(2) process on F rfft bins: S(f) = H(f) Sigma H(f)^H + floor, complex64
+    (what the ST stage hands to the AV stage, AV_compRoutines.py:395)."""
+    rng = np.random.default_rng(seed)
+    A1 = 0.5 * np.eye(C) + rng.normal(size=(C, C)) * (0.25 / np.sqrt(C))
+    A2 = -0.6 * np.eye(C) + rng.normal(size=(C, C)) * (0.15 / np.sqrt(C))
+    L = np.eye(C) + 0.1 * np.tril(rng.normal(size=(C, C)), -1)
+    Sigma = L @ L.T
+    w = np.pi * np.arange(F) / (F - 1)
+    A = np.eye(C)[None] - A1[None] * np.exp(-1j * w)[:, None, None] - A2[None] * np.exp(-2j * w)[:, None, None]
+    H = np.linalg.inv(A)
+    S = H @ Sigma[None] @ H.conj().transpose(0, 2, 1) + floor * np.eye(C)[None]
+    S = 0.5 * (S + S.conj().transpose(0, 2, 1))
+    return S.astype(np.complex64)
+
+
+@pytest.mark.parametrize("C", [16, 33, 64])
+def test_wilson_granger_vs_oracle(C):
+    """K6 at channel counts that use the 16x16 blocked inverse and the 32x32 zgemm tiles (16: one block; 33: ragged
+    edge; 64: several tiles) against O.wilson_sf / O.granger / O.regularize_csd on the same complex64 CSD."""
+    from syncopy_amd import backend
+    F = 65
+    csd = _var_csd(C, F, seed=C)
+    G, meta, H, Sigma = backend.granger(torch.from_numpy(csd).cuda(), want_factors=True)
+    G, H, Sigma = G.cpu().numpy(), H.cpu().numpy(), Sigma.cpu().numpy()
+    reg, factor, cn0 = O.regularize_csd(csd, cond_max=1e4, eps_max=1e-1)
+    Ho, So, conv, err = O.wilson_sf(reg.astype(np.complex128), nIter=100, rtol=5e-6)
+    assert conv and meta["converged"] and meta["max rel. err"] < 5e-6
+    assert meta["reg. factor"] == factor
+    np.testing.assert_allclose(meta["initial cond. num"], cn0, rtol=1e-4)
+    # the reference's own acceptance test (tests/backend/test_conn.py:197-202)
+    assert O.max_rel_err(reg.astype(np.complex128), H @ Sigma @ H.conj().transpose(0, 2, 1)) < 1e-5
+    np.testing.assert_allclose(H, Ho, rtol=2e-4, atol=2e-5 * np.abs(Ho).max())
+    np.testing.assert_allclose(Sigma, So, rtol=2e-4, atol=2e-5 * np.abs(So).max())
+    Go = O.granger(reg.astype(np.complex128), Ho, So)
+    np.testing.assert_allclose(G, Go, rtol=2e-3, atol=2e-4)
+
+
+def test_wilson_reconstruction_256x2049():
+    """BASELINE configs[4] AV stage at full size: the CSD of 120 trials x 7 tapers of 256 ch x 4096 (K1 + K4 on the
+    device), factorised by K6; acceptance = the reference's max_rel_err(CSD, H Sigma H^H) (test_conn.py:197-202),
+    evaluated with complex128 batched products on the device (checker only)."""
+    from syncopy_amd import backend
+    C, N, T = 256, 4096, 120
+    x = spy.synthdata.ar2_uncoupled_fast(C, N, T, seed=5)
+    x[:, 1:] += 0.3 * x[:, :-1]                                   # instantaneous mixing: off-diagonal CSD entries
+    trl = np.stack([np.arange(T) * N, np.arange(1, T + 1) * N, np.zeros(T)], axis=1)
+    data = spy.AnalogData(x.cpu().numpy(), samplerate=1000.0, trialdefinition=trl)
+    del x
+    csd = spy.connectivityanalysis(data, method="csd", tapsmofrq=1)
+    S = torch.from_numpy(np.ascontiguousarray(csd.data[0])).cuda()
+    G, meta, H, Sigma = backend.granger(S, want_factors=True)
+    assert meta["converged"] and meta["max rel. err"] < 5e-6 and meta["reg. factor"] == 0
+    rec = H @ Sigma.unsqueeze(0) @ H.conj().transpose(1, 2)
+    S128 = S.to(torch.complex128)
+    err = float(((S128 - rec).abs() / S128.abs()).max())
+    assert err < 1e-5, err
+    assert bool(torch.isfinite(G).all())
+    # Granger of (nearly) uncoupled channels is ~0 everywhere off the coupled neighbours; never negative beyond noise
+    assert float(G.min()) > -1e-3
+
+
+@pytest.mark.parametrize("C", [8, 48])
+def test_regularize_near_threshold(C):
+    """G1: the decision kappa >= cond_max (wilson_sf.py:239-248) with kappa within 0.5 % of the threshold, on both
+    sides, must follow np.linalg.cond (LAPACK SVD) - the device estimate comes from an eigenvalue iteration."""
+    from syncopy_amd import backend
+    rng = np.random.default_rng(C)
+    F = 17
+    S = np.empty((F, C, C), dtype=np.complex128)
+    for f in range(F):
+        q, _ = np.linalg.qr(rng.normal(size=(C, C)) + 1j * rng.normal(size=(C, C)))
+        lam = np.exp(rng.uniform(np.log(1.0), np.log(2000.0 + 400.0 * f), size=C))
+        lam[0], lam[-1] = 1.0, 2000.0 + 400.0 * f          # condition number grows with f; two bins nearly tie
+        S[f] = (q * lam) @ q.conj().T
+    S = (0.5 * (S + S.conj().transpose(0, 2, 1))).astype(np.complex64)
+    kappa = np.linalg.cond(S).max()
+    dev = torch.from_numpy(S).cuda()
+    for cmax in (kappa * 1.005, kappa * 0.995, kappa * 0.5):
+        _, factor, cn0 = O.regularize_csd(S, cond_max=cmax, eps_max=1e-1)
+        _, meta = backend.granger(dev, niter=2, cond_max=cmax)
+        np.testing.assert_allclose(meta["initial cond. num"], cn0, rtol=1e-4)
+        assert meta["reg. factor"] == pytest.approx(factor, rel=1e-9), (cmax, kappa)

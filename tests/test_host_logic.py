@@ -175,3 +175,44 @@ def test_cfg_style_calls_and_replay():
     again = spy.freqanalysis(d, spec.cfg, **ex)                           # replay from the record
     assert np.array_equal(again.data, spec.data)
     assert spy.get_defaults(spy.connectivityanalysis).method == "coh"
+
+
+def test_in_place_selection_is_honoured_and_kept():
+    """`select=` semantics of unwrap_select (shared/kwarg_decorators.py:302-415): a selection attached beforehand with
+    data.selectdata() is used and left in place; `select=` is attached for the call only; both at once is an error."""
+    from oracle_routines import ORACLE_CONN
+    from syncopy_amd.shared.errors import SPYError
+    data = _uneq()
+    kw = dict(method="mtmfft", taper="hann", compute_method="sequential", routine_classes=ORACLE_FREQ)
+    full = spy.freqanalysis(data, **kw)
+    ntr = data.trialdefinition.shape[0]
+    assert full.data.shape[0] == ntr and data.selection is None
+    via_kw = spy.freqanalysis(data, select={"trials": [2, 0], "channel": [1]}, **kw)
+    assert data.selection is None                                   # attached by the call -> removed by the call
+    data.selectdata({"trials": [2, 0], "channel": [1]})
+    in_place = spy.freqanalysis(data, **kw)
+    assert data.selection is not None and data.selection.trial_ids == [2, 0]     # the user's selection survives
+    assert in_place.data.shape == via_kw.data.shape == (2, 1, 901, 1)      # pad = longest SELECTED trial (1800)
+    assert np.array_equal(in_place.data, via_kw.data)
+    with pytest.raises(SPYError):
+        spy.freqanalysis(data, select={"trials": [1]}, **kw)
+    assert data.selection is not None
+    coh = spy.connectivityanalysis(data.selectdata({"channel": [0, 2]}), method="coh", taper="hann",
+                                   compute_method="sequential", routine_classes=ORACLE_CONN)
+    assert coh.data.shape[-2:] == (2, 2) and data.selection is not None
+    with pytest.raises(SPYError):
+        spy.connectivityanalysis(data, method="coh", select={"trials": [0]}, compute_method="sequential",
+                                 routine_classes=ORACLE_CONN)
+    data.selectdata(None)
+    assert data.selection is None
+
+
+def test_plan_cache_is_lru():
+    from syncopy_amd.specest import hip_spectral as hs
+    cache = {}
+    for k in range(hs.MAX_CACHED_PLANS):
+        hs._bounded_put(cache, k, f"plan{k}")
+    assert hs._cache_hit(cache, 0) == "plan0"                       # the oldest entry is used again ...
+    hs._bounded_put(cache, "new", "x")
+    assert 0 in cache and 1 not in cache and len(cache) == hs.MAX_CACHED_PLANS   # ... so the next one goes instead
+    assert hs._cache_hit(cache, "missing") is None
