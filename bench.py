@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1000, help="trials per FFT/CSD launch pair")
     ap.add_argument("--blocked", action="store_true",
                     help="FFT -> CSD hand-over in the channel-blocked layout (faster FFT stores, slower CSD fetch)")
+    ap.add_argument("--no-reference-mean", action="store_true",
+                    help="detrend with float64 block sums instead of the reference's float32 row-order mean (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the c2 / c4 / c5 secondary measurements")
     return ap.parse_args()
@@ -84,13 +86,20 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
+def _cpu_noop(_):
+    import numpy  # noqa: F401  (worker start-up: interpreter + NumPy/SciPy import, kept out of the timed map)
+    from oracle import spy_oracle  # noqa: F401
+    return 0
+
+
 def cpu_baseline(nchan, nsamp):
     """BASELINE.md section 4.2 on the GPU box's host: the reference's per-trial coherence ST stage
     (mtmfft + outer product + taper mean, csd.py:94-102) as restated by the oracle,
-      (a) one process, one trial at a time = compute_sequential (computational_routine.py:944), "reference-faithful"
-          (materialises the (K,F,C,C) product like csd.py:98) and "best-effort CPU" (einsum accumulation);
-      (b) one process per core over disjoint trials = the Dask LocalCluster trial map (:926), BLAS threads = 1 -
-          best-effort variant only (the faithful one needs 8.6 GB per process).
+      (a) one process, one trial at a time = compute_sequential (computational_routine.py:944);
+      (b) one process per physical core over disjoint trials = the Dask LocalCluster trial map (:926), BLAS threads
+          = 1, inputs in RAM, worker start-up not timed; as many processes as half the free memory allows;
+    each as "reference-faithful" (materialises the (K,F,C,C) product like csd.py:98, 8.6 GB per process at
+    256 x 4096) and as "best-effort CPU" (einsum accumulation, no temporary).
     `value` is (a)-faithful: the reference's own code path on one core."""
     import multiprocessing as mp
     try:
@@ -102,29 +111,31 @@ def cpu_baseline(nchan, nsamp):
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else phys
     ncore = max(1, min(phys, usable))
     t_f = _cpu_worker((nchan, nsamp, 1, True, 0))
-    t_e = _cpu_worker((nchan, nsamp, 2, False, 0)) / 2
-    # one process per core: each holds a (F,C,C) complex64 result + accumulator (~2.2 GB at 256 x 4096)
-    per_proc = 3 * (nsamp // 2 + 1) * nchan * nchan * 8
-    nproc = int(max(1, min(ncore, (avail // 2) // max(per_proc, 1))))
-    per = 2
+    t_e = _cpu_worker((nchan, nsamp, 1, False, 0))
+    res_bytes = (nsamp // 2 + 1) * nchan * nchan * 8
+    variants = {
+        "faithful_1core": {"value": 1.0 / t_f, "cores": 1, "s_per_trial": t_f},
+        "best_effort_einsum_1core": {"value": 1.0 / t_e, "cores": 1, "s_per_trial": t_e},
+    }
     ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
-    with ctx.Pool(nproc) as pool:
-        pool.map(_cpu_worker, [(nchan, nsamp, per, False, 100 + i) for i in range(nproc)])
-    t_all = time.perf_counter() - t0
+    for name, faithful, per_proc in (("faithful_process_per_core", True, 10 * res_bytes),
+                                     ("best_effort_einsum_process_per_core", False, 3 * res_bytes)):
+        nproc = int(max(1, min(ncore, (avail // 2) // max(per_proc, 1))))
+        with ctx.Pool(nproc) as pool:
+            pool.map(_cpu_noop, range(nproc), chunksize=1)
+            t0 = time.perf_counter()
+            pool.map(_cpu_worker, [(nchan, nsamp, 1, faithful, 100 + i) for i in range(nproc)], chunksize=1)
+            t_all = time.perf_counter() - t0
+        variants[name] = {"value": nproc / t_all, "cores": nproc, "trials": nproc, "wall_s": t_all}
     return {
         "value": 1.0 / t_f, "unit": "trials/s", "cores": 1, "kind": "port",
         "sample": f"1 trial of {nchan} ch x {nsamp} samples, cross_spectra_cF reference-faithful (mtmfft + (K,F,C,C) outer "
                   f"product + taper mean, as csd.py:94-102), {t_f:.1f} s on one host core",
         "cpu_model": _cpu_model(), "physical_cores": phys, "usable_cores": usable,
-        "variants": {
-            "faithful_1core": {"value": 1.0 / t_f, "cores": 1, "s_per_trial": t_f},
-            "best_effort_einsum_1core": {"value": 1.0 / t_e, "cores": 1, "s_per_trial": t_e},
-            "best_effort_einsum_process_per_core": {
-                "value": nproc * per / t_all, "cores": nproc, "trials": nproc * per, "wall_s": t_all,
-                "note": "one process per core (spawn, pool start-up included), BLAS threads = 1, inputs in RAM; "
-                        "processes limited to half the free memory"},
-        },
+        "free_memory_GB": avail / 1e9,
+        "variants": variants,
+        "note": "process-per-core variants: one trial per process, BLAS threads = 1, inputs in RAM, worker start-up "
+                "excluded, process count limited to half the free memory",
     }
 
 
@@ -190,7 +201,7 @@ def _event_ms(torch, fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-def secondary(torch, be, synthdata, data, N, C, T):
+def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
     """The other SURVEY 8(d) numbers, inputs resident in HBM, each priced against the bound SURVEY 8(d) names:
     frac = max(bytes / 8 TB/s, flops / peak) / measured time."""
     from scipy.signal import windows
@@ -199,7 +210,7 @@ def secondary(torch, be, synthdata, data, N, C, T):
     F = N // 2 + 1
     # ---- c2: mtmfft power spectra, 7 tapers, taper mean (configs[1])
     tapers = windows.dpss(N, 1.0 * N / 1000.0, K) * np.sqrt(N)
-    plan = be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, False, None, "pow", False)
+    plan = be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, False, None, "pow", False, reference_mean=refmean)
     starts = torch.arange(T, device="cuda", dtype=torch.int64) * N
     buf = torch.empty(plan.out_shape(T), dtype=torch.float32, device="cuda")
     ms = _event_ms(torch, lambda: plan.execute(data, starts, out=buf))
@@ -249,7 +260,7 @@ def secondary(torch, be, synthdata, data, N, C, T):
                 "flop_per_trial": flop_lo, "bound_us_per_trial": bound_us, "frac": bound_us / (1e3 * ms / T4)})
     del res, plan, d4
     # ---- c5: Wilson / Granger AV stage on the CSD of the resident trials (demean_taper as method='granger' sets it)
-    plan = be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, True, None, "fourier", True)
+    plan = be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, True, None, "fourier", True, reference_mean=refmean)
     acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
     Tg = min(T, 400)
     for b0 in range(0, Tg, 100):
@@ -310,8 +321,9 @@ def main():
     scale = np.sqrt(2) / N
     data = synthdata.ar2_uncoupled_fast(C, N, T, seed=1234 + rank)          # (T*N, C) float32 in HBM
     starts_all = torch.arange(T, device="cuda", dtype=torch.int64) * N
+    refmean = not args.no_reference_mean
     plan = be.FFTPlan(N, N, C, tapers, scale, detrend=0, demean_taper=False, freq_idx=None, output="fourier",
-                      keeptapers=True)
+                      keeptapers=True, reference_mean=refmean)
     blocked = args.blocked and plan.set_blocked(True)
     B = min(args.batch, T)
     spec = torch.empty(plan.out_shape(B), dtype=torch.complex64, device="cuda")
@@ -400,7 +412,7 @@ def main():
                             "polyremoval=0, output='abs', inputs resident in HBM",
                 "trials_per_gpu": T, "channels": C, "samples": N, "tapers": K, "freqs": F, "batch": B, "handover_layout": "blocked" if blocked else "standard",
                 "channel_samples_per_s": value * N * C,
-                "fft_kernel": plan.kernel_name,
+                "fft_kernel": plan.kernel_name + (" (+ seq_mean_kernel pre-pass)" if refmean else ""),
                 "fft_ms_per_trial": sum(fft_ms) / (T * args.steps),
                 "fft_stream_GBps": fft_bytes / (sum(fft_ms) * 1e-3) / 1e9,
                 "csd_ms_per_trial": sum(csd_ms) / (T * args.steps),
@@ -421,7 +433,7 @@ def main():
         }
         if world == 1 and not args.no_secondary:
             del spec
-            line["secondary"] = secondary(torch, be, synthdata, data, N, C, T)
+            line["secondary"] = secondary(torch, be, synthdata, data, N, C, T, refmean)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(C, N)
         print(json.dumps(line), flush=True)

@@ -38,6 +38,7 @@ extern "C" {
 typedef struct spyhip_ctx spyhip_ctx;
 typedef struct spyhip_fft_plan spyhip_fft_plan;
 typedef struct spyhip_cwt_plan spyhip_cwt_plan;
+typedef struct spyhip_queue spyhip_queue;
 
 /* output conversions = syncopy/shared/const_def.py:25-37 `spectralConversions` */
 enum spyhip_output {
@@ -64,6 +65,51 @@ int spyhip_ctx_destroy(spyhip_ctx* ctx);
 /* `stream` is a hipStream_t (NULL = the null stream) */
 int spyhip_ctx_set_stream(spyhip_ctx* ctx, void* stream);
 int spyhip_ctx_synchronize(spyhip_ctx* ctx);
+
+/* ---- device memory ---------------------------------------------------------
+ * The library can be driven from a host that has nothing but this header (NumPy + ctypes, C, ...): it allocates
+ * HBM, moves data and synchronises by itself.  Hosts that already own device memory (PyTorch tensors) pass their
+ * pointers instead - the two can be mixed freely.  Copies are enqueued on the context's stream and are complete
+ * when the call returns (the stream is synchronised). */
+int spyhip_alloc(spyhip_ctx* ctx, size_t bytes, void** ptr_d);
+int spyhip_free(spyhip_ctx* ctx, void* ptr_d);
+int spyhip_memset(spyhip_ctx* ctx, void* ptr_d, int value, size_t bytes);            /* asynchronous */
+int spyhip_upload(spyhip_ctx* ctx, void* dst_d, const void* src, size_t bytes);
+int spyhip_download(spyhip_ctx* ctx, void* dst, const void* src_d, size_t bytes);
+
+/* ---- the in-HBM trial queue -------------------------------------------------
+ * Replaces the per-trial HDF5 slab reads of ComputationalRoutine.compute_sequential
+ * (shared/computational_routine.py:1001-1007) and the trial bookkeeping of AnalogData
+ * (datatype/continuous_data.py:255,405; sampleinfo: datatype/base_data.py:993): the whole (nrows x nchan) float32
+ * matrix goes to HBM once, together with the trials' row ranges.  Trial t = rows
+ * [sampleinfo[2t], sampleinfo[2t+1]) - any order, overlaps and repeats allowed, exactly as given (integer work).
+ * spyhip_queue_segments hands out the device arrays spyhip_fft_exec / spyhip_cwt_exec take as
+ * seg_start_d (= seg_lo_d) and seg_hi_d. */
+int spyhip_queue_upload(spyhip_ctx* ctx, const float* data, int64_t nrows, int nchan, const int64_t* sampleinfo,
+                        int ntrials, spyhip_queue** queue);
+int spyhip_queue_destroy(spyhip_queue* queue);
+const float* spyhip_queue_data(const spyhip_queue* queue);            /* device pointer, ld = nchan */
+int spyhip_queue_segments(const spyhip_queue* queue, const int64_t** start_d, const int64_t** stop_d, int* ntrials);
+
+/* ---- C1: sums over ranks (RCCL) ---------------------------------------------
+ * Replaces the mutex-guarded `+=` of the reference's parallel trial map (shared/kwarg_decorators.py:723-735,
+ * shared/computational_routine.py:939-942): one process per GPU, each with the accumulator of its trial shard.
+ * Bootstrap: ONE rank calls spyhip_comm_unique_id, the host distributes the 128 bytes by any means it has (file,
+ * environment, MPI, a torch.distributed store ...), every rank calls spyhip_comm_init with the same id.  RCCL
+ * (librccl.so) is loaded on first use; single-GPU users never need it.
+ * spyhip_allreduce_csd: acc_d complex64 (nfreq, nchan, nchan) raw accumulator of spyhip_csd_accumulate; only its
+ *   lower triangle carries data, so that is what travels (packed into library scratch, summed over all ranks,
+ *   unpacked): 0.54 GB instead of 1.07 GB at 2049 x 256 x 256.
+ * spyhip_allreduce: in-place sum of n float32 (dtype 0) or float64 (dtype 1) values (phasor sums of K7, the
+ *   jackknife sums, trial sums of averaged spectra; complex arrays as interleaved reals).
+ * All are enqueued on the context's stream.  With a communicator of one rank they run all the same (identity). */
+#define SPYHIP_UNIQUE_ID_BYTES 128
+int spyhip_comm_unique_id(void* id_out);
+int spyhip_comm_init(spyhip_ctx* ctx, const void* id, int rank, int nranks);
+int spyhip_comm_destroy(spyhip_ctx* ctx);
+int spyhip_comm_info(const spyhip_ctx* ctx, int* rank, int* nranks);     /* -1 if there is no communicator */
+int spyhip_allreduce_csd(spyhip_ctx* ctx, void* acc_d, int nfreq, int nchan);
+int spyhip_allreduce(spyhip_ctx* ctx, void* buf_d, int64_t n, int dtype);
 
 /* ---- K1/K2: (multi-)tapered FFT of segments ------------------------------
  * Replaces mtmfft (specest/mtmfft.py:16-129) + the tail of mtmfft_cF
@@ -100,6 +146,14 @@ int spyhip_fft_exec(spyhip_fft_plan* plan, const float* data_d, int64_t ld,
  * so that every wave stores whole 2-KiB runs.  Channels beyond nchan in the last quad are written as 0.
  * Returns -3 for plans that cannot use it (other outputs, nfft not a power of two in 256..8192). */
 int spyhip_fft_plan_set_blocked(spyhip_fft_plan* plan, int on);
+/* Constant detrending (detrend = SPYHIP_DETREND_CONSTANT) with the per-channel mean taken EXACTLY as the reference
+ * takes it for whole trials: scipy.signal.detrend on the float32 (time x channel) array is data - np.mean(data, 0),
+ * and NumPy sums the slow axis sequentially in ONE float32 accumulator per channel (then one float32 division).
+ * For channels riding on an offset that rounding sequence is what the bins next to DC consist of.  on = 1: a
+ * pre-pass reproduces it literally (one thread per channel walks the rows in order); on = 0 (default): float64
+ * block sums inside the transform kernel - the better match for per-segment detrending of sliding windows, which
+ * the reference does in float64 (specest/stft.py:112-132). */
+int spyhip_fft_plan_set_reference_mean(spyhip_fft_plan* plan, int on);
 /* name of the dominant kernel a plan launches (for rocprof matching) */
 const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* plan);
 

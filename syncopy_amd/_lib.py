@@ -25,6 +25,22 @@ SIGNATURES = {
     "spyhip_ctx_destroy": (C.c_int, [vp]),
     "spyhip_ctx_set_stream": (C.c_int, [vp, vp]),
     "spyhip_ctx_synchronize": (C.c_int, [vp]),
+    "spyhip_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "spyhip_free": (C.c_int, [vp, vp]),
+    "spyhip_memset": (C.c_int, [vp, vp, C.c_int, C.c_size_t]),
+    "spyhip_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "spyhip_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "spyhip_queue_upload": (C.c_int, [vp, vp, C.c_int64, C.c_int, c_i64p, C.c_int, C.POINTER(vp)]),
+    "spyhip_queue_destroy": (C.c_int, [vp]),
+    "spyhip_queue_data": (vp, [vp]),
+    "spyhip_queue_segments": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]),
+    "spyhip_comm_unique_id": (C.c_int, [vp]),
+    "spyhip_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "spyhip_comm_destroy": (C.c_int, [vp]),
+    "spyhip_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "spyhip_allreduce_csd": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "spyhip_allreduce": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
+    "spyhip_fft_plan_set_reference_mean": (C.c_int, [vp, C.c_int]),
     "spyhip_fft_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, C.c_double, C.c_int,
                                          C.c_int, c_i32p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "spyhip_fft_plan_destroy": (C.c_int, [vp]),
@@ -67,7 +83,7 @@ class SpyHipError(RuntimeError):
 
 
 def load():
-    """Load libspyhip.so (once).  Import torch first so that both share one HIP runtime."""
+    """Load libspyhip.so (once)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -75,10 +91,8 @@ def load():
         raise SpyHipError(
             f"{LIB_PATH} is missing: build it with `python -m syncopy_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    try:
-        import torch  # noqa: F401  (loads libamdhip64.so.7 first; ours then binds to the same runtime)
-    except ImportError:
-        pass
+    # A host that uses PyTorch has libamdhip64 loaded already and ours binds to that runtime; a NumPy-only host
+    # (syncopy_amd/abi.py) gets the runtime through the library's own dependencies.  torch is never imported here.
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

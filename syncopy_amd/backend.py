@@ -123,7 +123,9 @@ class FFTPlan:
     """spyhip_fft_plan: tapered FFT of segments of a (rows x ld) float32 matrix."""
 
     def __init__(self, nsig, nfft, nchan, tapers, scale, detrend=None, demean_taper=False, freq_idx=None,
-                 output="pow", keeptapers=True, device=None):
+                 output="pow", keeptapers=True, device=None, reference_mean=False):
+        """`reference_mean`: constant detrending (detrend=0) subtracts the per-channel mean in the reference's own
+        float32 row-order summation (spyhip_fft_plan_set_reference_mean) - for whole trials."""
         self.ctx = context(device)
         tapers = np.ascontiguousarray(np.atleast_2d(tapers), dtype=np.float64)
         assert tapers.shape[1] == nsig, (tapers.shape, nsig)
@@ -147,6 +149,9 @@ class FFTPlan:
         self.kout = self.ntaper if self.keeptapers else 1
         self.out_dtype = torch.complex64 if self.kind == 2 else torch.float32
         self.blocked = False
+        self.reference_mean = bool(reference_mean)
+        if self.reference_mean:
+            check(self.ctx.lib.spyhip_fft_plan_set_reference_mean(self.handle, 1), "spyhip_fft_plan_set_reference_mean")
 
     def set_blocked(self, on=True):
         """Channel-quad-blocked hand-over layout (nseg*ntaper, ceil(nchan/4), nfsel, 4) for csd_accumulate(...,

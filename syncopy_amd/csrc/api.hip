@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace spy
 
-extern "C" int spyhip_version(void) { return 100; }
+extern "C" int spyhip_version(void) { return 200; }
 
 extern "C" const char* spyhip_last_error(void) { return spy::g_last_error.c_str(); }
 
@@ -42,7 +42,11 @@ extern "C" int spyhip_ctx_create(int device, spyhip_ctx** out) {
 }
 
 extern "C" int spyhip_ctx_destroy(spyhip_ctx* ctx) {
-    if (ctx && ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx) {
+        if (ctx->comm) (void)spyhip_comm_destroy(ctx);
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
+    }
     delete ctx;
     return 0;
 }
@@ -57,6 +61,116 @@ extern "C" int spyhip_ctx_synchronize(spyhip_ctx* ctx) {
     if (!ctx) { spy::set_error("ctx_synchronize: null ctx"); return -1; }
     SPY_HIP_CHECK(hipSetDevice(ctx->device));
     SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- device memory for hosts without a tensor library ----------------------------------------------------------
+extern "C" int spyhip_alloc(spyhip_ctx* ctx, size_t bytes, void** ptr_d) {
+    if (!ctx || !ptr_d) { spy::set_error("alloc: null argument"); return -1; }
+    *ptr_d = nullptr;
+    if (bytes == 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    SPY_HIP_CHECK(hipMalloc(ptr_d, bytes));
+    return 0;
+}
+
+extern "C" int spyhip_free(spyhip_ctx* ctx, void* ptr_d) {
+    if (!ctx) { spy::set_error("free: null ctx"); return -1; }
+    if (!ptr_d) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // nothing enqueued may still use the block
+    SPY_HIP_CHECK(hipFree(ptr_d));
+    return 0;
+}
+
+extern "C" int spyhip_memset(spyhip_ctx* ctx, void* ptr_d, int value, size_t bytes) {
+    if (!ctx || (!ptr_d && bytes)) { spy::set_error("memset: null argument"); return -1; }
+    if (bytes == 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    SPY_HIP_CHECK(hipMemsetAsync(ptr_d, value, bytes, ctx->stream));
+    return 0;
+}
+
+extern "C" int spyhip_upload(spyhip_ctx* ctx, void* dst_d, const void* src, size_t bytes) {
+    if (!ctx || ((!dst_d || !src) && bytes)) { spy::set_error("upload: null argument"); return -1; }
+    if (bytes == 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    SPY_HIP_CHECK(hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int spyhip_download(spyhip_ctx* ctx, void* dst, const void* src_d, size_t bytes) {
+    if (!ctx || ((!dst || !src_d) && bytes)) { spy::set_error("download: null argument"); return -1; }
+    if (bytes == 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    SPY_HIP_CHECK(hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- the in-HBM trial queue ----------------------------------------------------------------------------------------
+struct spyhip_queue {
+    spyhip_ctx* ctx = nullptr;
+    float* data = nullptr;          // (nrows x nchan)
+    long long* seg = nullptr;       // [0, T): first rows, [T, 2T): stop rows
+    int64_t nrows = 0;
+    int nchan = 0, ntrials = 0;
+};
+
+extern "C" int spyhip_queue_upload(spyhip_ctx* ctx, const float* data, int64_t nrows, int nchan,
+                                   const int64_t* sampleinfo, int ntrials, spyhip_queue** out) {
+    if (!ctx || !data || !sampleinfo || !out) { spy::set_error("queue_upload: null argument"); return -1; }
+    if (nrows < 1 || nchan < 1 || ntrials < 1) { spy::set_error("queue_upload: empty data (%lld rows, %d channels, %d trials)", (long long)nrows, nchan, ntrials); return -1; }
+    std::vector<long long> seg((size_t)2 * ntrials);
+    for (int t = 0; t < ntrials; ++t) {
+        const int64_t a = sampleinfo[2 * t], b = sampleinfo[2 * t + 1];
+        if (a < 0 || b < a || b > nrows) {       // exact indexing or nothing: a trial must lie inside the matrix
+            spy::set_error("queue_upload: trial %d = rows [%lld, %lld) outside the %lld rows of the data", t,
+                           (long long)a, (long long)b, (long long)nrows);
+            return -1;
+        }
+        seg[t] = a;
+        seg[(size_t)ntrials + t] = b;
+    }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    auto* q = new spyhip_queue();
+    q->ctx = ctx; q->nrows = nrows; q->nchan = nchan; q->ntrials = ntrials;
+    const size_t bytes = (size_t)nrows * nchan * sizeof(float);
+    if (hipMalloc(reinterpret_cast<void**>(&q->data), bytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&q->seg), seg.size() * sizeof(long long)) != hipSuccess) {
+        spy::set_error("queue_upload: cannot allocate %zu bytes of device memory", bytes);
+        (void)spyhip_queue_destroy(q);
+        return -2;
+    }
+    if (hipMemcpyAsync(q->data, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(q->seg, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        spy::set_error("queue_upload: host -> device copy failed");
+        (void)spyhip_queue_destroy(q);
+        return -2;
+    }
+    *out = q;
+    return 0;
+}
+
+extern "C" int spyhip_queue_destroy(spyhip_queue* q) {
+    if (!q) return 0;
+    if (q->ctx) { (void)hipSetDevice(q->ctx->device); (void)hipStreamSynchronize(q->ctx->stream); }
+    if (q->data) (void)hipFree(q->data);
+    if (q->seg) (void)hipFree(q->seg);
+    delete q;
+    return 0;
+}
+
+extern "C" const float* spyhip_queue_data(const spyhip_queue* q) { return q ? q->data : nullptr; }
+
+extern "C" int spyhip_queue_segments(const spyhip_queue* q, const int64_t** start_d, const int64_t** stop_d,
+                                     int* ntrials) {
+    if (!q) { spy::set_error("queue_segments: null queue"); return -1; }
+    if (start_d) *start_d = reinterpret_cast<const int64_t*>(q->seg);
+    if (stop_d) *stop_d = reinterpret_cast<const int64_t*>(q->seg + q->ntrials);
+    if (ntrials) *ntrials = q->ntrials;
     return 0;
 }
 

@@ -38,6 +38,9 @@ struct spyhip_fft_plan {
     spy::DevBuf<int> fpos;
     bool identity_freq = true;
     bool blocked = false;
+    bool ref_mean = false;      // constant detrending with the reference's float32 row-order means (seq_mean_kernel)
+    spy::DevBuf<float> means;
+    size_t means_cap = 0;
     std::string kernel_name;
 };
 
@@ -415,6 +418,12 @@ extern "C" int spyhip_fft_plan_set_blocked(spyhip_fft_plan* p, int on) {
     return 0;
 }
 
+extern "C" int spyhip_fft_plan_set_reference_mean(spyhip_fft_plan* p, int on) {
+    if (!p) { spy::set_error("fft_plan_set_reference_mean: null plan"); return -1; }
+    p->ref_mean = on != 0;
+    return 0;
+}
+
 extern "C" const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* p) {
     return p ? p->kernel_name.c_str() : "";
 }
@@ -436,6 +445,26 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     a.fpos = p->identity_freq ? nullptr : p->fpos.p;
     a.nfsel = p->nfsel; a.out_kind = p->output; a.out = out_d;
     a.blocked = p->blocked ? 1 : 0;
+    a.means = nullptr;
+    if (p->ref_mean && p->detrend == 0) {
+        // the per-channel means of every segment in the reference's summation order, ahead of the transform
+        const size_t need = (size_t)nseg * p->nchan;
+        if (need > p->means_cap) {
+            if (p->means.p) { SPY_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); (void)hipFree(p->means.p); p->means.p = nullptr; }
+            if (p->means.alloc(need)) return -2;
+            p->means_cap = need;
+        }
+        const int ncb = (p->nchan + 63) / 64;
+        for (int s0 = 0; s0 < nseg; s0 += 65535) {
+            MtmArgs m = a;
+            m.seg_start += s0; m.seg_lo += s0; m.seg_hi += s0;
+            const int ns = std::min(65535, nseg - s0);
+            hipLaunchKernelGGL(spyfft::seq_mean_kernel, dim3(ncb, ns), dim3(64), 0, p->ctx->stream, m,
+                               p->means.p + (size_t)s0 * p->nchan);
+        }
+        SPY_HIP_CHECK(hipGetLastError());
+        a.means = p->means.p;
+    }
     const int npairs = (p->nchan + 1) / 2;
     if (p->pow2) {
         // work items per segment: channel quads (packed kernel) or channel pairs (2^14)

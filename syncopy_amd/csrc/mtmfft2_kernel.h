@@ -96,8 +96,20 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         for (int e = 0; e < 16; ++e) x[e].r = x[e].i = splat(0.f);
     }
 
-    // ---- polynomial removal over the nsig samples (float64 sums, branch-free)
-    if (a.detrend >= 0) {
+    // ---- polynomial removal over the nsig samples (float64 sums, branch-free; constant: the reference-order means)
+    if (a.detrend == 0 && a.means) {
+        const float* mp = a.means + (size_t)b * a.nchan + c0;
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = has[i] ? mp[i] : 0.f;
+        const v2f mr = v2f{f[0], f[1]}, mi = v2f{f[2], f[3]};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool in = j0 + T * e < a.nsig;
+            x[e].r -= in ? mr : splat(0.f);
+            x[e].i -= in ? mi : splat(0.f);
+        }
+    } else if (a.detrend >= 0) {
         const float mid = 0.5f * (float)(a.nsig - 1);
         double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll

@@ -147,7 +147,10 @@ __global__ void __launch_bounds__(GEN_THREADS) mtmfft_generic_kernel(MtmArgs a, 
     // ---- detrend coefficients
     const double mid = 0.5 * (a.nsig - 1);
     double m0 = 0.0, m1 = 0.0, b0 = 0.0, b1 = 0.0;
-    if (a.detrend >= 0) {
+    if (a.detrend == 0 && a.means) {
+        m0 = (double)a.means[(size_t)b * a.nchan + c0];            // the reference-order float32 means
+        m1 = has1 ? (double)a.means[(size_t)b * a.nchan + c1] : 0.0;
+    } else if (a.detrend >= 0) {
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         for (int n = tid; n < a.nsig; n += GEN_THREADS) {
             const float2 u = load(n);

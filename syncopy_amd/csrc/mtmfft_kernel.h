@@ -51,7 +51,44 @@ struct MtmArgs {
     const float2* bhat;         // M entries: FFT_M of the wrapped conjugate chirp, / M
     int blocked;                // complex keeptapers output in the channel-quad-blocked layout
                                 // (nseg*ntaper, ceil(nchan/4), nfsel, 4) instead of (nseg, ntaper, nfsel, nchan)
+    const float* means;         // (nseg x nchan) per-channel means in the reference's summation order
+                                // (seq_mean_kernel) used for detrend == 0, or nullptr: float64 block sums
 };
+
+// Per-channel mean of a segment exactly as the reference takes it.  scipy.signal.detrend(type="constant") on the
+// float32 (time x channel) trial (specest/compRoutines.py:169-170, connectivity/ST_compRoutines.py:405-409) is
+// `data - np.mean(data, axis=0)`: NumPy reduces the slow axis of a C-ordered array row by row, i.e. ONE float32
+// accumulator per channel that takes the samples in time order, then one float32 division by the sample count.
+// That rounding sequence cannot be re-associated, and for channels with an offset its error (~1e-6 of the offset)
+// is what the bins next to DC are made of - so it is reproduced literally: one thread per (segment, channel), a
+// serial chain of v_add_f32 over the rows (loads batched 16 rows ahead; lanes = adjacent channels: coalesced).
+// Rows outside [seg_lo, seg_hi) count as +0 and leave the sum as it is.
+static __global__ void __launch_bounds__(64) seq_mean_kernel(MtmArgs a, float* means) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= a.nchan) return;
+    const long long col = a.chan_idx ? a.chan_idx[c] : c;
+    const long long start = a.seg_start[b];
+    const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
+    const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
+    const int rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
+    const float* p = a.data + (start + rlo) * a.ld + col;
+    float s = 0.f;
+    int n = rlo;
+    for (; n + 16 <= rhi; n += 16) {
+        float t[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t[e] = p[(long long)e * a.ld];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s = __fadd_rn(s, t[e]);
+        p += 16 * a.ld;
+    }
+    for (; n < rhi; ++n) {
+        s = __fadd_rn(s, *p);
+        p += a.ld;
+    }
+    means[(size_t)b * a.nchan + c] = __fdiv_rn(s, (float)a.nsig);
+}
 
 // output conversions of const_def.py:25-37; `kind` is wave-uniform.  Kept out of
 // line so that the compiler branches on `kind` instead of evaluating sqrt and
@@ -151,8 +188,17 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmfft
         for (int e = 0; e < 16; ++e) x0[e] = x1[e] = 0.f;
     }
 
-    // ---- polynomial removal over the nsig samples (float64 sums, branch-free)
-    if (a.detrend >= 0) {
+    // ---- polynomial removal over the nsig samples (float64 sums, branch-free; constant: the reference-order means)
+    if (a.detrend == 0 && a.means) {
+        const float* mp = a.means + (size_t)b * a.nchan;
+        const float f0 = has0 ? mp[c0] : 0.f, f1 = has1 ? mp[c1] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool in = j0 + T * e < a.nsig;
+            x0[e] -= in ? f0 : 0.f;
+            x1[e] -= in ? f1 : 0.f;
+        }
+    } else if (a.detrend >= 0) {
         const float mid = 0.5f * (float)(a.nsig - 1);
         double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

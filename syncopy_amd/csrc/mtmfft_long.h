@@ -148,7 +148,9 @@ __global__ void __launch_bounds__((Cfg2<LOG2L, G>::NTHREADS)) long_cols_kernel(L
         col[i] = has[i] ? (m.chan_idx ? m.chan_idx[c0 + i] : c0 + i) : 0;
         if (!has[i]) continue;
         const double* st = a.stats + ((size_t)b * m.nchan + c0 + i) * (2 + m.ntaper);
-        if (m.detrend >= 0) {
+        if (m.detrend == 0 && m.means) {
+            mean[i] = (double)m.means[(size_t)b * m.nchan + c0 + i];   // the reference-order float32 mean
+        } else if (m.detrend >= 0) {
             mean[i] = st[0] / m.nsig;
             if (m.detrend == 1 && m.nsig > 1)
                 slope[i] = st[1] * 12.0 / ((double)m.nsig * ((double)m.nsig * m.nsig - 1.0));

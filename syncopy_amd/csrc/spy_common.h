@@ -23,6 +23,10 @@ struct spyhip_ctx {
     hipStream_t stream = nullptr;
     void* scratch = nullptr;        // library-owned device scratch (partial sums of split launches), grown on demand
     size_t scratch_bytes = 0;
+    void* comm = nullptr;           // ncclComm_t of spyhip_comm_init (comm.hip), or nullptr
+    int comm_rank = -1, comm_nranks = 0;
+    void* comm_buf = nullptr;       // packed lower triangle travelling through spyhip_allreduce_csd
+    size_t comm_buf_bytes = 0;
 #endif
     int num_cu = 256;
     size_t lds_per_block = 160 * 1024;

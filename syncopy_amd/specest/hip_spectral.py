@@ -6,12 +6,10 @@ Used by the compute functions in compRoutines.py both for one trial at a time
 """
 import numpy as np
 import torch
-from scipy.signal import windows
-
 from .. import backend
+from .tapers import spec_scale, taper_table  # noqa: F401
 
 _plan_cache = {}
-_taper_cache = {}
 MAX_CACHED_PLANS = 64
 
 
@@ -31,44 +29,22 @@ def _cache_hit(cache, key):
     return value
 
 
-def taper_table(taper, nsig, nnorm, taper_opt=None):
-    """(K, nsig) float64 window rows, normalised for spectral power
-    (semantics of specest/_norm_spec.py:27-46; window length = actual signal
-    length, normalisation length = padded length, mtmfft.py:96-101)."""
-    taper = "boxcar" if taper is None else taper
-    opt = {} if not taper_opt else dict(taper_opt)
-    key = (taper, int(nsig), int(nnorm), tuple(sorted(opt.items())))
-    if key not in _taper_cache:
-        w = np.atleast_2d(getattr(windows, taper)(int(nsig), **opt)).astype(np.float64)
-        if taper == "dpss":
-            w = w * np.sqrt(nnorm)
-        elif taper == "boxcar":
-            w = w * np.sqrt(nnorm / w.sum())
-        else:
-            w = w * (np.sqrt(4 / 3) * np.sqrt(nnorm / w.sum()))
-        _taper_cache[key] = w
-    return _taper_cache[key]
-
-
-def spec_scale(nsig, nfft, ft_compat=False):
-    """sqrt(2)/N normalisation of every rfft bin (specest/_norm_spec.py:10-24, mtmfft.py:119-127)."""
-    if ft_compat:
-        return np.sqrt(2) / nfft
-    return np.sqrt(2) / (nsig * np.sqrt(nfft / nsig))
-
-
 def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_taper, freq_idx, output, keeptapers,
-             device, blocked=False):
+             device, blocked=False, whole_trials=True):
     """Cached FFTPlan; `blocked` asks for the channel-blocked hand-over layout of the CSD path (the plan's
-    `.blocked` tells whether the kernel serving this length supports it)."""
+    `.blocked` tells whether the kernel serving this length supports it).  `whole_trials`: the segments are trials
+    that the reference detrends as float32 arrays (compRoutines.py:169-170, ST_compRoutines.py:405-409), so the
+    mean is taken in its float32 row order; sliding-window frames are detrended in float64 there (stft.py:112-132)
+    and keep the kernels' float64 block sums."""
     fkey = None if freq_idx is None else np.asarray(freq_idx, dtype=np.int32).tobytes()
     key = (int(nsig), int(nfft), int(nchan), taper, tuple(sorted((taper_opt or {}).items())), int(nnorm),
-           float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device), bool(blocked))
+           float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device), bool(blocked),
+           bool(whole_trials))
     plan = _cache_hit(_plan_cache, key)
     if plan is None:
         tp = taper_table(taper, nsig, nnorm, taper_opt)
         plan = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
-                               keeptapers, device=device)
+                               keeptapers, device=device, reference_mean=whole_trials and detrend == 0)
         if blocked:
             plan.set_blocked(True)
         _bounded_put(_plan_cache, key, plan)
@@ -120,7 +96,7 @@ def run_stft(dev_data, row0, soi_start, soi_stop, frames, nperseg, step, boundar
     if taper == "dpss":
         opt["sym"] = False          # mtmconvol.py:110-111
     plan = get_plan(nperseg, nperseg, nchan, taper, opt, nperseg, np.sqrt(2) / nperseg, polyremoval, False,
-                    full_freq_idx(freq_idx, nperseg), output, keeptapers, device)
+                    full_freq_idx(freq_idx, nperseg), output, keeptapers, device, whole_trials=False)
     frames = np.asarray(frames, dtype=np.int64)
     lead = nperseg // 2 if boundary else 0
     starts = torch.from_numpy(row0 + soi_start + frames * step - lead).to(device)

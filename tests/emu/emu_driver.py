@@ -48,7 +48,41 @@ OUT_KINDS = {"pow": 0, "abs": 1, "fourier": 2, "complex": 2, "real": 3, "imag": 
 
 def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
              freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False,
-             force_long=False):
+             force_long=False, reference_mean=False):
+    """`reference_mean`: constant detrending with the means of seq_mean_kernel (spyhip_fft_plan_set_reference_mean)."""
+    if reference_mean and detrend == 0:
+        d32 = np.ascontiguousarray(data, dtype=np.float32)
+        nch = d32.shape[1] if chan_idx is None else len(chan_idx)
+        means = seq_mean(d32, seg_start, seg_lo, seg_hi, nsig, chan_idx)
+        assert means.shape == (len(seg_start), nch)
+        lib().emu_set_means(_p(means, C.c_float))
+        try:
+            return fft_exec(d32, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend, demean_taper, freq_idx,
+                            output, keeptapers, chan_idx, G, force_generic, blocked, force_long, False)
+        finally:
+            lib().emu_set_means(None)
+    return _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend, demean_taper, freq_idx,
+                     output, keeptapers, chan_idx, G, force_generic, blocked, force_long)
+
+
+def seq_mean(data, seg_start, seg_lo, seg_hi, nsig, chan_idx=None):
+    """Emulated seq_mean_kernel: (nseg, nchan) float32 means in the reference's summation order."""
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    ci = None if chan_idx is None else np.ascontiguousarray(chan_idx, dtype=np.int32)
+    nchan = data.shape[1] if ci is None else len(ci)
+    ss = np.ascontiguousarray(seg_start, dtype=np.int64)
+    sl = np.ascontiguousarray(seg_lo, dtype=np.int64)
+    sh = np.ascontiguousarray(seg_hi, dtype=np.int64)
+    means = np.full((len(ss), nchan), np.nan, dtype=np.float32)
+    lib().emu_seq_mean(_p(data, C.c_float), C.c_longlong(data.shape[1]), _p(ci, C.c_int), _p(ss, C.c_longlong),
+                       _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(len(ss)), C.c_int(nsig), C.c_int(nchan),
+                       _p(means, C.c_float))
+    return means
+
+
+def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
+              freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False,
+              force_long=False):
     """Emulated spyhip_fft_exec.  data: (rows, ld) float32; tapers: (K, nsig) float64.
     blocked: channel-blocked hand-over layout (nseg*K, ceil(nchan/4), nfsel, 4) (fourier, keeptapers)."""
     data = np.ascontiguousarray(data, dtype=np.float32)

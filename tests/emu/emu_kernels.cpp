@@ -107,6 +107,7 @@ int run_long(const spyfft::LongArgs& a, int l, int stage, long long items) {
 }  // namespace
 
 static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD entry points
+static const float* g_means = nullptr;   // (nseg x nchan) reference-order means for the next FFT call, or none
 
 template <int LOG2N, int G>
 static void emu_launch_ccov(const spyfft::CcovArgs& a) {
@@ -118,6 +119,17 @@ static void emu_launch_ccov(const spyfft::CcovArgs& a) {
 extern "C" {
 
 void emu_set_blocked(int on) { g_blocked = on; }
+void emu_set_means(const float* m) { g_means = m; }
+
+// spyfft::seq_mean_kernel as spyhip_fft_exec launches it (plan option spyhip_fft_plan_set_reference_mean)
+void emu_seq_mean(const float* data, long long ld, const int* chan_idx, const long long* seg_start,
+                  const long long* seg_lo, const long long* seg_hi, int nseg, int nsig, int nchan, float* means) {
+    MtmArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan;
+    emu::launch(dim3((nchan + 63) / 64, nseg), dim3(64), 0, [&] { spyfft::seq_mean_kernel(a, means); }, -1);
+}
 
 // Mirrors the argument marshalling of spyhip_fft_exec for the power-of-two kernels
 // (packed quad kernel up to 2^13, pair kernel for 2^14).
@@ -134,6 +146,7 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
     a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
     a.out_kind = out_kind; a.out = out;
+    a.means = g_means;
     a.blocked = g_blocked;
     const bool quad = log2n <= 13;
     const int nitem = quad ? (nchan + 3) / 4 : (nchan + 1) / 2;
@@ -171,6 +184,7 @@ int emu_mtmfft_blue(int log2m, int G, int nfft, const float* chirp, const float*
     a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
     a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
     a.out_kind = out_kind; a.out = out;
+    a.means = g_means;
     a.nfft = nfft; a.chirp = reinterpret_cast<const float2*>(chirp); a.bhat = reinterpret_cast<const float2*>(bhat);
     const int nitem = (nchan + 3) / 4;
     a.npg = (nitem + G - 1) / G;
@@ -205,6 +219,7 @@ int emu_mtmfft_long(int l1, int l2, int nfft, const float* chirp, const float* b
     a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
     a.tapers = tapers; a.scale = scale; a.detrend = detrend; a.demean_taper = demean_taper;
     a.fpos = fpos; a.nfsel = nfsel; a.out_kind = out_kind; a.out = out; a.nfft = nfft;
+    a.means = g_means;
     spyfft::LongArgs L{};
     L.m = a;
     L.M1 = 1 << l1; L.M2 = 1 << l2;
@@ -255,6 +270,7 @@ int emu_mtmfft_generic(int n, int nfac, const int* radix, int nfft, int bluestei
     a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
     a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
     a.out_kind = out_kind; a.out = out;
+    a.means = g_means;
     GenPlan g{};
     g.n = n; g.nfac = nfac; g.nfft = nfft; g.bluestein = bluestein; g.stage_x = stage_x;
     for (int i = 0; i < nfac; ++i) g.radix[i] = radix[i];

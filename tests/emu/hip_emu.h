@@ -35,6 +35,9 @@ struct double2 { double x, y; };
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline double2 make_double2(double a, double b) { return double2{a, b}; }
+// IEEE round-to-nearest float32 add / divide (the host compiler does not contract or re-associate them)
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 
 namespace emu {
 struct BlockCtx {

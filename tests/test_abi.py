@@ -63,3 +63,21 @@ def test_package_never_imports_the_oracle():
                 if "hip_emu.h" in txt:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_numpy_only_host_does_not_pull_torch_in():
+    """`syncopy_amd.abi` (the NumPy + ctypes host of INTEGRATION.md) and the package itself import without PyTorch;
+    on a box without a GPU the context creation fails loudly."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import syncopy_amd as spy\n"
+            "from syncopy_amd import abi\n"
+            "from syncopy_amd.specest.tapers import taper_table\n"
+            "assert 'torch' not in sys.modules, 'torch was imported'\n"
+            "lib = abi._lib.load()\n"
+            "assert lib.spyhip_version() >= 200\n"
+            "assert 'torch' not in sys.modules\n"
+            "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

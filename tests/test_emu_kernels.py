@@ -332,3 +332,49 @@ def test_wilson_granger_small_vs_oracle():
     assert O.max_rel_err(acc.astype(np.complex128), rec) < 1e-5
     np.testing.assert_allclose(G[2:-1], Gr[0, 2:-1], rtol=5e-3, atol=5e-4)
     np.testing.assert_allclose(G, Gr[0], atol=1e-2)
+
+
+def test_reference_order_mean_is_numpy_bit_for_bit():
+    """seq_mean_kernel = np.mean(float32 (time x channel), axis=0) bit for bit: NumPy reduces the slow axis with one
+    float32 accumulator per channel in time order (what scipy.signal.detrend(type='constant') subtracts,
+    specest/compRoutines.py:169-170).  Offsets make the rounding sequence matter; zero-extended segments, channel
+    selections and channel counts around the 64-lane edge are covered."""
+    rng = np.random.default_rng(7)
+    x = (rng.normal(size=(5000, 70)) * rng.uniform(0.1, 30, size=70) + rng.uniform(-500, 500, size=70)).astype(np.float32)
+    got = E.seq_mean(x, [0, 17, 1000], [0, 17, 1000], [4096, 17 + 3001, 1000 + 33], 4096)
+    assert np.array_equal(got[0], np.mean(x[:4096], axis=0))
+    assert got[0].dtype == np.float32
+    # rows outside [lo, hi) count as zeros: sum over the valid rows, divided by nsig
+    assert np.array_equal(got[1], np.add.reduce(x[17:17 + 3001], axis=0) / np.float32(4096))
+    assert np.array_equal(got[2], np.add.reduce(x[1000:1033], axis=0) / np.float32(4096))
+    ci = [69, 0, 5, 5, 64, 63]
+    got = E.seq_mean(x, [3], [3], [3 + 2000], 2000, chan_idx=ci)
+    assert np.array_equal(got[0], np.mean(np.ascontiguousarray(x[3:2003][:, ci]), axis=0))    # C order, as a trial is
+    # the float64 block sums differ from this by up to ~1e-6 of the offset - that is the whole point
+    exact = x[:4096].astype(np.float64).mean(axis=0)
+    assert np.abs(np.mean(x[:4096], axis=0) - exact).max() > 1e-5
+
+
+@pytest.mark.parametrize("nsig,nfft,kw", [(4096, 4096, {}), (1000, 1024, {}), (2000, 2000, {}),
+                                          (600, 600, {"force_generic": True}), (5003, 5003, {"force_long": True}),
+                                          (16384, 16384, {})])
+def test_offset_channels_match_the_reference_next_to_dc(nsig, nfft, kw):
+    """Every kernel family with `reference_mean`: a channel riding on an offset 1000x its fluctuations reproduces the
+    oracle (float32 sequential mean, then float64 taper and FFT) within the unwidened criterion; with the float64
+    block sums the bins next to DC miss it (which is why the golden tests used to carry a wider floor)."""
+    rng = np.random.default_rng(nsig)
+    C = 6
+    x = rng.normal(size=(nsig, C)).astype(np.float32)
+    x[:, 1] += 1000.0
+    x[:, 4] -= 313.7
+    topt = {"NW": 3, "Kmax": 4}
+    tap = O.taper_table("dpss", nsig, nfft, topt)
+    sc = O.spec_scale(nsig, nfft)
+    ref, _ = O.mtmfft(O.detrend(x, 0), 1000.0, nfft, "dpss", topt)
+    got = E.fft_exec(x, [0], [0], [nsig], nsig, nfft, tap, sc, detrend=0, output="fourier", keeptapers=True,
+                     reference_mean=True, **kw)[0]
+    for c in range(C):                       # per channel: the criterion relative to THAT channel's largest bin
+        assert_parity(got[:, :, c], ref[:, :, c], what=f"channel {c} with reference-order mean")
+    plain = E.fft_exec(x, [0], [0], [nsig], nsig, nfft, tap, sc, detrend=0, output="fourier", keeptapers=True, **kw)[0]
+    if nsig >= 1000:                         # (short sums happen to round well)
+        assert excess(plain[:, :, 1], ref[:, :, 1]) > 1.0
