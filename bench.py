@@ -107,7 +107,16 @@ def cpu_baseline(nchan, nsamp):
         phys = psutil.cpu_count(logical=False) or 1
         avail = psutil.virtual_memory().available
     except Exception:
-        phys, avail = os.cpu_count() or 1, 64 << 30
+        phys, avail = os.cpu_count() or 1, 16 << 30
+    # the memory this process may really use: a container's cgroup limit can be far below what the host reports
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            lim = open(path).read().strip()
+            if lim.isdigit():
+                avail = min(avail, int(lim))
+        except OSError:
+            pass
+    budget = avail // 4                       # never more than a quarter of it, whatever the core count
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else phys
     ncore = max(1, min(phys, usable))
     t_f = _cpu_worker((nchan, nsamp, 1, True, 0))
@@ -118,9 +127,12 @@ def cpu_baseline(nchan, nsamp):
         "best_effort_einsum_1core": {"value": 1.0 / t_e, "cores": 1, "s_per_trial": t_e},
     }
     ctx = mp.get_context("spawn")
-    for name, faithful, per_proc in (("faithful_process_per_core", True, 10 * res_bytes),
+    for name, faithful, per_proc in (("faithful_process_per_core", True, 14 * res_bytes),
                                      ("best_effort_einsum_process_per_core", False, 3 * res_bytes)):
-        nproc = int(max(1, min(ncore, (avail // 2) // max(per_proc, 1))))
+        nproc = int(min(ncore, budget // max(per_proc, 1)))
+        if nproc < 2:
+            variants[name] = {"value": None, "cores": 0, "note": "skipped: not enough memory for two processes"}
+            continue
         with ctx.Pool(nproc) as pool:
             pool.map(_cpu_noop, range(nproc), chunksize=1)
             t0 = time.perf_counter()
@@ -132,10 +144,11 @@ def cpu_baseline(nchan, nsamp):
         "sample": f"1 trial of {nchan} ch x {nsamp} samples, cross_spectra_cF reference-faithful (mtmfft + (K,F,C,C) outer "
                   f"product + taper mean, as csd.py:94-102), {t_f:.1f} s on one host core",
         "cpu_model": _cpu_model(), "physical_cores": phys, "usable_cores": usable,
-        "free_memory_GB": avail / 1e9,
+        "usable_memory_GB": avail / 1e9, "memory_budget_GB": budget / 1e9,
         "variants": variants,
         "note": "process-per-core variants: one trial per process, BLAS threads = 1, inputs in RAM, worker start-up "
-                "excluded, process count limited to half the free memory",
+                "excluded, processes limited so that their arrays stay within a quarter of the usable memory "
+                "(cgroup limit respected)",
     }
 
 

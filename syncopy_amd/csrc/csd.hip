@@ -2,8 +2,11 @@
 // normalisation (spyhip_csd_accumulate / spyhip_csd_finalize / spyhip_coh_normalize).
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "spy_common.h"
 #include "csd_kernel.h"
+#include "csd3m_kernel.h"
 
 using spycsd::CsdArgs;
 
@@ -42,6 +45,59 @@ int launch_accum(spyhip_ctx* ctx, CsdArgs a, long long item_base, long long item
     if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nsplit), dim3(spycsd::CSD_THREADS), lds, ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// The workgroups beyond the last full round of a launch, re-cut: 1 tile per wave AND the rows split over blockIdx.y, so
+// that the short workgroups fill the chip once; splits > 0 leave partial sums in library scratch that a fixed-order
+// reduction adds afterwards (deterministic, no atomics).  `first` = first item of the tail.
+int launch_tail(spyhip_ctx* ctx, CsdArgs a, long long first, int64_t nrows, int nfreq, int nchan) {
+    const long long tail_wg = (a.nitems - first + 7) / 8;
+    long long nsplit = ctx->num_cu / tail_wg;
+    const long long max_split = (nrows + 63) / 64;          // at least 64 rows per split
+    if (nsplit > max_split) nsplit = max_split;
+    // the partial sums of the splits are reduced per whole frequency from f0 on: the tail must start on a
+    // frequency boundary (always true on the fast paths, whose items per workgroup are a multiple of ntiles; the
+    // (5,4) path of the blocked layout has 36 whatever ntiles is)
+    if (nsplit < 2 || first % a.ntiles != 0) return launch_accum<1, 1>(ctx, a, first, a.nitems);
+    const int f0 = (int)(first / a.ntiles), nf = nfreq - f0;
+    const size_t need = (size_t)(nsplit - 1) * nf * nchan * nchan * sizeof(float2);
+    if (need > ctx->scratch_bytes) {
+        if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+        SPY_HIP_CHECK(hipMalloc(&ctx->scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    a.rows_per_split = ((nrows + nsplit - 1) / nsplit + 3) & ~3LL;
+    nsplit = (nrows + a.rows_per_split - 1) / a.rows_per_split;
+    a.part = reinterpret_cast<float2*>(ctx->scratch);
+    a.part_f0 = f0;
+    a.part_nf = nf;
+    int rc = launch_accum<1, 1>(ctx, a, first, a.nitems, (int)nsplit);
+    if (rc) return rc;
+    if (nsplit > 1) {
+        const long long n = (long long)nf * nchan * nchan;
+        hipLaunchKernelGGL(spycsd::csd_reduce_parts_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)),
+                           dim3(256), 0, ctx->stream, a.acc, a.part, (int)nsplit - 1, f0, nf, nchan);
+        SPY_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+// 256 channels: the 3-multiplication kernel, one workgroup of 8 waves per frequency (csd3m_kernel.h)
+int launch_3m(spyhip_ctx* ctx, CsdArgs a, long long f_end) {
+    if (f_end <= 0) return 0;
+    a.item_base = 0;
+    a.item_end = f_end * spycsd::M3_TILES_PER_F;
+    auto kern = spycsd::csd3m_kernel<8>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          spycsd::M3_LDS_BYTES));
+        attr_set = true;
+    }
+    if (f_end > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)f_end), dim3(512), spycsd::M3_LDS_BYTES, ctx->stream, a);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -98,6 +154,18 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
         if (rc || f_main == nfreq) return rc;
         return launch_accum<1, 1>(ctx, a, f_main * a.ntiles, a.nitems);     // the last partial round, re-cut
     }
+    // 256 channels, row-major spectra: the 3-multiplication kernel, one workgroup per frequency; the workgroups
+    // beyond the last full round (F = 2049 on 256 CUs: one frequency) go to the re-cut tail like on the other paths.
+    // SPYHIP_CSD_4M=1 keeps the 4-multiplication kernel (A/B measurements, cross-checks).
+    static const bool force_4m = std::getenv("SPYHIP_CSD_4M") != nullptr;
+    if (!blocked && nchan == 256 && !force_4m) {
+        const long long nwg = nfreq, rem = nwg % ctx->num_cu;
+        long long f_main = nfreq;
+        if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) f_main = nwg - rem;
+        int rc = launch_3m(ctx, a, f_main);
+        if (rc || f_main == nfreq) return rc;
+        return launch_tail(ctx, a, f_main * a.ntiles, nrows, nfreq, nchan);
+    }
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
     if (fast || a.ntiles >= 21) {
         // One workgroup per CU: F = 2049 frequencies on 256 CUs would leave a 9th, almost empty round.
@@ -111,38 +179,7 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
                            : (nchan == 256 ? launch_accum<5, 4, 1>(ctx, a, 0, full * per)
                                              : launch_accum<5, 4, 2>(ctx, a, 0, full * per));
             if (rc) return rc;
-            // tail: 1 tile per wave AND the rows split over blockIdx.y, so that its rem*4.5*nsplit short
-            // workgroups fill the chip once; splits > 0 leave partial sums in library scratch that a
-            // fixed-order reduction adds afterwards (deterministic, no atomics)
-            const long long tail_wg = (a.nitems - full * per + 7) / 8;
-            long long nsplit = ctx->num_cu / tail_wg;
-            const long long max_split = (nrows + 63) / 64;          // at least 64 rows per split
-            if (nsplit > max_split) nsplit = max_split;
-            // the partial sums of the splits are reduced per whole frequency from f0 on: the tail must start on a
-            // frequency boundary (always true on the fast path, whose `per` is a multiple of ntiles; the (5,4)
-            // path of the blocked layout has per = 36 whatever ntiles is)
-            if (nsplit < 2 || (full * per) % a.ntiles != 0) return launch_accum<1, 1>(ctx, a, full * per, a.nitems);
-            const int f0 = (int)(full * per / a.ntiles), nf = nfreq - f0;
-            const size_t need = (size_t)(nsplit - 1) * nf * nchan * nchan * sizeof(float2);
-            if (need > ctx->scratch_bytes) {
-                if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
-                SPY_HIP_CHECK(hipMalloc(&ctx->scratch, need));
-                ctx->scratch_bytes = need;
-            }
-            a.rows_per_split = ((nrows + nsplit - 1) / nsplit + 3) & ~3LL;
-            nsplit = (nrows + a.rows_per_split - 1) / a.rows_per_split;
-            a.part = reinterpret_cast<float2*>(ctx->scratch);
-            a.part_f0 = f0;
-            a.part_nf = nf;
-            rc = launch_accum<1, 1>(ctx, a, full * per, a.nitems, (int)nsplit);
-            if (rc) return rc;
-            if (nsplit > 1) {
-                const long long n = (long long)nf * nchan * nchan;
-                hipLaunchKernelGGL(spycsd::csd_reduce_parts_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)),
-                                   dim3(256), 0, ctx->stream, a.acc, a.part, (int)nsplit - 1, f0, nf, nchan);
-                SPY_HIP_CHECK(hipGetLastError());
-            }
-            return 0;
+            return launch_tail(ctx, a, full * per, nrows, nfreq, nchan);
         }
         if (!fast) return launch_accum<5, 4>(ctx, a, 0, a.nitems);
         return nchan == 256 ? launch_accum<5, 4, 1>(ctx, a, 0, a.nitems) : launch_accum<5, 4, 2>(ctx, a, 0, a.nitems);

@@ -1,0 +1,281 @@
+// K4 for 256 channels with the 3-multiplication complex product (Karatsuba / "3M"):
+//
+//     acc[f,i,j] += sum_r X[r,f,i] * conj(X[r,f,j])                                  (i >= j at 16-channel granularity)
+//     P1 = sum Ar Br,  P2 = sum Ai Bi,  P3 = sum (Ar + Ai)(Br - Bi)     (A = X[.,i], B = X[.,j])
+//     re = P1 + P2,    im = P3 - P1 + P2
+//
+// = 3 matrix instructions per sub-tile and group of rows instead of the 4 of csd_kernel.h: a quarter less matrix work
+// for the same 8 algorithmic flop per complex MAC.  Reference semantics as csd_kernel.h
+// (connectivity/csd.py:94-102 + the trial sum of shared/computational_routine.py:1022-1032).
+//
+// Three accumulators per output element do not fit one CU (36 x 1024 x 3 floats = 84 % of its whole register file,
+// and matrix accumulators live in the 256 AGPRs of a lane), so ONE frequency is shared by TWO workgroups of 4 waves,
+// ONE wave per SIMD.  The unit of work is the 16 x 16 sub-tile on v_mfma_f32_16x16x4_f32: the lower triangle of the
+// 16 x 16 block matrix has 136 sub-tiles = 8 waves x 17, so every wave carries exactly 51 accumulators (204 AGPRs)
+// and the same matrix work (the 16 diagonal sub-tiles are computed in full: 6 % of the work lands above the
+// diagonal, where nobody reads it).  Every wave's 17 sub-tiles touch 8 of the 16 channel blocks (M3_BLK): 8 LDS
+// fragment reads + <= 13 additions feed 51 MFMAs of 32 cycles - everything that is not a matrix instruction issues
+// in their shadow.  Both workgroups of a frequency stage the whole rows X[r, f, :] (2 KiB each) global -> LDS
+// directly (global_load_lds_dwordx4: no staging registers, no ds_write pass) into three 16-row buffers: iteration c
+// multiplies chunk c while chunk c+2 lands; the second reader of a row is served by the L2 / Infinity Cache or, at
+// worst, by HBM at a rate (2.7 TB/s) the kernel's matrix time covers.  Rows past the end of a ragged last chunk are
+// zero-filled with plain LDS stores.
+//
+// The imaginary part of a diagonal element is P3 - P1 + P2 of rounded sums, i.e. rounding noise instead of the
+// exact zero of X conj(X): csd_finalize_kernel / coh_from_acc_kernel (the readers of the diagonal) set it to zero,
+// exactly as they do for the other kernels.
+#pragma once
+#include <type_traits>
+
+#ifndef SPY_M3_KATTR
+#ifndef SPY_HOST_EMU
+#define SPY_M3_KATTR(WPG) __attribute__((amdgpu_waves_per_eu((WPG) / 4, (WPG) / 4)))
+#else
+#define SPY_M3_KATTR(WPG)
+#endif
+#endif
+
+namespace spycsd {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) - tile / block indices stay constants
+template <int I, int N, typename F>
+__device__ __forceinline__ void m3_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        m3_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ void m3_sched_fence() {
+#ifndef SPY_HOST_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+constexpr int M3_ROWLEN = 256;                       // channels = float2 elements per LDS row
+constexpr int M3_KB = 16;                            // rows per chunk
+constexpr int M3_CHUNK_BYTES = M3_KB * M3_ROWLEN * 8;   // 32 KiB per buffer, three buffers
+constexpr int M3_LDS_BYTES = 3 * M3_CHUNK_BYTES;
+constexpr int M3_NT = 17;                            // sub-tiles per wave
+constexpr int M3_NB = 8;                             // distinct 16-channel blocks per wave
+constexpr int M3_TILES_PER_F = 36;                   // 32 x 32 tiles per frequency in CsdArgs' item units
+
+// ---- ownership of the 136 lower-triangle sub-tiles: "wave" g = 4 * (workgroup of the pair) + wave; its sub-tile t is
+// (row block M3_BLK[g][M3_TA[g][t]], column block M3_BLK[g][M3_TB[g][t]]), row block >= column block.
+//   g 0-3: the four 4 x 4 squares of rows 8-15 x columns 0-7, plus one sub-tile of a triangle each
+//   g 4, 5: the squares rows 4-7 x columns 0-3 and rows 12-15 x columns 8-11, plus one
+//   g 6, 7: the lower triangles of blocks {0-3}, {4-7} and of {8-11}, {12-15}, minus the six given away
+constexpr int M3_BLK[8][8] = {
+    { 0,  1,  2,  3,  8,  9, 10, 11},
+    { 4,  5,  6,  7,  8,  9, 10, 11},
+    { 0,  1,  2,  3, 12, 13, 14, 15},
+    { 4,  5,  6,  7, 12, 13, 14, 15},
+    { 0,  1,  2,  3,  4,  5,  6,  7},
+    { 8,  9, 10, 11, 12, 13, 14, 15},
+    { 0,  1,  2,  3,  4,  5,  6,  7},
+    { 8,  9, 10, 11, 12, 13, 14, 15},
+};
+constexpr int M3_TA[8][17] = {
+    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
+    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  7},
+    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
+    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  7},
+    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
+    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
+    { 0,  1,  1,  2,  2,  2,  3,  4,  5,  5,  6,  6,  6,  7,  7,  7,  7},
+    { 0,  1,  1,  2,  2,  2,  3,  3,  4,  5,  5,  6,  6,  6,  7,  7,  7},
+};
+constexpr int M3_TB[8][17] = {
+    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0},
+    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  4},
+    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  1},
+    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  4},
+    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  2},
+    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  1},
+    { 0,  0,  1,  0,  1,  2,  3,  4,  4,  5,  4,  5,  6,  4,  5,  6,  7},
+    { 0,  0,  1,  0,  1,  2,  2,  3,  4,  4,  5,  4,  5,  6,  5,  6,  7},
+};
+
+__host__ __device__ constexpr bool m3_is_row(int g, int i) {      // block i of wave g is the row block of some sub-tile
+    for (int t = 0; t < M3_NT; ++t)
+        if (M3_TA[g][t] == i) return true;
+    return false;
+}
+__host__ __device__ constexpr bool m3_is_col(int g, int i) {
+    for (int t = 0; t < M3_NT; ++t)
+        if (M3_TB[g][t] == i) return true;
+    return false;
+}
+
+#ifndef SPY_HOST_EMU
+// 16 bytes per lane global -> LDS: destination = wave-uniform LDS byte address + 16 * lane.  Issued as inline
+// assembly ON PURPOSE: hipcc would otherwise guard the next ds_read of the loop with s_waitcnt vmcnt(0) and park
+// the matrix pipe for a whole DMA latency once per chunk.  The copies are ordered by hand instead: one
+// s_waitcnt vmcnt(0) before the barrier that ends the iteration they were issued in, two iterations before anybody
+// reads the buffer.  No compiler-generated vector memory access is in flight while these are (the accumulator
+// read-modify-write comes after the loop's last wait), so hipcc's own vmcnt bookkeeping is not disturbed.  M0 (the
+// LDS base of the copy) is saved and restored around the instruction.
+__device__ __forceinline__ void m3_glds16(const void* gsrc, char* lds_wave_base) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+#else
+// emulator: the same copy, lane by lane
+inline void m3_glds16(const void* gsrc, char* lds_wave_base) {
+    std::memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16);
+}
+#endif
+
+// G: which 17 sub-tiles; WPG: waves per workgroup (8: one workgroup per frequency, two waves per SIMD; 4: two
+// workgroups per frequency, one wave per SIMD); wave WV of the workgroup stages rows (16 / WPG) WV ... of every chunk
+template <int G, int WPG>
+__device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int lane) {
+    constexpr int WV = G % WPG;
+    constexpr int RPW = M3_KB / WPG;                  // rows a wave stages per chunk
+    constexpr int RG = 4 * M3_ROWLEN * 8;            // bytes per group of four rows
+    const int l15 = lane & 15, lq = lane >> 4;
+    const size_t rowstride = (size_t)a.F * M3_ROWLEN;               // float2 elements between rows
+    const char* const gbase = reinterpret_cast<const char*>(a.spec + (size_t)f * M3_ROWLEN);
+    const size_t rowbytes = rowstride * 8;
+    const long long nrows = a.nrows;
+    const long long nchunk = (nrows + M3_KB - 1) / M3_KB;
+
+    // ---- staging: two 1-KiB halves per row
+    auto stage = [&](long long c, int buf) {
+        const long long r0 = c * M3_KB;
+        const long long left = nrows - r0;
+        const int rleft = left < M3_KB ? (int)left : M3_KB;
+        char* const dst = Xb + buf * M3_CHUNK_BYTES;
+#pragma unroll
+        for (int v = 0; v < 2 * RPW; ++v) {
+            const int row = RPW * WV + (v >> 1), half = v & 1;
+            if (row < rleft) {                                          // wave-uniform
+                m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + half * 1024 + lane * 16,
+                          dst + row * (M3_ROWLEN * 8) + half * 1024);
+            } else {
+                *reinterpret_cast<float4*>(dst + row * (M3_ROWLEN * 8) + half * 1024 + lane * 16) =
+                    make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    f32x4 p1[M3_NT], p2[M3_NT], p3[M3_NT];
+#pragma unroll
+    for (int t = 0; t < M3_NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p1[t][r] = 0.f;
+            p2[t][r] = 0.f;
+            p3[t][r] = 0.f;
+        }
+
+    stage(0, 0);
+    if (nchunk > 1) stage(1, 1);
+    if (nchunk > 2) stage(2, 2);
+#ifndef SPY_HOST_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+
+    // LDS address of this lane's fragments for the current group of four rows: channel (lane & 15) of a block, row
+    // (lane >> 4) of the group; the block is an immediate offset (16 channels = 128 bytes apart)
+    const char* fp = Xb + (unsigned)(lq * M3_ROWLEN + l15) * 8u;
+    float2 x[M3_NB];
+    float sm[M3_NB], df[M3_NB];
+    auto load = [&]() {
+        m3_for<0, M3_NB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            x[i] = *reinterpret_cast<const float2*>(fp + 128 * M3_BLK[G][i]);
+        });
+    };
+    // An MFMA blocks the wave that issued it for its 32 cycles, so everything else of a group - 8 fragment reads, 13
+    // sums / differences, the address bump - is time the matrix pipe only keeps working through if ANOTHER wave of
+    // the SIMD has MFMAs to issue (WPG = 8).  Kept minimal either way.
+    load();
+    int b0 = 0;
+    for (long long c = 0; c < nchunk; ++c) {
+        if (c >= 1 && c + 2 < nchunk) stage(c + 2, b0 == 0 ? 2 : b0 - 1);     // buffer (c + 2) % 3: read last iteration
+        // fragment addresses advance by 8 KiB per group of four rows; after the fourth group of a chunk on to the
+        // next buffer (+ 32 KiB, or back by 64 KiB).  The next chunk has landed: its DMA was waited for before
+        // the barrier that ended the previous iteration.
+        const int wrap = ((b0 == 2) ? -2 * M3_CHUNK_BYTES : M3_CHUNK_BYTES) - (M3_KB / 4 - 1) * RG;
+#pragma unroll 1
+        for (int st = 0; st < M3_KB / 4; ++st) {
+            m3_for<0, M3_NB>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                sm[i] = m3_is_row(G, i) ? x[i].x + x[i].y : 0.f;
+                df[i] = m3_is_col(G, i) ? x[i].x - x[i].y : 0.f;
+            });
+            float re[M3_NB], im[M3_NB];
+            m3_for<0, M3_NB>([&](auto ic) { constexpr int i = decltype(ic)::value; re[i] = x[i].x; im[i] = x[i].y; });
+            fp += st + 1 < M3_KB / 4 ? RG : wrap;
+            m3_sched_fence();
+            // the P3 products first: they free the fragment registers' successors (the reads of the next group
+            // overwrite x) only after the P1 / P2 products, which come last
+            m3_for<0, M3_NT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[M3_TA[G][t]], df[M3_TB[G][t]], p3[t], 0, 0, 0);
+            });
+            m3_for<0, M3_NT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                p1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(re[M3_TA[G][t]], re[M3_TB[G][t]], p1[t], 0, 0, 0);
+                p2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(im[M3_TA[G][t]], im[M3_TB[G][t]], p2[t], 0, 0, 0);
+            });
+            m3_sched_fence();
+            if (st + 1 < M3_KB / 4 || c + 1 < nchunk) load();
+        }
+#ifndef SPY_HOST_EMU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's share of chunk c + 2 has landed
+#endif
+        __syncthreads();
+        b0 = b0 == 2 ? 0 : b0 + 1;
+    }
+
+    // ---- acc += sub-tile (each has one owner: plain read-modify-write).  Lane l holds column (l & 15) and rows
+    // 4 (l >> 4) + r of the 16 x 16 block.
+    float2* const abase = a.acc + (size_t)f * M3_ROWLEN * M3_ROWLEN;
+    m3_for<0, M3_NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int bi = M3_BLK[G][M3_TA[G][t]], bj = M3_BLK[G][M3_TB[G][t]];
+        float2* const pb = abase + (size_t)(bi * 16 + 4 * lq) * M3_ROWLEN + bj * 16 + l15;
+        float2 old[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) old[r] = pb[(size_t)r * M3_ROWLEN];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            pb[(size_t)r * M3_ROWLEN] =
+                make_float2(old[r].x + (p1[t][r] + p2[t][r]), old[r].y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+    });
+}
+
+// WPG = 8: one workgroup of 8 waves per frequency (block b -> frequency item_base / 36 + b);
+// WPG = 4: two workgroups of 4 waves per frequency (block b -> frequency ... + b / 2, sub-tile sets of half b % 2).
+template <int WPG>
+__global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdArgs a) {
+    SPY_DYN_SMEM(char, Xb);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifndef SPY_HOST_EMU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    const int wave = tid >> 6;
+#endif
+    const int f = (int)(a.item_base / M3_TILES_PER_F) + (int)(WPG == 8 ? blockIdx.x : blockIdx.x >> 1);
+    if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
+    switch (WPG == 8 ? wave : 4 * (int)(blockIdx.x & 1) + wave) {
+        case 0: m3_wave<0, WPG>(a, Xb, f, lane); break;
+        case 1: m3_wave<1, WPG>(a, Xb, f, lane); break;
+        case 2: m3_wave<2, WPG>(a, Xb, f, lane); break;
+        case 3: m3_wave<3, WPG>(a, Xb, f, lane); break;
+        case 4: m3_wave<4, WPG>(a, Xb, f, lane); break;
+        case 5: m3_wave<5, WPG>(a, Xb, f, lane); break;
+        case 6: m3_wave<6, WPG>(a, Xb, f, lane); break;
+        default: m3_wave<7, WPG>(a, Xb, f, lane); break;
+    }
+}
+
+}  // namespace spycsd

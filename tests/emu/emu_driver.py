@@ -214,9 +214,16 @@ def set_blocked(on):
     lib().emu_set_blocked(C.c_int(int(bool(on))))
 
 
-def csd_accumulate(spec, acc, force_tpw=0, blocked=False):
+def csd_accumulate(spec, acc, force_tpw=0, blocked=False, force_4m=False):
     """Emulated spyhip_csd_accumulate: spec (R, F, C) complex64 - or (R, ceil(C/4), F, 4) with blocked=True -,
-    acc (F, C, C) complex64 (in place)."""
+    acc (F, C, C) complex64 (in place).  `force_4m`: 256 channels on the 4-multiplication kernel (SPYHIP_CSD_4M).
+    Returns a code for the kernel that ran (8 = the 3-multiplication kernel)."""
+    if force_4m:
+        lib().emu_set_force_4m(1)
+        try:
+            return csd_accumulate(spec, acc, force_tpw, blocked)
+        finally:
+            lib().emu_set_force_4m(0)
     spec = np.ascontiguousarray(spec, dtype=np.complex64)
     assert acc.dtype == np.complex64 and acc.flags.c_contiguous
     if blocked:

@@ -16,6 +16,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
 #include "../../syncopy_amd/csrc/csd_kernel.h"
+#include "../../syncopy_amd/csrc/csd3m_kernel.h"
 #include "../../syncopy_amd/csrc/ppc_kernel.h"
 #include "../../syncopy_amd/csrc/ccov_kernel.h"
 #include "../../syncopy_amd/csrc/jack_kernel.h"
@@ -107,6 +108,8 @@ int run_long(const spyfft::LongArgs& a, int l, int stage, long long items) {
 }  // namespace
 
 static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD entry points
+static int g_force_4m = 0;  // SPYHIP_CSD_4M: 256 channels on the 4-multiplication kernel
+static int g_m3_wpg = 8;    // waves per workgroup of the 3-multiplication kernel
 static const float* g_means = nullptr;   // (nseg x nchan) reference-order means for the next FFT call, or none
 
 template <int LOG2N, int G>
@@ -119,6 +122,8 @@ static void emu_launch_ccov(const spyfft::CcovArgs& a) {
 extern "C" {
 
 void emu_set_blocked(int on) { g_blocked = on; }
+void emu_set_force_4m(int on) { g_force_4m = on; }
+void emu_set_m3_wpg(int n) { g_m3_wpg = n; }
 void emu_set_means(const float* m) { g_means = m; }
 
 // spyfft::seq_mean_kernel as spyhip_fft_exec launches it (plan option spyhip_fft_plan_set_reference_mean)
@@ -341,6 +346,16 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
         emu::launch(dim3(grid), dim3(T), 3 * (size_t)16 * 256 * sizeof(float2) + 512,
                     [&] { spycsd::csd_accum_kernel<5, 4, 3>(a); });
         return 7;
+    }
+    if (fast && C == 256 && !g_force_4m) {
+        // as csd.hip: 256 channels take the 3-multiplication kernel, one workgroup of 8 waves per frequency
+        // (g_m3_wpg = 4: the variant with two workgroups of 4 waves per frequency)
+        a.item_end = (long long)F * spycsd::M3_TILES_PER_F;
+        if (g_m3_wpg == 4)
+            emu::launch(dim3((unsigned)(2 * F)), dim3(256), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<4>(a); });
+        else
+            emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<8>(a); });
+        return 8;
     }
     if (fast && C == 256) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });
     else if (fast) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 2>(a); });

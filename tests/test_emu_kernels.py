@@ -166,6 +166,45 @@ def test_csd_mfma_kernel(C, F, R, tpw):
         assert_parity(E.coh_normalize(acc, output), O.normalize_csd(acc, output), what=output)
 
 
+@pytest.mark.parametrize("R", [7, 33])
+def test_csd_3m_kernel_256_channels(R):
+    """csd3m_kernel (3-multiplication complex product, 16 x 16 sub-tiles, two workgroups per frequency, rows global ->
+    LDS by DMA): all 136 sub-tiles land where they belong, ragged last chunks are zero-filled, the accumulation
+    continues across launches, and the result agrees with the 4-multiplication kernel to rounding.  The spectra
+    carry a 40 dB spread over channels and a strong common component (coherent channels, small imaginary parts) -
+    the dynamic range the 3M form is sensitive to."""
+    C, F = 256, 3
+    rng = np.random.default_rng(R)
+    gain = 10 ** rng.uniform(-1, 1, size=C)
+    common = rng.normal(size=(R, F, 1)) + 1j * rng.normal(size=(R, F, 1))
+    spec = ((rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C)) + 2.0 * common) * gain).astype(np.complex64)
+    acc = np.zeros((F, C, C), np.complex64)
+    assert E.csd_accumulate(spec[:R // 2], acc) == 8 and E.csd_accumulate(spec[R // 2:], acc) == 8
+    if R == 33:                                  # the two-workgroups-per-frequency variant: same sums, same order
+        E.lib().emu_set_m3_wpg(4)
+        try:
+            alt = np.zeros((F, C, C), np.complex64)
+            E.csd_accumulate(spec[:R // 2], alt)
+            E.csd_accumulate(spec[R // 2:], alt)
+        finally:
+            E.lib().emu_set_m3_wpg(8)
+        ii0, jj0 = np.tril_indices(C)
+        assert np.array_equal(alt[:, ii0, jj0], acc[:, ii0, jj0])
+    acc4 = np.zeros((F, C, C), np.complex64)
+    assert E.csd_accumulate(spec, acc4, force_4m=True) == 6
+    ref = np.einsum("rfi,rfj->fij", spec.astype(np.complex128), spec.conj().astype(np.complex128))
+    ii, jj = np.tril_indices(C)
+    # element-wise against the exact product: the error scale of an entry is sqrt(S_ii S_jj), not the global maximum
+    scale = np.sqrt(np.abs(ref[:, ii, ii]) * np.abs(ref[:, jj, jj]))
+    for got in (acc, acc4):
+        err = np.abs(got[:, ii, jj] - ref[:, ii, jj]) / scale
+        assert err.max() < 3e-6, err.max()
+    assert_parity(acc[:, ii, jj], ref[:, ii, jj].astype(np.complex64), what="3M csd, lower triangle")
+    E.csd_finalize(acc, 1.0 / R)
+    assert np.array_equal(acc, acc.conj().transpose(0, 2, 1)) and np.all(acc.imag[:, range(C), range(C)] == 0)
+    assert_parity(acc, (ref / R).astype(np.complex64), what="3M csd finalised")
+
+
 @pytest.mark.parametrize("C,F,T,K", [(5, 4, 6, 3), (40, 2, 7, 1), (70, 1, 5, 7)])
 def test_ppc_kernel(C, F, T, K):
     """K7's kernel source on the CPU: phasor sums + closed form = the oracle's walk over all trial pairs."""
