@@ -295,6 +295,9 @@ def csd_kernel_name(nchan, blocked=False):
     csrc/csd.hip), for matching rocprofv3 rows."""
     nt = (nchan + 31) // 32
     ntiles = nt * (nt + 1) // 2
+    import os
+    if not blocked and nchan == 256 and not os.environ.get("SPYHIP_CSD_4M"):
+        return "spycsd::csd3m_kernel<8>"
     if not blocked and nchan <= 256:
         return "spycsd::csd_accum_kernel<5, 4, %d>" % (1 if nchan == 256 else 2)
     if not blocked and nchan <= 512:

@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
         for (int n = 0; n < N; ++n) tp[(size_t)k * N + n] = std::sin(M_PI * (k + 1) * (n + 0.5) / N) * std::sqrt(2.0);
     spyhip_fft_plan* plan;
     SK(spyhip_fft_plan_create(ctx, N, N, C, K, tp.data(), std::sqrt(2.0) / N, 0, 0, nullptr, 0, SPYHIP_OUT_FOURIER, 1, &plan));
+    SK(spyhip_fft_plan_set_reference_mean(plan, 1));     // as the front ends do for whole trials
     if (blocked) SK(spyhip_fft_plan_set_blocked(plan, 1));
     void *spec, *acc;
     CK(hipMalloc(&spec, (size_t)B * K * F * C * 8));
