@@ -403,7 +403,7 @@ def main():
         achieved = sum(flops) / (sum(csd_ms) * 1e-3) / 1e12
         fft_bytes = sum(nb * (N * C * 4 + K * F * C * 8) for _, _, nb in ev_fft)
         # matrix flops the 3-multiplication kernel really issues: 136 sub-tiles x 3 MFMAs of 16x16x4 per 4 rows
-        is3m = C == 256 and not blocked and not os.environ.get("SPYHIP_CSD_4M")
+        is3m = C == 256 and not os.environ.get("SPYHIP_CSD_4M")
         executed = ((rows[0] + 3) // 4) * F * 136 * 3 * 2048.0 if is3m else None
         value = world * T * args.steps / el
         coll = {"executed": bool(dist_on), "backend": "nccl (RCCL)" if dist_on else None}

@@ -303,6 +303,10 @@ int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, dou
                    double cond_max, double eps_max, void* granger_d, void* H_d, void* Sigma_d,
                    double* info);
 
+/* Wilson iterations the last spyhip_granger call on this context ran (the reference's loop counter,
+ * wilson_sf.py:77-109); for benchmarks and diagnostics. */
+int spyhip_granger_last_iterations(const spyhip_ctx* ctx);
+
 /* ---- utilities on the in-HBM trial queue ----------------------------------
  * y[i] = (y[i] + x[i]) elementwise float32 sum used by keeptrials=False
  * accumulation of real spectra (computational_routine.py:1022-1032). */

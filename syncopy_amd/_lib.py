@@ -73,6 +73,7 @@ SIGNATURES = {
     "spyhip_cwt_exec": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp, C.c_int]),
     "spyhip_granger": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, vp, vp, vp,
                                  c_f64p]),
+    "spyhip_granger_last_iterations": (C.c_int, [vp]),
     "spyhip_axpy_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float]),
     "spyhip_trial_mean_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64]),
 }

@@ -296,7 +296,7 @@ def csd_kernel_name(nchan, blocked=False):
     nt = (nchan + 31) // 32
     ntiles = nt * (nt + 1) // 2
     import os
-    if not blocked and nchan == 256 and not os.environ.get("SPYHIP_CSD_4M"):
+    if nchan == 256 and not os.environ.get("SPYHIP_CSD_4M"):
         return "spycsd::csd3m_kernel<8>"
     if not blocked and nchan <= 256:
         return "spycsd::csd_accum_kernel<5, 4, %d>" % (1 if nchan == 256 else 2)
@@ -520,6 +520,12 @@ def granger(csd, rtol=5e-6, niter=100, cond_max=1e4, eps_max=1e-1, want_factors=
     elif meta["reg. factor"] == -1.0:
         meta["reg. factor"] = -1
     return (out, meta, H, Sig) if want_factors else (out, meta)
+
+
+def granger_stats(device=None):
+    """Diagnostics of the last granger() call on the device: {'iterations': Wilson iterations run}."""
+    ctx = context(device)
+    return {"iterations": int(ctx.lib.spyhip_granger_last_iterations(ctx.handle))}
 
 
 def trial_mean(x):

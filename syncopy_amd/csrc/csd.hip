@@ -158,7 +158,7 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
     // beyond the last full round (F = 2049 on 256 CUs: one frequency) go to the re-cut tail like on the other paths.
     // SPYHIP_CSD_4M=1 keeps the 4-multiplication kernel (A/B measurements, cross-checks).
     static const bool force_4m = std::getenv("SPYHIP_CSD_4M") != nullptr;
-    if (!blocked && nchan == 256 && !force_4m) {
+    if (nchan == 256 && !force_4m) {         // either hand-over layout: the kernel's LDS copies gather
         const long long nwg = nfreq, rem = nwg % ctx->num_cu;
         long long f_main = nfreq;
         if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) f_main = nwg - rem;

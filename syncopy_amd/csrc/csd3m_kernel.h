@@ -139,8 +139,13 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     constexpr int RG = 4 * M3_ROWLEN * 8;            // bytes per group of four rows
     const int l15 = lane & 15, lq = lane >> 4;
     const size_t rowstride = (size_t)a.F * M3_ROWLEN;               // float2 elements between rows
-    const char* const gbase = reinterpret_cast<const char*>(a.spec + (size_t)f * M3_ROWLEN);
     const size_t rowbytes = rowstride * 8;
+    // source of this lane's 16 bytes of (row 0, half h): row-major spectra (r, f, c): 16 consecutive bytes of the 2-KiB
+    // row; channel-quad-blocked spectra (r, c/4, f, 4) (spyhip_fft_plan_set_blocked): lanes (2q, 2q+1) take the two
+    // halves of quad q's 32 bytes - the copy gathers, the LDS image is the same
+    const char* const gbase = reinterpret_cast<const char*>(a.spec) +
+                              (a.blocked ? ((size_t)(lane >> 1) * a.F + f) * 32 + (lane & 1) * 16 : (size_t)f * M3_ROWLEN * 8 + lane * 16);
+    const size_t halfstep = a.blocked ? (size_t)32 * a.F * 32 : 1024;     // from half 0 (channels 0-127) to half 1
     const long long nrows = a.nrows;
     const long long nchunk = (nrows + M3_KB - 1) / M3_KB;
 
@@ -154,8 +159,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
         for (int v = 0; v < 2 * RPW; ++v) {
             const int row = RPW * WV + (v >> 1), half = v & 1;
             if (row < rleft) {                                          // wave-uniform
-                m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + half * 1024 + lane * 16,
-                          dst + row * (M3_ROWLEN * 8) + half * 1024);
+                m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + half * halfstep, dst + row * (M3_ROWLEN * 8) + half * 1024);
             } else {
                 *reinterpret_cast<float4*>(dst + row * (M3_ROWLEN * 8) + half * 1024 + lane * 16) =
                     make_float4(0.f, 0.f, 0.f, 0.f);

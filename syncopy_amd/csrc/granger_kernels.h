@@ -95,11 +95,41 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int MT = 64;   // output tile
 constexpr int MK = 8;    // k per stage
-__global__ void __launch_bounds__(256) zgemm_mfma_kernel(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB,
-                                                         long long sC, int opB, int addI) {
+// Badd (n x n, or nullptr): op(B) + Badd is multiplied - the skew matrix S of wilson_sf.py:97-98 joins g+ here instead
+// of in a pass of its own.  Ref / part (or nullptr): instead of storing C, the workgroup writes
+// max |Ref - C| / |Ref| over its tile to part[linear block id] (max_rel_err, wilson_sf.py:190-194: psi psi^H is only
+// ever compared with the CSD, never kept).
+// MODE 3: Hermitian product (op(B) = A^H given as B = A, opB = 1): only the tiles on and below the diagonal are
+// computed, tiles below it are also stored mirrored (conjugated) above it - 10 tile products instead of 16 at
+// n = 256.  MODE 2 likewise skips the tiles above the diagonal (|Ref - C| / |Ref| is symmetric for Hermitian Ref, C).
+// MODE 0: plain, 1: with Badd, 2: error check (separate instances: the plain product keeps its 90 registers and
+// three waves per SIMD - with the extra operands in one kernel it dropped to two and ran at half speed)
+#ifndef SPY_HOST_EMU
+#define SPY_ZGEMM_KATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#else
+#define SPY_ZGEMM_KATTR
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB,
+                                                         long long sC, int opB, int addI, const cd* Badd, const cd* Ref,
+                                                         double* part, int nbatch) {
     __shared__ cd As[MT][MK + 1];
     __shared__ cd Bs[MK][MT + 1];
-    const int b = blockIdx.z, ti = blockIdx.y * MT, tj = blockIdx.x * MT;
+    // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs, so id % 8 picks the XCD and all tiles of
+    // one matrix get ids that are congruent mod 8 and consecutive in that XCD's order: the A / B panels the tiles share
+    // meet in ONE L2 (with a 3-D grid the 16 tiles of a 256 x 256 matrix landed on all 8 XCDs and every panel was
+    // fetched from HBM / Infinity Cache up to 8 times: the kernel ran at memory speed, 16.8 GB per product).
+    const int ntx = (n + MT - 1) / MT, ntile = ntx * ntx;
+    const int lin = blockIdx.x, slot = lin >> 3;
+    const int b = (slot / ntile) * 8 + (lin & 7), tt = slot % ntile;
+    const int by = tt / ntx, bx = tt - by * ntx;
+    if (b >= nbatch) return;
+    const size_t pidx = (size_t)b * ntile + tt;
+    if ((MODE == 2 || MODE == 3) && bx > by) {                        // above the diagonal: nothing to do
+        if (MODE == 2 && threadIdx.x == 0) part[pidx] = 0.0;
+        return;
+    }
+    const int ti = by * MT, tj = bx * MT;
     const cd* Ab = A + (size_t)b * sA;
     const cd* Bb = B + (size_t)b * sB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,23 +142,46 @@ __global__ void __launch_bounds__(256) zgemm_mfma_kernel(const cd* A, const cd* 
         for (int w = 0; w < 2; ++w)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { cr[u][w][r] = 0.0; ci[u][w][r] = 0.0; }
-    for (int k0 = 0; k0 < n; k0 += MK) {
-        // 256 threads stage 64 x 8 of A and 8 x 64 of op(B): two elements each
+    // 256 threads stage 64 x 8 of A and 8 x 64 of op(B): two elements each.  The elements of the NEXT k-step are
+    // requested before the MFMAs of the current one (register prefetch), and B^H is read along its rows (k contiguous:
+    // whole 128-byte lines) and transposed on the way into LDS - read by columns every lane touched its own line.
+    cd pa[2], pb[2];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = tid + 256 * q;
             const int r = e >> 3, kk = e & 7;
             const int gi = ti + r, gk = k0 + kk;
-            As[r][kk] = (gi < n && gk < n) ? Ab[(size_t)gi * n + gk] : make_double2(0.0, 0.0);
-            const int kk2 = e >> 6, cc = e & 63;
-            const int gk2 = k0 + kk2, gj = tj + cc;
+            pa[q] = (gi < n && gk < n) ? Ab[(size_t)gi * n + gk] : make_double2(0.0, 0.0);
             cd v = make_double2(0.0, 0.0);
-            if (gk2 < n && gj < n) {
-                if (opB == 0) v = Bb[(size_t)gk2 * n + gj];
-                else { v = Bb[(size_t)gj * n + gk2]; v.y = -v.y; }
+            if (opB == 0) {
+                const int kk2 = e >> 6, cc = e & 63;
+                const int gk2 = k0 + kk2, gj = tj + cc;
+                if (gk2 < n && gj < n) {
+                    v = Bb[(size_t)gk2 * n + gj];
+                    if (MODE == 1) v = cadd(v, Badd[(size_t)gk2 * n + gj]);
+                }
+            } else {
+                const int gj = tj + r;                           // row r of B = column r of B^H, k = kk
+                if (gj < n && gk < n) {
+                    v = Bb[(size_t)gj * n + gk];
+                    v.y = -v.y;
+                    if (MODE == 1) v = cadd(v, Badd[(size_t)gk * n + gj]);
+                }
             }
-            Bs[kk2][cc] = v;
+            pb[q] = v;
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < n; k0 += MK) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q;
+            As[e >> 3][e & 7] = pa[q];
+            if (opB == 0) Bs[e >> 6][e & 63] = pb[q];
+            else Bs[e & 7][e >> 3] = pb[q];
+        }
+        if (k0 + MK < n) fetch(k0 + MK);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < MK; ks += 4) {
@@ -149,6 +202,36 @@ __global__ void __launch_bounds__(256) zgemm_mfma_kernel(const cd* A, const cd* 
         }
         __syncthreads();
     }
+    if constexpr (MODE == 2) {
+        const cd* Rb = Ref + (size_t)b * sC;
+        double m = 0.0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = ti + wr + 16 * u + l4 + 4 * r, gj = tj + wc + 16 * w + l15;
+                    if (gi < n && gj < n) {
+                        const cd a = Rb[(size_t)gi * n + gj];
+                        const cd d = make_double2(a.x - cr[u][w][r], a.y - ci[u][w][r]);
+                        const double e = sqrt(cabs2(d)) / sqrt(cabs2(a));
+                        if (e > m || e != e) m = e;
+                    }
+                }
+        __shared__ double red[256];
+        red[tid] = m;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                const double o = red[tid + st];
+                if (o > red[tid] || o != o) red[tid] = o;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) part[pidx] = red[0];
+        return;
+    }
     cd* Cb = Cm + (size_t)b * sC;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -161,8 +244,42 @@ __global__ void __launch_bounds__(256) zgemm_mfma_kernel(const cd* A, const cd* 
                     cd v = make_double2(cr[u][w][r], ci[u][w][r]);
                     if (addI && gi == gj) v.x += 1.0;
                     Cb[(size_t)gi * n + gj] = v;
+                    if (MODE == 3 && bx < by) Cb[(size_t)gj * n + gi] = make_double2(v.x, -v.y);
                 }
             }
+}
+
+// S = triu(g0) - triu(g0)^H (wilson_sf.py:97-98) and g0 + S, both n x n
+__global__ void __launch_bounds__(256) skew_kernel(const cd* g0, cd* S, cd* g0S, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e / n, j = e - i * n;
+    cd v = make_double2(0.0, 0.0);
+    if (j > i) v = g0[(size_t)i * n + j];
+    else if (j < i) { const cd t = g0[(size_t)j * n + i]; v = make_double2(-t.x, t.y); }
+    else { const cd t = g0[(size_t)i * n + i]; v = make_double2(0.0, 2.0 * t.y); }
+    S[e] = v;
+    g0S[e] = cadd(g0[e], v);
+}
+
+// max of a vector of partial maxima (NaN wins), one workgroup
+__global__ void __launch_bounds__(256) maxred_kernel(const double* part, int n, double* out) {
+    __shared__ double red[256];
+    double m = 0.0;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const double v = part[e];
+        if (v > m || v != v) m = v;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const double o = red[threadIdx.x + st];
+            if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 // ---- batched in-place inverse, blocked: Gauss-Jordan on ZB x ZB blocks.  The unblocked kernel below
@@ -256,6 +373,187 @@ __global__ void __launch_bounds__(256) zinv_blocked_kernel(cd* M, int n, int* in
         for (int e = tid; e < ZB * n; e += 256) {
             const int m = e / n, j = e - m * n;
             if (k0 + m < n) A[(size_t)(k0 + m) * n + j] = Rk[(size_t)m * npad + j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) info[blockIdx.x] = 0;
+    __syncthreads();
+    if (bad) info[blockIdx.x] = 2;
+}
+
+// ---- the blocked inverse on the fp64 matrix cores.  Same algorithm as zinv_blocked_kernel with blocks of ZM = 32:
+//   for every block row k:  D = A_kk^-1;  R = D A_k* (R_kk = D);  A_i* <- [A_i* off block k] - A_ik R  (i != k);  A_k* <- R
+// but the two products run as v_mfma_f64_16x16x4_f64 tiles (layouts as zgemm_mfma_kernel): the trailing update - all
+// of the 8 n^3 flops - is 16 x 16 output tiles C = A_ij + (-A_ik) R_kj whose accumulators start as the tile itself,
+// a wave owns whole rows of tiles (so the in-place update has no hazards between waves) and reads R from LDS.
+// Twice the block size halves the sweeps over the matrix (8 x 2 MB instead of 16 x 2 MB at n = 256: the VALU
+// kernel sat at HBM / Infinity-Cache speed, 23 ms for 2049 matrices).  Pivots inside the diagonal block only, in
+// order; info = 2 flags a (relatively) tiny pivot exactly as zinv_blocked_kernel does.
+constexpr int ZM = 32;
+constexpr int ZT = 512;      // threads: 8 waves = two per SIMD (an MFMA blocks its wave; the partner keeps the pipe busy)
+constexpr int ZJ = 4;        // column tiles per pass of the trailing update: 8 independent accumulators per wave
+// `src` != nullptr: out of place - the first sweep reads src, everything lands in M (saves the caller a copy)
+__global__ void __launch_bounds__(ZT) zinv_mfma_kernel(cd* M, const cd* src, int n, int* info) {
+    SPY_DYN_SMEM(char, raw);
+    const int npad = ((n + ZM - 1) / ZM) * ZM;
+    const int ldr = npad + 1;                        // row stride of R in LDS (cd units; odd: spreads the banks)
+    cd* Rk = reinterpret_cast<cd*>(raw);             // ZM x ldr
+    cd* D = Rk + (size_t)ZM * ldr;                   // ZM x (ZM + 1)
+    constexpr int LDD = ZM + 1;
+    __shared__ double s_scale;
+    cd* A = M + (size_t)blockIdx.x * n * n;
+    const cd* S0 = src ? src + (size_t)blockIdx.x * n * n : A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int dr = tid >> 4, dc0 = tid & 15;         // diagonal block: row dr, columns dc0 and dc0 + 16
+    const int ntile = npad / 16;
+    int bad = 0;
+    for (int k0 = 0; k0 < npad; k0 += ZM) {
+        const cd* S = k0 == 0 ? S0 : A;              // where this sweep reads the matrix
+        // (a) D = A_kk (identity padding beyond n), inverted in LDS
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = k0 + dr, j = k0 + dc0 + 16 * q;
+            D[dr * LDD + dc0 + 16 * q] = (i < n && j < n) ? S[(size_t)i * n + j] : make_double2(i == j ? 1.0 : 0.0, 0.0);
+        }
+        __syncthreads();
+        if (tid < 64) {                              // largest |entry|^2 of the block (pivot threshold)
+            double m = 0.0;
+            for (int e = tid; e < ZM * ZM; e += 64) m = fmax(m, cabs2(D[(e / ZM) * LDD + (e % ZM)]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+            if (tid == 0) s_scale = m;
+        }
+        __syncthreads();
+        for (int p = 0; p < ZM; ++p) {
+            const cd piv = D[p * LDD + p], pcol = D[dr * LDD + p];
+            cd prow[2], own[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                prow[q] = D[p * LDD + dc0 + 16 * q];
+                own[q] = D[dr * LDD + dc0 + 16 * q];
+            }
+            __syncthreads();
+            const double d = cabs2(piv);
+            if (!(d > 1e-26 * s_scale)) bad = 1;
+            const cd pinv = d > 0.0 ? make_double2(piv.x / d, -piv.y / d) : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = dc0 + 16 * q;
+                cd v;
+                if (dr == p) {
+                    v = (c == p) ? pinv : cmul(prow[q], pinv);
+                } else {
+                    const cd f = cmul(pcol, pinv);
+                    v = (c == p) ? make_double2(-f.x, -f.y) : csub(own[q], cmul(f, prow[q]));
+                }
+                D[dr * LDD + c] = v;
+            }
+            __syncthreads();
+        }
+        // (b) R = D A_k* on the matrix cores (column tiles dealt to the waves); the two tiles of block k get D itself
+        for (int jt = wave; jt < ntile; jt += ZT / 64) {
+            const int j = 16 * jt + l15;
+            const bool inblk = 16 * jt >= k0 && 16 * jt < k0 + ZM;
+            f64x4 cr[2], ci[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cr[u][r] = 0.0; ci[u][r] = 0.0; }
+            if (!inblk) {
+#pragma unroll
+                for (int ks = 0; ks < ZM; ks += 4) {
+                    const int gk = k0 + ks + l4;
+                    const cd bb = (gk < n && j < n) ? S[(size_t)gk * n + j] : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const cd a = D[(16 * u + l15) * LDD + ks + l4];
+                        cr[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bb.x, cr[u], 0, 0, 0);
+                        ci[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bb.y, ci[u], 0, 0, 0);
+                        cr[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, bb.y, cr[u], 0, 0, 0);
+                        ci[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bb.x, ci[u], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * u + l4 + 4 * r;
+                    Rk[(size_t)m * ldr + j] = inblk ? D[m * LDD + (j - k0)] : make_double2(cr[u][r], ci[u][r]);
+                }
+        }
+        __syncthreads();
+        // (c) rows outside block k, one row of 16 x 16 tiles per wave, ZJ column tiles at a time:
+        //     A_ij <- (j in block k ? 0 : A_ij) + (-A_i,blockk) R_kj
+        for (int it = wave; it < ntile; it += ZT / 64) {
+            if (16 * it >= k0 && 16 * it < k0 + ZM) continue;           // wave-uniform
+            const int gi = 16 * it + l15;
+            cd ta[ZM / 4];                                               // -A[gi][k0 + 4 q + l4]
+#pragma unroll
+            for (int q = 0; q < ZM / 4; ++q) {
+                const int gk = k0 + 4 * q + l4;
+                const cd t = (gi < n && gk < n) ? S[(size_t)gi * n + gk] : make_double2(0.0, 0.0);
+                ta[q] = make_double2(-t.x, -t.y);
+            }
+            // the tiles of the NEXT pass are requested before the MFMAs of the current one (an MFMA blocks its wave:
+            // loads issued after them would only start when they are over)
+            auto fetch = [&](int jt0, cd (&c)[ZJ][4]) {
+#pragma unroll
+                for (int v = 0; v < ZJ; ++v) {
+                    const int jt = jt0 + v, j = 16 * jt + l15;
+                    const bool inblk = 16 * jt >= k0 && 16 * jt < k0 + ZM;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + l4 + 4 * r;
+                        c[v][r] = (jt < ntile && !inblk && i < n && j < n) ? S[(size_t)i * n + j] : make_double2(0.0, 0.0);
+                    }
+                }
+            };
+            cd cn[ZJ][4];
+            fetch(0, cn);
+            for (int jt0 = 0; jt0 < ntile; jt0 += ZJ) {
+                f64x4 cr[ZJ], ci[ZJ];
+#pragma unroll
+                for (int v = 0; v < ZJ; ++v)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        cr[v][r] = cn[v][r].x;
+                        ci[v][r] = cn[v][r].y;
+                    }
+                if (jt0 + ZJ < ntile) fetch(jt0 + ZJ, cn);
+#pragma unroll
+                for (int q = 0; q < ZM / 4; ++q) {
+                    cd bb[ZJ];
+#pragma unroll
+                    for (int v = 0; v < ZJ; ++v)
+                        bb[v] = jt0 + v < ntile ? Rk[(size_t)(4 * q + l4) * ldr + 16 * (jt0 + v) + l15] : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int v = 0; v < ZJ; ++v) {
+                        cr[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[q].x, bb[v].x, cr[v], 0, 0, 0);
+                        ci[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[q].x, bb[v].y, ci[v], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int v = 0; v < ZJ; ++v) {
+                        cr[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ta[q].y, bb[v].y, cr[v], 0, 0, 0);
+                        ci[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[q].y, bb[v].x, ci[v], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < ZJ; ++v) {
+                    const int jt = jt0 + v, j = 16 * jt + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + l4 + 4 * r;
+                        if (jt < ntile && i < n && j < n) A[(size_t)i * n + j] = make_double2(cr[v][r], ci[v][r]);
+                    }
+                }
+            }
+        }
+        // (d) rows of block k
+        for (int e = tid; e < ZM * n; e += ZT) {
+            const int m = e / n, j = e - m * n;
+            if (k0 + m < n) A[(size_t)(k0 + m) * n + j] = Rk[(size_t)m * ldr + j];
         }
         __syncthreads();
     }

@@ -369,7 +369,7 @@ def cwt_exec(data, seg_start, trial_lo, trial_hi, nsig, scales, dt, w0=6.0, detr
 
 # ---------------------------------------------------------------- Wilson / Granger (mirror of the host loop in granger.hip)
 def _dp(a):
-    return a.ctypes.data_as(C.c_void_p)
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 def w_gemm(A, B, opB=0, addI=0):
@@ -383,22 +383,51 @@ def w_gemm(A, B, opB=0, addI=0):
     return out
 
 
+def w_gemm_fused(A, B, opB=0, badd=None, ref=None):
+    """zgemm_mfma_kernel's fused forms (n >= 48): A op(B + ...) with `badd` (n, n) joined to op(B); with `ref` the
+    return value is max |ref - A op(B)| / |ref| and no product is stored."""
+    A = np.ascontiguousarray(A, dtype=np.complex128)
+    B = np.ascontiguousarray(B, dtype=np.complex128)
+    batch, n = A.shape[0], A.shape[1]
+    out = np.zeros_like(A)
+    ba = None if badd is None else np.ascontiguousarray(badd, dtype=np.complex128)
+    rf = None if ref is None else np.ascontiguousarray(ref, dtype=np.complex128)
+    lib().emu_w_gemm_fused.restype = C.c_double
+    err = lib().emu_w_gemm_fused(_dp(A), _dp(B), _dp(out), C.c_int(n), C.c_int(batch), C.c_longlong(n * n), C.c_int(opB),
+                                 _dp(ba), _dp(rf))
+    return err if ref is not None else out
+
+
+def w_skew(g0):
+    g0 = np.ascontiguousarray(g0, dtype=np.complex128)
+    n = g0.shape[0]
+    S, g0S = np.zeros_like(g0), np.zeros_like(g0)
+    lib().emu_w_skew(_dp(g0), _dp(S), _dp(g0S), C.c_int(n))
+    return S, g0S
+
+
 def w_inv(M, blocked=False):
     M = np.array(M, dtype=np.complex128, order="C")
     batch, n = (M.shape[0], M.shape[1]) if M.ndim == 3 else (1, M.shape[0])
     info = np.zeros(batch, dtype=np.int32)
-    (lib().emu_w_inv_blocked if blocked else lib().emu_w_inv)(_dp(M), C.c_int(n), C.c_int(batch), _dp(info))
+    fn = {False: lib().emu_w_inv, True: lib().emu_w_inv_blocked, "mfma": lib().emu_w_inv_mfma}[blocked]
+    fn(_dp(M), C.c_int(n), C.c_int(batch), _dp(info))
     return M, info
 
 
-def w_plus(g):
-    """Emulated plus operator on a half spectrum g (F, n, n) complex128 -> (gp (F, n, n), g0 (n, n))."""
+def w_plus(g, fast=False):
+    """Emulated plus operator on a half spectrum g (F, n, n) complex128 -> (gp (F, n, n), g0 (n, n)).
+    `fast`: plus4_kernel (power-of-two lag-domain lengths; two entries per complex transform)."""
     g = np.ascontiguousarray(g, dtype=np.complex128)
     F, n, _ = g.shape
     L = 2 * (F - 1)
     tw = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(L) / L))
     gp = np.zeros_like(g)
     g0 = np.zeros((n, n), dtype=np.complex128)
+    if fast:
+        rc = lib().emu_w_plus4(_dp(g), C.c_int(F), C.c_int(n), _dp(tw), _dp(gp), _dp(g0))
+        assert rc == 0, f"no plus4 kernel for F = {F}"
+        return gp, g0
     lib().emu_w_plus(_dp(g), C.c_int(F), C.c_int(n), _dp(tw), _dp(gp), _dp(g0))     # returns the number of passes
     return gp, g0
 

@@ -25,6 +25,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_long.h"
 #include "../../syncopy_amd/csrc/cwt_kernel.h"
 #include "../../syncopy_amd/csrc/granger_kernels.h"
+#include "../../syncopy_amd/csrc/wilson_plus_kernel.h"
 
 namespace spy {
 void set_error(const char*, ...) {}
@@ -117,6 +118,15 @@ static void emu_launch_ccov(const spyfft::CcovArgs& a) {
     using C = spyfft::Cfg2<LOG2N, G>;
     const long long grid = 8 * (((a.npairs + 2 * G - 1) / (2 * G) + 7) / 8);
     emu::launch(dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::ccov_lags_kernel<LOG2N, G>(a); });
+}
+
+// plus4_kernel (power-of-two lag-domain lengths 256 .. 4096); returns 0, or 1 if there is no such kernel for F
+template <int LOG2L>
+void run_plus4(const double* g, int F, int n, const double* tw, double* gp, double* g0) {
+    using C = spywil::PCfg<LOG2L>;
+    emu::launch(dim3((unsigned)((n * n + 3) / 4)), dim3(C::T), C::LDS_BYTES, [&] {
+        spywil::plus4_kernel<LOG2L>(reinterpret_cast<const spywil::cd*>(g), F, n, reinterpret_cast<const spywil::cd*>(tw),
+                                    reinterpret_cast<spywil::cd*>(gp), reinterpret_cast<spywil::cd*>(g0)); });
 }
 
 extern "C" {
@@ -347,7 +357,7 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
                     [&] { spycsd::csd_accum_kernel<5, 4, 3>(a); });
         return 7;
     }
-    if (fast && C == 256 && !g_force_4m) {
+    if (force_tpw == 0 && C == 256 && !g_force_4m) {
         // as csd.hip: 256 channels take the 3-multiplication kernel, one workgroup of 8 waves per frequency
         // (g_m3_wpg = 4: the variant with two workgroups of 4 waves per frequency)
         a.item_end = (long long)F * spycsd::M3_TILES_PER_F;
@@ -521,12 +531,37 @@ void emu_w_widen(const float* in, double* out, int C, long long n, double eps) {
 }
 void emu_w_gemm(const double* A, const double* B, double* Cm, int n, int batch, long long sA, long long sB, long long sC, int opB, int addI) {
     if (n >= 48) {      // as granger.hip: fp64 MFMA tiles
-        dim3 g((n + 63) / 64, (n + 63) / 64, batch);
-        emu::launch(g, dim3(256), 0, [&] { spywil::zgemm_mfma_kernel(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI); });
+        const int ntx = (n + 63) / 64;
+        dim3 g(ntx * ntx * ((batch + 7) / 8) * 8);
+        if (opB == 1 && A == B && sA == sB)     // as granger.hip: X X^H takes the Hermitian instance
+            emu::launch(g, dim3(256), 0, [&] { spywil::zgemm_mfma_kernel<3>(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI, nullptr, nullptr, nullptr, batch); });
+        else
+            emu::launch(g, dim3(256), 0, [&] { spywil::zgemm_mfma_kernel<0>(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI, nullptr, nullptr, nullptr, batch); });
         return;
     }
     dim3 grid((n + 31) / 32, (n + 31) / 32, batch);
     emu::launch(grid, dim3(256), 0, [&] { spywil::zgemm_kernel(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI); });
+}
+// the fused forms of the matrix-core gemm: op(B) + Badd, and max |Ref - A op(B)| / |Ref| instead of the product
+double emu_w_gemm_fused(const double* A, const double* B, double* Cm, int n, int batch, long long sB, int opB, const double* Badd,
+                        const double* Ref) {
+    const int ntx = (n + 63) / 64;
+    dim3 g(ntx * ntx * ((batch + 7) / 8) * 8);
+    std::vector<double> part((size_t)ntx * ntx * batch, -1.0);
+    emu::launch(g, dim3(256), 0, [&] {
+        if (Ref)
+            spywil::zgemm_mfma_kernel<2>(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n,
+                                         (long long)n * n, sB, (long long)n * n, opB, 0, nullptr, reinterpret_cast<const cd*>(Ref), part.data(), batch);
+        else
+            spywil::zgemm_mfma_kernel<1>(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n,
+                                         (long long)n * n, sB, (long long)n * n, opB, 0, reinterpret_cast<const cd*>(Badd), nullptr, nullptr, batch); });
+    if (!Ref) return 0.0;
+    double out = -1.0;
+    emu::launch(dim3(1), dim3(256), 0, [&] { spywil::maxred_kernel(part.data(), (int)part.size(), &out); });
+    return out;
+}
+void emu_w_skew(const double* g0, double* S, double* g0S, int n) {
+    emu::launch(dim3((n * n + 255) / 256), dim3(256), 0, [&] { spywil::skew_kernel(reinterpret_cast<const cd*>(g0), reinterpret_cast<cd*>(S), reinterpret_cast<cd*>(g0S), n); });
 }
 void emu_w_inv(double* M, int n, int batch, int* info) {
     emu::launch(dim3(batch), dim3(256), (size_t)n * 36, [&] { spywil::zinv_kernel(reinterpret_cast<cd*>(M), n, info); });
@@ -535,6 +570,14 @@ void emu_w_inv_blocked(double* M, int n, int batch, int* info) {
     const int npad = ((n + spywil::ZB - 1) / spywil::ZB) * spywil::ZB;
     emu::launch(dim3(batch), dim3(256), ((size_t)spywil::ZB * npad + spywil::ZB * spywil::ZB) * 16,
                 [&] { spywil::zinv_blocked_kernel(reinterpret_cast<cd*>(M), n, info); });
+}
+void emu_w_inv_mfma(double* M, int n, int batch, int* info) {
+    const int npad = ((n + spywil::ZM - 1) / spywil::ZM) * spywil::ZM;
+    // out of place from a copy of the input, as the Wilson iteration calls it
+    std::vector<double> src(M, M + (size_t)batch * n * n * 2);
+    std::fill(M, M + (size_t)batch * n * n * 2, -777.0);
+    emu::launch(dim3(batch), dim3(spywil::ZT), ((size_t)spywil::ZM * (npad + 1) + spywil::ZM * (spywil::ZM + 1)) * 16,
+                [&] { spywil::zinv_mfma_kernel(reinterpret_cast<cd*>(M), reinterpret_cast<const cd*>(src.data()), n, info); });
 }
 void emu_w_chol(double* M, int n, int batch, int* info) {
     emu::launch(dim3(batch), dim3(256), (size_t)n * 16, [&] { spywil::zchol_kernel(reinterpret_cast<cd*>(M), n, info); });
@@ -553,6 +596,16 @@ int emu_w_plus(const double* g, int F, int n, const double* tw, double* gp, doub
     pl.nfac = k;
     emu::launch(dim3(n * n), dim3(256), (size_t)2 * L * 16, [&] { spywil::plus_kernel(reinterpret_cast<const cd*>(g), F, n, pl, reinterpret_cast<const cd*>(tw), reinterpret_cast<cd*>(gp), reinterpret_cast<cd*>(g0)); });
     return k;
+}
+int emu_w_plus4(const double* g, int F, int n, const double* tw, double* gp, double* g0) {
+    switch (2 * (F - 1)) {
+        case 256: run_plus4<8>(g, F, n, tw, gp, g0); return 0;
+        case 512: run_plus4<9>(g, F, n, tw, gp, g0); return 0;
+        case 1024: run_plus4<10>(g, F, n, tw, gp, g0); return 0;
+        case 2048: run_plus4<11>(g, F, n, tw, gp, g0); return 0;
+        case 4096: run_plus4<12>(g, F, n, tw, gp, g0); return 0;
+        default: return 1;
+    }
 }
 void emu_w_addS(double* gp, const double* g0, double* out0, int F, int n) {
     emu::launch(dim3(4), dim3(256), 0, [&] { spywil::add_S_kernel(reinterpret_cast<cd*>(gp), reinterpret_cast<const cd*>(g0), reinterpret_cast<cd*>(out0), F, n); });

@@ -304,6 +304,23 @@ def test_blocked_inverse(n):
     assert info[0] == 2
 
 
+@pytest.mark.parametrize("n", [64, 37, 70, 96])
+def test_blocked_inverse_on_f64_matrix_cores(n):
+    """zinv_mfma_kernel (32 x 32 blocks, R = D A_k* and the trailing update as v_mfma_f64_16x16x4_f64 tiles): ragged
+    sizes (identity padding, partial tiles), asymmetric complex matrices (a row/column swap of a fragment layout would
+    show), the tiny-pivot flag."""
+    rng = np.random.default_rng(n)
+    B = 2
+    A = rng.normal(size=(B, n, n)) + 1j * rng.normal(size=(B, n, n)) + 3 * np.sqrt(n) * np.eye(n)
+    inv, info = E.w_inv(A, blocked="mfma")
+    assert not info.any()
+    np.testing.assert_allclose(inv, np.linalg.inv(A), rtol=1e-9, atol=1e-11)
+    P = np.zeros((1, n, n), complex)
+    P[0] = np.eye(n)[::-1]
+    _, info = E.w_inv(P, blocked="mfma")
+    assert info[0] == 2
+
+
 @pytest.mark.parametrize("F", [9, 17, 11, 8])       # L = 16 (4*4), 32 (4*4*2), 20 (4*5), 14 (2*7)
 def test_plus_operator(F):
     rng = np.random.default_rng(F)
@@ -318,6 +335,25 @@ def test_plus_operator(F):
     np.testing.assert_allclose(g0, ref0, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("F,n", [(129, 3), (257, 2), (513, 5), (1025, 2), (2049, 2)])
+def test_plus_operator_two_entries_per_transform(F, n):
+    """plus4_kernel: two real lag sequences per complex radix-16 transform, four adjacent entries per workgroup
+    (n = 3, 5: ragged last workgroup / odd pair), complex DC and Nyquist bins (their imaginary parts must be
+    ignored as real(ifft(.)) ignores them) - against the oracle's fft/ifft formulation and the radix-4 kernel."""
+    rng = np.random.default_rng(F + n)
+    L = 2 * (F - 1)
+    g = rng.normal(size=(F, n, n)) + 1j * rng.normal(size=(F, n, n))
+    full = np.zeros((L, n, n), complex)
+    full[:F] = g
+    full[F:] = np.conj(g[1:F - 1][::-1])
+    ref, ref0 = O.plus_operator(full)
+    gp, g0 = E.w_plus(g, fast=True)
+    np.testing.assert_allclose(gp, ref[:F], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g0, ref0, rtol=1e-12, atol=1e-12)
+    old, old0 = E.w_plus(g)
+    np.testing.assert_allclose(gp, old, rtol=1e-12, atol=1e-12)
+
+
 def test_zgemm_on_f64_matrix_cores():
     """n >= 48 takes the v_mfma_f64_16x16x4_f64 tiles (asymmetric operands catch row/column swaps; n = 50 leaves
     ragged tiles)."""
@@ -328,6 +364,29 @@ def test_zgemm_on_f64_matrix_cores():
     np.testing.assert_allclose(E.w_gemm(A, Bm), A @ Bm, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(E.w_gemm(A, Bm, opB=1, addI=1), A @ Bm.conj().transpose(0, 2, 1) + np.eye(n), rtol=1e-12,
                                atol=1e-12)
+
+
+def test_zgemm_fused_skew_and_error_check():
+    """The two fused forms of the matrix-core gemm used inside the Wilson iteration: psi (g+ + S) with
+    S = triu(g0) - triu(g0)^H joined to the B operand, and max_rel_err(CSD, psi psi^H) without storing the product
+    (wilson_sf.py:97-101,190-194); n = 70 leaves partial 64 x 64 tiles."""
+    rng = np.random.default_rng(12)
+    n, B = 70, 2
+    psi = rng.normal(size=(B, n, n)) + 1j * rng.normal(size=(B, n, n))
+    gp = rng.normal(size=(B, n, n)) + 1j * rng.normal(size=(B, n, n))
+    g0 = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    S, g0S = E.w_skew(g0)
+    Sref = np.triu(g0) - np.triu(g0).conj().T
+    np.testing.assert_allclose(S, Sref, rtol=0, atol=0)
+    np.testing.assert_allclose(g0S, g0 + Sref, rtol=1e-15)
+    np.testing.assert_allclose(E.w_gemm_fused(psi, gp, badd=S), psi @ (gp + Sref), rtol=1e-12, atol=1e-12)
+    # X X^H + I through the Hermitian instance (lower tiles computed, mirrored above the diagonal)
+    np.testing.assert_allclose(E.w_gemm(psi, psi, opB=1, addI=1), psi @ psi.conj().transpose(0, 2, 1) + np.eye(n),
+                               rtol=1e-12, atol=1e-12)
+    herm = rng.normal(size=(B, n, n)) * 1e-3
+    ref = psi @ psi.conj().transpose(0, 2, 1) * (1 + herm + herm.transpose(0, 2, 1))        # Hermitian reference
+    err = E.w_gemm_fused(psi, psi, opB=1, ref=ref)
+    np.testing.assert_allclose(err, O.max_rel_err(ref, psi @ psi.conj().transpose(0, 2, 1)), rtol=1e-10)
 
 
 def test_wilson_building_blocks():
