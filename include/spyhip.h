@@ -303,6 +303,41 @@ int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, dou
                    double cond_max, double eps_max, void* granger_d, void* H_d, void* Sigma_d,
                    double* info);
 
+/* ---- K6 in steps, for frequency shards ---------------------------
+ * One rank holds the bins [f_lo, f_lo + nf) of the nftot rfft bins of the trial-averaged CSD.  Regularisation,
+ * Cholesky factor, inverse, products and the error are per frequency (local); the plus operator
+ * (wilson_sf.py:154-184) works along the frequency axis: the host transposes g between "my frequencies x all entries"
+ * and "all frequencies x my entries" around spyhip_wilson_plus (one all-to-all each way) and reduces three small
+ * quantities over ranks (gamma_0: sum; condition number, error: max).  Host side:
+ * syncopy_amd/connectivity/wilson_sharded.py; with one rank the sequence equals spyhip_granger.
+ * Arrays are complex128 on the device unless stated; "work" arrays are scratch of the stated size.
+ *   spyhip_wilson_cond   A = complex128(csd) + eps I (regularize_csd, wilson_sf.py:239-248); *cond_out = largest
+ *                        2-norm condition number of the local bins.  work_d: 3 nf n^2.
+ *   spyhip_wilson_init   U = Cholesky factor of A per bin (:76); gamma_part_d (n, n) = this shard's part of
+ *                        gamma_0 = fft(CSD_full)[0] (:135-140), to be summed over ranks.
+ *   spyhip_wilson_psi0   psi0 = chol(gamma_0)^T (:144-151) from the summed gamma_0 (overwritten), tiled into psi_d.
+ *   spyhip_wilson_g      g = (psi^-1 U)(psi^-1 U)^H + I (:80-92).  work_d: 2 nf n^2.  Returns 1 (not an error) if
+ *                        the block inverse met a tiny pivot: restart the factorisation with pivoted = 1.
+ *   spyhip_wilson_plus   g+ and the halved zero-lag coefficients g0 for nent entries over all nftot frequencies:
+ *                        g_d, gp_d (nftot, nent), g0_d (nent).
+ *   spyhip_wilson_update psi <- psi (g+ + S), psi0 <- psi0 (g0 + S), S = triu(g0) - triu(g0)^H (:97-101);
+ *                        *err_out = this shard's max |A - psi psi^H| / |A| (:103,190-194).  g0_d: all n^2 entries.
+ *                        work_d: nf n^2.
+ *   spyhip_wilson_finish Sigma = psi0 psi0^T, H = psi psi0^-1, Granger causality (granger.py:53-77) on the local
+ *                        bins: granger_d float32 (nf, n, n); H_d / Sigma_d may be NULL.  work_d: nf n^2. */
+int spyhip_wilson_cond(spyhip_ctx* ctx, const void* csd_c64_d, int nf, int n, double eps, void* A_d, void* work_d,
+                       double* cond_out);
+int spyhip_wilson_init(spyhip_ctx* ctx, const void* A_d, int nf, int n, int f_lo, int nftot, void* U_d,
+                       void* gamma_part_d);
+int spyhip_wilson_psi0(spyhip_ctx* ctx, void* gamma0_d, int n, int nf, void* psi0_d, void* psi_d);
+int spyhip_wilson_g(spyhip_ctx* ctx, const void* psi_d, const void* U_d, int nf, int n, int pivoted, void* work_d,
+                    void* g_d);
+int spyhip_wilson_plus(spyhip_ctx* ctx, const void* g_d, int nftot, int64_t nent, void* gp_d, void* g0_d);
+int spyhip_wilson_update(spyhip_ctx* ctx, void* psi_d, const void* gp_d, const void* g0_d, void* psi0_d,
+                         const void* A_d, int nf, int n, void* work_d, double* err_out);
+int spyhip_wilson_finish(spyhip_ctx* ctx, const void* A_d, const void* psi_d, const void* psi0_d, int nf, int n,
+                         void* work_d, void* granger_d, void* H_d, void* Sigma_d);
+
 /* Wilson iterations the last spyhip_granger call on this context ran (the reference's loop counter,
  * wilson_sf.py:77-109); for benchmarks and diagnostics. */
 int spyhip_granger_last_iterations(const spyhip_ctx* ctx);

@@ -74,6 +74,13 @@ SIGNATURES = {
     "spyhip_granger": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, vp, vp, vp,
                                  c_f64p]),
     "spyhip_granger_last_iterations": (C.c_int, [vp]),
+    "spyhip_wilson_cond": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, vp, vp, c_f64p]),
+    "spyhip_wilson_init": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "spyhip_wilson_psi0": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "spyhip_wilson_g": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "spyhip_wilson_plus": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp, vp]),
+    "spyhip_wilson_update": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, c_f64p]),
+    "spyhip_wilson_finish": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "spyhip_axpy_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float]),
     "spyhip_trial_mean_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64]),
 }

@@ -3,7 +3,7 @@ normalize_csd_cF:36 / NormalizeCrossSpectra:115, granger_cF:293 / GrangerCausali
 import numpy as np
 import torch
 
-from .. import backend
+from .. import backend, parallel
 from ..shared.computational_routine import ComputationalRoutine
 from ..shared.const_def import spectralDTypes
 from ..shared.errors import SPYValueError
@@ -123,18 +123,28 @@ class GrangerCausality(_AverageRoutine):
     def evaluate_device(self, csd):
         """AV stage on one device CSD (F, C, C) -> Granger (F, C, C) float32; keeps the metadata of the first call
         (the direct estimate) for `out.info`."""
-        G, meta = backend.granger(csd.contiguous(), rtol=self.cfg["rtol"], niter=self.cfg["nIter"],
-                                  cond_max=self.cfg["cond_max"], eps_max=1e-1)
-        if not self.metadata:
+        if not self.metadata:                    # the direct estimate: every rank calls with the same CSD
+            G, meta = self._granger(csd.contiguous())
             self.metadata = [_granger_metadata(meta)]
-        return G
+            return G
+        # jackknife replicates belong to the rank that owns the left-out trial: no collective here
+        return backend.granger(csd.contiguous(), rtol=self.cfg["rtol"], niter=self.cfg["nIter"],
+                               cond_max=self.cfg["cond_max"], eps_max=1e-1)[0]
+
+    def _granger(self, csd):
+        """One trial-averaged CSD every rank holds -> Granger values on every rank.  With a process group the
+        frequencies are sharded over the ranks (wilson_sharded.py); otherwise one spyhip_granger call."""
+        kw = dict(rtol=self.cfg["rtol"], niter=self.cfg["nIter"], cond_max=self.cfg["cond_max"], eps_max=1e-1)
+        if parallel.collective_active():
+            from .wilson_sharded import granger_hip_sharded
+            return granger_hip_sharded(csd, **kw)
+        return backend.granger(csd, **kw)
 
     def compute_hip(self, data, out):
         dev = self._device_input(data)
         res, self.metadata = [], []
         for t in range(dev.shape[0]):            # one trial average, or the jackknife's leave-one-out replicates
-            G, meta = backend.granger(dev[t].contiguous(), rtol=self.cfg["rtol"], niter=self.cfg["nIter"],
-                                      cond_max=self.cfg["cond_max"], eps_max=1e-1)
+            G, meta = self._granger(dev[t].contiguous())
             res.append(G)
             self.metadata.append(_granger_metadata(meta))
         out._dev = torch.stack(res, dim=0)

@@ -145,7 +145,7 @@ int max_cond(spyhip_ctx* ctx, const cd* A, cd* work, cd* w1, cd* w2, int n, int 
 
 // plus operator for power-of-two lag-domain lengths 256 .. 4096 (wilson_plus_kernel.h); false: no such kernel
 template <int LOG2L>
-int launch_plus4(spyhip_ctx* ctx, const cd* g, int F, int n, const cd* tw, cd* gp, cd* g0) {
+int launch_plus4(spyhip_ctx* ctx, const cd* g, int F, long long nent, const cd* tw, cd* gp, cd* g0) {
     using C = spywil::PCfg<LOG2L>;
     auto kern = spywil::plus4_kernel<LOG2L>;
     static bool attr_set = false;
@@ -154,18 +154,17 @@ int launch_plus4(spyhip_ctx* ctx, const cd* g, int F, int n, const cd* tw, cd* g
                                           (int)C::LDS_BYTES));
         attr_set = true;
     }
-    const size_t nn = (size_t)n * n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((nn + 3) / 4)), dim3(C::T), C::LDS_BYTES, ctx->stream, g, F, n, tw, gp, g0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((nent + 3) / 4)), dim3(C::T), C::LDS_BYTES, ctx->stream, g, F, nent, tw, gp, g0);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int plus4(spyhip_ctx* ctx, int L, const cd* g, int F, int n, const cd* tw, cd* gp, cd* g0) {
+int plus4(spyhip_ctx* ctx, int L, const cd* g, int F, long long nent, const cd* tw, cd* gp, cd* g0) {
     switch (L) {
-        case 256: return launch_plus4<8>(ctx, g, F, n, tw, gp, g0);
-        case 512: return launch_plus4<9>(ctx, g, F, n, tw, gp, g0);
-        case 1024: return launch_plus4<10>(ctx, g, F, n, tw, gp, g0);
-        case 2048: return launch_plus4<11>(ctx, g, F, n, tw, gp, g0);
-        case 4096: return launch_plus4<12>(ctx, g, F, n, tw, gp, g0);
+        case 256: return launch_plus4<8>(ctx, g, F, nent, tw, gp, g0);
+        case 512: return launch_plus4<9>(ctx, g, F, nent, tw, gp, g0);
+        case 1024: return launch_plus4<10>(ctx, g, F, nent, tw, gp, g0);
+        case 2048: return launch_plus4<11>(ctx, g, F, nent, tw, gp, g0);
+        case 4096: return launch_plus4<12>(ctx, g, F, nent, tw, gp, g0);
         default: return 1;
     }
 }
@@ -248,7 +247,7 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
     SPY_HIP_CHECK(hipMemcpyAsync(U, A, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
     if (cholesky(ctx, U, n, F, inf)) return -2;
     if (int rc = check_info(ctx, inf, F, "Cholesky factorisation of the CSD (not positive definite)")) return rc;
-    hipLaunchKernelGGL(spywil::gamma0_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, A, F, n, scr);
+    hipLaunchKernelGGL(spywil::gamma0_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, A, F, n, scr, 0, F);
     if (cholesky(ctx, scr, n, 1, inf)) return -2;
     if (int rc = check_info(ctx, inf, 1, "Cholesky factorisation of gamma_0 (not positive definite)")) return rc;
     hipLaunchKernelGGL(spywil::transpose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, scr, psi0, n);
@@ -276,11 +275,11 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
         if (gemm(ctx, T1, U, T2, n, F, nn, nn, nn, 0, 0)) return -2;                       // psi^-1 U
         if (gemm(ctx, T2, T2, T1, n, F, nn, nn, nn, 1, 1)) return -2;                      // g + I
         {                                                                                   // T2 = [g+I]^+
-            const int prc = use_plus4 ? plus4(ctx, L, T1, F, n, tw, T2, g0) : 1;
+            const int prc = use_plus4 ? plus4(ctx, L, T1, F, (long long)nn, tw, T2, g0) : 1;
             if (prc < 0) return prc;
             if (prc > 0)
                 hipLaunchKernelGGL(spywil::plus_kernel, dim3((unsigned)nn), dim3(256), 2 * L * sizeof(cd), ctx->stream,
-                                   T1, F, n, pl, tw, T2, g0);
+                                   T1, F, (long long)nn, pl, tw, T2, g0);
         }
         const bool fused = n >= 48;               // the matrix-core gemm takes S and the error check along
         if (fused) {
@@ -334,3 +333,219 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
 }
 
 extern "C" int spyhip_granger_last_iterations(const spyhip_ctx* ctx) { return ctx ? ctx->granger_iters : -1; }
+
+// =====================================================================================================================
+// The Wilson factorisation in steps, for frequency shards: every rank holds the bins [f_lo, f_lo + nf) of
+// the nftot rfft bins of the CSD.  Everything per frequency (regularisation, Cholesky factor, inverse, products, error)
+// is local; the plus operator works along the frequency axis, so the host transposes g = psi^-1 S psi^-H between
+// "frequency shards x all entries" and "all frequencies x entry shards" around spyhip_wilson_plus (an all-to-all),
+// and sums / maximises three small quantities over ranks (gamma_0, the condition number, the error).  The host side
+// is syncopy_amd/connectivity/wilson_sharded.py; with one rank the sequence equals spyhip_granger.
+// All arrays are complex128 on the device unless stated; work_d: 3 x nf x n x n complex128.
+// =====================================================================================================================
+namespace {
+struct Tmp {        // small per-call device scratch
+    void* p = nullptr;
+    ~Tmp() { if (p) (void)hipFree(p); }
+    int get(size_t bytes) { return hipMalloc(&p, bytes) == hipSuccess ? 0 : -2; }
+};
+}  // namespace
+
+// A = widen(csd) + eps I on the local bins (regularize_csd's CSD + eps*eye, wilson_sf.py:244); cond_out (host): the
+// largest 2-norm condition number of the local bins.  work_d as above.
+extern "C" int spyhip_wilson_cond(spyhip_ctx* ctx, const void* csd_c64_d, int nf, int n, double eps, void* A_d, void* work_d,
+                                  double* cond_out) {
+    if (!ctx || !csd_c64_d || !A_d || !work_d || !cond_out) { spy::set_error("wilson_cond: null argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t tot = (size_t)nf * n * n;
+    cd* A = reinterpret_cast<cd*>(A_d);
+    cd* W = reinterpret_cast<cd*>(work_d);
+    Tmp t;
+    if (t.get(2 * (size_t)nf * sizeof(double) + nf * sizeof(int))) { spy::set_error("wilson_cond: out of device memory"); return -2; }
+    double* lam = reinterpret_cast<double*>(t.p);
+    int* inf = reinterpret_cast<int*>(lam + 2 * (size_t)nf);
+    const unsigned eb = (unsigned)std::min<size_t>((tot + 255) / 256, 8192);
+    hipLaunchKernelGGL(spywil::widen_kernel, dim3(eb), dim3(256), 0, ctx->stream, reinterpret_cast<const float2*>(csd_c64_d), A, n,
+                       (long long)tot, eps);
+    SPY_HIP_CHECK(hipGetLastError());
+    return max_cond(ctx, A, W, W + tot, W + 2 * tot, n, nf, lam, inf, cond_out);
+}
+
+// U = Cholesky factor of A per local bin (wilson_sf.py:76) and this shard's part of gamma_0 = fft(CSD_full)[0]
+// (wilson_sf.py:135-140, symmetrised real part): gamma_part_d (n x n) is to be summed over ranks.
+extern "C" int spyhip_wilson_init(spyhip_ctx* ctx, const void* A_d, int nf, int n, int f_lo, int nftot, void* U_d,
+                                  void* gamma_part_d) {
+    if (!ctx || !A_d || !U_d || !gamma_part_d) { spy::set_error("wilson_init: null argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n, tot = (size_t)nf * nn;
+    Tmp t;
+    if (t.get((size_t)nf * sizeof(int))) return -2;
+    int* inf = reinterpret_cast<int*>(t.p);
+    SPY_HIP_CHECK(hipMemcpyAsync(U_d, A_d, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    if (cholesky(ctx, reinterpret_cast<cd*>(U_d), n, nf, inf)) return -2;
+    if (int rc = check_info(ctx, inf, nf, "Cholesky factorisation of the CSD (not positive definite)")) return rc;
+    hipLaunchKernelGGL(spywil::gamma0_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const cd*>(A_d), nf, n, reinterpret_cast<cd*>(gamma_part_d), f_lo, nftot);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// psi0 = chol(gamma_0)^T (wilson_sf.py:144-151) from the summed gamma_0, tiled over the local bins into psi_d
+extern "C" int spyhip_wilson_psi0(spyhip_ctx* ctx, void* gamma0_d, int n, int nf, void* psi0_d, void* psi_d) {
+    if (!ctx || !gamma0_d || !psi0_d || !psi_d) { spy::set_error("wilson_psi0: null argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n, tot = (size_t)nf * nn;
+    Tmp t;
+    if (t.get(sizeof(int))) return -2;
+    int* inf = reinterpret_cast<int*>(t.p);
+    if (cholesky(ctx, reinterpret_cast<cd*>(gamma0_d), n, 1, inf)) return -2;
+    if (int rc = check_info(ctx, inf, 1, "Cholesky factorisation of gamma_0 (not positive definite)")) return rc;
+    hipLaunchKernelGGL(spywil::transpose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const cd*>(gamma0_d), reinterpret_cast<cd*>(psi0_d), n);
+    const unsigned eb = (unsigned)std::min<size_t>((tot + 255) / 256, 8192);
+    hipLaunchKernelGGL(spywil::tile_kernel, dim3(eb), dim3(256), 0, ctx->stream, reinterpret_cast<const cd*>(psi0_d),
+                       reinterpret_cast<cd*>(psi_d), nf, n);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// g = (psi^-1 U)(psi^-1 U)^H + I on the local bins (wilson_sf.py:80-92).  work_d: 2 x nf x n x n.  Returns 1 (not an
+// error) if the block inverse met a tiny pivot: repeat the whole factorisation with pivoted = 1.
+extern "C" int spyhip_wilson_g(spyhip_ctx* ctx, const void* psi_d, const void* U_d, int nf, int n, int pivoted, void* work_d,
+                               void* g_d) {
+    if (!ctx || !psi_d || !U_d || !work_d || !g_d) { spy::set_error("wilson_g: null argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long nn = (long long)n * n;
+    const size_t tot = (size_t)nf * nn;
+    cd* T1 = reinterpret_cast<cd*>(work_d);
+    cd* T2 = T1 + tot;
+    Tmp t;
+    if (t.get((size_t)nf * sizeof(int))) return -2;
+    int* inf = reinterpret_cast<int*>(t.p);
+    if (invert(ctx, T1, n, nf, inf, !pivoted, reinterpret_cast<const cd*>(psi_d))) return -2;
+    std::vector<int> h(nf);
+    SPY_HIP_CHECK(hipMemcpyAsync(h.data(), inf, nf * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (gemm(ctx, T1, reinterpret_cast<const cd*>(U_d), T2, n, nf, nn, nn, nn, 0, 0)) return -2;
+    if (gemm(ctx, T2, T2, reinterpret_cast<cd*>(g_d), n, nf, nn, nn, nn, 1, 1)) return -2;
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < nf; ++f)
+        if (h[f] == 2) return 1;
+    return 0;
+}
+
+// plus operator (wilson_sf.py:154-184) for nent matrix entries over ALL nftot frequencies: g_d, gp_d (nftot, nent),
+// g0_d (nent): the zero-lag coefficients (halved, real).
+extern "C" int spyhip_wilson_plus(spyhip_ctx* ctx, const void* g_d, int nftot, int64_t nent, void* gp_d, void* g0_d) {
+    if (!ctx || !g_d || !gp_d || !g0_d) { spy::set_error("wilson_plus: null argument"); return -1; }
+    if (nent <= 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const int L = 2 * (nftot - 1);
+    spywil::PlusPlan pl;
+    if (!plus_plan(L, &pl) || (size_t)2 * L * sizeof(cd) > ctx->lds_per_block) {
+        spy::set_error("wilson_plus: lag-domain length %d exceeds the LDS FFT of the plus operator", L);
+        return -3;
+    }
+    Tmp t;
+    if (t.get((size_t)L * sizeof(cd))) return -2;
+    cd* tw = reinterpret_cast<cd*>(t.p);
+    std::vector<cd> h(L);
+    for (int m = 0; m < L; ++m) { const double a = -2.0 * PI * m / L; h[m] = make_double2(std::cos(a), std::sin(a)); }
+    SPY_HIP_CHECK(hipMemcpyAsync(tw, h.data(), L * sizeof(cd), hipMemcpyHostToDevice, ctx->stream));
+    const int prc = plus4(ctx, L, reinterpret_cast<const cd*>(g_d), nftot, (long long)nent, tw, reinterpret_cast<cd*>(gp_d),
+                          reinterpret_cast<cd*>(g0_d));
+    if (prc < 0) return prc;
+    if (prc > 0) {
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::plus_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * L * sizeof(cd))));
+        hipLaunchKernelGGL(spywil::plus_kernel, dim3((unsigned)nent), dim3(256), 2 * L * sizeof(cd), ctx->stream,
+                           reinterpret_cast<const cd*>(g_d), nftot, (long long)nent, pl, tw, reinterpret_cast<cd*>(gp_d),
+                           reinterpret_cast<cd*>(g0_d));
+        SPY_HIP_CHECK(hipGetLastError());
+    }
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));        // tw is freed on return
+    return 0;
+}
+
+// psi <- psi (g+ + S), psi0 <- psi0 (g0 + S) with S = triu(g0) - triu(g0)^H (wilson_sf.py:97-101); err_out (host): this
+// shard's max |A - psi psi^H| / |A| (:103, :190-194).  g0_d (n x n) holds ALL entries (gathered by the host).
+// work_d: nf x n x n.
+extern "C" int spyhip_wilson_update(spyhip_ctx* ctx, void* psi_d, const void* gp_d, const void* g0_d, void* psi0_d,
+                                    const void* A_d, int nf, int n, void* work_d, double* err_out) {
+    if (!ctx || !psi_d || !gp_d || !g0_d || !psi0_d || !A_d || !work_d || !err_out) { spy::set_error("wilson_update: null argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long nn = (long long)n * n;
+    const size_t tot = (size_t)nf * nn;
+    cd* psi = reinterpret_cast<cd*>(psi_d);
+    cd* T1 = reinterpret_cast<cd*>(work_d);
+    const int mt = (n + spywil::MT - 1) / spywil::MT;
+    const size_t npart = std::max<size_t>((size_t)mt * mt * nf, 1024);
+    Tmp t;
+    if (t.get(3 * (size_t)nn * sizeof(cd) + (npart + 1) * sizeof(double))) return -2;
+    cd* S = reinterpret_cast<cd*>(t.p);
+    cd* g0S = S + nn;
+    cd* p0n = g0S + nn;
+    double* part = reinterpret_cast<double*>(p0n + nn);
+    hipLaunchKernelGGL(spywil::skew_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const cd*>(g0_d), S, g0S, n);
+    SPY_HIP_CHECK(hipGetLastError());
+    const bool fused = n >= 48;
+    if (fused) {
+        if (gemm(ctx, psi, reinterpret_cast<const cd*>(gp_d), T1, n, nf, nn, nn, nn, 0, 0, S)) return -2;
+    } else {
+        // small matrices: g+ + S in a pass of its own, into the work array (gp_d is left alone)
+        SPY_HIP_CHECK(hipMemcpyAsync(T1, gp_d, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+        const unsigned eb = (unsigned)std::min<size_t>((tot + 255) / 256, 8192);
+        hipLaunchKernelGGL(spywil::add_S_kernel, dim3(eb), dim3(256), 0, ctx->stream, T1, reinterpret_cast<const cd*>(g0_d), g0S, nf, n);
+        Tmp t2;
+        if (t2.get(tot * sizeof(cd))) return -2;
+        if (gemm(ctx, psi, T1, reinterpret_cast<cd*>(t2.p), n, nf, nn, nn, nn, 0, 0)) return -2;
+        SPY_HIP_CHECK(hipMemcpyAsync(T1, t2.p, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+        SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    SPY_HIP_CHECK(hipMemcpyAsync(psi, T1, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    if (gemm(ctx, reinterpret_cast<cd*>(psi0_d), g0S, p0n, n, 1, nn, nn, nn, 0, 0)) return -2;
+    SPY_HIP_CHECK(hipMemcpyAsync(psi0_d, p0n, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    double* outp = part + npart;
+    if (fused) {
+        if (gemm(ctx, psi, psi, nullptr, n, nf, nn, nn, nn, 1, 0, nullptr, reinterpret_cast<const cd*>(A_d), part)) return -2;
+        hipLaunchKernelGGL(spywil::maxred_kernel, dim3(1), dim3(256), 0, ctx->stream, part, mt * mt * nf, outp);
+    } else {
+        if (gemm(ctx, psi, psi, T1, n, nf, nn, nn, nn, 1, 0)) return -2;
+        hipLaunchKernelGGL(spywil::relerr_kernel, dim3(1024), dim3(256), 0, ctx->stream, reinterpret_cast<const cd*>(A_d), T1,
+                           (long long)tot, part);
+        hipLaunchKernelGGL(spywil::maxred_kernel, dim3(1), dim3(256), 0, ctx->stream, part, 1024, outp);
+    }
+    SPY_HIP_CHECK(hipGetLastError());
+    SPY_HIP_CHECK(hipMemcpyAsync(err_out, outp, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Sigma = psi0 psi0^T, H = psi psi0^-1, Granger-Geweke causality on the local bins (wilson_sf.py:113-120,
+// granger.py:53-77).  granger_d float32 (nf, n, n); H_d (nf, n, n) / Sigma_d (n, n) complex128 may be NULL.
+extern "C" int spyhip_wilson_finish(spyhip_ctx* ctx, const void* A_d, const void* psi_d, const void* psi0_d, int nf, int n,
+                                    void* work_d, void* granger_d, void* H_d, void* Sigma_d) {
+    if (!ctx || !A_d || !psi_d || !psi0_d || !work_d || !granger_d) { spy::set_error("wilson_finish: null argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long nn = (long long)n * n;
+    const size_t tot = (size_t)nf * nn;
+    cd* T1 = reinterpret_cast<cd*>(work_d);
+    Tmp t;
+    if (t.get(2 * (size_t)nn * sizeof(cd) + sizeof(int))) return -2;
+    cd* Sig = reinterpret_cast<cd*>(t.p);
+    cd* inv0 = Sig + nn;
+    int* inf = reinterpret_cast<int*>(inv0 + nn);
+    const cd* psi0 = reinterpret_cast<const cd*>(psi0_d);
+    if (gemm(ctx, psi0, psi0, Sig, n, 1, nn, nn, nn, 1, 0)) return -2;
+    SPY_HIP_CHECK(hipMemcpyAsync(inv0, psi0, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    if (invert(ctx, inv0, n, 1, inf)) return -2;
+    if (gemm(ctx, reinterpret_cast<const cd*>(psi_d), inv0, T1, n, nf, nn, 0, nn, 0, 0)) return -2;
+    const unsigned eb = (unsigned)std::min<size_t>((tot + 255) / 256, 8192);
+    hipLaunchKernelGGL(spywil::granger_kernel, dim3(eb), dim3(256), 0, ctx->stream, reinterpret_cast<const cd*>(A_d), T1, Sig, nf, n,
+                       reinterpret_cast<float*>(granger_d));
+    SPY_HIP_CHECK(hipGetLastError());
+    if (H_d) SPY_HIP_CHECK(hipMemcpyAsync(H_d, T1, tot * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    if (Sigma_d) SPY_HIP_CHECK(hipMemcpyAsync(Sigma_d, Sig, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}

@@ -676,13 +676,14 @@ __global__ void __launch_bounds__(256) zchol_kernel(cd* M, int n, int* info) {
 
 // ---- gamma0 = sum over the full (mirrored) frequency axis = A[0] + A[F-1] + sum_{0<f<F-1} 2 Re-part...
 // (fft(CSD_full)[0], wilson_sf.py:135-140), then symmetrised real part: out[i,j] = Re((g[i,j] + conj(g[j,i]))/2)
-__global__ void __launch_bounds__(256) gamma0_kernel(const cd* A, int F, int n, cd* out) {
+// (A holds the F bins [f_lo, f_lo + F) of Ftot: a frequency shard contributes its part of the sum)
+__global__ void __launch_bounds__(256) gamma0_kernel(const cd* A, int F, int n, cd* out, int f_lo, int Ftot) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * n) return;
     const int i = e / n, j = e - i * n;
     double s = 0.0;
     for (int f = 0; f < F; ++f) {
-        const double w = (f == 0 || f == F - 1) ? 1.0 : 2.0;   // +f and -f: a + conj(a) = 2 Re(a) ... per entry pair
+        const double w = (f + f_lo == 0 || f + f_lo == Ftot - 1) ? 1.0 : 2.0;   // +f and -f: a + conj(a) = 2 Re(a) ... per entry pair
         // full-spectrum sum of entry (i,j): A[f][i][j] + conj(A[f][i][j]) for mirrored f
         const cd a = A[((size_t)f * n + i) * n + j], b = A[((size_t)f * n + j) * n + i];
         // Re( (g_ij + conj(g_ji)) / 2 ) with g = sum over full spectrum
@@ -762,13 +763,14 @@ __device__ __forceinline__ void po_pass_any(const cd* in, cd* out, int L, int R,
     else po_pass(in, out, L, R, Ns, tw, sign, tid);
 }
 
-__global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, int n, PlusPlan pl, const cd* tw, cd* gp, cd* g0) {
+// nent = entries per frequency row (n^2 for the whole matrix, fewer for an entry shard of the sharded factorisation)
+__global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, long long nent, PlusPlan pl, const cd* tw, cd* gp, cd* g0) {
     SPY_DYN_SMEM(cd, buf);          // 2 x L
     const int L = pl.L, tid = threadIdx.x;
     const int e = blockIdx.x;       // entry i*n + j
     cd* a = buf;
     cd* b = buf + L;
-    const size_t fs = (size_t)n * n;
+    const size_t fs = (size_t)nent;
     for (int f = tid; f < F; f += 256) {
         const cd v = g[(size_t)f * fs + e];
         a[f] = v;

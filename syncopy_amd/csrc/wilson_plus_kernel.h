@@ -226,17 +226,18 @@ __device__ __forceinline__ void p_pair(cd (&ga)[8], cd (&gb)[8], cd& gn_a, cd& g
     }
 }
 
-// grid = ceil(n^2 / 4) workgroups of T threads; g, gp: (F, n, n) complex128; g0: (n, n).  The two pairs of a
+// grid = ceil(nent / 4) workgroups of T threads; g, gp: (F, nent) complex128 (nent = n^2 for a whole matrix, fewer for
+// an entry shard of the frequency-sharded factorisation); g0: (nent).  The two pairs of a
 // workgroup are loaded, transformed and stored one after the other (one pair = 32 bytes per frequency row; the second
 // pair finds its half of the 64-byte pieces in the L2 / Infinity Cache): 64 data registers instead of 128, two
 // workgroups per CU.
 template <int LOG2L>
-__global__ void __launch_bounds__((PCfg<LOG2L>::T)) SPY_PLUS_KATTR plus4_kernel(const cd* g, int F, int n, const cd* tw, cd* gp, cd* g0) {
+__global__ void __launch_bounds__((PCfg<LOG2L>::T)) SPY_PLUS_KATTR plus4_kernel(const cd* g, int F, long long nent, const cd* tw, cd* gp, cd* g0) {
     using C = PCfg<LOG2L>;
     constexpr int T = C::T, half = C::L / 2;
     SPY_DYN_SMEM(cd, lds);
     const int j = threadIdx.x;
-    const size_t nn = (size_t)n * n;
+    const size_t nn = (size_t)nent;          // entries per frequency row
 #pragma unroll 1
     for (int pair = 0; pair < 2; ++pair) {
         const size_t e0 = (size_t)blockIdx.x * 4 + 2 * pair;

@@ -73,3 +73,55 @@ def gather_trials(local):
     parts = [None] * size
     dist.all_gather_object(parts, local)
     return np.concatenate([p for p in parts if p is not None and p.shape[0] > 0], axis=0)
+
+
+def allreduce_max(value):
+    """Largest value of a host scalar over the ranks (condition numbers, convergence errors)."""
+    if not collective_active():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def exchange(send, recv_shapes):
+    """Personalised all-to-all: rank q receives send[q] of every rank.  `send`: one contiguous tensor per rank,
+    `recv_shapes`: the shape of what rank r sends to me, per r.  Point-to-point (isend / irecv), so it runs on RCCL
+    and on gloo alike; complex tensors travel as interleaved reals."""
+    rank, size = world()
+    if size == 1 or not collective_active():
+        return [send[0]]
+    out = [torch.empty(tuple(recv_shapes[r]), dtype=send[rank].dtype, device=send[rank].device) for r in range(size)]
+    out[rank].copy_(send[rank])
+    ops = []
+    view = (lambda t: torch.view_as_real(t)) if send[rank].is_complex() else (lambda t: t)
+    for r in range(size):
+        if r == rank:
+            continue
+        if send[r].numel():
+            ops.append(dist.P2POp(dist.isend, view(send[r]), r))
+        if out[r].numel():
+            ops.append(dist.P2POp(dist.irecv, view(out[r]), r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+def allgather_cat(local, sizes, dim=0):
+    """Concatenate per-rank tensors whose extent along `dim` is sizes[r] (all-gather with padding to the largest)."""
+    rank, size = world()
+    if size == 1 or not collective_active():
+        return local
+    big = max(sizes)
+    shape = list(local.shape)
+    shape[dim] = big
+    pad = torch.zeros(shape, dtype=local.dtype, device=local.device)
+    pad.narrow(dim, 0, local.shape[dim]).copy_(local)
+    parts = [torch.empty_like(pad) for _ in range(size)]
+    cplx = local.is_complex()
+    dist.all_gather([torch.view_as_real(p) for p in parts] if cplx else parts,
+                    torch.view_as_real(pad) if cplx else pad)
+    return torch.cat([parts[r].narrow(dim, 0, sizes[r]) for r in range(size)], dim=dim)

@@ -125,7 +125,7 @@ template <int LOG2L>
 void run_plus4(const double* g, int F, int n, const double* tw, double* gp, double* g0) {
     using C = spywil::PCfg<LOG2L>;
     emu::launch(dim3((unsigned)((n * n + 3) / 4)), dim3(C::T), C::LDS_BYTES, [&] {
-        spywil::plus4_kernel<LOG2L>(reinterpret_cast<const spywil::cd*>(g), F, n, reinterpret_cast<const spywil::cd*>(tw),
+        spywil::plus4_kernel<LOG2L>(reinterpret_cast<const spywil::cd*>(g), F, (long long)n * n, reinterpret_cast<const spywil::cd*>(tw),
                                     reinterpret_cast<spywil::cd*>(gp), reinterpret_cast<spywil::cd*>(g0)); });
 }
 
@@ -583,7 +583,7 @@ void emu_w_chol(double* M, int n, int batch, int* info) {
     emu::launch(dim3(batch), dim3(256), (size_t)n * 16, [&] { spywil::zchol_kernel(reinterpret_cast<cd*>(M), n, info); });
 }
 void emu_w_gamma0(const double* A, int F, int n, double* out) {
-    emu::launch(dim3((n * n + 255) / 256), dim3(256), 0, [&] { spywil::gamma0_kernel(reinterpret_cast<const cd*>(A), F, n, reinterpret_cast<cd*>(out)); });
+    emu::launch(dim3((n * n + 255) / 256), dim3(256), 0, [&] { spywil::gamma0_kernel(reinterpret_cast<const cd*>(A), F, n, reinterpret_cast<cd*>(out), 0, F); });
 }
 int emu_w_plus(const double* g, int F, int n, const double* tw, double* gp, double* g0) {
     spywil::PlusPlan pl{};
@@ -594,7 +594,7 @@ int emu_w_plus(const double* g, int F, int n, const double* tw, double* gp, doub
     for (int c : cand) while (m % c == 0 && m > 1) { pl.radix[k++] = c; m /= c; }
     for (int p = 17; m > 1; p += 2) while (m % p == 0) { pl.radix[k++] = p; m /= p; }
     pl.nfac = k;
-    emu::launch(dim3(n * n), dim3(256), (size_t)2 * L * 16, [&] { spywil::plus_kernel(reinterpret_cast<const cd*>(g), F, n, pl, reinterpret_cast<const cd*>(tw), reinterpret_cast<cd*>(gp), reinterpret_cast<cd*>(g0)); });
+    emu::launch(dim3(n * n), dim3(256), (size_t)2 * L * 16, [&] { spywil::plus_kernel(reinterpret_cast<const cd*>(g), F, (long long)n * n, pl, reinterpret_cast<const cd*>(tw), reinterpret_cast<cd*>(gp), reinterpret_cast<cd*>(g0)); });
     return k;
 }
 int emu_w_plus4(const double* g, int F, int n, const double* tw, double* gp, double* g0) {

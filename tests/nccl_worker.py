@@ -32,6 +32,11 @@ def main(out_path):
         res["corr"] = spy.connectivityanalysis(data, method="corr").data
         res["pow_avg"] = spy.freqanalysis(data, method="mtmfft", tapsmofrq=3, keeptrials=False).data
         res["pow"] = spy.freqanalysis(data, method="mtmfft", tapsmofrq=3).data
+        # AV stage with the frequencies sharded over the ranks (spyhip_wilson_* steps, wilson_sharded.py)
+        gr = spy.connectivityanalysis(data, method="granger", tapsmofrq=3)
+        res["granger"] = gr.data
+        res["granger_info"] = np.array([gr.info["converged"], gr.info["max rel. err"], gr.info["reg. factor"],
+                                        gr.info["initial cond. num"]], dtype=np.float64)
         # bench.py's own sequence on a raw accumulator, bit-compared with the untouched lower triangle
         g = torch.Generator(device="cuda").manual_seed(1)
         spec = torch.view_as_complex(torch.randn((21, 130, 256, 2), generator=g, device="cuda"))

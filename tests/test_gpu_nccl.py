@@ -63,6 +63,12 @@ def test_front_ends_under_nccl_group(tmp_path):
             from parity import assert_parity
             assert_parity(z[k], v, what=k)
     assert np.array_equal(z["pow"], ref["pow"])           # stacked trials: bit-identical for any number of ranks
+    # Granger: the group-less run is ONE spyhip_granger call, the group run the stepped, frequency-sharded sequence
+    gr = spy.connectivityanalysis(data, method="granger", tapsmofrq=3)
+    assert bool(z["granger_info"][0]) and gr.info["converged"]
+    assert z["granger_info"][2] == gr.info["reg. factor"]
+    np.testing.assert_allclose(z["granger_info"][3], gr.info["initial cond. num"], rtol=1e-6)
+    np.testing.assert_allclose(z["granger"], gr.data, rtol=1e-4, atol=1e-6)
 
 
 def test_bench_distributed_branch():

@@ -152,6 +152,60 @@ def test_wilson_granger_vs_oracle(C):
     np.testing.assert_allclose(G, Go, rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("C,F", [(16, 65), (33, 129), (64, 257), (256, 2049)])
+def test_wilson_steps_equal_monolithic(C, F):
+    """The stepped K6 entry points (spyhip_wilson_*, the frequency-shard ABI) driven by wilson_sharded.granger_sharded
+    with one rank run the same kernels in the same order as spyhip_granger: same iteration count, same values."""
+    from syncopy_amd import backend
+    from syncopy_amd.connectivity.wilson_sharded import HipPrims, granger_sharded
+    csd = torch.from_numpy(_var_csd(C, F, seed=C + 1)).cuda()
+    G0, meta0, H0, S0 = backend.granger(csd, want_factors=True)
+    it0 = backend.granger_stats()["iterations"]
+    G1, meta1, H1, S1 = granger_sharded(csd, 0, F, HipPrims(csd.device))
+    assert meta1["converged"] and meta0["converged"] and meta1["iterations"] == it0
+    assert meta1["reg. factor"] == meta0["reg. factor"]
+    np.testing.assert_allclose(meta1["initial cond. num"], meta0["initial cond. num"], rtol=1e-9)
+    np.testing.assert_allclose(H1.cpu().numpy(), H0.cpu().numpy(), rtol=1e-9, atol=1e-11 * float(H0.abs().max()))
+    np.testing.assert_allclose(S1.cpu().numpy(), S0.cpu().numpy(), rtol=1e-9, atol=1e-11 * float(S0.abs().max()))
+    np.testing.assert_allclose(G1.cpu().numpy(), G0.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_wilson_shards_of_one_device():
+    """Two and three frequency shards emulated on ONE device: per-shard steps on slices, the exchanges replaced by
+    slicing/concatenation - checks the f_lo/nftot and nent arguments of the step ABI against the unsharded call."""
+    from syncopy_amd import backend
+    from syncopy_amd import parallel
+    from syncopy_amd.connectivity.wilson_sharded import HipPrims
+    C, F = 33, 129
+    csd = torch.from_numpy(_var_csd(C, F, seed=9)).cuda()
+    G0, meta0, H0, S0 = backend.granger(csd, want_factors=True)
+    it0 = backend.granger_stats()["iterations"]
+    P = HipPrims(csd.device)
+    for R in (2, 3):
+        fb, eb = parallel.shard_bounds(F, R), parallel.shard_bounds(C * C, R)
+        A, U, gam = [], [], 0
+        for lo, hi in fb:
+            a, _ = P.cond(csd[lo:hi].contiguous(), 0.0)
+            u, gp = P.init(a, lo, F)
+            A.append(a); U.append(u); gam = gam + gp
+        psi0s, psis = zip(*[P.psi0(gam.clone(), hi - lo) for lo, hi in fb])
+        for it in range(it0):
+            g = torch.cat([P.g(psis[r], U[r], False)[0].reshape(-1, C * C) for r in range(R)], dim=0)
+            parts = [P.plus(g[:, lo:hi].contiguous()) for lo, hi in eb]
+            gp = torch.cat([p[0] for p in parts], dim=1)
+            g0 = torch.cat([p[1] for p in parts]).reshape(C, C)
+            err = max(P.update(psis[r], gp[lo:hi].reshape(-1, C, C).contiguous(), g0, psi0s[r], A[r])
+                      for r, (lo, hi) in enumerate(fb))
+        assert err < 5e-6
+        outs = [P.finish(A[r], psis[r], psi0s[r]) for r in range(R)]
+        G = torch.cat([o[0] for o in outs], dim=0)
+        H = torch.cat([o[1] for o in outs], dim=0)
+        np.testing.assert_allclose(H.cpu().numpy(), H0.cpu().numpy(), rtol=1e-8, atol=1e-10 * float(H0.abs().max()))
+        np.testing.assert_allclose(G.cpu().numpy(), G0.cpu().numpy(), rtol=1e-5, atol=1e-7)
+        for o in outs:
+            np.testing.assert_allclose(o[2].cpu().numpy(), S0.cpu().numpy(), rtol=1e-9, atol=1e-11 * float(S0.abs().max()))
+
+
 def test_wilson_reconstruction_256x2049():
     """BASELINE configs[4] AV stage at full size: the CSD of 120 trials x 7 tapers of 256 ch x 4096 (K1 + K4 on the
     device), factorised by K6; acceptance = the reference's max_rel_err(CSD, H Sigma H^H) (test_conn.py:197-202),
