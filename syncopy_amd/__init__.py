@@ -11,6 +11,7 @@ __version__ = "0.1.0"
 
 from .datatype import AnalogData, CrossSpectralData, SpectralData  # noqa: F401
 from . import synthdata  # noqa: F401
+from .io import load, save  # noqa: F401
 from .shared.kwarg_decorators import StructDict, get_defaults  # noqa: F401
 
 # The front ends keep their tensors in PyTorch (device memory, streams, torch.distributed) and are imported on first

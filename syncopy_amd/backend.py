@@ -77,10 +77,7 @@ def to_host(t):
     flat = t.view(-1).view(torch.uint8) if not t.is_complex() else torch.view_as_real(t).view(-1).view(torch.uint8)
     out = np.empty(t.shape, dtype=_NP_DTYPE[t.dtype])
     dst = out.reshape(-1).view(np.uint8)
-    stage = _pin.get("buf")
-    if stage is None:
-        stage = _pin["buf"] = (torch.empty(_PIN_BYTES, dtype=torch.uint8, pin_memory=True),
-                               torch.empty(_PIN_BYTES, dtype=torch.uint8, pin_memory=True))
+    stage = _staging()
     stream = torch.cuda.current_stream(t.device)
     pending = None                                   # (event, staging buffer, offset, length) of the copy in flight
     for k, off in enumerate(range(0, nbytes, _PIN_BYTES)):
@@ -96,6 +93,48 @@ def to_host(t):
     pending[0].synchronize()
     dst[pending[2]:pending[2] + pending[3]] = pending[1][:pending[3]].numpy()
     return out
+
+
+def _staging():
+    stage = _pin.get("buf")
+    if stage is None:
+        stage = _pin["buf"] = (torch.empty(_PIN_BYTES, dtype=torch.uint8, pin_memory=True),
+                               torch.empty(_PIN_BYTES, dtype=torch.uint8, pin_memory=True))
+    return stage
+
+
+def to_device(host, device, time_axis=0):
+    """Host recording -> (time x channel) float32 matrix in HBM: the ingress of the in-HBM trial queue.
+    `host` may be an np.memmap onto a `.spy` data file (io/spy_container.py) of any size: blocks of rows are read
+    (and, if needed, converted to float32 / transposed - dimord ["channel", "time"], compRoutines.py:143-146) straight
+    into two alternating pinned staging buffers and copied to the device asynchronously, so the file is never held in
+    host memory as a whole and the disk read of block k+1 overlaps the PCIe copy of block k."""
+    ntime, nchan = (host.shape if time_axis == 0 else host.shape[::-1])
+    dev = torch.empty((ntime, nchan), dtype=torch.float32, device=device)
+    nbytes = ntime * nchan * 4
+    direct = (time_axis == 0 and host.dtype == np.float32 and host.flags["C_CONTIGUOUS"]
+              and not isinstance(host, np.memmap))
+    if direct and nbytes < (64 << 20):
+        dev.copy_(torch.from_numpy(host))
+        return dev
+    stage = _staging()
+    rows_per = max(1, _PIN_BYTES // (4 * max(nchan, 1)))
+    stream = torch.cuda.current_stream(dev.device)
+    events = [None, None]
+    for k, r0 in enumerate(range(0, ntime, rows_per)):
+        r1 = min(ntime, r0 + rows_per)
+        buf = stage[k & 1]
+        if events[k & 1] is not None:
+            events[k & 1].synchronize()                # the copy that last used this buffer has left it
+        view = buf[:(r1 - r0) * nchan * 4].view(torch.float32).view(r1 - r0, nchan).numpy()
+        np.copyto(view, host[r0:r1] if time_axis == 0 else host[:, r0:r1].T, casting="unsafe")
+        dev[r0:r1].copy_(buf[:(r1 - r0) * nchan * 4].view(torch.float32).view(r1 - r0, nchan), non_blocking=True)
+        events[k & 1] = torch.cuda.Event()
+        events[k & 1].record(stream)
+    for ev in events:
+        if ev is not None:
+            ev.synchronize()
+    return dev
 
 
 # reusable (rows, F, C) spectra buffers of the coherence path, one per (shape, device): the FFT -> CSD hand-over

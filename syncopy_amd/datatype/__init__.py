@@ -150,9 +150,8 @@ class AnalogData(_Base):
         # the copy belongs to one host array in one orientation: a new array object, shape or dimord uploads again
         key = (id(self._data), self._data.shape, tuple(self.dimord), str(dev))
         if self._device is None or self._device_key != key:
-            host = self.data if self.dimord.index("time") == 0 else self.data.T
-            host = np.ascontiguousarray(host, dtype=np.float32)
-            self._device = torch.from_numpy(host).to(dev)
+            from ..backend import to_device
+            self._device = to_device(self.data, dev, time_axis=self.dimord.index("time"))
             self._device_key = key
         return self._device
 

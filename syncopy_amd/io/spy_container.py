@@ -1,0 +1,281 @@
+"""Syncopy's on-disk format, read and written without h5py (io/load_spy_container.py:34, io/save_spy_container.py:19).
+
+A Syncopy object on disk is a pair: `<name>.<class>` - an HDF5 file with the datasets "data" and "trialdefinition"
+- and `<name>.<class>.info` - a JSON side-car with the class name, dimord, samplerate, labels, cfg, log and the
+raw-access triple (data_dtype, data_shape, data_offset).  Pairs usually live in a container directory `<session>.spy`
+as `<session>[_<tag>].<class>`.
+
+load(): JSON -> class, HDF5 -> datasets.  "data" is a read-only np.memmap onto the file (never copied on the host):
+`AnalogData.device_data()` streams it into the in-HBM trial queue through pinned staging buffers, honouring dimord
+(time axis second: transposed while staging), `trialdefinition` and in-place selections exactly as for in-memory data.
+save(): writes results (SpectralData / CrossSpectralData / AnalogData) as a pair unmodified Syncopy loads:
+required JSON fields of load_spy_container.py:265-273, datasets readable by any libhdf5, checksum as
+io/utils.py:49-60 computes it.
+"""
+import getpass
+import hashlib
+import json
+import os
+import socket
+import time
+from glob import glob
+
+import numpy as np
+
+from .. import __version__ as _pkg_version
+from ..datatype import AnalogData, CrossSpectralData, SpectralData
+from ..shared.errors import SPYError, SPYIOError, SPYTypeError, SPYValueError, SPYWarning
+from . import hdf5_min
+
+FILE_EXT = {"dir": ".spy", "info": ".info", "data": (".analog", ".spectral", ".crossspectral")}
+_CLASSES = {"AnalogData": (AnalogData, ".analog", ("samplerate", "channel")),
+            "SpectralData": (SpectralData, ".spectral", ("samplerate", "channel", "taper", "freq")),
+            "CrossSpectralData": (CrossSpectralData, ".crossspectral", ("samplerate", "channel_i", "channel_j", "freq"))}
+_BASE_INFO = ("dimord", "_version", "_log", "cfg", "info")
+_START_INFO = ("filename", "dataclass", "data_dtype", "data_shape", "data_offset", "trl_dtype", "trl_shape", "trl_offset",
+               "file_checksum", "order", "checksum_algorithm")
+_UNSUPPORTED = (".spike", ".event", ".timelock")
+
+
+def _parse(path):
+    """Split a path into folder / container / file name / basename / extension / tag (shared/parsers.py:603-732)."""
+    path = os.path.abspath(os.path.expanduser(path))
+    folder, fname = os.path.split(path)
+    container = os.path.basename(folder)
+    base, ext = os.path.splitext(fname)
+    if fname.count(".") > 2:
+        raise SPYValueError(f"single extension, found {fname.count('.')}", varname="filename", actual=fname)
+    if ext == FILE_EXT["info"]:
+        fname = base
+        base, ext = os.path.splitext(fname)
+    elif ext == FILE_EXT["dir"]:
+        if base.count("."):
+            raise SPYValueError(f"no extension, found {base.count('.')}", varname="container", actual=base)
+        return {"filename": None, "container": fname, "folder": folder, "tag": None, "basename": base, "extension": ext}
+    if ext in _UNSUPPORTED:
+        raise SPYValueError(str(FILE_EXT["data"]), varname="filename extension",
+                            actual=f"{ext} (outside the spectral / connectivity path this package covers)")
+    if ext not in FILE_EXT["data"]:
+        raise SPYValueError(str(FILE_EXT["data"]), varname="filename extension", actual=ext)
+    tag = None
+    if os.path.splitext(container)[1] == FILE_EXT["dir"]:
+        cbase = os.path.splitext(container)[0]
+        if not base.startswith(cbase):
+            raise SPYValueError(cbase, varname="start of filename", actual=fname)
+        tag = base[len(cbase):].lstrip("_") or None
+    return {"filename": fname, "container": container if container.endswith(FILE_EXT["dir"]) else None,
+            "folder": folder, "tag": tag, "basename": base, "extension": ext}
+
+
+def hash_file(path, bsize=65536):
+    """SHA-1 of the file contents (io/utils.py:49-60 with the package default `openssl_sha1`)."""
+    h = hashlib.sha1()
+    with open(path, "rb") as fh:
+        for block in iter(lambda: fh.read(bsize), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
+def _plain(value, seen=None):
+    """A JSON-serialisable copy: arrays -> lists, NumPy scalars -> Python scalars, anything else -> str."""
+    seen = set() if seen is None else seen
+    if isinstance(value, dict):
+        if id(value) in seen:
+            return "<cycle>"
+        seen.add(id(value))
+        return {str(k): _plain(v, seen) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [_plain(v, seen) for v in value]
+    if isinstance(value, np.ndarray):
+        return _plain(value.tolist(), seen)
+    if isinstance(value, np.generic):
+        value = value.item()
+    if value is None or isinstance(value, (bool, int, str)):
+        return value
+    if isinstance(value, float):
+        return value
+    if isinstance(value, complex):
+        return str(value)
+    return str(value)
+
+
+def _log_entry(text):
+    stamp = time.strftime("%a %b %d %H:%M:%S %Y")
+    try:
+        who = getpass.getuser()
+    except Exception:
+        who = "user"
+    return f"\n\n|=== {who}@{socket.gethostname()}: {stamp} ===|\n\n\t{text}"
+
+
+# ------------------------------------------------------------------------------------------------------ save
+def save(out, container=None, tag=None, filename=None, overwrite=False):
+    """Write `out` as `<name>.<class>` + `<name>.<class>.info` (argument meaning and errors as
+    save_spy_container.py:19-166: `container` [+ `tag`] or `filename`, never both; the class extension is added
+    when missing and checked when present; existing files need overwrite=True)."""
+    cls = type(out).__name__
+    if cls not in _CLASSES or out.data is None:
+        raise SPYTypeError(out, varname="out", expected="non-empty AnalogData, SpectralData or CrossSpectralData")
+    ext = _CLASSES[cls][1]
+    if filename is None and container is None:
+        raise SPYError("filename and container cannot both be `None`")
+    if container is not None and filename is not None:
+        raise SPYError("container and filename cannot be used at the same time")
+    if container is not None:
+        if not isinstance(container, str):
+            raise SPYTypeError(container, varname="container", expected="str")
+        if os.path.splitext(container)[1] != FILE_EXT["dir"]:
+            container += FILE_EXT["dir"]
+        info = _parse(container)
+        filename = os.path.join(info["folder"], info["container"], info["basename"])
+        if tag is not None:
+            if not isinstance(tag, str):
+                raise SPYTypeError(tag, varname="tag", expected="str")
+            filename += "_" + tag
+    if not isinstance(filename, str):
+        raise SPYTypeError(filename, varname="filename", expected="str")
+    if "." not in os.path.splitext(filename)[1]:
+        filename += ext
+    if not isinstance(overwrite, bool):
+        raise SPYTypeError(overwrite, varname="overwrite", expected="bool")
+    info = _parse(filename)
+    if info["extension"] != ext:
+        raise SPYError(f"Extension in filename ('{info['extension']}') does not match data class ({cls}), "
+                       f"expected '{ext}'.")
+    data_file = os.path.join(info["folder"], info["filename"])
+    info_file = data_file + FILE_EXT["info"]
+    os.makedirs(info["folder"], exist_ok=True)
+    if os.path.exists(data_file):
+        if not os.path.isfile(data_file):
+            raise SPYIOError(f"{data_file} is not a file")
+        if not overwrite:
+            raise SPYIOError(f"{data_file} already exists (pass overwrite=True)")
+    data = out.data
+    if isinstance(data, np.memmap) and os.path.abspath(getattr(data, "filename", "") or "") == data_file:
+        data = np.array(data)                      # the object replaces its own backing file: detach first
+    trl = np.array(out.trialdefinition, dtype=np.float64)
+    out.log = (out.log or "") + _log_entry(f"save: Wrote files {data_file}\n\t\t\t  {info_file}")
+    meta = {"filename": info["filename"], "dataclass": cls, "data_dtype": np.dtype(data.dtype).name,
+            "data_shape": list(data.shape), "data_offset": None, "trl_dtype": trl.dtype.name, "trl_shape": list(trl.shape),
+            "trl_offset": None, "file_checksum": None, "order": "C", "checksum_algorithm": "openssl_sha1",
+            "dimord": list(out.dimord), "_version": f"syncopy_amd-{_pkg_version}", "_log": out.log,
+            "cfg": _plain(out.cfg or {}), "info": _plain(out.info or {})}
+    for key in _CLASSES[cls][2]:
+        meta[key] = _plain(getattr(out, key))
+    attrs = {}
+    for key in ("dimord", "_version", "_log") + _CLASSES[cls][2]:      # the root attributes mirror the side-car
+        v = meta[key]
+        if v is None:
+            attrs[key] = "None"
+        elif isinstance(v, list) and len(v) > 512:
+            attrs[key] = [str(v[0]), "...", str(v[-1])]                 # truncated as save_spy_container.py:263-272
+        elif isinstance(v, list) and v and not isinstance(v[0], str):
+            attrs[key] = np.asarray(v)
+        else:
+            attrs[key] = v
+    offsets = hdf5_min.write_file(data_file, {"data": np.asarray(data), "trialdefinition": trl}, attrs)
+    meta["data_offset"], meta["trl_offset"] = offsets["data"], offsets["trialdefinition"]
+    meta["_hdfFileDatasetProperties"] = ["data"]
+    meta["file_checksum"] = hash_file(data_file)
+    with open(info_file, "w") as fh:
+        json.dump(meta, fh, indent=4)
+    out.filename = data_file
+
+
+# ------------------------------------------------------------------------------------------------------ load
+def load(filename, tag=None, dataclass=None, checksum=False, mode="r", out=None):
+    """Load one object (a data file, its .info file, or a container holding one match) or all matches of a container
+    as {file name: object} (load_spy_container.py:34-233).  `mode`: data are memory-mapped read-only whatever is
+    asked - results are new objects here, loaded inputs are never edited in place."""
+    if not isinstance(filename, str):
+        raise SPYTypeError(filename, varname="filename", expected="str")
+    if not os.path.splitext(os.path.abspath(os.path.expanduser(filename)))[1]:
+        filename += FILE_EXT["dir"]
+    info = _parse(filename)
+    if mode not in ("r", "r+", "w", "c"):
+        raise SPYValueError("'r', 'r+', 'w' or 'c'", varname="mode", actual=str(mode))
+    if not isinstance(checksum, bool):
+        raise SPYTypeError(checksum, varname="checksum", expected="bool")
+    tags = ["*"]
+    if tag is not None:
+        tags = [tag] if isinstance(tag, str) else list(tag)
+        if not all(isinstance(t, str) for t in tags):
+            raise SPYTypeError(tag, varname="tag", expected="str or list of str")
+        if info["filename"] is not None:
+            raise SPYError("Only containers can be loaded with `tag` keyword!")
+        tags = ["*" + t + "*" for t in tags]
+    exts = FILE_EXT["data"]
+    if dataclass is not None:
+        wanted = [dataclass] if isinstance(dataclass, str) else list(dataclass)
+        if not all(isinstance(d, str) for d in wanted):
+            raise SPYTypeError(dataclass, varname="dataclass", expected="str or list of str")
+        wanted = [d if d.startswith(".") else "." + d for d in wanted]
+        exts = tuple(e for e in FILE_EXT["data"] if e in wanted)
+        if not exts:
+            raise SPYValueError("extension(s) " + " or ".join(FILE_EXT["data"]), varname="dataclass", actual=str(wanted))
+    if info["filename"] is not None:
+        if dataclass is not None and info["extension"] not in exts:
+            raise SPYValueError("extension " + " or ".join(exts), varname="filename", actual=info["filename"])
+        return _load_one(os.path.join(info["folder"], info["filename"]), checksum, out)
+    container = os.path.join(info["folder"], info["container"])
+    if not os.path.isdir(container):
+        raise SPYIOError(f"Cannot read {container}: no such container")
+    files = sorted({f for e in exts for t in tags for f in glob(os.path.join(container, t + e))})
+    if not files:
+        raise SPYIOError(f"Cannot read {container}: no data file matching tag {tags} with extension {exts}")
+    if len(files) == 1:
+        return _load_one(files[0], checksum, out)
+    if out is not None:
+        SPYWarning("When loading multiple objects, the `out` keyword is ignored")
+    return {os.path.basename(f): _load_one(f, checksum, None) for f in files}
+
+
+def _load_one(data_file, checksum, out):
+    info_file = data_file + FILE_EXT["info"]
+    for f in (data_file, info_file):
+        if not os.path.isfile(f):
+            raise SPYIOError(f"Cannot read {f}: file does not exist")
+    with open(info_file, "r") as fh:
+        meta = json.load(fh)
+    if "dataclass" not in meta:
+        raise SPYError(f"Info file {info_file} does not contain a dataclass field")
+    if meta["dataclass"] not in _CLASSES:
+        raise SPYError(f"Unknown or unsupported data class {meta['dataclass']} (this package loads "
+                       f"{', '.join(_CLASSES)})")
+    klass, _, extra = _CLASSES[meta["dataclass"]]
+    for key in _START_INFO + _BASE_INFO + extra:
+        if key not in meta and key not in ("info", "cfg", "order", "checksum_algorithm"):
+            raise SPYError(f"Required field {key} for {meta['dataclass']} not in {info_file}")
+    if checksum:
+        h = hash_file(data_file)
+        if h != meta["file_checksum"]:
+            raise SPYValueError(f"hash = {meta['file_checksum']}", varname=os.path.basename(data_file),
+                                actual=f"hash = {h}")
+    dsets = hdf5_min.read_datasets(data_file, ["data", "trialdefinition"])
+    data, off = dsets["data"]
+    if list(data.shape) != list(meta["data_shape"]) or np.dtype(data.dtype).name != meta["data_dtype"]:
+        raise SPYError(f"{data_file}: dataset 'data' is {data.dtype}{data.shape}, the info file says "
+                       f"{meta['data_dtype']}{tuple(meta['data_shape'])}")
+    if meta.get("data_offset") is not None and off is not None and int(meta["data_offset"]) != off:
+        raise SPYError(f"{data_file}: 'data' starts at byte {off}, the info file says {meta['data_offset']}")
+    trl = np.array(dsets["trialdefinition"][0], dtype=np.float64)
+    if out is None:
+        obj = klass(dimord=meta["dimord"])
+    else:
+        if type(out) is not klass or out.data is not None:
+            raise SPYTypeError(out, varname="out", expected=f"empty {meta['dataclass']} object")
+        obj = out
+        obj.dimord = list(meta["dimord"])
+    obj.data = data
+    obj.trialdefinition = trl
+    for key in extra:
+        v = meta[key]
+        if key == "samplerate":
+            obj.samplerate = None if v is None else float(v)
+        else:
+            setattr(obj, key, None if v is None else np.array(v))
+    obj.cfg = meta.get("cfg") or {}
+    obj.info = meta.get("info") or {}
+    obj.log = (meta.get("_log") or "") + _log_entry(f"load: Read files v. {meta['_version']} {data_file}\n\t\t{info_file}")
+    obj.filename = data_file
+    return obj if out is None else None

@@ -1,0 +1,185 @@
+"""`.spy` container ingress / egress without h5py.  The fixture container under
+tests/golden/spy_container was written by the REAL reference (`spy.save`, oracle/gen_spy_container.py): chunked
+trialdefinition, contiguous data, variable-length string attributes - whatever h5py produced."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import syncopy_amd as spy
+from syncopy_amd.io import hdf5_min
+from syncopy_amd.shared.errors import SPYError, SPYIOError, SPYTypeError, SPYValueError
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CONT = os.path.join(HERE, "golden", "spy_container", "session.spy")
+
+
+def _recording():
+    """The arrays oracle/gen_spy_container.py handed to the reference."""
+    rng = np.random.default_rng(0)
+    t = np.arange(600) / 500.0
+    x = rng.standard_normal((600, 5)).astype(np.float32)
+    x[:, 1] += np.sin(2 * np.pi * 40 * t).astype(np.float32)
+    x[:, 2] += 0.5 * x[:, 1] + 3.0
+    return x, np.array([[0, 200, -50], [200, 400, -50], [400, 600, -50]], dtype=float)
+
+
+def test_reads_reference_written_container():
+    x, trl = _recording()
+    objs = spy.load(CONT)
+    assert sorted(objs) == ["session.analog", "session_chantime.analog", "session_coh.crossspectral",
+                            "session_csd.crossspectral", "session_pow.spectral", "session_powsel.spectral"]
+    a = objs["session.analog"]
+    assert isinstance(a, spy.AnalogData) and isinstance(a.data, np.memmap)        # mapped, not copied
+    assert np.array_equal(a.data, x) and np.array_equal(a.trialdefinition, trl)
+    assert list(a.channel) == ["a", "b", "c", "d", "e"] and a.samplerate == 500.0 and a.dimord == ["time", "channel"]
+    assert [t.shape for t in a.trials] == [(200, 5)] * 3 and a.time[0][0] == -0.1
+    aT = objs["session_chantime.analog"]
+    assert aT.dimord == ["channel", "time"] and np.array_equal(aT.data, x.T)
+    assert [t.shape for t in aT.trials] == [(5, 200)] * 3
+    p = objs["session_pow.spectral"]
+    assert isinstance(p, spy.SpectralData) and p.data.shape == (3, 1, 101, 5) and p.data.dtype == np.float32
+    assert list(p.taper) == ["dpss0"] and p.freq[1] == 2.5 and p.cfg["freqanalysis"]["method"] == "mtmfft"
+    q = objs["session_csd.crossspectral"]
+    assert isinstance(q, spy.CrossSpectralData) and q.data.dtype == np.complex64 and q.data.shape == (1, 101, 5, 5)
+    assert np.allclose(q.data[0], np.conj(np.swapaxes(q.data[0], 1, 2)), atol=1e-6)      # a CSD is Hermitian
+    assert list(q.channel_i) == list(q.channel_j) == ["a", "b", "c", "d", "e"]
+
+
+def test_load_selectors_and_errors(tmp_path):
+    assert isinstance(spy.load(CONT, tag="powsel", dataclass="spectral"), spy.SpectralData)
+    assert sorted(spy.load(CONT, tag="pow")) == ["session_pow.spectral", "session_powsel.spectral"]   # '*pow*'
+    assert isinstance(spy.load(CONT[:-4], tag="coh"), spy.CrossSpectralData)           # '.spy' appended
+    assert sorted(spy.load(CONT, dataclass=[".analog"])) == ["session.analog", "session_chantime.analog"]
+    one = spy.load(os.path.join(CONT, "session_coh.crossspectral.info"))               # the .info file names the pair
+    assert one.data.shape == (1, 101, 5, 5)
+    out = spy.AnalogData()
+    assert spy.load(os.path.join(CONT, "session.analog"), out=out) is None and out.data.shape == (600, 5)
+    with pytest.raises(SPYError):
+        spy.load(os.path.join(CONT, "session.analog"), tag="pow")                      # tag needs a container
+    with pytest.raises(SPYValueError):
+        spy.load(CONT, dataclass="nonsense")
+    with pytest.raises(SPYValueError):
+        spy.load(os.path.join(CONT, "session.analog"), dataclass="spectral")
+    with pytest.raises(SPYIOError):
+        spy.load(str(tmp_path / "missing.spy"))
+    with pytest.raises(SPYIOError):
+        spy.load(CONT, tag="no_such_tag")
+    with pytest.raises(SPYTypeError):
+        spy.load(12)
+    with pytest.raises(SPYTypeError):
+        spy.load(os.path.join(CONT, "session.analog"), out=spy.SpectralData())
+    # a data file whose side-car lost a required field / names another class
+    broken = tmp_path / "b.spy"
+    shutil.copytree(CONT, broken / "session.spy")
+    info = broken / "session.spy" / "session.analog.info"
+    meta = json.loads(info.read_text())
+    del meta["samplerate"]
+    info.write_text(json.dumps(meta))
+    with pytest.raises(SPYError, match="samplerate"):
+        spy.load(str(broken / "session.spy" / "session.analog"))
+    meta["samplerate"], meta["dataclass"] = 500.0, "SpikeData"
+    info.write_text(json.dumps(meta))
+    with pytest.raises(SPYError, match="SpikeData"):
+        spy.load(str(broken / "session.spy" / "session.analog"))
+    # corrupted payload: the checksum notices
+    meta["dataclass"] = "AnalogData"
+    info.write_text(json.dumps(meta))
+    f = broken / "session.spy" / "session_pow.spectral"
+    raw = bytearray(f.read_bytes())
+    raw[4000] ^= 0xFF
+    f.write_bytes(bytes(raw))
+    spy.load(str(f))
+    with pytest.raises(SPYValueError, match="hash"):
+        spy.load(str(f), checksum=True)
+
+
+def test_save_round_trip_and_layout(tmp_path):
+    src = spy.load(CONT)
+    cont = str(tmp_path / "mine")
+    spy.save(src["session.analog"], container=cont)
+    spy.save(src["session_pow.spectral"], container=cont + ".spy", tag="pow")
+    spy.save(src["session_csd.crossspectral"], container=cont, tag="csd")
+    assert sorted(os.listdir(cont + ".spy")) == ["mine.analog", "mine.analog.info", "mine_csd.crossspectral",
+                                                  "mine_csd.crossspectral.info", "mine_pow.spectral",
+                                                  "mine_pow.spectral.info"]
+    back = spy.load(cont, checksum=True)
+    for mine, ref in (("mine.analog", "session.analog"), ("mine_pow.spectral", "session_pow.spectral"),
+                      ("mine_csd.crossspectral", "session_csd.crossspectral")):
+        a, b = back[mine], src[ref]
+        assert a.data.dtype == b.data.dtype and np.array_equal(a.data, b.data)
+        assert np.array_equal(a.trialdefinition, b.trialdefinition) and a.dimord == b.dimord
+        assert a.samplerate == b.samplerate and a.cfg == b.cfg
+    assert list(back["mine_pow.spectral"].freq) == list(src["session_pow.spectral"].freq)
+    # the side-car carries every field unmodified Syncopy requires (load_spy_container.py:265-273) and the raw-access
+    # triple is true: np.memmap at data_offset IS the data (the container's documented access without HDF5)
+    meta = json.load(open(os.path.join(cont + ".spy", "mine_pow.spectral.info")))
+    for key in ("filename", "dataclass", "data_dtype", "data_shape", "data_offset", "trl_dtype", "trl_shape",
+                "trl_offset", "file_checksum", "order", "checksum_algorithm", "dimord", "_version", "_log", "cfg",
+                "info", "samplerate", "channel", "taper", "freq", "_hdfFileDatasetProperties"):
+        assert key in meta, key
+    raw = np.memmap(os.path.join(cont + ".spy", "mine_pow.spectral"), dtype=meta["data_dtype"], mode="r",
+                    offset=meta["data_offset"], shape=tuple(meta["data_shape"]))
+    assert np.array_equal(raw, src["session_pow.spectral"].data)
+    trl = np.memmap(os.path.join(cont + ".spy", "mine_pow.spectral"), dtype=meta["trl_dtype"], mode="r",
+                    offset=meta["trl_offset"], shape=tuple(meta["trl_shape"]))
+    assert np.array_equal(trl, src["session_pow.spectral"].trialdefinition)
+    # refusing to clobber, wrong extension, both / neither target
+    with pytest.raises(SPYIOError):
+        spy.save(src["session.analog"], container=cont)
+    spy.save(src["session.analog"], container=cont, overwrite=True)
+    with pytest.raises(SPYError):
+        spy.save(src["session.analog"], filename=str(tmp_path / "x.spectral"))
+    with pytest.raises(SPYError):
+        spy.save(src["session.analog"])
+    with pytest.raises(SPYError):
+        spy.save(src["session.analog"], container=cont, filename=str(tmp_path / "x"))
+    with pytest.raises(SPYTypeError):
+        spy.save(spy.AnalogData(), filename=str(tmp_path / "empty"))
+    spy.save(src["session.analog"], filename=str(tmp_path / "plain"))                  # outside a container
+    assert os.path.isfile(tmp_path / "plain.analog") and os.path.isfile(tmp_path / "plain.analog.info")
+
+
+def test_hdf5_min_types_and_limits(tmp_path):
+    rng = np.random.default_rng(3)
+    arrays = {"f32": rng.standard_normal((4, 3, 2)).astype(np.float32), "f64": rng.standard_normal(7),
+              "c64": (rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))).astype(np.complex64),
+              "c128": rng.standard_normal(2) + 1j * rng.standard_normal(2), "i64": np.arange(-3, 3),
+              "i32": np.arange(5, dtype=np.int32), "u8": np.arange(9, dtype=np.uint8), "empty": np.zeros((0, 3))}
+    path = str(tmp_path / "t.h5")
+    off = hdf5_min.write_file(path, arrays, {"samplerate": 1000.0, "dimord": ["time", "channel"], "_log": "a\nb",
+                                             "freq": np.arange(3.0), "n": 3})
+    back = hdf5_min.read_datasets(path)
+    assert sorted(back) == sorted(arrays)
+    for k, a in arrays.items():
+        b, o = back[k]
+        assert b.dtype == a.dtype and b.shape == a.shape and np.array_equal(b, a), k
+        assert o == off[k]
+        assert o is None or o % hdf5_min.DATA_ALIGN == 0
+    with pytest.raises(KeyError):
+        hdf5_min.read_datasets(path, ["nope"])
+    with pytest.raises(hdf5_min.HDF5FormatError):
+        hdf5_min.write_file(path, {f"d{k}": np.zeros(1) for k in range(9)})
+    with pytest.raises(hdf5_min.HDF5FormatError):
+        hdf5_min.write_file(path, {"o": np.array([{}], dtype=object)})
+    (tmp_path / "junk").write_bytes(b"not hdf5 at all" * 100)
+    with pytest.raises(hdf5_min.HDF5FormatError):
+        hdf5_min.read_datasets(str(tmp_path / "junk"))
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference/syncopy") and os.path.exists("/opt/conda/bin/python3.9")),
+                    reason="build container only: needs the reference and its interpreter")
+def test_unmodified_reference_loads_what_we_save(tmp_path):
+    """Egress: syncopy.load(checksum=True, mode='r+') of a container written here, then the reference recomputes the
+    stored spectrum from the stored recording (oracle/gen_spy_container.py --check)."""
+    src = spy.load(CONT)
+    cont = str(tmp_path / "egress.spy")
+    spy.save(src["session.analog"], container=cont)
+    spy.save(src["session_pow.spectral"], container=cont, tag="pow")
+    spy.save(src["session_csd.crossspectral"], container=cont, tag="csd")
+    r = subprocess.run(["bash", os.path.join(HERE, "..", "oracle", "make_golden.sh"), "--check-container", cont],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
