@@ -12,6 +12,12 @@
 #include "mtmfft_blue_kernel.h"
 #include "mtmfft_long.h"
 #include "mtmfft_generic.h"
+#include "mtmfft_mixed_plan.h"
+
+namespace spyfft {
+int mixed_launch(hipStream_t stream, const MtmArgs& a, const MixPlan& g, int threads, size_t lds, unsigned grid, int outk,
+                 bool mean);
+}
 
 using spyfft::GenPlan;
 using spyfft::MtmArgs;
@@ -22,6 +28,9 @@ struct spyhip_fft_plan {
     int detrend = -1, demean_taper = 0;
     float scale = 1.f;
     bool pow2 = false;
+    bool mixed = false;         // packed mixed-radix engine for 5-smooth lengths (mtmfft_mixed.h)
+    spyfft::MixPlan mix{};
+    int mix_threads = 0;
     bool blue = false;          // Bluestein on the packed power-of-two engine (nfft <= 4096, not a power of two)
     bool longp = false;         // Bluestein with four-step length-M transforms through HBM (mtmfft_long.h)
     bool long_direct = false;   // ... or, for power-of-two nfft, one plain four-step transform
@@ -284,6 +293,19 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
                       p->log2n, p->G, mode);
         p->kernel_name = buf;
+    } else if (!std::getenv("SPYHIP_NO_MIXED") && !std::getenv("SPYHIP_FORCE_GENERIC") && !std::getenv("SPYHIP_FORCE_LONG") &&
+               spyfft::mix_schedule(nfft, (nchan + 3) / 4, &p->mix, &p->mix_threads, &p->lds_bytes) &&
+               p->lds_bytes <= ctx->lds_per_block) {
+        // 5-smooth lengths (2000, 3000, 5000, 500 ...): the packed mixed-radix engine
+        p->mixed = true;
+        p->G = 1 << p->mix.lg;
+        if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
+        std::string sched;
+        for (int i = 0; i < p->mix.npass; ++i) sched += (i ? "x" : "") + std::to_string(p->mix.radix[i]);
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "mtmfft_mixed_kernel<%s> N=%d (%s) %d threads x %d quads", mode, nfft, sched.c_str(),
+                      p->mix.th, p->G);
+        p->kernel_name = buf;
     } else if (nfft >= 2 && 2 * nfft - 1 <= 8192 && !std::getenv("SPYHIP_FORCE_GENERIC")) {
         // Bluestein on the packed power-of-two engine: M = 2^log2n >= 2 nfft - 1 (at least 256)
         int M = 256;
@@ -489,6 +511,20 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             case 14: return launch_pow2_mode<14, 1>(p, a, g);
             default: spy::set_error("no kernel for log2n=%d", p->log2n); return -1;
         }
+    }
+    if (p->mixed) {
+        const int G = p->G;
+        const int nitem = (p->nchan + 3) / 4;
+        a.npg = (nitem + G - 1) / G;
+        int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+        a.S = S;
+        a.ncl = (a.npg + S - 1) / S;
+        const long long nclusters = (long long)nseg * a.ncl;
+        const long long grid = ((nclusters + 7) / 8) * S * 8;
+        if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
+        const bool mean = !p->keeptapers;
+        const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+        return spyfft::mixed_launch(p->ctx->stream, a, p->mix, p->mix_threads, p->lds_bytes, (unsigned)grid, outk, mean);
     }
     if (p->longp) {
         spyfft::LongArgs L{};

@@ -48,7 +48,7 @@ OUT_KINDS = {"pow": 0, "abs": 1, "fourier": 2, "complex": 2, "real": 3, "imag": 
 
 def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
              freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False,
-             force_long=False, reference_mean=False):
+             force_long=False, reference_mean=False, no_mixed=False, mixed_nostage=False):
     """`reference_mean`: constant detrending with the means of seq_mean_kernel (spyhip_fft_plan_set_reference_mean)."""
     if reference_mean and detrend == 0:
         d32 = np.ascontiguousarray(data, dtype=np.float32)
@@ -58,11 +58,12 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
         lib().emu_set_means(_p(means, C.c_float))
         try:
             return fft_exec(d32, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend, demean_taper, freq_idx,
-                            output, keeptapers, chan_idx, G, force_generic, blocked, force_long, False)
+                            output, keeptapers, chan_idx, G, force_generic, blocked, force_long, False, no_mixed,
+                            mixed_nostage)
         finally:
             lib().emu_set_means(None)
     return _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend, demean_taper, freq_idx,
-                     output, keeptapers, chan_idx, G, force_generic, blocked, force_long)
+                     output, keeptapers, chan_idx, G, force_generic, blocked, force_long, no_mixed, mixed_nostage)
 
 
 def seq_mean(data, seg_start, seg_lo, seg_hi, nsig, chan_idx=None):
@@ -80,9 +81,12 @@ def seq_mean(data, seg_start, seg_lo, seg_hi, nsig, chan_idx=None):
     return means
 
 
+LAST_MIXED = {}
+
+
 def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
               freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False,
-              force_long=False):
+              force_long=False, no_mixed=False, mixed_nostage=False):
     """Emulated spyhip_fft_exec.  data: (rows, ld) float32; tapers: (K, nsig) float64.
     blocked: channel-blocked hand-over layout (nseg*K, ceil(nchan/4), nfsel, 4) (fourier, keeptapers)."""
     data = np.ascontiguousarray(data, dtype=np.float32)
@@ -127,6 +131,19 @@ def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detren
         set_blocked(False)
         assert rc == 0, f"no emulated kernel for log2n={log2n} G={G}"
         return out
+    if not force_generic and not force_long and not no_mixed:
+        # 5-smooth lengths: the packed mixed-radix engine with the schedule of spyhip_fft_plan_create
+        info = np.zeros(7, dtype=np.int32)
+        rc = lib().emu_mtmfft_mixed(
+            C.c_int(nfft), C.c_int(int(mixed_nostage)), _p(info, C.c_int), _p(data, C.c_float), C.c_longlong(ld),
+            _p(ci, C.c_int), _p(ss, C.c_longlong), _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg),
+            C.c_int(nsig), C.c_int(nchan), C.c_int(K), _p(tp, C.c_float), _p(twiddles(nfft), C.c_float),
+            C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), _p(fpos, C.c_int), C.c_int(nfsel),
+            C.c_int(kind), C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
+        if rc == 0:
+            LAST_MIXED.update(dict(zip(("th", "G", "npass", "stage", "threads", "radix0", "radix_last"),
+                                       (int(v) for v in info))), nfft=nfft)
+            return out
     if force_long or (not pow2 and nfft > 4096 and not force_generic):
         # Bluestein with four-step length-M transforms through (emulated) HBM - mirror of spyhip_fft_plan_create
         m = 12

@@ -22,6 +22,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/jack_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
+#include "../../syncopy_amd/csrc/mtmfft_mixed.h"
 #include "../../syncopy_amd/csrc/mtmfft_long.h"
 #include "../../syncopy_amd/csrc/cwt_kernel.h"
 #include "../../syncopy_amd/csrc/granger_kernels.h"
@@ -303,6 +304,53 @@ int emu_mtmfft_generic(int n, int nfac, const int* radix, int nfft, int bluestei
         case 3: go([&] { spyfft::mtmfft_generic_kernel<1, true>(a, g); }); break;
         case 4: go([&] { spyfft::mtmfft_generic_kernel<2, false>(a, g); }); break;
         default: go([&] { spyfft::mtmfft_generic_kernel<2, true>(a, g); }); break;
+    }
+    return 0;
+}
+
+// The packed mixed-radix engine (mtmfft_mixed.h) with the schedule spyhip_fft_plan_create computes (mix_schedule).
+// Returns 1 if the length is not served by it.  force_nostage: take the re-read-per-taper path although the segment
+// would fit into LDS; info (7 ints): th, G, npass, stage, threads, radix[0], radix[last].
+int emu_mtmfft_mixed(int nfft, int force_nostage, int* info, const float* data, long long ld, const int* chan_idx,
+                     const long long* seg_start, const long long* seg_lo, const long long* seg_hi, int nseg,
+                     int nsig, int nchan, int ntaper, const float* tapers, const float* tw, float scale,
+                     int detrend, int demean_taper, const int* fpos, int nfsel, int out_kind, int keeptapers,
+                     void* out) {
+    spyfft::MixPlan g{};
+    int threads = 0;
+    size_t lds = 0;
+    if (!spyfft::mix_schedule(nfft, (nchan + 3) / 4, &g, &threads, &lds)) return 1;
+    if (force_nostage) g.stage = 0;
+    if (info) {
+        info[0] = g.th; info[1] = 1 << g.lg; info[2] = g.npass; info[3] = g.stage; info[4] = threads;
+        info[5] = g.radix[0]; info[6] = g.radix[g.npass - 1];
+    }
+    MtmArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
+    a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
+    a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
+    a.out_kind = out_kind; a.out = out;
+    a.means = g_means;
+    const int G = 1 << g.lg;
+    const int nitem = (nchan + 3) / 4;
+    a.npg = (nitem + G - 1) / G;
+    int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+    a.S = S;
+    a.ncl = (a.npg + S - 1) / S;
+    const long long nclusters = (long long)nseg * a.ncl;
+    const unsigned grid = (unsigned)(((nclusters + 7) / 8) * S * 8);
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    const bool mean = !keeptapers;
+    auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(threads), lds, fn); };
+    switch (outk * 2 + (mean ? 1 : 0)) {
+        case 0: go([&] { spyfft::mtmfft_mixed_kernel<0, false, 1024>(a, g); }); break;
+        case 1: go([&] { spyfft::mtmfft_mixed_kernel<0, true, 1024>(a, g); }); break;
+        case 2: go([&] { spyfft::mtmfft_mixed_kernel<1, false, 1024>(a, g); }); break;
+        case 3: go([&] { spyfft::mtmfft_mixed_kernel<1, true, 1024>(a, g); }); break;
+        case 4: go([&] { spyfft::mtmfft_mixed_kernel<2, false, 1024>(a, g); }); break;
+        default: go([&] { spyfft::mtmfft_mixed_kernel<2, true, 1024>(a, g); }); break;
     }
     return 0;
 }

@@ -38,6 +38,7 @@ static inline double2 make_double2(double a, double b) { return double2{a, b}; }
 // IEEE round-to-nearest float32 add / divide (the host compiler does not contract or re-associate them)
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 namespace emu {
 struct BlockCtx {

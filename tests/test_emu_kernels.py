@@ -11,14 +11,15 @@ from parity import assert_parity, excess
 
 
 def _fft_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=False, G=None, generic=False,
-              freq_idx=None, chan_idx=None, nseg=2, seed=1, long=False):
+              freq_idx=None, chan_idx=None, nseg=2, seed=1, long=False, no_mixed=False, nostage=False):
     rng = np.random.default_rng(seed)
     data = rng.normal(size=(nsig * nseg + 9, nchan)).astype("f4")
     ss = np.array([4 + i * nsig for i in range(nseg)])
     taper, topt = ("dpss", {"NW": (K + 1) / 2, "Kmax": K}) if K > 1 else ("hann", {})
     tapers = O.taper_table(taper, nsig, nfft, topt)
     out = E.fft_exec(data, ss, ss, ss + nsig, nsig, nfft, tapers, O.spec_scale(nsig, nfft), detrend, demean_taper,
-                     freq_idx, output, keeptapers, chan_idx=chan_idx, G=G, force_generic=generic, force_long=long)
+                     freq_idx, output, keeptapers, chan_idx=chan_idx, G=G, force_generic=generic, force_long=long,
+                     no_mixed=no_mixed, mixed_nostage=nostage)
     freqs = np.fft.rfftfreq(nfft, 1e-3)
     foi = freqs if freq_idx is None else freqs[freq_idx]
     for b in range(nseg):
@@ -78,8 +79,8 @@ def test_pow2_kernel_modes():
 @pytest.mark.parametrize("nsig,nfft", [(2000, 2000), (500, 1000), (360, 360), (77, 154), (101, 202), (64, 64)])
 def test_generic_kernel_lengths(nsig, nfft):
     # lengths that are not powers of two: Bluestein on the packed engine (M = 256 ... 4096) ...
-    _fft_case(nsig, nfft, 3, 2, "pow", False, 0)
-    _fft_case(nsig, nfft, 2, 1, "fourier", True, 1, demean_taper=True, nseg=1)
+    _fft_case(nsig, nfft, 3, 2, "pow", False, 0, no_mixed=True)
+    _fft_case(nsig, nfft, 2, 1, "fourier", True, 1, demean_taper=True, nseg=1, no_mixed=True)
     # ... and the mixed-radix / Bluestein LDS kernel that still serves nfft > 4096
     _fft_case(nsig, nfft, 3, 2, "pow", False, 0, generic=True, nseg=1)
 
@@ -93,13 +94,41 @@ def test_long_transform_path():
 
 
 def test_bluestein_kernel_modes():
-    _fft_case(500, 500, 8, 1, "pow", True, 0)                     # full quads: float4 stores
-    _fft_case(500, 500, 5, 3, "abs", False, 1)
-    _fft_case(300, 360, 6, 2, "fourier", False, -1)
+    _fft_case(500, 500, 8, 1, "pow", True, 0, no_mixed=True)       # full quads: float4 stores
+    _fft_case(500, 500, 5, 3, "abs", False, 1, no_mixed=True)
+    _fft_case(300, 360, 6, 2, "fourier", False, -1, no_mixed=True)
     _fft_case(77, 77, 4, 2, "real", True, 0, freq_idx=np.array([3, 0, 38, 20]), chan_idx=[3, 3, 0, 1])
     for n in (3, 5, 7, 13):                                        # trials of a handful of samples
         _fft_case(n, n, 3, 1, "fourier", True, 0, nseg=2)
     _fft_case(3, 8, 2, 1, "pow", False, -1, nseg=1)
+
+
+@pytest.mark.parametrize("nsig,nfft,sched", [
+    (2000, 2000, (200, 10, 2)),      # BASELINE config 1: 10 x 10 x 10 x 2
+    (500, 1000, (100, 10, 10)),      # padded: 10 x 10 x 10
+    (360, 360, (45, 5, 8)),          # 5 x 3 x 3 x 8
+    (3000, 3000, (334, 3, 10)),      # 3 x 10 x 10 x 10: ragged butterfly counts per thread
+    (5000, 5000, (500, 5, 10)),      # 5 x 10 x 10 x 10, 512 threads, segment re-read per taper
+    (64, 64, (8, 8, 8)), (16, 16, (2, 8, 2)), (25, 30, (4, 3, 10)), (1215, 1215, (135, 5, 3)),
+])
+def test_mixed_radix_kernel_lengths(nsig, nfft, sched):
+    """K1m, the packed engine for 5-smooth lengths, with the schedule mix_schedule (the code plan_create runs) picks."""
+    _fft_case(nsig, nfft, 5, 2, "pow", False, 0, nseg=2)
+    assert E.LAST_MIXED["nfft"] == nfft
+    assert (E.LAST_MIXED["th"], E.LAST_MIXED["radix0"], E.LAST_MIXED["radix_last"]) == sched
+    _fft_case(nsig, nfft, 2, 1, "fourier", True, 1, demean_taper=True, nseg=1)
+
+
+def test_mixed_radix_kernel_modes():
+    _fft_case(500, 500, 8, 1, "pow", True, 0)                      # full quads: float4 stores
+    _fft_case(500, 500, 5, 3, "abs", False, 1)
+    _fft_case(300, 360, 6, 2, "fourier", False, -1)
+    _fft_case(300, 360, 9, 2, "fourier", True, 0, demean_taper=True, nostage=True)     # the re-read path on a short length
+    _fft_case(250, 250, 17, 2, "pow", False, 1, nostage=True, nseg=3)                 # several quad groups, ragged last quad
+    _fft_case(80, 80, 4, 2, "real", True, 0, freq_idx=np.array([3, 0, 40, 20]), chan_idx=[3, 3, 0, 1])
+    _fft_case(150, 150, 4, 3, "angle", False, -1)
+    _fft_case(400, 400, 4, 1, "fourier", True, 0)                   # 10 x 10 x 4
+    assert E.LAST_MIXED["nfft"] == 400 and E.LAST_MIXED["radix_last"] == 4
 
 
 def test_generic_kernel_matches_pow2_kernel():
