@@ -298,6 +298,11 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
                p->lds_bytes <= ctx->lds_per_block) {
         // 5-smooth lengths (2000, 3000, 5000, 500 ...): the packed mixed-radix engine
         p->mixed = true;
+        if (const char* e = std::getenv("SPYHIP_MIX_LAYOUT")) {        // tuning aid: "<log2 quads>,<stage 0|1>"
+            int lg = p->mix.lg, st = p->mix.stage;
+            if (std::sscanf(e, "%d,%d", &lg, &st) == 2 && lg >= 0 && lg <= 4 && (p->mix.th << lg) <= 1024)
+                spyfft::mix_layout(&p->mix, lg, st, &p->mix_threads, &p->lds_bytes);
+        }
         p->G = 1 << p->mix.lg;
         if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
         std::string sched;

@@ -108,7 +108,7 @@ def test_bluestein_kernel_modes():
     (500, 1000, (100, 10, 10)),      # padded: 10 x 10 x 10
     (360, 360, (45, 5, 8)),          # 5 x 3 x 3 x 8
     (3000, 3000, (334, 3, 10)),      # 3 x 10 x 10 x 10: ragged butterfly counts per thread
-    (5000, 5000, (500, 5, 10)),      # 5 x 10 x 10 x 10, 512 threads, segment re-read per taper
+    (5000, 5000, (500, 5, 10)),      # 5 x 10 x 10 x 10, 512 threads, 160 KB of LDS
     (64, 64, (8, 8, 8)), (16, 16, (2, 8, 2)), (25, 30, (4, 3, 10)), (1215, 1215, (135, 5, 3)),
 ])
 def test_mixed_radix_kernel_lengths(nsig, nfft, sched):
@@ -127,8 +127,8 @@ def test_mixed_radix_kernel_modes():
     _fft_case(250, 250, 17, 2, "pow", False, 1, nostage=True, nseg=3)                 # several quad groups, ragged last quad
     _fft_case(80, 80, 4, 2, "real", True, 0, freq_idx=np.array([3, 0, 40, 20]), chan_idx=[3, 3, 0, 1])
     _fft_case(150, 150, 4, 3, "angle", False, -1)
-    _fft_case(400, 400, 4, 1, "fourier", True, 0)                   # 10 x 10 x 4
-    assert E.LAST_MIXED["nfft"] == 400 and E.LAST_MIXED["radix_last"] == 4
+    _fft_case(36, 36, 4, 1, "fourier", True, 0)                     # 3 x 3 x 4
+    assert E.LAST_MIXED["nfft"] == 36 and E.LAST_MIXED["radix_last"] == 4
 
 
 def test_generic_kernel_matches_pow2_kernel():
