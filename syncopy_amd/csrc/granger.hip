@@ -98,6 +98,17 @@ int invert(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d, bool blocked =
     return 0;
 }
 
+// inverse of ONE matrix (psi0): block Gauss-Jordan first (the pivoted kernel is a 256-step serial chain, 17.6 ms at
+// n = 256 against < 1 ms), the pivoted kernel only if a diagonal block met a tiny pivot
+int invert_one(spyhip_ctx* ctx, cd* dst, const cd* src, int n, int* inf) {
+    if (invert(ctx, dst, n, 1, inf, true, src)) return -2;
+    int h = 0;
+    SPY_HIP_CHECK(hipMemcpyAsync(&h, inf, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (h == 0) return 0;
+    return invert(ctx, dst, n, 1, inf, false, src);
+}
+
 int cholesky(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d) {
     hipLaunchKernelGGL(spywil::zchol_kernel, dim3(batch), dim3(256), (size_t)n * sizeof(cd), ctx->stream, M, n, info_d);
     SPY_HIP_CHECK(hipGetLastError());
@@ -272,7 +283,7 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
         ctx->granger_iters = it + 1;
         if (invert(ctx, T1, n, F, inf, blocked, psi)) return -2;                          // T1 = psi^-1
         SPY_HIP_CHECK(hipMemcpyAsync(hinf.data(), inf, F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        if (gemm(ctx, T1, U, T2, n, F, nn, nn, nn, 0, 0)) return -2;                       // psi^-1 U
+        if (gemm(ctx, T1, U, T2, n, F, nn, nn, nn, 0, n >= 48 ? 2 : 0)) return -2;          // psi^-1 U (U lower triangular)
         if (gemm(ctx, T2, T2, T1, n, F, nn, nn, nn, 1, 1)) return -2;                      // g + I
         {                                                                                   // T2 = [g+I]^+
             const int prc = use_plus4 ? plus4(ctx, L, T1, F, (long long)nn, tw, T2, g0) : 1;
@@ -316,8 +327,7 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
   }
     // ---- noise covariance, transfer function, Granger causality (wilson_sf.py:113-120, granger.py:53-77)
     if (gemm(ctx, psi0, psi0, Sig, n, 1, nn, nn, nn, 1, 0)) return -2;                     // psi0 psi0^T (psi0 is real)
-    SPY_HIP_CHECK(hipMemcpyAsync(scr, psi0, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
-    if (invert(ctx, scr, n, 1, inf)) return -2;
+    if (invert_one(ctx, scr, psi0, n, inf)) return -2;
     if (gemm(ctx, psi, scr, T1, n, F, nn, 0, nn, 0, 0)) return -2;                         // H = psi psi0^-1
     hipLaunchKernelGGL(spywil::granger_kernel, dim3(eb), dim3(256), 0, ctx->stream, A, T1, Sig, F, n,
                        reinterpret_cast<float*>(granger_d));
@@ -425,7 +435,7 @@ extern "C" int spyhip_wilson_g(spyhip_ctx* ctx, const void* psi_d, const void* U
     if (invert(ctx, T1, n, nf, inf, !pivoted, reinterpret_cast<const cd*>(psi_d))) return -2;
     std::vector<int> h(nf);
     SPY_HIP_CHECK(hipMemcpyAsync(h.data(), inf, nf * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (gemm(ctx, T1, reinterpret_cast<const cd*>(U_d), T2, n, nf, nn, nn, nn, 0, 0)) return -2;
+    if (gemm(ctx, T1, reinterpret_cast<const cd*>(U_d), T2, n, nf, nn, nn, nn, 0, n >= 48 ? 2 : 0)) return -2;
     if (gemm(ctx, T2, T2, reinterpret_cast<cd*>(g_d), n, nf, nn, nn, nn, 1, 1)) return -2;
     SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int f = 0; f < nf; ++f)
@@ -537,8 +547,7 @@ extern "C" int spyhip_wilson_finish(spyhip_ctx* ctx, const void* A_d, const void
     int* inf = reinterpret_cast<int*>(inv0 + nn);
     const cd* psi0 = reinterpret_cast<const cd*>(psi0_d);
     if (gemm(ctx, psi0, psi0, Sig, n, 1, nn, nn, nn, 1, 0)) return -2;
-    SPY_HIP_CHECK(hipMemcpyAsync(inv0, psi0, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));
-    if (invert(ctx, inv0, n, 1, inf)) return -2;
+    if (invert_one(ctx, inv0, psi0, n, inf)) return -2;
     if (gemm(ctx, reinterpret_cast<const cd*>(psi_d), inv0, T1, n, nf, nn, 0, nn, 0, 0)) return -2;
     const unsigned eb = (unsigned)std::min<size_t>((tot + 255) / 256, 8192);
     hipLaunchKernelGGL(spywil::granger_kernel, dim3(eb), dim3(256), 0, ctx->stream, reinterpret_cast<const cd*>(A_d), T1, Sig, nf, n,

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) zgemm_kernel(const cd* A, const cd* B, cd
             const int gi = ti + ty * 2 + u, gj = tj + tx * 2 + w;
             if (gi < n && gj < n) {
                 cd v = acc[u][w];
-                if (addI && gi == gj) v.x += 1.0;
+                if ((addI & 1) && gi == gj) v.x += 1.0;
                 Cb[(size_t)gi * n + gj] = v;
             }
         }
@@ -172,8 +172,10 @@ __global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const c
             pb[q] = v;
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < n; k0 += MK) {
+    // addI & 2: B is LOWER triangular (the Cholesky factor U in psi^-1 U): rows k < tj of this column tile are zero
+    const int kbeg = (addI & 2) ? (tj / MK) * MK : 0;
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < n; k0 += MK) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = tid + 256 * q;
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const c
                 const int gi = ti + wr + 16 * u + l4 + 4 * r, gj = tj + wc + 16 * w + l15;
                 if (gi < n && gj < n) {
                     cd v = make_double2(cr[u][w][r], ci[u][w][r]);
-                    if (addI && gi == gj) v.x += 1.0;
+                    if ((addI & 1) && gi == gj) v.x += 1.0;
                     Cb[(size_t)gi * n + gj] = v;
                     if (MODE == 3 && bx < by) Cb[(size_t)gj * n + gi] = make_double2(v.x, -v.y);
                 }

@@ -393,6 +393,11 @@ def test_zgemm_on_f64_matrix_cores():
     np.testing.assert_allclose(E.w_gemm(A, Bm), A @ Bm, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(E.w_gemm(A, Bm, opB=1, addI=1), A @ Bm.conj().transpose(0, 2, 1) + np.eye(n), rtol=1e-12,
                                atol=1e-12)
+    # addI & 2: B declared lower triangular (the Cholesky factor): the zero rows above a column tile are skipped
+    n = 150
+    A = rng.normal(size=(2, n, n)) + 1j * rng.normal(size=(2, n, n))
+    L = np.tril(rng.normal(size=(2, n, n)) + 1j * rng.normal(size=(2, n, n)))
+    np.testing.assert_allclose(E.w_gemm(A, L, addI=2), A @ L, rtol=1e-12, atol=1e-12)
 
 
 def test_zgemm_fused_skew_and_error_check():
