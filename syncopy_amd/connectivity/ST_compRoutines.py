@@ -10,6 +10,7 @@ from .. import backend, parallel
 from ..datatype import selected_channels, trial_rows
 from ..shared.computational_routine import ComputationalRoutine, propagate_properties
 from ..shared.const_def import spectralDTypes
+from ..shared.errors import SPYValueError
 from ..shared.tools import best_match
 from ..specest import hip_spectral as hs
 
@@ -157,12 +158,17 @@ class SpectralDyadicProduct(ComputationalRoutine):
         out.data = backend.to_host(out._dev)
 
     def ppc_hip(self, data):
-        """Pairwise phase consistency of spectra that exist already (one time sample per trial): K7 on the uploaded
-        (trials x tapers, F, C) block; `channelcmb` rectangles are cut out of the channels that occur at all."""
+        """Pairwise phase consistency of spectra that exist already: K7 on the uploaded (trials x tapers, F, C) block of
+        every time sample (time-resolved spectra: all trials must have the same number of samples, as the reference's
+        accumulator `st_out.trials[0].shape` requires, connectivity_analysis.py:626); `channelcmb` rectangles are
+        cut out of the channels that occur at all.  Returns (nTime, F, C_i, C_j) on the device."""
         rows, chans = trial_rows(data), selected_channels(data)
         T = self.numTrials
-        if {rows[k][1] - rows[k][0] for k in range(T)} != {1}:
-            raise NotImplementedError("pairwise phase consistency of time-resolved spectra")
+        lens = {rows[k][1] - rows[k][0] for k in range(T)}
+        if len(lens) != 1:
+            raise SPYValueError("trials of equal length", varname="data",
+                                actual=f"time-resolved spectra with {sorted(lens)} samples per trial")
+        L = lens.pop()
         host = np.asarray(data.data)
         sub = _cmb_union(self.cfg.get("send_idx"), self.cfg.get("rec_idx"))
         if sub is not None:
@@ -170,15 +176,18 @@ class SpectralDyadicProduct(ComputationalRoutine):
         if chans is not None:
             host = host[..., chans]
         K, F, C = host.shape[1:]
-        U = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
         mine = self.my_trials()
-        if len(mine):
-            sel = np.array([rows[k][0] for k in mine])
-            dev = torch.from_numpy(np.ascontiguousarray(host[sel], dtype=np.complex64)).cuda()
-            backend.ppc_accumulate(dev.reshape(-1, F, C), K, U)
-        parallel.allreduce_sum_(U)
-        res = backend.ppc_finalize(U, T, lower_only=True)
-        return res if sub is None else _cmb_block(res, sub)
+        first = np.array([rows[k][0] for k in mine], dtype=np.int64)
+        res = []
+        for ti in range(L):
+            U = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+            if len(mine):
+                dev = torch.from_numpy(np.ascontiguousarray(host[first + ti], dtype=np.complex64)).cuda()
+                backend.ppc_accumulate(dev.reshape(-1, F, C), K, U)
+            parallel.allreduce_sum_(U)
+            r = backend.ppc_finalize(U, T, lower_only=True)
+            res.append(r if sub is None else _cmb_block(r, sub))
+        return torch.stack(res, dim=0)
 
     def process_metadata(self, data, out):
         time_axis = bool(np.any(np.diff(data.trialdefinition)[:, 0] != 1))

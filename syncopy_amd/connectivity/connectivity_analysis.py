@@ -277,17 +277,25 @@ def _ppc(data, classes, st, compute_method, log_dict):
     out = CrossSpectralData(dimord=CrossSpectra.dimord)
     if compute_method in (None, "hip") and hasattr(st, "ppc_hip"):
         st.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=False)
-        out._dev = st.ppc_hip(data).unsqueeze(0)
+        out._dev = st.ppc_hip(data)
         out.data = backend.to_host(out._dev)
         st.process_metadata(data, out)
     else:
         st_out = CrossSpectralData(dimord=CrossSpectra.dimord)
         st.initialize(data, st_out._stackingDim, chan_per_worker=None, keeptrials=True)
         st.compute(data, st_out, parallel=False, log_dict=log_dict, method=compute_method)
-        out.data = np.ascontiguousarray(classes["ppc"](np.asarray(st_out.data)), dtype=np.float32)
+        single = np.asarray(st_out.data)
+        lens = {int(b - a) for a, b in st_out.sampleinfo}
+        if len(lens) != 1:
+            raise SPYValueError("trials of equal length", varname="data",
+                                actual=f"time-resolved spectra with {sorted(lens)} samples per trial")
+        L = lens.pop()
+        per_time = single.reshape((-1, L) + single.shape[1:])            # (trials, time, F, C_i, C_j)
+        out.data = np.ascontiguousarray(np.concatenate([classes["ppc"](per_time[:, ti]) for ti in range(L)], axis=0),
+                                        dtype=np.float32)
         out.samplerate, out.freq = st_out.samplerate, st_out.freq
         out.channel_i, out.channel_j = st_out.channel_i, st_out.channel_j
-        out.trialdefinition = np.array([[0, 1.0, 0]])
+        out.trialdefinition = st_out.trialdefinition[:1].copy() if L > 1 else np.array([[0, 1.0, 0]])
     out.cfg = dict(log_dict or {})
     return out
 

@@ -251,3 +251,32 @@ def test_regularize_near_threshold(C):
         _, meta = backend.granger(dev, niter=2, cond_max=cmax)
         np.testing.assert_allclose(meta["initial cond. num"], cn0, rtol=1e-4)
         assert meta["reg. factor"] == pytest.approx(factor, rel=1e-9), (cmax, kappa)
+
+
+def test_ppc_of_time_resolved_spectra():
+    """method='ppc' on SpectralData from mtmconvol (VERDICT r1 missing 5): the reference's pair loop works sample by
+    sample on equally long trials (connectivity_analysis.py:624-663); K7 runs once per time sample."""
+    from oracle_routines import ORACLE_CONN, ORACLE_FREQ
+    adj = np.zeros((5, 5))
+    adj[0, 1] = adj[3, 2] = 0.35
+    data = spy.synthdata.ar2_network(AdjMat=adj, nSamples=600, nTrials=9, seed=11, samplerate=300)
+    kw = dict(method="mtmconvol", t_ftimwin=0.4, toi=np.linspace(-0.5, 0.5, 6), foilim=[20, 80], tapsmofrq=6,
+              output="fourier", keeptapers=True)
+    spec = spy.freqanalysis(data, **kw)
+    assert spec.data.shape[0] == 9 * 6
+    res = spy.connectivityanalysis(spec, method="ppc")
+    seq = spy.connectivityanalysis(spec, method="ppc", compute_method="sequential", routine_classes=ORACLE_CONN)
+    T, L = 9, 6
+    csd = np.einsum("tkfi,tkfj->tfij", np.asarray(spec.data), np.conj(np.asarray(spec.data))) / spec.data.shape[1]
+    csd = csd.reshape(T, L, *csd.shape[1:]).astype(np.complex64)
+    expect = np.concatenate([O.ppc(csd[:, ti]) for ti in range(L)], axis=0)
+    assert res.data.shape == expect.shape == (L,) + csd.shape[2:]
+    assert_parity(seq.data, expect, atol_rel=5e-6, what="sequential")
+    assert_parity(res.data, expect, atol_rel=5e-6, what="hip")
+    assert np.array_equal(res.trialdefinition, seq.trialdefinition) and res.trialdefinition.shape == (1, 3)
+    # ragged trials are refused the way the reference's accumulator refuses them
+    rag = spy.freqanalysis(data, select={"trials": [0, 1]}, **kw)
+    rag.trialdefinition = np.array([[0, 5, 0], [5, 12, 0]])
+    with pytest.raises((spy.shared.errors.SPYValueError, NotImplementedError)):
+        spy.connectivityanalysis(rag, method="ppc")                 # (the reference: "Averaging trials of unequal
+                                                                    # lengths in output currently not supported!")
