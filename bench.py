@@ -236,6 +236,25 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
                 "bytes_per_trial": byt, "flop_per_trial": flop, "frac": bound_us / (1e3 * ms / T),
                 "hbm_GBps": byt * T / (ms * 1e-3) / 1e9})
     del buf, plan
+    # ---- c2 at trial lengths that are not powers of two (1 kHz x 2 s / 5 s; BASELINE configs[0] is N = 2000):
+    # the packed mixed-radix engine K1m
+    for N2 in (2000, 5000):
+        T2 = 200
+        d2 = synthdata.ar2_uncoupled_fast(C, N2, T2, seed=78)
+        tp2 = windows.dpss(N2, 1.0 * N2 / 1000.0, K) * np.sqrt(N2)
+        plan = be.FFTPlan(N2, N2, C, tp2, np.sqrt(2) / N2, 0, False, None, "pow", False, reference_mean=refmean)
+        st2 = torch.arange(T2, device="cuda", dtype=torch.int64) * N2
+        buf = torch.empty(plan.out_shape(T2), dtype=torch.float32, device="cuda")
+        ms = _event_ms(torch, lambda: plan.execute(d2, st2, out=buf))
+        F2 = N2 // 2 + 1
+        byt, flop = N2 * C * 4 + F2 * C * 4, K * C * 2.5 * N2 * np.log2(N2)
+        bound_us = max(byt / (PEAK_HBM_GBS * 1e9), flop / (PEAK_MFMA_F32_TFLOPS * 1e12)) * 1e6
+        out.append({"name": "c2 shape at N = %d (not a power of two): %d ch x %d samp x %d trials, 7 DPSS tapers, taper mean" % (N2, C, N2, T2),
+                    "value": T2 / (ms * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms / T2,
+                    "channel_samples_per_s": T2 / (ms * 1e-3) * N2 * C, "kernel": plan.kernel_name,
+                    "bound": "fft-flop (fp32 vector peak) vs hbm, whichever is larger", "bound_us_per_trial": bound_us,
+                    "bytes_per_trial": byt, "flop_per_trial": flop, "frac": bound_us / (1e3 * ms / T2)})
+        del buf, plan, d2
     # ---- c4: 128 ch x 16384 samples (configs[3]); (i) 512-sample Hann windows, 50 % overlap
     C4, N4, T4 = 128, 16384, 200
     d4 = synthdata.ar2_uncoupled_fast(C4, N4, T4, seed=77)
@@ -290,7 +309,7 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
     entry = {"name": "c5 Granger AV stage (BASELINE configs[4], one GPU): regularize_csd + wilson_sf + granger on %d x %d x %d" % (F, C, C),
              "value": dt, "unit": "s", "higher_is_better": False, "converged": meta["converged"],
              "max_rel_err": meta["max rel. err"], "cond0": meta["initial cond. num"], "iterations": iters,
-             "kernel": "spywil::zgemm_mfma_kernel / zinv_blocked_kernel", "bound": "fp64 %.1f TFLOP/s" % PEAK_F64_TFLOPS,
+             "kernel": "spywil::zinv_mfma_kernel / zgemm_mfma_kernel<0..3> / plus4_kernel", "bound": "fp64 %.1f TFLOP/s" % PEAK_F64_TFLOPS,
              "flop_per_iteration": flop_it}
     if iters:
         entry["frac"] = iters * flop_it / (PEAK_F64_TFLOPS * 1e12) / dt
