@@ -478,7 +478,7 @@ def ccov_nfft(nsamples):
     from ._lib import load
     n = load().spyhip_ccov_nfft(int(nsamples))
     if n < 0:
-        raise ValueError(f"cross-covariance: trials of {nsamples} samples exceed the supported 5461")
+        raise ValueError(f"cross-covariance: trials of {nsamples} samples exceed the supported 349525")
     return n
 
 

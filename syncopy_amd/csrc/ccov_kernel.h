@@ -97,6 +97,47 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) ccov_lags_kernel(C
     }
 }
 
+// ---- trials longer than 5461 samples (L > 8192: the inverse transform no longer fits the in-LDS engine).
+// R_ab = irfft(S_ab) is taken with the FORWARD real transform the mtmfft kernels already provide for any length:
+// S_ext[k] (Hermitian extension) = p[k] + i q[k] with p even and q odd, so
+//     R(+tau) = (Re FFT(p)[tau] + Im FFT(q)[tau]) / L,      R(-tau) = (Re FFT(p)[tau] - Im FFT(q)[tau]) / L.
+// ccov_extend_kernel lays p and q of a chunk of channel pairs out as the "channels" of one (L x 2 npairs) real
+// segment; spyhip_fft_exec transforms it (2^14: the in-LDS kernel, longer: the four-step path); ccov_combine_kernel
+// applies the reference's lag conventions exactly as ccov_lags_kernel does.
+__global__ void __launch_bounds__(256) ccov_extend_kernel(const float2* acc, int Cn, int L, long long pair0, int npc, int cap,
+                                                          float* pq) {
+    const long long tot = (long long)L * cap;
+    const size_t cc = (size_t)Cn * Cn;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long long)gridDim.x * 256) {
+        const int k = (int)(idx / cap), p = (int)(idx % cap);
+        float2 s = make_float2(0.f, 0.f);
+        if (p < npc) {
+            int ca, cb;
+            pair_of(pair0 + p, ca, cb);
+            const bool mir = k > L / 2;
+            s = acc[(size_t)(mir ? L - k : k) * cc + (size_t)ca * Cn + cb];
+            if (mir) s.y = -s.y;
+        }
+        reinterpret_cast<float2*>(pq)[idx] = s;            // (k, 2p) = p[k], (k, 2p + 1) = q[k]
+    }
+}
+
+__global__ void __launch_bounds__(256) ccov_combine_kernel(const float2* spec, int L, long long pair0, int npc, int cap, int Cn,
+                                                           int nsamples, int nlag, int q, float scale, float* out) {
+    const long long tot = (long long)(L / 2 + 1) * cap;
+    const size_t C = (size_t)Cn;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long long)gridDim.x * 256) {
+        const int tau = (int)(idx / cap), p = (int)(idx % cap);
+        if (p >= npc) continue;
+        int ca, cb;
+        pair_of(pair0 + p, ca, cb);
+        const float2 P = spec[(size_t)tau * (2 * cap) + 2 * p], Q = spec[(size_t)tau * (2 * cap) + 2 * p + 1];
+        if (tau < nlag) out[((size_t)tau * C + ca) * C + cb] = (P.x + Q.y) * (scale / (float)(nsamples - tau));
+        const int l = tau - q;                               // the mirrored element holds R_ab(-(l + q))
+        if (l >= 0 && l < nlag && ca != cb) out[((size_t)l * C + cb) * C + ca] = (P.x - Q.y) * (scale / (float)(nsamples - l));
+    }
+}
+
 // d[a]: what the normalisation divides by, per channel (before the square root of the product of two):
 //   mode 1  CC[0,a,a]                                  zero-lag auto-covariance of the trial average
 //                                                       (normalize_ccov_cF, AV_compRoutines.py:215-225)

