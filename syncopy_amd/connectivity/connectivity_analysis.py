@@ -277,7 +277,8 @@ def _ppc(data, classes, st, compute_method, log_dict):
     out = CrossSpectralData(dimord=CrossSpectra.dimord)
     if compute_method in (None, "hip") and hasattr(st, "ppc_hip"):
         st.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=False)
-        out._dev = st.ppc_hip(data)
+        res = st.ppc_hip(data)                       # (F, Ci, Cj) from raw trials, (nTime, F, Ci, Cj) from spectra
+        out._dev = res if res.dim() == 4 else res.unsqueeze(0)
         out.data = backend.to_host(out._dev)
         st.process_metadata(data, out)
     else:
