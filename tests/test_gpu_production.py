@@ -123,6 +123,13 @@ def _var_csd(C, F, seed, floor=0.05):
     L = np.eye(C) + 0.1 * np.tril(rng.normal(size=(C, C)), -1)
     Sigma = L @ L.T
     w = np.pi * np.arange(F) / (F - 1)
+    if C >= 128:                      # test fixture only: 2049 inversions of 256 x 256 take a minute in NumPy
+        t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.complex128)).cuda()      # noqa: E731
+        A = t(np.eye(C))[None] - t(A1)[None] * t(np.exp(-1j * w))[:, None, None] - t(A2)[None] * t(np.exp(-2j * w))[:, None, None]
+        H = torch.linalg.inv(A)
+        S = H @ t(Sigma)[None] @ H.conj().transpose(1, 2) + floor * t(np.eye(C))[None]
+        S = 0.5 * (S + S.conj().transpose(1, 2))
+        return S.to(torch.complex64).cpu().numpy()
     A = np.eye(C)[None] - A1[None] * np.exp(-1j * w)[:, None, None] - A2[None] * np.exp(-2j * w)[:, None, None]
     H = np.linalg.inv(A)
     S = H @ Sigma[None] @ H.conj().transpose(0, 2, 1) + floor * np.eye(C)[None]
@@ -165,9 +172,22 @@ def test_wilson_steps_equal_monolithic(C, F):
     assert meta1["converged"] and meta0["converged"] and meta1["iterations"] == it0
     assert meta1["reg. factor"] == meta0["reg. factor"]
     np.testing.assert_allclose(meta1["initial cond. num"], meta0["initial cond. num"], rtol=1e-9)
-    np.testing.assert_allclose(H1.cpu().numpy(), H0.cpu().numpy(), rtol=1e-9, atol=1e-11 * float(H0.abs().max()))
-    np.testing.assert_allclose(S1.cpu().numpy(), S0.cpu().numpy(), rtol=1e-9, atol=1e-11 * float(S0.abs().max()))
-    np.testing.assert_allclose(G1.cpu().numpy(), G0.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    # compared on the device: at 256 x 2049 the factors are 2 GB each
+    assert float((H1 - H0).abs().max()) <= 1e-9 * float(H0.abs().max())
+    assert float((S1 - S0).abs().max()) <= 1e-9 * float(S0.abs().max())
+    assert bool(torch.isfinite(G1).all()) and float((G1 - G0).abs().max()) <= 1e-5 * float(G0.abs().max()) + 1e-7
+    if C == 256:
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        granger_sharded(csd, 0, F, HipPrims(csd.device))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        backend.granger(csd)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"\nWilson 2049 x 256 x 256: stepped ABI (one shard) {t1 - t0:.3f} s, spyhip_granger {t2 - t1:.3f} s")
+        assert t1 - t0 < 3.0 * (t2 - t1) + 1.0               # the steps add allocations and copies, not another algorithm
 
 
 def test_wilson_shards_of_one_device():
