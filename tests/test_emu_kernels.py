@@ -195,7 +195,7 @@ def test_csd_mfma_kernel(C, F, R, tpw):
         assert_parity(E.coh_normalize(acc, output), O.normalize_csd(acc, output), what=output)
 
 
-@pytest.mark.parametrize("R", [7, 33])
+@pytest.mark.parametrize("R", [7, 19])
 def test_csd_3m_kernel_256_channels(R):
     """csd3m_kernel (3-multiplication complex product, 16 x 16 sub-tiles, two workgroups per frequency, rows global ->
     LDS by DMA): all 136 sub-tiles land where they belong, ragged last chunks are zero-filled, the accumulation
@@ -333,7 +333,7 @@ def test_blocked_inverse(n):
     assert info[0] == 2
 
 
-@pytest.mark.parametrize("n", [64, 37, 70, 96])
+@pytest.mark.parametrize("n", [64, 37, 70])
 def test_blocked_inverse_on_f64_matrix_cores(n):
     """zinv_mfma_kernel (32 x 32 blocks, R = D A_k* and the trailing update as v_mfma_f64_16x16x4_f64 tiles): ragged
     sizes (identity padding, partial tiles), asymmetric complex matrices (a row/column swap of a fragment layout would
@@ -394,9 +394,9 @@ def test_zgemm_on_f64_matrix_cores():
     np.testing.assert_allclose(E.w_gemm(A, Bm, opB=1, addI=1), A @ Bm.conj().transpose(0, 2, 1) + np.eye(n), rtol=1e-12,
                                atol=1e-12)
     # addI & 2: B declared lower triangular (the Cholesky factor): the zero rows above a column tile are skipped
-    n = 150
-    A = rng.normal(size=(2, n, n)) + 1j * rng.normal(size=(2, n, n))
-    L = np.tril(rng.normal(size=(2, n, n)) + 1j * rng.normal(size=(2, n, n)))
+    n = 130
+    A = rng.normal(size=(1, n, n)) + 1j * rng.normal(size=(1, n, n))
+    L = np.tril(rng.normal(size=(1, n, n)) + 1j * rng.normal(size=(1, n, n)))
     np.testing.assert_allclose(E.w_gemm(A, L, addI=2), A @ L, rtol=1e-12, atol=1e-12)
 
 
