@@ -84,20 +84,22 @@ int launch_tail(spyhip_ctx* ctx, CsdArgs a, long long first, int64_t nrows, int 
     return 0;
 }
 
-// 256 channels: the 3-multiplication kernel, one workgroup of 8 waves per frequency (csd3m_kernel.h)
-int launch_3m(spyhip_ctx* ctx, CsdArgs a, long long f_end) {
-    if (f_end <= 0) return 0;
+// 256 / 128 channels: the 3-multiplication kernel, one workgroup of 8 waves per packed row of 256 / CH frequencies
+// (csd3m_kernel.h); nprow = packed rows to serve from row 0
+template <int CH>
+int launch_3m(spyhip_ctx* ctx, CsdArgs a, long long nprow) {
+    if (nprow <= 0) return 0;
     a.item_base = 0;
-    a.item_end = f_end * spycsd::M3_TILES_PER_F;
-    auto kern = spycsd::csd3m_kernel<8>;
+    a.item_end = nprow * spycsd::M3_TILES_PER_F;
+    auto kern = spycsd::csd3m_kernel<CH, 8>;
     static bool attr_set = false;
     if (!attr_set) {
         SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           spycsd::M3_LDS_BYTES));
         attr_set = true;
     }
-    if (f_end > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)f_end), dim3(512), spycsd::M3_LDS_BYTES, ctx->stream, a);
+    if (nprow > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, ctx->stream, a);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -162,9 +164,20 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
         const long long nwg = nfreq, rem = nwg % ctx->num_cu;
         long long f_main = nfreq;
         if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) f_main = nwg - rem;
-        int rc = launch_3m(ctx, a, f_main);
+        int rc = launch_3m<256>(ctx, a, f_main);
         if (rc || f_main == nfreq) return rc;
         return launch_tail(ctx, a, f_main * a.ntiles, nrows, nfreq, nchan);
+    }
+    // 128 / 64 / 32 channels, row-major spectra: the same kernel with 2 / 4 / 8 frequencies per workgroup (the last
+    // packed row may be partial)
+    if ((nchan == 128 || nchan == 64 || nchan == 32) && !blocked && !force_4m) {
+        const int fpr = 256 / nchan;
+        const long long nwg = (nfreq + fpr - 1) / fpr, rem = nwg % ctx->num_cu;
+        long long p_main = nwg;
+        if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) p_main = nwg - rem;
+        int rc = nchan == 128 ? launch_3m<128>(ctx, a, p_main) : nchan == 64 ? launch_3m<64>(ctx, a, p_main) : launch_3m<32>(ctx, a, p_main);
+        if (rc || p_main == nwg) return rc;
+        return launch_tail(ctx, a, fpr * p_main * a.ntiles, nrows, nfreq, nchan);
     }
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
     if (fast || a.ntiles >= 21) {

@@ -56,54 +56,130 @@ constexpr int M3_ROWLEN = 256;                       // channels = float2 elemen
 constexpr int M3_KB = 16;                            // rows per chunk
 constexpr int M3_CHUNK_BYTES = M3_KB * M3_ROWLEN * 8;   // 32 KiB per buffer, three buffers
 constexpr int M3_LDS_BYTES = 3 * M3_CHUNK_BYTES;
-constexpr int M3_NT = 17;                            // sub-tiles per wave
-constexpr int M3_NB = 8;                             // distinct 16-channel blocks per wave
-constexpr int M3_TILES_PER_F = 36;                   // 32 x 32 tiles per frequency in CsdArgs' item units
+constexpr int M3_TILES_PER_F = 36;                   // 32 x 32 tiles per frequency in CsdArgs' item units (256 channels)
 
-// ---- ownership of the 136 lower-triangle sub-tiles: "wave" g = 4 * (workgroup of the pair) + wave; its sub-tile t is
-// (row block M3_BLK[g][M3_TA[g][t]], column block M3_BLK[g][M3_TB[g][t]]), row block >= column block.
+// ---- ownership of the lower-triangle 16 x 16 sub-tiles.  CH channels per frequency: one 256-element LDS row holds
+// 256 / CH consecutive frequencies of a row of spectra (they are contiguous in memory: (rows, F, C) with C = CH), so
+// "block" b = 0 ... 15 is channel block b % (CH / 16) of frequency (packed row) * (256 / CH) + b / (CH / 16).
+// Wave g's sub-tile t is (row block BLK[g][TA[g][t]], column block BLK[g][TB[g][t]]), row block >= column block.
+template <int CH>
+struct M3Tab;
+
+// 256 channels: 136 sub-tiles = 8 waves x 17, every wave touches 8 blocks
 //   g 0-3: the four 4 x 4 squares of rows 8-15 x columns 0-7, plus one sub-tile of a triangle each
 //   g 4, 5: the squares rows 4-7 x columns 0-3 and rows 12-15 x columns 8-11, plus one
 //   g 6, 7: the lower triangles of blocks {0-3}, {4-7} and of {8-11}, {12-15}, minus the six given away
-constexpr int M3_BLK[8][8] = {
-    { 0,  1,  2,  3,  8,  9, 10, 11},
-    { 4,  5,  6,  7,  8,  9, 10, 11},
-    { 0,  1,  2,  3, 12, 13, 14, 15},
-    { 4,  5,  6,  7, 12, 13, 14, 15},
-    { 0,  1,  2,  3,  4,  5,  6,  7},
-    { 8,  9, 10, 11, 12, 13, 14, 15},
-    { 0,  1,  2,  3,  4,  5,  6,  7},
-    { 8,  9, 10, 11, 12, 13, 14, 15},
-};
-constexpr int M3_TA[8][17] = {
-    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
-    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  7},
-    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
-    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  7},
-    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
-    { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
-    { 0,  1,  1,  2,  2,  2,  3,  4,  5,  5,  6,  6,  6,  7,  7,  7,  7},
-    { 0,  1,  1,  2,  2,  2,  3,  3,  4,  5,  5,  6,  6,  6,  7,  7,  7},
-};
-constexpr int M3_TB[8][17] = {
-    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0},
-    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  4},
-    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  1},
-    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  4},
-    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  2},
-    { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  1},
-    { 0,  0,  1,  0,  1,  2,  3,  4,  4,  5,  4,  5,  6,  4,  5,  6,  7},
-    { 0,  0,  1,  0,  1,  2,  2,  3,  4,  4,  5,  4,  5,  6,  5,  6,  7},
+template <>
+struct M3Tab<256> {
+    static constexpr int NT = 17, NB = 8;
+    static constexpr int BLK[8][8] = {
+        { 0,  1,  2,  3,  8,  9, 10, 11},
+        { 4,  5,  6,  7,  8,  9, 10, 11},
+        { 0,  1,  2,  3, 12, 13, 14, 15},
+        { 4,  5,  6,  7, 12, 13, 14, 15},
+        { 0,  1,  2,  3,  4,  5,  6,  7},
+        { 8,  9, 10, 11, 12, 13, 14, 15},
+        { 0,  1,  2,  3,  4,  5,  6,  7},
+        { 8,  9, 10, 11, 12, 13, 14, 15},
+    };
+    static constexpr int TA[8][17] = {
+        { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
+        { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  7},
+        { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
+        { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  7},
+        { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
+        { 4,  4,  4,  4,  5,  5,  5,  5,  6,  6,  6,  6,  7,  7,  7,  7,  3},
+        { 0,  1,  1,  2,  2,  2,  3,  4,  5,  5,  6,  6,  6,  7,  7,  7,  7},
+        { 0,  1,  1,  2,  2,  2,  3,  3,  4,  5,  5,  6,  6,  6,  7,  7,  7},
+    };
+    static constexpr int TB[8][17] = {
+        { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0},
+        { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  4},
+        { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  1},
+        { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  4},
+        { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  2},
+        { 0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  0,  1,  2,  3,  1},
+        { 0,  0,  1,  0,  1,  2,  3,  4,  4,  5,  4,  5,  6,  4,  5,  6,  7},
+        { 0,  0,  1,  0,  1,  2,  2,  3,  4,  4,  5,  4,  5,  6,  5,  6,  7},
+    };
 };
 
+// 128 channels: two frequencies per LDS row, 2 x 36 sub-tiles = 8 waves x 9; waves 0-3 own the first frequency
+// (blocks 0-7), waves 4-7 the second (blocks 8-15).  Within a frequency:
+//   wave 0: rows 4-5 x columns 0-3 + (3,0)      wave 1: rows 6-7 x columns 0-3 + (7,6)
+//   wave 2: the triangle of blocks 0-3 minus (3,0)   wave 3: the triangle of blocks 4-7 minus (7,6)
+template <>
+struct M3Tab<128> {
+    static constexpr int NT = 9, NB = 6;
+    static constexpr int BLK[8][6] = {
+        { 0,  1,  2,  3,  4,  5},
+        { 0,  1,  2,  3,  6,  7},
+        { 0,  1,  2,  3,  0,  0},
+        { 4,  5,  6,  7,  4,  4},
+        { 8,  9, 10, 11, 12, 13},
+        { 8,  9, 10, 11, 14, 15},
+        { 8,  9, 10, 11,  8,  8},
+        {12, 13, 14, 15, 12, 12},
+    };
+    static constexpr int TA[8][9] = {
+        { 4,  4,  4,  4,  5,  5,  5,  5,  3},
+        { 4,  4,  4,  4,  5,  5,  5,  5,  5},
+        { 0,  1,  1,  2,  2,  2,  3,  3,  3},
+        { 0,  1,  1,  2,  2,  2,  3,  3,  3},
+        { 4,  4,  4,  4,  5,  5,  5,  5,  3},
+        { 4,  4,  4,  4,  5,  5,  5,  5,  5},
+        { 0,  1,  1,  2,  2,  2,  3,  3,  3},
+        { 0,  1,  1,  2,  2,  2,  3,  3,  3},
+    };
+    static constexpr int TB[8][9] = {
+        { 0,  1,  2,  3,  0,  1,  2,  3,  0},
+        { 0,  1,  2,  3,  0,  1,  2,  3,  4},
+        { 0,  0,  1,  0,  1,  2,  1,  2,  3},
+        { 0,  0,  1,  0,  1,  2,  0,  1,  3},
+        { 0,  1,  2,  3,  0,  1,  2,  3,  0},
+        { 0,  1,  2,  3,  0,  1,  2,  3,  4},
+        { 0,  0,  1,  0,  1,  2,  1,  2,  3},
+        { 0,  0,  1,  0,  1,  2,  0,  1,  3},
+    };
+};
+
+// 64 channels: four frequencies per LDS row, 4 x 10 sub-tiles = 8 waves x 5; waves 2d, 2d + 1 own frequency d (blocks 4d...)
+template <>
+struct M3Tab<64> {
+    static constexpr int NT = 5, NB = 4;
+    static constexpr int BLK[8][4] = {
+        { 0,  1,  2,  0}, { 0,  1,  2,  3}, { 4,  5,  6,  4}, { 4,  5,  6,  7},
+        { 8,  9, 10,  8}, { 8,  9, 10, 11}, {12, 13, 14, 12}, {12, 13, 14, 15},
+    };
+    static constexpr int TA[8][5] = {
+        {0, 1, 1, 2, 2}, {2, 3, 3, 3, 3}, {0, 1, 1, 2, 2}, {2, 3, 3, 3, 3},
+        {0, 1, 1, 2, 2}, {2, 3, 3, 3, 3}, {0, 1, 1, 2, 2}, {2, 3, 3, 3, 3},
+    };
+    static constexpr int TB[8][5] = {
+        {0, 0, 1, 0, 1}, {2, 0, 1, 2, 3}, {0, 0, 1, 0, 1}, {2, 0, 1, 2, 3},
+        {0, 0, 1, 0, 1}, {2, 0, 1, 2, 3}, {0, 0, 1, 0, 1}, {2, 0, 1, 2, 3},
+    };
+};
+
+// 32 channels: eight frequencies per LDS row, wave g owns frequency g (blocks 2g, 2g + 1): 3 sub-tiles
+template <>
+struct M3Tab<32> {
+    static constexpr int NT = 3, NB = 2;
+    static constexpr int BLK[8][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {10, 11}, {12, 13}, {14, 15}};
+    static constexpr int TA[8][3] = {{0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}};
+    static constexpr int TB[8][3] = {{0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}};
+};
+
+template <int CH>
 __host__ __device__ constexpr bool m3_is_row(int g, int i) {      // block i of wave g is the row block of some sub-tile
-    for (int t = 0; t < M3_NT; ++t)
-        if (M3_TA[g][t] == i) return true;
+    for (int t = 0; t < M3Tab<CH>::NT; ++t)
+        if (M3Tab<CH>::TA[g][t] == i) return true;
     return false;
 }
+template <int CH>
 __host__ __device__ constexpr bool m3_is_col(int g, int i) {
-    for (int t = 0; t < M3_NT; ++t)
-        if (M3_TB[g][t] == i) return true;
+    for (int t = 0; t < M3Tab<CH>::NT; ++t)
+        if (M3Tab<CH>::TB[g][t] == i) return true;
     return false;
 }
 
@@ -132,13 +208,16 @@ inline void m3_glds16(const void* gsrc, char* lds_wave_base) {
 
 // G: which 17 sub-tiles; WPG: waves per workgroup (8: one workgroup per frequency, two waves per SIMD; 4: two
 // workgroups per frequency, one wave per SIMD); wave WV of the workgroup stages rows (16 / WPG) WV ... of every chunk
-template <int G, int WPG>
+template <int CH, int G, int WPG>
 __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int lane) {
+    using TAB = M3Tab<CH>;
+    constexpr int M3_NT = TAB::NT, M3_NB = TAB::NB;
+    constexpr int FPR = M3_ROWLEN / CH;              // frequencies per LDS row; f = index of the packed row
     constexpr int WV = G % WPG;
     constexpr int RPW = M3_KB / WPG;                  // rows a wave stages per chunk
     constexpr int RG = 4 * M3_ROWLEN * 8;            // bytes per group of four rows
     const int l15 = lane & 15, lq = lane >> 4;
-    const size_t rowstride = (size_t)a.F * M3_ROWLEN;               // float2 elements between rows
+    const size_t rowstride = (size_t)a.F * CH;                      // float2 elements between rows
     const size_t rowbytes = rowstride * 8;
     // source of this lane's 16 bytes of (row 0, half h): row-major spectra (r, f, c): 16 consecutive bytes of the 2-KiB
     // row; channel-quad-blocked spectra (r, c/4, f, 4) (spyhip_fft_plan_set_blocked): lanes (2q, 2q+1) take the two
@@ -146,6 +225,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     const char* const gbase = reinterpret_cast<const char*>(a.spec) +
                               (a.blocked ? ((size_t)(lane >> 1) * a.F + f) * 32 + (lane & 1) * 16 : (size_t)f * M3_ROWLEN * 8 + lane * 16);
     const size_t halfstep = a.blocked ? (size_t)32 * a.F * 32 : 1024;     // from half 0 (channels 0-127) to half 1
+    const int vbytes = (a.F - f * FPR) * CH * 8;                     // valid bytes of this packed row (>= 2048: all)
     const long long nrows = a.nrows;
     const long long nchunk = (nrows + M3_KB - 1) / M3_KB;
 
@@ -158,8 +238,12 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 #pragma unroll
         for (int v = 0; v < 2 * RPW; ++v) {
             const int row = RPW * WV + (v >> 1), half = v & 1;
+            // (CH < 256: the last packed row may hold fewer than 256 / CH frequencies; the bytes behind the last one
+            // belong to the next row of spectra - or to nobody - and are not copied: those lanes sit the copy out and
+            // leave stale LDS behind, which only sub-tiles of the missing frequencies read, and they are never stored)
             if (row < rleft) {                                          // wave-uniform
-                m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + half * halfstep, dst + row * (M3_ROWLEN * 8) + half * 1024);
+                if (FPR == 1 || half * 1024 + lane * 16 < vbytes)
+                    m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + half * halfstep, dst + row * (M3_ROWLEN * 8) + half * 1024);
             } else {
                 *reinterpret_cast<float4*>(dst + row * (M3_ROWLEN * 8) + half * 1024 + lane * 16) =
                     make_float4(0.f, 0.f, 0.f, 0.f);
@@ -193,7 +277,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     auto load = [&]() {
         m3_for<0, M3_NB>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            x[i] = *reinterpret_cast<const float2*>(fp + 128 * M3_BLK[G][i]);
+            x[i] = *reinterpret_cast<const float2*>(fp + 128 * TAB::BLK[G][i]);
         });
     };
     // An MFMA blocks the wave that issued it for its 32 cycles, so everything else of a group - 8 fragment reads, 13
@@ -211,8 +295,8 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
         for (int st = 0; st < M3_KB / 4; ++st) {
             m3_for<0, M3_NB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                sm[i] = m3_is_row(G, i) ? x[i].x + x[i].y : 0.f;
-                df[i] = m3_is_col(G, i) ? x[i].x - x[i].y : 0.f;
+                sm[i] = m3_is_row<CH>(G, i) ? x[i].x + x[i].y : 0.f;
+                df[i] = m3_is_col<CH>(G, i) ? x[i].x - x[i].y : 0.f;
             });
             float re[M3_NB], im[M3_NB];
             m3_for<0, M3_NB>([&](auto ic) { constexpr int i = decltype(ic)::value; re[i] = x[i].x; im[i] = x[i].y; });
@@ -222,12 +306,12 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
             // overwrite x) only after the P1 / P2 products, which come last
             m3_for<0, M3_NT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[M3_TA[G][t]], df[M3_TB[G][t]], p3[t], 0, 0, 0);
+                p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[TAB::TA[G][t]], df[TAB::TB[G][t]], p3[t], 0, 0, 0);
             });
             m3_for<0, M3_NT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                p1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(re[M3_TA[G][t]], re[M3_TB[G][t]], p1[t], 0, 0, 0);
-                p2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(im[M3_TA[G][t]], im[M3_TB[G][t]], p2[t], 0, 0, 0);
+                p1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(re[TAB::TA[G][t]], re[TAB::TB[G][t]], p1[t], 0, 0, 0);
+                p2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(im[TAB::TA[G][t]], im[TAB::TB[G][t]], p2[t], 0, 0, 0);
             });
             m3_sched_fence();
             if (st + 1 < M3_KB / 4 || c + 1 < nchunk) load();
@@ -241,25 +325,31 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 
     // ---- acc += sub-tile (each has one owner: plain read-modify-write).  Lane l holds column (l & 15) and rows
     // 4 (l >> 4) + r of the 16 x 16 block.
-    float2* const abase = a.acc + (size_t)f * M3_ROWLEN * M3_ROWLEN;
+    constexpr int BPF = CH / 16;                     // blocks per frequency
     m3_for<0, M3_NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        constexpr int bi = M3_BLK[G][M3_TA[G][t]], bj = M3_BLK[G][M3_TB[G][t]];
-        float2* const pb = abase + (size_t)(bi * 16 + 4 * lq) * M3_ROWLEN + bj * 16 + l15;
-        float2 old[4];
+        constexpr int bi = TAB::BLK[G][TAB::TA[G][t]], bj = TAB::BLK[G][TAB::TB[G][t]];
+        static_assert(bi / BPF == bj / BPF && bi >= bj, "a sub-tile lies inside one frequency, on or below the diagonal");
+        const int fr = f * FPR + bi / BPF;           // this sub-tile's frequency
+        if (fr < a.F) {                              // wave-uniform
+            float2* const pb = a.acc + (size_t)fr * CH * CH + (size_t)((bi % BPF) * 16 + 4 * lq) * CH + (bj % BPF) * 16 + l15;
+            float2 old[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) old[r] = pb[(size_t)r * M3_ROWLEN];
+            for (int r = 0; r < 4; ++r) old[r] = pb[(size_t)r * CH];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            pb[(size_t)r * M3_ROWLEN] =
-                make_float2(old[r].x + (p1[t][r] + p2[t][r]), old[r].y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+            for (int r = 0; r < 4; ++r)
+                pb[(size_t)r * CH] =
+                    make_float2(old[r].x + (p1[t][r] + p2[t][r]), old[r].y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+        }
     });
 }
 
 // WPG = 8: one workgroup of 8 waves per frequency (block b -> frequency item_base / 36 + b);
 // WPG = 4: two workgroups of 4 waves per frequency (block b -> frequency ... + b / 2, sub-tile sets of half b % 2).
-template <int WPG>
+// CH: channels (256: one frequency per workgroup; 128: two; 64: four; 32: eight).  The workgroup serves packed row item_base / 36 + block.
+template <int CH, int WPG>
 __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdArgs a) {
+    static_assert(CH == 256 || WPG == 8, "the two-workgroup split exists for 256 channels only");
     SPY_DYN_SMEM(char, Xb);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -271,14 +361,14 @@ __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdAr
     const int f = (int)(a.item_base / M3_TILES_PER_F) + (int)(WPG == 8 ? blockIdx.x : blockIdx.x >> 1);
     if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
     switch (WPG == 8 ? wave : 4 * (int)(blockIdx.x & 1) + wave) {
-        case 0: m3_wave<0, WPG>(a, Xb, f, lane); break;
-        case 1: m3_wave<1, WPG>(a, Xb, f, lane); break;
-        case 2: m3_wave<2, WPG>(a, Xb, f, lane); break;
-        case 3: m3_wave<3, WPG>(a, Xb, f, lane); break;
-        case 4: m3_wave<4, WPG>(a, Xb, f, lane); break;
-        case 5: m3_wave<5, WPG>(a, Xb, f, lane); break;
-        case 6: m3_wave<6, WPG>(a, Xb, f, lane); break;
-        default: m3_wave<7, WPG>(a, Xb, f, lane); break;
+        case 0: m3_wave<CH, 0, WPG>(a, Xb, f, lane); break;
+        case 1: m3_wave<CH, 1, WPG>(a, Xb, f, lane); break;
+        case 2: m3_wave<CH, 2, WPG>(a, Xb, f, lane); break;
+        case 3: m3_wave<CH, 3, WPG>(a, Xb, f, lane); break;
+        case 4: m3_wave<CH, 4, WPG>(a, Xb, f, lane); break;
+        case 5: m3_wave<CH, 5, WPG>(a, Xb, f, lane); break;
+        case 6: m3_wave<CH, 6, WPG>(a, Xb, f, lane); break;
+        default: m3_wave<CH, 7, WPG>(a, Xb, f, lane); break;
     }
 }
 

@@ -410,10 +410,20 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
         // (g_m3_wpg = 4: the variant with two workgroups of 4 waves per frequency)
         a.item_end = (long long)F * spycsd::M3_TILES_PER_F;
         if (g_m3_wpg == 4)
-            emu::launch(dim3((unsigned)(2 * F)), dim3(256), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<4>(a); });
+            emu::launch(dim3((unsigned)(2 * F)), dim3(256), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 4>(a); });
         else
-            emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<8>(a); });
+            emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8>(a); });
         return 8;
+    }
+    if (force_tpw == 0 && (C == 128 || C == 64 || C == 32) && !g_force_4m) {
+        // as csd.hip: 128 / 64 / 32 channels take the same kernel with 2 / 4 / 8 frequencies per workgroup
+        const int fpr = 256 / C;
+        const long long nprow = (F + fpr - 1) / fpr;
+        a.item_end = nprow * spycsd::M3_TILES_PER_F;
+        if (C == 128) emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<128, 8>(a); });
+        else if (C == 64) emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<64, 8>(a); });
+        else emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<32, 8>(a); });
+        return 9;
     }
     if (fast && C == 256) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });
     else if (fast) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 2>(a); });

@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     hipMemset(acc, 0, (size_t)F * C * C * 8);
     a.spec = (const float2*)spec; a.nrows = rows; a.F = F; a.C = C; a.acc = (float2*)acc;
     a.nt = 8; a.ntiles = 36; a.nitems = (long long)F * 36; a.cpad = 256; a.item_base = 0; a.item_end = a.nitems;
-    auto kern = spycsd::csd3m_kernel<NW>;
+    auto kern = spycsd::csd3m_kernel<256, NW>;
     const int grid = NW == 8 ? F : 2 * F, threads = 64 * NW;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, spycsd::M3_LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
