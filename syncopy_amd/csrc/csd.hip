@@ -168,14 +168,32 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
         if (rc || f_main == nfreq) return rc;
         return launch_tail(ctx, a, f_main * a.ntiles, nrows, nfreq, nchan);
     }
-    // 128 / 64 / 32 channels, row-major spectra: the same kernel with 2 / 4 / 8 frequencies per workgroup (the last
-    // packed row may be partial)
-    if ((nchan == 128 || nchan == 64 || nchan == 32) && !blocked && !force_4m) {
+    // every other multiple of 16 up to 240 channels, row-major spectra: the same kernel with floor(256 / C) frequencies
+    // per workgroup (the last packed row may be partial; hand-made sub-tile tables for 128 / 64 / 32, generated ones
+    // for the rest)
+    if (nchan % 16 == 0 && nchan < 256 && !blocked && !force_4m) {
         const int fpr = 256 / nchan;
         const long long nwg = (nfreq + fpr - 1) / fpr, rem = nwg % ctx->num_cu;
         long long p_main = nwg;
         if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) p_main = nwg - rem;
-        int rc = nchan == 128 ? launch_3m<128>(ctx, a, p_main) : nchan == 64 ? launch_3m<64>(ctx, a, p_main) : launch_3m<32>(ctx, a, p_main);
+        int rc;
+        switch (nchan) {
+            case 16: rc = launch_3m<16>(ctx, a, p_main); break;
+            case 32: rc = launch_3m<32>(ctx, a, p_main); break;
+            case 48: rc = launch_3m<48>(ctx, a, p_main); break;
+            case 64: rc = launch_3m<64>(ctx, a, p_main); break;
+            case 80: rc = launch_3m<80>(ctx, a, p_main); break;
+            case 96: rc = launch_3m<96>(ctx, a, p_main); break;
+            case 112: rc = launch_3m<112>(ctx, a, p_main); break;
+            case 128: rc = launch_3m<128>(ctx, a, p_main); break;
+            case 144: rc = launch_3m<144>(ctx, a, p_main); break;
+            case 160: rc = launch_3m<160>(ctx, a, p_main); break;
+            case 176: rc = launch_3m<176>(ctx, a, p_main); break;
+            case 192: rc = launch_3m<192>(ctx, a, p_main); break;
+            case 208: rc = launch_3m<208>(ctx, a, p_main); break;
+            case 224: rc = launch_3m<224>(ctx, a, p_main); break;
+            default: rc = launch_3m<240>(ctx, a, p_main); break;
+        }
         if (rc || p_main == nwg) return rc;
         return launch_tail(ctx, a, fpr * p_main * a.ntiles, nrows, nfreq, nchan);
     }

@@ -62,8 +62,68 @@ constexpr int M3_TILES_PER_F = 36;                   // 32 x 32 tiles per freque
 // 256 / CH consecutive frequencies of a row of spectra (they are contiguous in memory: (rows, F, C) with C = CH), so
 // "block" b = 0 ... 15 is channel block b % (CH / 16) of frequency (packed row) * (256 / CH) + b / (CH / 16).
 // Wave g's sub-tile t is (row block BLK[g][TA[g][t]], column block BLK[g][TB[g][t]]), row block >= column block.
+// Primary template: tables generated at compile time for any CH = 16 nb <= 256 (FPR = 256 / CH frequencies per
+// row): the sub-tiles are listed frequency by frequency, 4 x 4 super-tile by super-tile (so that consecutive ones share
+// channel blocks) and cut into 8 runs of NT; wave g's run may be shorter (CNT[g]).  Hand-made tables below for the
+// counts that matter most.
 template <int CH>
-struct M3Tab;
+struct M3Tab {
+    static_assert(CH % 16 == 0 && CH >= 16 && CH <= 256, "channel count of the generated 3M tables");
+    static constexpr int BPF = CH / 16, FPR = 256 / CH, NSUB = BPF * (BPF + 1) / 2, NTOT = FPR * NSUB;
+    static constexpr int NT = (NTOT + 7) / 8;
+    struct Gen {
+        int blk[8][16];
+        int nb[8];
+        int ta[8][NT];
+        int tb[8][NT];
+        int cnt[8];
+        int nbmax;
+    };
+    static constexpr Gen make() {
+        Gen g{};
+        int seq_r[NTOT > 0 ? NTOT : 1] = {}, seq_c[NTOT > 0 ? NTOT : 1] = {};
+        int n = 0;
+        for (int d = 0; d < FPR; ++d)
+            for (int I = 0; I < (BPF + 3) / 4; ++I)
+                for (int J = 0; J <= I; ++J)
+                    for (int r = 4 * I; r < 4 * I + 4 && r < BPF; ++r)
+                        for (int c = 4 * J; c < 4 * J + 4 && c <= r; ++c) {
+                            seq_r[n] = d * BPF + r;
+                            seq_c[n] = d * BPF + c;
+                            ++n;
+                        }
+        g.nbmax = 1;
+        for (int w = 0; w < 8; ++w) {
+            g.nb[w] = 0;
+            g.cnt[w] = 0;
+            for (int i = 0; i < 16; ++i) g.blk[w][i] = 0;
+            for (int t = 0; t < NT; ++t) { g.ta[w][t] = 0; g.tb[w][t] = 0; }
+            for (int t = 0; t < NT; ++t) {
+                const int k = w * NT + t;
+                if (k >= NTOT) break;
+                int ia = -1, ib = -1;
+                for (int i = 0; i < g.nb[w]; ++i) {
+                    if (g.blk[w][i] == seq_r[k]) ia = i;
+                    if (g.blk[w][i] == seq_c[k]) ib = i;
+                }
+                if (ia < 0) { ia = g.nb[w]; g.blk[w][g.nb[w]++] = seq_r[k]; }
+                if (seq_c[k] == seq_r[k]) ib = ia;
+                if (ib < 0) { ib = g.nb[w]; g.blk[w][g.nb[w]++] = seq_c[k]; }
+                g.ta[w][t] = ia;
+                g.tb[w][t] = ib;
+                g.cnt[w] = t + 1;
+            }
+            if (g.nb[w] > g.nbmax) g.nbmax = g.nb[w];
+        }
+        return g;
+    }
+    static constexpr Gen T = make();
+    static constexpr int NB = T.nbmax;
+    static constexpr int blk(int g, int i) { return T.blk[g][i]; }
+    static constexpr int ta(int g, int t) { return T.ta[g][t]; }
+    static constexpr int tb(int g, int t) { return T.tb[g][t]; }
+    static constexpr int cnt(int g) { return T.cnt[g]; }
+};
 
 // 256 channels: 136 sub-tiles = 8 waves x 17, every wave touches 8 blocks
 //   g 0-3: the four 4 x 4 squares of rows 8-15 x columns 0-7, plus one sub-tile of a triangle each
@@ -102,6 +162,10 @@ struct M3Tab<256> {
         { 0,  0,  1,  0,  1,  2,  3,  4,  4,  5,  4,  5,  6,  4,  5,  6,  7},
         { 0,  0,  1,  0,  1,  2,  2,  3,  4,  4,  5,  4,  5,  6,  5,  6,  7},
     };
+    static constexpr int blk(int g, int i) { return BLK[g][i]; }
+    static constexpr int ta(int g, int t) { return TA[g][t]; }
+    static constexpr int tb(int g, int t) { return TB[g][t]; }
+    static constexpr int cnt(int) { return NT; }
 };
 
 // 128 channels: two frequencies per LDS row, 2 x 36 sub-tiles = 8 waves x 9; waves 0-3 own the first frequency
@@ -141,6 +205,10 @@ struct M3Tab<128> {
         { 0,  0,  1,  0,  1,  2,  1,  2,  3},
         { 0,  0,  1,  0,  1,  2,  0,  1,  3},
     };
+    static constexpr int blk(int g, int i) { return BLK[g][i]; }
+    static constexpr int ta(int g, int t) { return TA[g][t]; }
+    static constexpr int tb(int g, int t) { return TB[g][t]; }
+    static constexpr int cnt(int) { return NT; }
 };
 
 // 64 channels: four frequencies per LDS row, 4 x 10 sub-tiles = 8 waves x 5; waves 2d, 2d + 1 own frequency d (blocks 4d...)
@@ -159,6 +227,10 @@ struct M3Tab<64> {
         {0, 0, 1, 0, 1}, {2, 0, 1, 2, 3}, {0, 0, 1, 0, 1}, {2, 0, 1, 2, 3},
         {0, 0, 1, 0, 1}, {2, 0, 1, 2, 3}, {0, 0, 1, 0, 1}, {2, 0, 1, 2, 3},
     };
+    static constexpr int blk(int g, int i) { return BLK[g][i]; }
+    static constexpr int ta(int g, int t) { return TA[g][t]; }
+    static constexpr int tb(int g, int t) { return TB[g][t]; }
+    static constexpr int cnt(int) { return NT; }
 };
 
 // 32 channels: eight frequencies per LDS row, wave g owns frequency g (blocks 2g, 2g + 1): 3 sub-tiles
@@ -168,18 +240,22 @@ struct M3Tab<32> {
     static constexpr int BLK[8][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {10, 11}, {12, 13}, {14, 15}};
     static constexpr int TA[8][3] = {{0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}};
     static constexpr int TB[8][3] = {{0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}};
+    static constexpr int blk(int g, int i) { return BLK[g][i]; }
+    static constexpr int ta(int g, int t) { return TA[g][t]; }
+    static constexpr int tb(int g, int t) { return TB[g][t]; }
+    static constexpr int cnt(int) { return NT; }
 };
 
 template <int CH>
 __host__ __device__ constexpr bool m3_is_row(int g, int i) {      // block i of wave g is the row block of some sub-tile
-    for (int t = 0; t < M3Tab<CH>::NT; ++t)
-        if (M3Tab<CH>::TA[g][t] == i) return true;
+    for (int t = 0; t < M3Tab<CH>::cnt(g); ++t)
+        if (M3Tab<CH>::ta(g, t) == i) return true;
     return false;
 }
 template <int CH>
 __host__ __device__ constexpr bool m3_is_col(int g, int i) {
-    for (int t = 0; t < M3Tab<CH>::NT; ++t)
-        if (M3Tab<CH>::TB[g][t] == i) return true;
+    for (int t = 0; t < M3Tab<CH>::cnt(g); ++t)
+        if (M3Tab<CH>::tb(g, t) == i) return true;
     return false;
 }
 
@@ -223,9 +299,10 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     // row; channel-quad-blocked spectra (r, c/4, f, 4) (spyhip_fft_plan_set_blocked): lanes (2q, 2q+1) take the two
     // halves of quad q's 32 bytes - the copy gathers, the LDS image is the same
     const char* const gbase = reinterpret_cast<const char*>(a.spec) +
-                              (a.blocked ? ((size_t)(lane >> 1) * a.F + f) * 32 + (lane & 1) * 16 : (size_t)f * M3_ROWLEN * 8 + lane * 16);
+                              (a.blocked ? ((size_t)(lane >> 1) * a.F + f) * 32 + (lane & 1) * 16 : (size_t)f * FPR * CH * 8 + lane * 16);
     const size_t halfstep = a.blocked ? (size_t)32 * a.F * 32 : 1024;     // from half 0 (channels 0-127) to half 1
-    const int vbytes = (a.F - f * FPR) * CH * 8;                     // valid bytes of this packed row (>= 2048: all)
+    // valid bytes of this packed row: its FPR frequencies (fewer in the last one), CH channels each
+    const int vbytes = ((a.F - f * FPR) < FPR ? (a.F - f * FPR) : FPR) * CH * 8;
     const long long nrows = a.nrows;
     const long long nchunk = (nrows + M3_KB - 1) / M3_KB;
 
@@ -242,7 +319,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
             // belong to the next row of spectra - or to nobody - and are not copied: those lanes sit the copy out and
             // leave stale LDS behind, which only sub-tiles of the missing frequencies read, and they are never stored)
             if (row < rleft) {                                          // wave-uniform
-                if (FPR == 1 || half * 1024 + lane * 16 < vbytes)
+                if ((FPR == 1 && CH == M3_ROWLEN) || half * 1024 + lane * 16 < vbytes)
                     m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + half * halfstep, dst + row * (M3_ROWLEN * 8) + half * 1024);
             } else {
                 *reinterpret_cast<float4*>(dst + row * (M3_ROWLEN * 8) + half * 1024 + lane * 16) =
@@ -277,7 +354,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     auto load = [&]() {
         m3_for<0, M3_NB>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            x[i] = *reinterpret_cast<const float2*>(fp + 128 * TAB::BLK[G][i]);
+            x[i] = *reinterpret_cast<const float2*>(fp + 128 * TAB::blk(G, i));
         });
     };
     // An MFMA blocks the wave that issued it for its 32 cycles, so everything else of a group - 8 fragment reads, 13
@@ -306,12 +383,15 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
             // overwrite x) only after the P1 / P2 products, which come last
             m3_for<0, M3_NT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[TAB::TA[G][t]], df[TAB::TB[G][t]], p3[t], 0, 0, 0);
+                if constexpr (t < TAB::cnt(G))
+                    p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[TAB::ta(G, t)], df[TAB::tb(G, t)], p3[t], 0, 0, 0);
             });
             m3_for<0, M3_NT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                p1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(re[TAB::TA[G][t]], re[TAB::TB[G][t]], p1[t], 0, 0, 0);
-                p2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(im[TAB::TA[G][t]], im[TAB::TB[G][t]], p2[t], 0, 0, 0);
+                if constexpr (t < TAB::cnt(G)) {
+                    p1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(re[TAB::ta(G, t)], re[TAB::tb(G, t)], p1[t], 0, 0, 0);
+                    p2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(im[TAB::ta(G, t)], im[TAB::tb(G, t)], p2[t], 0, 0, 0);
+                }
             });
             m3_sched_fence();
             if (st + 1 < M3_KB / 4 || c + 1 < nchunk) load();
@@ -328,10 +408,10 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     constexpr int BPF = CH / 16;                     // blocks per frequency
     m3_for<0, M3_NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        constexpr int bi = TAB::BLK[G][TAB::TA[G][t]], bj = TAB::BLK[G][TAB::TB[G][t]];
+        constexpr int bi = TAB::blk(G, TAB::ta(G, t)), bj = TAB::blk(G, TAB::tb(G, t));
         static_assert(bi / BPF == bj / BPF && bi >= bj, "a sub-tile lies inside one frequency, on or below the diagonal");
         const int fr = f * FPR + bi / BPF;           // this sub-tile's frequency
-        if (fr < a.F) {                              // wave-uniform
+        if (t < TAB::cnt(G) && fr < a.F) {           // wave-uniform
             float2* const pb = a.acc + (size_t)fr * CH * CH + (size_t)((bi % BPF) * 16 + 4 * lq) * CH + (bj % BPF) * 16 + l15;
             float2 old[4];
 #pragma unroll

@@ -415,14 +415,23 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
             emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8>(a); });
         return 8;
     }
-    if (force_tpw == 0 && (C == 128 || C == 64 || C == 32) && !g_force_4m) {
-        // as csd.hip: 128 / 64 / 32 channels take the same kernel with 2 / 4 / 8 frequencies per workgroup
+    if (force_tpw == 0 && C % 16 == 0 && C < 256 && !g_force_4m) {
+        // as csd.hip: the 3-multiplication kernel with floor(256 / C) frequencies per workgroup
         const int fpr = 256 / C;
         const long long nprow = (F + fpr - 1) / fpr;
         a.item_end = nprow * spycsd::M3_TILES_PER_F;
-        if (C == 128) emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<128, 8>(a); });
-        else if (C == 64) emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<64, 8>(a); });
-        else emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<32, 8>(a); });
+        const dim3 g((unsigned)nprow), b(512);
+        switch (C) {
+            case 16: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<16, 8>(a); }); break;
+            case 32: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<32, 8>(a); }); break;
+            case 48: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<48, 8>(a); }); break;
+            case 64: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<64, 8>(a); }); break;
+            case 96: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<96, 8>(a); }); break;
+            case 128: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<128, 8>(a); }); break;
+            case 192: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<192, 8>(a); }); break;
+            case 240: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<240, 8>(a); }); break;
+            default: return -1;            // (the emulator instantiates a sample of the channel counts)
+        }
         return 9;
     }
     if (fast && C == 256) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });
