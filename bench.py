@@ -442,8 +442,10 @@ def main():
         achieved = sum(flops) / (sum(csd_ms) * 1e-3) / 1e12
         fft_bytes = sum(nb * (N * C * 4 + K * F * C * 8) for _, _, nb in ev_fft)
         # matrix flops the 3-multiplication kernel really issues: 136 sub-tiles x 3 MFMAs of 16x16x4 per 4 rows
-        is3m = C == 256 and not os.environ.get("SPYHIP_CSD_4M")
-        executed = ((rows[0] + 3) // 4) * F * 136 * 3 * 2048.0 if is3m else None
+        # (every multiple of 16 up to 256 channels: floor(256 / C) frequencies per workgroup, nb (nb + 1) / 2 sub-tiles each)
+        is3m = (C == 256 or (C % 16 == 0 and C < 256 and not blocked)) and not os.environ.get("SPYHIP_CSD_4M")
+        nsub = (C // 16) * (C // 16 + 1) // 2
+        executed = ((rows[0] + 3) // 4) * F * nsub * 3 * 2048.0 if is3m else None
         value = world * T * args.steps / el
         coll = {"executed": bool(dist_on), "backend": "nccl (RCCL)" if dist_on else None}
         if ev_coll:
@@ -484,13 +486,13 @@ def main():
                 "executed_mfma_flop_per_launch": executed,
                 "executed_frac_of_peak": (executed / flops[0]) * achieved / PEAK_MFMA_F32_TFLOPS if executed else None,
                 "note": "achieved counts 8 flop per complex multiply-accumulate on the Hermitian-minimal triangle "
-                        "(SURVEY 8d); the 256-channel kernel uses the 3-multiplication complex product, so it "
+                        "(SURVEY 8d); the kernel for multiples of 16 channels uses the 3-multiplication complex product, so it "
                         "executes fewer flops than it is credited with and frac may exceed 1 - "
                         "executed_frac_of_peak is the matrix pipe's own utilisation",
                 "avg_launch_ms": float(np.mean(csd_ms)),
                 # spectra once + read-modify-write of the accumulator's lower triangle (16 x 16 sub-tiles for the
                 # 3-multiplication kernel, 32 x 32 tiles otherwise)
-                "algorithmic_hbm_bytes_per_launch": rows[0] * F * C * 8 + (2 * F * 136 * 256 * 8 if is3m else 2 * F * (((C + 31) // 32) * ((C + 31) // 32 + 1) // 2) * 1024 * 8),
+                "algorithmic_hbm_bytes_per_launch": rows[0] * F * C * 8 + (2 * F * nsub * 256 * 8 if is3m else 2 * F * (((C + 31) // 32) * ((C + 31) // 32 + 1) // 2) * 1024 * 8),
                 "traffic": pmc_traffic(rows[0], F, C),
             },
         }
