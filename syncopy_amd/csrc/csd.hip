@@ -6,7 +6,7 @@
 
 #include "spy_common.h"
 #include "csd_kernel.h"
-#include "csd3m_kernel.h"
+#include "csd3m_launch.h"
 
 using spycsd::CsdArgs;
 
@@ -84,24 +84,11 @@ int launch_tail(spyhip_ctx* ctx, CsdArgs a, long long first, int64_t nrows, int 
     return 0;
 }
 
-// 256 / 128 channels: the 3-multiplication kernel, one workgroup of 8 waves per packed row of 256 / CH frequencies
-// (csd3m_kernel.h); nprow = packed rows to serve from row 0
-template <int CH>
-int launch_3m(spyhip_ctx* ctx, CsdArgs a, long long nprow) {
-    if (nprow <= 0) return 0;
-    a.item_base = 0;
-    a.item_end = nprow * spycsd::M3_TILES_PER_F;
-    auto kern = spycsd::csd3m_kernel<CH, 8>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          spycsd::M3_LDS_BYTES));
-        attr_set = true;
-    }
-    if (nprow > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, ctx->stream, a);
-    SPY_HIP_CHECK(hipGetLastError());
-    return 0;
+// packed rows to give the 3M kernel when the workgroups beyond the last full round of the chip go to the re-cut tail
+long long m3_main_rows(spyhip_ctx* ctx, long long nprow, int np) {
+    const long long nwg = nprow * np, rem = nwg % ctx->num_cu;
+    if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) return nprow - (rem + np - 1) / np;
+    return nprow;
 }
 
 }  // namespace
@@ -145,7 +132,10 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
     }
     // C in (256, 512]: the same path with 512-element rows; the tiles of a frequency are shared by
     // ceil(ntiles / 40) workgroups (512 channels: 4 x 34 tiles), each staging the whole row.
-    if (!blocked && nchan > 256 && nchan <= 512) {
+    // SPYHIP_CSD_4M=1 keeps the 4-multiplication kernels everywhere (A/B measurements, cross-checks).
+    static const bool force_4m = std::getenv("SPYHIP_CSD_4M") != nullptr;
+    const bool wide3m = !force_4m && nchan > 256 && spycsd::m3_available(nchan);
+    if (!blocked && nchan > 256 && nchan <= 512 && !wide3m) {
         a.fast_nwgf = (a.ntiles + 39) / 40;
         a.fast_per = (a.ntiles + a.fast_nwgf - 1) / a.fast_nwgf;
         const long long nwg = (long long)nfreq * a.fast_nwgf;
@@ -158,43 +148,26 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
     }
     // 256 channels, row-major spectra: the 3-multiplication kernel, one workgroup per frequency; the workgroups
     // beyond the last full round (F = 2049 on 256 CUs: one frequency) go to the re-cut tail like on the other paths.
-    // SPYHIP_CSD_4M=1 keeps the 4-multiplication kernel (A/B measurements, cross-checks).
-    static const bool force_4m = std::getenv("SPYHIP_CSD_4M") != nullptr;
     if (nchan == 256 && !force_4m) {         // either hand-over layout: the kernel's LDS copies gather
         const long long nwg = nfreq, rem = nwg % ctx->num_cu;
         long long f_main = nfreq;
         if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) f_main = nwg - rem;
-        int rc = launch_3m<256>(ctx, a, f_main);
+        int rc = spycsd::m3_launch(256, ctx->stream, a, f_main);
+        if (rc == -100) { spy::set_error("csd_accumulate: no 3M kernel for 256 channels"); return -1; }
         if (rc || f_main == nfreq) return rc;
         return launch_tail(ctx, a, f_main * a.ntiles, nrows, nfreq, nchan);
     }
-    // every other multiple of 16 up to 240 channels, row-major spectra: the same kernel with floor(256 / C) frequencies
-    // per workgroup (the last packed row may be partial; hand-made sub-tile tables for 128 / 64 / 32, generated ones
-    // for the rest)
-    if (nchan % 16 == 0 && nchan < 256 && !blocked && !force_4m) {
-        const int fpr = 256 / nchan;
-        const long long nwg = (nfreq + fpr - 1) / fpr, rem = nwg % ctx->num_cu;
-        long long p_main = nwg;
-        if (nwg > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) p_main = nwg - rem;
-        int rc;
-        switch (nchan) {
-            case 16: rc = launch_3m<16>(ctx, a, p_main); break;
-            case 32: rc = launch_3m<32>(ctx, a, p_main); break;
-            case 48: rc = launch_3m<48>(ctx, a, p_main); break;
-            case 64: rc = launch_3m<64>(ctx, a, p_main); break;
-            case 80: rc = launch_3m<80>(ctx, a, p_main); break;
-            case 96: rc = launch_3m<96>(ctx, a, p_main); break;
-            case 112: rc = launch_3m<112>(ctx, a, p_main); break;
-            case 128: rc = launch_3m<128>(ctx, a, p_main); break;
-            case 144: rc = launch_3m<144>(ctx, a, p_main); break;
-            case 160: rc = launch_3m<160>(ctx, a, p_main); break;
-            case 176: rc = launch_3m<176>(ctx, a, p_main); break;
-            case 192: rc = launch_3m<192>(ctx, a, p_main); break;
-            case 208: rc = launch_3m<208>(ctx, a, p_main); break;
-            case 224: rc = launch_3m<224>(ctx, a, p_main); break;
-            default: rc = launch_3m<240>(ctx, a, p_main); break;
-        }
-        if (rc || p_main == nwg) return rc;
+    // the other channel counts the 3M kernel is built for (csd3m_launch.h), row-major spectra: below 256 channels
+    // floor(256 / C) frequencies per workgroup (the last packed row may be partial; hand-made sub-tile tables for
+    // 128 / 64 / 32, generated ones for the rest); 320 / 384 / 512 channels: 512-element LDS rows, several
+    // workgroups per frequency
+    if (nchan != 256 && !blocked && !force_4m && spycsd::m3_available(nchan)) {
+        const int fpr = nchan < 256 ? 256 / nchan : 1;
+        const long long nprow = (nfreq + fpr - 1) / fpr;
+        const long long p_main = m3_main_rows(ctx, nprow, spycsd::m3_parts(nchan));
+        const int rc = spycsd::m3_launch(nchan, ctx->stream, a, p_main);
+        if (rc == -100) { spy::set_error("csd_accumulate: no 3M kernel for %d channels", nchan); return -1; }
+        if (rc || p_main == nprow) return rc;
         return launch_tail(ctx, a, fpr * p_main * a.ntiles, nrows, nfreq, nchan);
     }
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency

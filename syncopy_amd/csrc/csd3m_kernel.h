@@ -52,9 +52,7 @@ __device__ __forceinline__ void m3_sched_fence() {
 #endif
 }
 
-constexpr int M3_ROWLEN = 256;                       // channels = float2 elements per LDS row
-constexpr int M3_KB = 16;                            // rows per chunk
-constexpr int M3_CHUNK_BYTES = M3_KB * M3_ROWLEN * 8;   // 32 KiB per buffer, three buffers
+constexpr int M3_CHUNK_BYTES = 32 * 1024;            // per buffer (16 rows of 256 channels or 8 rows of 512), three buffers
 constexpr int M3_LDS_BYTES = 3 * M3_CHUNK_BYTES;
 constexpr int M3_TILES_PER_F = 36;                   // 32 x 32 tiles per frequency in CsdArgs' item units (256 channels)
 
@@ -68,15 +66,22 @@ constexpr int M3_TILES_PER_F = 36;                   // 32 x 32 tiles per freque
 // counts that matter most.
 template <int CH>
 struct M3Tab {
-    static_assert(CH % 16 == 0 && CH >= 16 && CH <= 256, "channel count of the generated 3M tables");
-    static constexpr int BPF = CH / 16, FPR = 256 / CH, NSUB = BPF * (BPF + 1) / 2, NTOT = FPR * NSUB;
-    static constexpr int NT = (NTOT + 7) / 8;
+    static_assert(CH % 16 == 0 && CH >= 16 && CH <= 512, "channel count of the generated 3M tables");
+    // up to 256 channels: 256-element LDS rows holding 256 / CH frequencies, 16-row chunks, one workgroup per packed
+    // row; 272 ... 512 channels: 512-element rows (one frequency), 8-row chunks (the same 32 KiB per buffer), and the
+    // sub-tiles of a frequency shared by NP workgroups that each stage the whole rows (<= 14 sub-tiles per wave there:
+    // the fragments of up to 16 distinct channel blocks need registers too)
+    static constexpr int ROWLEN = CH <= 256 ? 256 : 512, KB = CH <= 256 ? 16 : 8;
+    static constexpr int BPF = CH / 16, FPR = ROWLEN / CH, NSUB = BPF * (BPF + 1) / 2, NTOT = FPR * NSUB;
+    static constexpr int NP = CH <= 256 ? 1 : (NTOT + 111) / 112;
+    static constexpr int NW = 8 * NP;
+    static constexpr int NT = (NTOT + NW - 1) / NW;
     struct Gen {
-        int blk[8][16];
-        int nb[8];
-        int ta[8][NT];
-        int tb[8][NT];
-        int cnt[8];
+        int blk[NW][32];
+        int nb[NW];
+        int ta[NW][NT];
+        int tb[NW][NT];
+        int cnt[NW];
         int nbmax;
     };
     static constexpr Gen make() {
@@ -93,10 +98,10 @@ struct M3Tab {
                             ++n;
                         }
         g.nbmax = 1;
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < NW; ++w) {
             g.nb[w] = 0;
             g.cnt[w] = 0;
-            for (int i = 0; i < 16; ++i) g.blk[w][i] = 0;
+            for (int i = 0; i < 32; ++i) g.blk[w][i] = 0;
             for (int t = 0; t < NT; ++t) { g.ta[w][t] = 0; g.tb[w][t] = 0; }
             for (int t = 0; t < NT; ++t) {
                 const int k = w * NT + t;
@@ -131,6 +136,7 @@ struct M3Tab {
 //   g 6, 7: the lower triangles of blocks {0-3}, {4-7} and of {8-11}, {12-15}, minus the six given away
 template <>
 struct M3Tab<256> {
+    static constexpr int ROWLEN = 256, KB = 16, NP = 1, NW = 8;
     static constexpr int NT = 17, NB = 8;
     static constexpr int BLK[8][8] = {
         { 0,  1,  2,  3,  8,  9, 10, 11},
@@ -174,6 +180,7 @@ struct M3Tab<256> {
 //   wave 2: the triangle of blocks 0-3 minus (3,0)   wave 3: the triangle of blocks 4-7 minus (7,6)
 template <>
 struct M3Tab<128> {
+    static constexpr int ROWLEN = 256, KB = 16, NP = 1, NW = 8;
     static constexpr int NT = 9, NB = 6;
     static constexpr int BLK[8][6] = {
         { 0,  1,  2,  3,  4,  5},
@@ -214,6 +221,7 @@ struct M3Tab<128> {
 // 64 channels: four frequencies per LDS row, 4 x 10 sub-tiles = 8 waves x 5; waves 2d, 2d + 1 own frequency d (blocks 4d...)
 template <>
 struct M3Tab<64> {
+    static constexpr int ROWLEN = 256, KB = 16, NP = 1, NW = 8;
     static constexpr int NT = 5, NB = 4;
     static constexpr int BLK[8][4] = {
         { 0,  1,  2,  0}, { 0,  1,  2,  3}, { 4,  5,  6,  4}, { 4,  5,  6,  7},
@@ -236,6 +244,7 @@ struct M3Tab<64> {
 // 32 channels: eight frequencies per LDS row, wave g owns frequency g (blocks 2g, 2g + 1): 3 sub-tiles
 template <>
 struct M3Tab<32> {
+    static constexpr int ROWLEN = 256, KB = 16, NP = 1, NW = 8;
     static constexpr int NT = 3, NB = 2;
     static constexpr int BLK[8][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {10, 11}, {12, 13}, {14, 15}};
     static constexpr int TA[8][3] = {{0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}, {0, 1, 1}};
@@ -288,41 +297,44 @@ template <int CH, int G, int WPG>
 __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int lane) {
     using TAB = M3Tab<CH>;
     constexpr int M3_NT = TAB::NT, M3_NB = TAB::NB;
-    constexpr int FPR = M3_ROWLEN / CH;              // frequencies per LDS row; f = index of the packed row
-    constexpr int WV = G % WPG;
-    constexpr int RPW = M3_KB / WPG;                  // rows a wave stages per chunk
-    constexpr int RG = 4 * M3_ROWLEN * 8;            // bytes per group of four rows
+    constexpr int ROWLEN = TAB::ROWLEN, KB = TAB::KB;  // LDS row length (elements), rows per chunk: 32 KiB per buffer
+    static_assert(KB * ROWLEN * 8 == M3_CHUNK_BYTES, "chunk geometry");
+    constexpr int FPR = ROWLEN / CH;                 // frequencies per LDS row; f = index of the packed row
+    constexpr int WV = G % WPG;                      // this wave's place in its workgroup
+    constexpr int PPR = ROWLEN * 8 / 1024;           // 1-KiB pieces per row (one wave-wide 16-byte copy each)
+    constexpr int NPW = KB * PPR / WPG;              // pieces a wave stages per chunk
+    constexpr int RG = 4 * ROWLEN * 8;               // bytes per group of four rows
     const int l15 = lane & 15, lq = lane >> 4;
     const size_t rowstride = (size_t)a.F * CH;                      // float2 elements between rows
     const size_t rowbytes = rowstride * 8;
-    // source of this lane's 16 bytes of (row 0, half h): row-major spectra (r, f, c): 16 consecutive bytes of the 2-KiB
-    // row; channel-quad-blocked spectra (r, c/4, f, 4) (spyhip_fft_plan_set_blocked): lanes (2q, 2q+1) take the two
-    // halves of quad q's 32 bytes - the copy gathers, the LDS image is the same
+    // source of this lane's 16 bytes of (row 0, piece p): row-major spectra (r, f, c): 16 consecutive bytes of the
+    // row; channel-quad-blocked spectra (r, c/4, f, 4) (spyhip_fft_plan_set_blocked, 256 channels only): lanes
+    // (2q, 2q+1) take the two halves of quad q's 32 bytes - the copy gathers, the LDS image is the same
     const char* const gbase = reinterpret_cast<const char*>(a.spec) +
                               (a.blocked ? ((size_t)(lane >> 1) * a.F + f) * 32 + (lane & 1) * 16 : (size_t)f * FPR * CH * 8 + lane * 16);
-    const size_t halfstep = a.blocked ? (size_t)32 * a.F * 32 : 1024;     // from half 0 (channels 0-127) to half 1
+    const size_t piecestep = a.blocked ? (size_t)32 * a.F * 32 : 1024;    // from piece p (128 channels) to piece p + 1
     // valid bytes of this packed row: its FPR frequencies (fewer in the last one), CH channels each
     const int vbytes = ((a.F - f * FPR) < FPR ? (a.F - f * FPR) : FPR) * CH * 8;
     const long long nrows = a.nrows;
-    const long long nchunk = (nrows + M3_KB - 1) / M3_KB;
+    const long long nchunk = (nrows + KB - 1) / KB;
 
-    // ---- staging: two 1-KiB halves per row
+    // ---- staging: 1-KiB pieces, NPW per wave and chunk
     auto stage = [&](long long c, int buf) {
-        const long long r0 = c * M3_KB;
+        const long long r0 = c * KB;
         const long long left = nrows - r0;
-        const int rleft = left < M3_KB ? (int)left : M3_KB;
+        const int rleft = left < KB ? (int)left : KB;
         char* const dst = Xb + buf * M3_CHUNK_BYTES;
 #pragma unroll
-        for (int v = 0; v < 2 * RPW; ++v) {
-            const int row = RPW * WV + (v >> 1), half = v & 1;
-            // (CH < 256: the last packed row may hold fewer than 256 / CH frequencies; the bytes behind the last one
-            // belong to the next row of spectra - or to nobody - and are not copied: those lanes sit the copy out and
-            // leave stale LDS behind, which only sub-tiles of the missing frequencies read, and they are never stored)
+        for (int v = 0; v < NPW; ++v) {
+            const int id = NPW * WV + v, row = id / PPR, piece = id % PPR;
+            // (a row shorter than the LDS row - fewer channels, or a last packed row with fewer frequencies: the bytes
+            // behind it belong to the next row of spectra, or to nobody, and are not copied: those lanes sit the copy
+            // out and leave stale LDS behind, which only sub-tiles of missing frequencies read - never stored)
             if (row < rleft) {                                          // wave-uniform
-                if ((FPR == 1 && CH == M3_ROWLEN) || half * 1024 + lane * 16 < vbytes)
-                    m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + half * halfstep, dst + row * (M3_ROWLEN * 8) + half * 1024);
+                if ((FPR == 1 && CH == ROWLEN) || piece * 1024 + lane * 16 < vbytes)
+                    m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + piece * piecestep, dst + row * (ROWLEN * 8) + piece * 1024);
             } else {
-                *reinterpret_cast<float4*>(dst + row * (M3_ROWLEN * 8) + half * 1024 + lane * 16) =
+                *reinterpret_cast<float4*>(dst + row * (ROWLEN * 8) + piece * 1024 + lane * 16) =
                     make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -348,7 +360,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 
     // LDS address of this lane's fragments for the current group of four rows: channel (lane & 15) of a block, row
     // (lane >> 4) of the group; the block is an immediate offset (16 channels = 128 bytes apart)
-    const char* fp = Xb + (unsigned)(lq * M3_ROWLEN + l15) * 8u;
+    const char* fp = Xb + (unsigned)(lq * ROWLEN + l15) * 8u;
     float2 x[M3_NB];
     float sm[M3_NB], df[M3_NB];
     auto load = [&]() {
@@ -367,9 +379,9 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
         // fragment addresses advance by 8 KiB per group of four rows; after the fourth group of a chunk on to the
         // next buffer (+ 32 KiB, or back by 64 KiB).  The next chunk has landed: its DMA was waited for before
         // the barrier that ended the previous iteration.
-        const int wrap = ((b0 == 2) ? -2 * M3_CHUNK_BYTES : M3_CHUNK_BYTES) - (M3_KB / 4 - 1) * RG;
+        const int wrap = ((b0 == 2) ? -2 * M3_CHUNK_BYTES : M3_CHUNK_BYTES) - (KB / 4 - 1) * RG;
 #pragma unroll 1
-        for (int st = 0; st < M3_KB / 4; ++st) {
+        for (int st = 0; st < KB / 4; ++st) {
             m3_for<0, M3_NB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 sm[i] = m3_is_row<CH>(G, i) ? x[i].x + x[i].y : 0.f;
@@ -377,7 +389,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
             });
             float re[M3_NB], im[M3_NB];
             m3_for<0, M3_NB>([&](auto ic) { constexpr int i = decltype(ic)::value; re[i] = x[i].x; im[i] = x[i].y; });
-            fp += st + 1 < M3_KB / 4 ? RG : wrap;
+            fp += st + 1 < KB / 4 ? RG : wrap;
             m3_sched_fence();
             // the P3 products first: they free the fragment registers' successors (the reads of the next group
             // overwrite x) only after the P1 / P2 products, which come last
@@ -394,7 +406,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
                 }
             });
             m3_sched_fence();
-            if (st + 1 < M3_KB / 4 || c + 1 < nchunk) load();
+            if (st + 1 < KB / 4 || c + 1 < nchunk) load();
         }
 #ifndef SPY_HOST_EMU
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's share of chunk c + 2 has landed
@@ -426,10 +438,27 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 
 // WPG = 8: one workgroup of 8 waves per frequency (block b -> frequency item_base / 36 + b);
 // WPG = 4: two workgroups of 4 waves per frequency (block b -> frequency ... + b / 2, sub-tile sets of half b % 2).
-// CH: channels (256: one frequency per workgroup; 128: two; 64: four; 32: eight).  The workgroup serves packed row item_base / 36 + block.
+// run-time wave index -> compile-time sub-tile set
+template <int CH, int WPG, int G0, int G1>
+__device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, int f, int lane) {
+    if constexpr (G0 + 1 == G1) {
+        m3_wave<CH, G0, WPG>(a, Xb, f, lane);
+    } else {
+        constexpr int GM = (G0 + G1) / 2;
+        if (g < GM) m3_dispatch<CH, WPG, G0, GM>(g, a, Xb, f, lane);
+        else m3_dispatch<CH, WPG, GM, G1>(g, a, Xb, f, lane);
+    }
+}
+
+// CH: channels.  Up to 256: one workgroup per packed row of floor(256 / CH) frequencies, block b -> packed row
+// item_base / 36 + b.  272 ... 512: NP workgroups per frequency; block b -> XCD b % 8, slot b / 8, frequency
+// (slot / NP) * 8 + XCD, part slot % NP - all parts of a frequency run on ONE XCD, one after the other in its
+// dispatch order, so the rows they all stage are fetched from HBM once and found in that XCD's L2 afterwards.
+// WPG = 4 (256 channels only): two workgroups of 4 waves per frequency, one wave per SIMD (the measured dead end).
 template <int CH, int WPG>
 __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdArgs a) {
     static_assert(CH == 256 || WPG == 8, "the two-workgroup split exists for 256 channels only");
+    constexpr int NP = M3Tab<CH>::NP;
     SPY_DYN_SMEM(char, Xb);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -438,18 +467,21 @@ __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdAr
 #else
     const int wave = tid >> 6;
 #endif
-    const int f = (int)(a.item_base / M3_TILES_PER_F) + (int)(WPG == 8 ? blockIdx.x : blockIdx.x >> 1);
-    if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
-    switch (WPG == 8 ? wave : 4 * (int)(blockIdx.x & 1) + wave) {
-        case 0: m3_wave<CH, 0, WPG>(a, Xb, f, lane); break;
-        case 1: m3_wave<CH, 1, WPG>(a, Xb, f, lane); break;
-        case 2: m3_wave<CH, 2, WPG>(a, Xb, f, lane); break;
-        case 3: m3_wave<CH, 3, WPG>(a, Xb, f, lane); break;
-        case 4: m3_wave<CH, 4, WPG>(a, Xb, f, lane); break;
-        case 5: m3_wave<CH, 5, WPG>(a, Xb, f, lane); break;
-        case 6: m3_wave<CH, 6, WPG>(a, Xb, f, lane); break;
-        default: m3_wave<CH, 7, WPG>(a, Xb, f, lane); break;
+    int f, g;
+    if (WPG == 4) {
+        f = (int)(blockIdx.x >> 1);
+        g = 4 * (int)(blockIdx.x & 1) + wave;
+    } else if (NP == 1) {
+        f = (int)blockIdx.x;
+        g = wave;
+    } else {
+        const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+        f = (slot / NP) * 8 + xcd;
+        g = 8 * (slot % NP) + wave;
     }
+    f += (int)(a.item_base / M3_TILES_PER_F);
+    if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
+    m3_dispatch<CH, WPG, 0, (WPG == 4 ? 8 : M3Tab<CH>::NW)>(g, a, Xb, f, lane);
 }
 
 }  // namespace spycsd

@@ -396,7 +396,8 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     a.item_base = 0; a.item_end = a.nitems;
     unsigned grid = (unsigned)((a.nitems + per - 1) / per);
     const unsigned T = spycsd::CSD_THREADS;
-    if (force_tpw == 0 && !g_blocked && C > 256 && C <= 512) {      // as csd.hip: the wide variant
+    const bool wide3m = !g_force_4m && (C == 320 || C == 384);        // (csd.hip: 320 / 384 / 448 / 512)
+    if (force_tpw == 0 && !g_blocked && C > 256 && C <= 512 && !wide3m) {      // as csd.hip: the wide variant
         a.fast_nwgf = (a.ntiles + 39) / 40;
         a.fast_per = (a.ntiles + a.fast_nwgf - 1) / a.fast_nwgf;
         a.kb = 8;
@@ -415,23 +416,25 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
             emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8>(a); });
         return 8;
     }
-    if (force_tpw == 0 && C % 16 == 0 && C < 256 && !g_force_4m) {
-        // as csd.hip: the 3-multiplication kernel with floor(256 / C) frequencies per workgroup
-        const int fpr = 256 / C;
+    if (force_tpw == 0 && C % 16 == 0 && (C < 256 || C == 320 || C == 384) && !g_force_4m) {
+        // as csd.hip: the 3-multiplication kernel with floor(256 / C) frequencies per workgroup, or (above 256
+        // channels) NP workgroups per frequency in XCD-aware order
+        const int fpr = C < 256 ? 256 / C : 1;
         const long long nprow = (F + fpr - 1) / fpr;
         a.item_end = nprow * spycsd::M3_TILES_PER_F;
-        const dim3 g((unsigned)nprow), b(512);
+        const dim3 b(512);
+#define EMU_M3(CH)                                                                                                      \
+    case CH: {                                                                                                          \
+        const int np = spycsd::M3Tab<CH>::NP;                                                                           \
+        const dim3 g((unsigned)(np == 1 ? nprow : ((nprow + 7) / 8) * 8 * np));                                          \
+        emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<CH, 8>(a); });                                \
+        break;                                                                                                          \
+    }
         switch (C) {
-            case 16: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<16, 8>(a); }); break;
-            case 32: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<32, 8>(a); }); break;
-            case 48: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<48, 8>(a); }); break;
-            case 64: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<64, 8>(a); }); break;
-            case 96: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<96, 8>(a); }); break;
-            case 128: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<128, 8>(a); }); break;
-            case 192: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<192, 8>(a); }); break;
-            case 240: emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<240, 8>(a); }); break;
+            EMU_M3(16) EMU_M3(32) EMU_M3(48) EMU_M3(64) EMU_M3(96) EMU_M3(128) EMU_M3(192) EMU_M3(240) EMU_M3(320) EMU_M3(384)
             default: return -1;            // (the emulator instantiates a sample of the channel counts)
         }
+#undef EMU_M3
         return 9;
     }
     if (fast && C == 256) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });

@@ -195,7 +195,7 @@ def test_csd_mfma_kernel(C, F, R, tpw):
         assert_parity(E.coh_normalize(acc, output), O.normalize_csd(acc, output), what=output)
 
 
-@pytest.mark.parametrize("C,F,R", [(256, 3, 7), (256, 3, 19), (128, 5, 9), (64, 7, 9), (32, 11, 6), (192, 2, 6), (96, 5, 6)])
+@pytest.mark.parametrize("C,F,R", [(256, 3, 7), (256, 3, 19), (128, 5, 9), (64, 7, 9), (32, 11, 6), (192, 2, 6), (96, 5, 6), (320, 3, 6)])
 def test_csd_3m_kernel(C, F, R):
     """csd3m_kernel (3-multiplication complex product, 16 x 16 sub-tiles, two workgroups per frequency, rows global ->
     LDS by DMA): all 136 sub-tiles land where they belong, ragged last chunks are zero-filled, the accumulation

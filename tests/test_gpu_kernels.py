@@ -231,8 +231,8 @@ def test_csd_tail_row_split(be):
                                    (256, 259, 10),     # 259 workgroups on 256 CUs: exercises the re-cut tail
                                    (128, 131, 20), (64, 1027, 9), (192, 300, 12),   # lean path, several f per row
                                    # 3M kernel with generated sub-tile tables: partial last packed rows, its tail
-                                   (48, 1283, 9), (80, 11, 30), (112, 5, 17), (144, 7, 12), (160, 259, 10), (176, 3, 20),
-                                   (208, 4, 9), (224, 6, 13), (240, 258, 10), (96, 515, 9), (32, 2051, 5),
+                                   (160, 259, 10), (224, 6, 13), (96, 515, 9), (32, 2051, 5), (320, 131, 9), (384, 87, 10),
+                                   (48, 1283, 9), (240, 258, 10),     # (4-multiplication lean path: no 3M instance)
                                    (384, 7, 40), (512, 65, 20), (300, 130, 10),     # wide variant (+ its tail)
                                    (255, 270, 9), (63, 33, 14), (127, 3, 40), (301, 5, 12)])   # odd channel counts
 def test_csd_accumulate_vs_oracle(be, C, F, R):

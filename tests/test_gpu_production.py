@@ -123,11 +123,13 @@ def _var_csd(C, F, seed, floor=0.05):
     L = np.eye(C) + 0.1 * np.tril(rng.normal(size=(C, C)), -1)
     Sigma = L @ L.T
     w = np.pi * np.arange(F) / (F - 1)
-    if C >= 128:                      # test fixture only: 2049 inversions of 256 x 256 take a minute in NumPy
+    if C >= 128:
+        # test fixture only (2049 inversions of 256 x 256 take a minute in NumPy): the spectrum of a moving-average
+        # process instead, S = B Sigma B^H + floor with B(f) = I + B1 e^{-iw} + B2 e^{-2iw}, products on the device
         t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.complex128)).cuda()      # noqa: E731
-        A = t(np.eye(C))[None] - t(A1)[None] * t(np.exp(-1j * w))[:, None, None] - t(A2)[None] * t(np.exp(-2j * w))[:, None, None]
-        H = torch.linalg.inv(A)
-        S = H @ t(Sigma)[None] @ H.conj().transpose(1, 2) + floor * t(np.eye(C))[None]
+        B = t(np.eye(C))[None] + t(A1 - 0.2 * np.eye(C))[None] * t(np.exp(-1j * w))[:, None, None] \
+            + t(A2 + 0.75 * np.eye(C))[None] * t(np.exp(-2j * w))[:, None, None]
+        S = B @ t(Sigma)[None] @ B.conj().transpose(1, 2) + floor * t(np.eye(C))[None]
         S = 0.5 * (S + S.conj().transpose(1, 2))
         return S.to(torch.complex64).cpu().numpy()
     A = np.eye(C)[None] - A1[None] * np.exp(-1j * w)[:, None, None] - A2[None] * np.exp(-2j * w)[:, None, None]
