@@ -473,6 +473,9 @@ __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdAr
         g = 4 * (int)(blockIdx.x & 1) + wave;
     } else if (NP == 1) {
         f = (int)blockIdx.x;
+        // channel-quad-blocked spectra (256 channels): a 128-byte line holds one quad of FOUR consecutive frequencies,
+        // so those four workgroups must share an L2: runs of four frequencies per XCD (block b -> XCD b % 8)
+        if (CH == 256 && a.blocked) f = ((f >> 5) << 5) + ((f & 7) << 2) + ((f >> 3) & 3);
         g = wave;
     } else {
         const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);

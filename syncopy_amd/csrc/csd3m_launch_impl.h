@@ -19,7 +19,8 @@ int m3_launch_one(hipStream_t stream, CsdArgs a, long long nprow) {
                                           M3_LDS_BYTES));
         attr_set = true;
     }
-    const long long grid = NP == 1 ? nprow : ((nprow + 7) / 8) * 8 * NP;      // XCD-aware groups of 8 frequencies
+    // XCD-aware groups of 8 frequencies (NP > 1) / of 32 for the channel-quad-blocked layout (the kernel permutes them)
+    const long long grid = NP > 1 ? ((nprow + 7) / 8) * 8 * NP : (a.blocked ? ((nprow + 31) / 32) * 32 : nprow);
     if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), M3_LDS_BYTES, stream, a);
     SPY_HIP_CHECK(hipGetLastError());
