@@ -14,7 +14,7 @@ f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1)
 cp "$f" $R/gpurun_out/bench_kernel_stats.csv
 head -8 "$f" | cut -c1-160
 cd $R
-bash tools/pmc_run.sh 500 0 > /tmp/pmc.log 2>&1
+bash tools/pmc_run.sh 1000 0 > /tmp/pmc.log 2>&1
 cp gpurun_out/pmc/summary.txt gpurun_out/pmc_summary.txt
 rm -rf gpurun_out/pmc
 tail -45 gpurun_out/pmc_summary.txt
