@@ -342,10 +342,7 @@ int spyhip_wilson_finish(spyhip_ctx* ctx, const void* A_d, const void* psi_d, co
  * wilson_sf.py:77-109); for benchmarks and diagnostics. */
 int spyhip_granger_last_iterations(const spyhip_ctx* ctx);
 
-/* ---- utilities on the in-HBM trial queue ----------------------------------
- * y[i] = (y[i] + x[i]) elementwise float32 sum used by keeptrials=False
- * accumulation of real spectra (computational_routine.py:1022-1032). */
-int spyhip_axpy_f32(spyhip_ctx* ctx, const float* x_d, float* y_d, int64_t n, float alpha);
+/* ---- utilities on the in-HBM trial queue ---------------------------------- */
 /* out[r, :] = alpha * sum_t in[t, r, :]  (trial mean of (T, n) float32) */
 int spyhip_trial_mean_f32(spyhip_ctx* ctx, const float* in_d, float* out_d, int64_t ntrials, int64_t n);
 

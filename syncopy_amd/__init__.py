@@ -19,6 +19,12 @@ from .shared.kwarg_decorators import StructDict, get_defaults  # noqa: F401
 _LAZY = {"freqanalysis": ".specest.freqanalysis", "connectivityanalysis": ".connectivity.connectivity_analysis"}
 
 
+def release_device_buffers():
+    """Free the device / pinned buffers the package caches between calls (spectra hand-over buffer, staging buffers)."""
+    from . import backend
+    backend.release_buffers()
+
+
 def __getattr__(name):
     if name in _LAZY:
         import importlib

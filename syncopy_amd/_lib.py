@@ -81,7 +81,6 @@ SIGNATURES = {
     "spyhip_wilson_plus": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp, vp]),
     "spyhip_wilson_update": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, c_f64p]),
     "spyhip_wilson_finish": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
-    "spyhip_axpy_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float]),
     "spyhip_trial_mean_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64]),
 }
 

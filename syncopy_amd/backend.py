@@ -142,6 +142,16 @@ def to_device(host, device, time_axis=0):
 _handover = {}
 
 
+def release_buffers():
+    """Give back what the library keeps alive between calls: the spectra hand-over buffer (tens of GB at production
+    shapes - kept because re-allocating it per call costs more than the kernels) and the pinned staging buffers.
+    Exposed as `syncopy_amd.release_device_buffers()`."""
+    _handover.clear()
+    _pin.clear()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
 def handover_buffer(shape, device, dtype=torch.complex64):
     key = (tuple(shape), str(device), dtype)
     buf = _handover.get(key)

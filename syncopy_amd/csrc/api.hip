@@ -175,11 +175,6 @@ extern "C" int spyhip_queue_segments(const spyhip_queue* q, const int64_t** star
 }
 
 // ---- elementwise helpers for keeptrials=False accumulation ---------------------------------
-__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float alpha) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += alpha * x[i];
-}
-
 __global__ void trial_mean_kernel(const float* __restrict__ in, float* __restrict__ out, long long ntrials,
                                   long long n) {
     // sequential sum over trials in float32, one division at the end: the order of
@@ -190,17 +185,6 @@ __global__ void trial_mean_kernel(const float* __restrict__ in, float* __restric
         for (long long t = 0; t < ntrials; ++t) s += in[t * n + i];
         out[i] = s / (float)ntrials;
     }
-}
-
-extern "C" int spyhip_axpy_f32(spyhip_ctx* ctx, const float* x_d, float* y_d, int64_t n, float alpha) {
-    if (!ctx || !x_d || !y_d) { spy::set_error("axpy: null argument"); return -1; }
-    if (n <= 0) return 0;
-    SPY_HIP_CHECK(hipSetDevice(ctx->device));
-    long long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x_d, y_d, (long long)n, alpha);
-    SPY_HIP_CHECK(hipGetLastError());
-    return 0;
 }
 
 extern "C" int spyhip_trial_mean_f32(spyhip_ctx* ctx, const float* in_d, float* out_d, int64_t ntrials, int64_t n) {
