@@ -30,8 +30,8 @@ struct Dev {
 int gemm(spyhip_ctx* ctx, const cd* A, const cd* B, cd* C, int n, int batch, long long sA, long long sB, long long sC,
          int opB, int addI, const cd* Badd = nullptr, const cd* Ref = nullptr, double* part = nullptr) {
     if (n >= 48) {      // fp64 matrix cores, 64 x 64 tiles
-        const int ntx = (n + spywil::MT - 1) / spywil::MT;
-        dim3 grid((unsigned)(ntx * ntx * ((batch + 7) / 8) * 8));      // XCD-aware 1-D grid, see the kernel
+        const bool herm = part || (!Badd && opB == 1 && A == B && sA == sB);
+        dim3 grid((unsigned)(spywil::zgemm_tiles(n, herm) * ((batch + 7) / 8) * 8));      // XCD-aware 1-D grid, see the kernel
         if (!part && !Badd && opB == 1 && A == B && sA == sB)               // X X^H: Hermitian product
             hipLaunchKernelGGL(spywil::zgemm_mfma_kernel<3>, grid, dim3(256), 0, ctx->stream, A, B, C, n, sA, sB, sC, opB, addI,
                                Badd, Ref, part, batch);
@@ -307,7 +307,7 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
         std::swap(psi0, psi0n);
         std::vector<double> hp(fused ? 1 : nred);
         if (fused) {
-            const int tiles = (n + spywil::MT - 1) / spywil::MT, nwg = tiles * tiles * F;
+            const int nwg = spywil::zgemm_tiles(n, true) * F;
             if (gemm(ctx, psi, psi, nullptr, n, F, nn, nn, nn, 1, 0, nullptr, A, bigpart)) return -2;   // |A - psi psi^H| / |A|
             hipLaunchKernelGGL(spywil::maxred_kernel, dim3(1), dim3(256), 0, ctx->stream, bigpart, nwg, part);
         } else {
@@ -518,7 +518,7 @@ extern "C" int spyhip_wilson_update(spyhip_ctx* ctx, void* psi_d, const void* gp
     double* outp = part + npart;
     if (fused) {
         if (gemm(ctx, psi, psi, nullptr, n, nf, nn, nn, nn, 1, 0, nullptr, reinterpret_cast<const cd*>(A_d), part)) return -2;
-        hipLaunchKernelGGL(spywil::maxred_kernel, dim3(1), dim3(256), 0, ctx->stream, part, mt * mt * nf, outp);
+        hipLaunchKernelGGL(spywil::maxred_kernel, dim3(1), dim3(256), 0, ctx->stream, part, spywil::zgemm_tiles(n, true) * nf, outp);
     } else {
         if (gemm(ctx, psi, psi, T1, n, nf, nn, nn, nn, 1, 0)) return -2;
         hipLaunchKernelGGL(spywil::relerr_kernel, dim3(1024), dim3(256), 0, ctx->stream, reinterpret_cast<const cd*>(A_d), T1,

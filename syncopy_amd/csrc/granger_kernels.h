@@ -109,26 +109,42 @@ constexpr int MK = 8;    // k per stage
 #else
 #define SPY_ZGEMM_KATTR
 #endif
+// 64 x 64 output tiles per matrix: all of them, or the lower triangle for the Hermitian modes (2: error check, 3: X X^H)
+__host__ __device__ inline int zgemm_tiles(int n, bool hermitian) {
+    const int ntx = (n + 63) / 64;
+    return hermitian ? ntx * (ntx + 1) / 2 : ntx * ntx;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB,
                                                          long long sC, int opB, int addI, const cd* Badd, const cd* Ref,
                                                          double* part, int nbatch) {
     __shared__ cd As[MT][MK + 1];
-    __shared__ cd Bs[MK][MT + 1];
+    // op(B) = B: Bs[k][j] (row stride MT + 1); op(B) = B^H: stored as it is read from memory, Bs[j][k] (row stride
+    // MK + 1, like As) - the transposed store of 16-byte elements ran into 4-way bank conflicts and left the matrix
+    // pipe at 45 % in the two Hermitian products
+    __shared__ cd Bsm[MT * (MK + 1) > MK * (MT + 1) ? MT * (MK + 1) : MK * (MT + 1)];
     // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs, so id % 8 picks the XCD and all tiles of
     // one matrix get ids that are congruent mod 8 and consecutive in that XCD's order: the A / B panels the tiles share
     // meet in ONE L2 (with a 3-D grid the 16 tiles of a 256 x 256 matrix landed on all 8 XCDs and every panel was
     // fetched from HBM / Infinity Cache up to 8 times: the kernel ran at memory speed, 16.8 GB per product).
-    const int ntx = (n + MT - 1) / MT, ntile = ntx * ntx;
+    // The Hermitian modes launch the lower-triangle tiles ONLY (zgemm_tiles): a workgroup that exits at once still
+    // costs a dispatch slot, and at ~1 workgroup per microsecond and XCD the dispatcher - not the matrix pipe - set
+    // the pace: with 6 of 16 workgroups idle the two Hermitian products took as long as the full ones (4.7 ms).
+    const int ntx = (n + MT - 1) / MT, ntile = zgemm_tiles(n, MODE == 2 || MODE == 3);
     const int lin = blockIdx.x, slot = lin >> 3;
     const int b = (slot / ntile) * 8 + (lin & 7), tt = slot % ntile;
-    const int by = tt / ntx, bx = tt - by * ntx;
+    int by, bx;
+    if (MODE == 2 || MODE == 3) {
+        by = 0;
+        while ((by + 1) * (by + 2) / 2 <= tt) ++by;
+        bx = tt - by * (by + 1) / 2;
+    } else {
+        by = tt / ntx;
+        bx = tt - by * ntx;
+    }
     if (b >= nbatch) return;
     const size_t pidx = (size_t)b * ntile + tt;
-    if ((MODE == 2 || MODE == 3) && bx > by) {                        // above the diagonal: nothing to do
-        if (MODE == 2 && threadIdx.x == 0) part[pidx] = 0.0;
-        return;
-    }
     const int ti = by * MT, tj = bx * MT;
     const cd* Ab = A + (size_t)b * sA;
     const cd* Bb = B + (size_t)b * sB;
@@ -180,8 +196,8 @@ __global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const c
         for (int q = 0; q < 2; ++q) {
             const int e = tid + 256 * q;
             As[e >> 3][e & 7] = pa[q];
-            if (opB == 0) Bs[e >> 6][e & 63] = pb[q];
-            else Bs[e & 7][e >> 3] = pb[q];
+            if (opB == 0) Bsm[(e >> 6) * (MT + 1) + (e & 63)] = pb[q];
+            else Bsm[(e >> 3) * (MK + 1) + (e & 7)] = pb[q];
         }
         if (k0 + MK < n) fetch(k0 + MK);
         __syncthreads();
@@ -191,7 +207,8 @@ __global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const c
 #pragma unroll
             for (int u = 0; u < 2; ++u) a[u] = As[wr + 16 * u + l15][ks + l4];
 #pragma unroll
-            for (int w = 0; w < 2; ++w) bb[w] = Bs[ks + l4][wc + 16 * w + l15];
+            for (int w = 0; w < 2; ++w)
+                bb[w] = opB == 0 ? Bsm[(ks + l4) * (MT + 1) + wc + 16 * w + l15] : Bsm[(wc + 16 * w + l15) * (MK + 1) + ks + l4];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll

@@ -601,9 +601,9 @@ void emu_w_widen(const float* in, double* out, int C, long long n, double eps) {
 }
 void emu_w_gemm(const double* A, const double* B, double* Cm, int n, int batch, long long sA, long long sB, long long sC, int opB, int addI) {
     if (n >= 48) {      // as granger.hip: fp64 MFMA tiles
-        const int ntx = (n + 63) / 64;
-        dim3 g(ntx * ntx * ((batch + 7) / 8) * 8);
-        if (opB == 1 && A == B && sA == sB)     // as granger.hip: X X^H takes the Hermitian instance
+        const bool herm = opB == 1 && A == B && sA == sB;
+        dim3 g(spywil::zgemm_tiles(n, herm) * ((batch + 7) / 8) * 8);
+        if (herm)     // as granger.hip: X X^H takes the Hermitian instance (lower-triangle tiles only)
             emu::launch(g, dim3(256), 0, [&] { spywil::zgemm_mfma_kernel<3>(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI, nullptr, nullptr, nullptr, batch); });
         else
             emu::launch(g, dim3(256), 0, [&] { spywil::zgemm_mfma_kernel<0>(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI, nullptr, nullptr, nullptr, batch); });
@@ -615,9 +615,9 @@ void emu_w_gemm(const double* A, const double* B, double* Cm, int n, int batch, 
 // the fused forms of the matrix-core gemm: op(B) + Badd, and max |Ref - A op(B)| / |Ref| instead of the product
 double emu_w_gemm_fused(const double* A, const double* B, double* Cm, int n, int batch, long long sB, int opB, const double* Badd,
                         const double* Ref) {
-    const int ntx = (n + 63) / 64;
-    dim3 g(ntx * ntx * ((batch + 7) / 8) * 8);
-    std::vector<double> part((size_t)ntx * ntx * batch, -1.0);
+    const int ntile = spywil::zgemm_tiles(n, Ref != nullptr);
+    dim3 g(ntile * ((batch + 7) / 8) * 8);
+    std::vector<double> part((size_t)ntile * batch, -1.0);
     emu::launch(g, dim3(256), 0, [&] {
         if (Ref)
             spywil::zgemm_mfma_kernel<2>(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n,
