@@ -31,7 +31,7 @@ int gemm(spyhip_ctx* ctx, const cd* A, const cd* B, cd* C, int n, int batch, lon
          int opB, int addI, const cd* Badd = nullptr, const cd* Ref = nullptr, double* part = nullptr) {
     if (n >= 48) {      // fp64 matrix cores, 64 x 64 tiles
         const bool herm = part || (!Badd && opB == 1 && A == B && sA == sB);
-        dim3 grid((unsigned)(spywil::zgemm_tiles(n, herm) * ((batch + 7) / 8) * 8));      // XCD-aware 1-D grid, see the kernel
+        dim3 grid((unsigned)(spywil::zgemm_groups(n, herm) * ((batch + 7) / 8) * 8));      // XCD-aware 1-D grid, see the kernel
         if (!part && !Badd && opB == 1 && A == B && sA == sB)               // X X^H: Hermitian product
             hipLaunchKernelGGL(spywil::zgemm_mfma_kernel<3>, grid, dim3(256), 0, ctx->stream, A, B, C, n, sA, sB, sC, opB, addI,
                                Badd, Ref, part, batch);
@@ -126,9 +126,10 @@ int max_cond(spyhip_ctx* ctx, const cd* A, cd* work, cd* w1, cd* w2, int n, int 
     std::vector<double> h(2 * (size_t)F);
     std::vector<int> hi(F);
     auto power8 = [&](const cd* X, double* lam) -> int {
-        if (gemm(ctx, X, X, w1, n, F, nn, nn, nn, 0, 0)) return -2;        // X^2
-        if (gemm(ctx, w1, w1, w2, n, F, nn, nn, nn, 0, 0)) return -2;      // X^4
-        if (gemm(ctx, w2, w2, w1, n, F, nn, nn, nn, 0, 0)) return -2;      // X^8
+        // (X is Hermitian: X^2 = X X^H, the product that computes the lower-triangle tiles only)
+        if (gemm(ctx, X, X, w1, n, F, nn, nn, nn, 1, 0)) return -2;        // X^2
+        if (gemm(ctx, w1, w1, w2, n, F, nn, nn, nn, 1, 0)) return -2;      // X^4
+        if (gemm(ctx, w2, w2, w1, n, F, nn, nn, nn, 1, 0)) return -2;      // X^8
         hipLaunchKernelGGL(spywil::power_kernel, dim3(F), dim3(256), lds, ctx->stream, w1, n, iters, lam);
         SPY_HIP_CHECK(hipGetLastError());
         return 0;

@@ -115,36 +115,15 @@ __host__ __device__ inline int zgemm_tiles(int n, bool hermitian) {
     return hermitian ? ntx * (ntx + 1) / 2 : ntx * ntx;
 }
 
+// one 64 x 64 output tile (by, bx) of matrix b; `pidx`: where MODE 2 leaves its maximum
 template <int MODE>
-__global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB,
-                                                         long long sC, int opB, int addI, const cd* Badd, const cd* Ref,
-                                                         double* part, int nbatch) {
+__device__ __forceinline__ void zgemm_tile(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB, long long sC,
+                                           int opB, int addI, const cd* Badd, const cd* Ref, double* part, int b, int by,
+                                           int bx, size_t pidx) {
     __shared__ cd As[MT][MK + 1];
     // op(B) = B: Bs[k][j] (row stride MT + 1); op(B) = B^H: stored as it is read from memory, Bs[j][k] (row stride
-    // MK + 1, like As) - the transposed store of 16-byte elements ran into 4-way bank conflicts and left the matrix
-    // pipe at 45 % in the two Hermitian products
+    // MK + 1, like As)
     __shared__ cd Bsm[MT * (MK + 1) > MK * (MT + 1) ? MT * (MK + 1) : MK * (MT + 1)];
-    // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs, so id % 8 picks the XCD and all tiles of
-    // one matrix get ids that are congruent mod 8 and consecutive in that XCD's order: the A / B panels the tiles share
-    // meet in ONE L2 (with a 3-D grid the 16 tiles of a 256 x 256 matrix landed on all 8 XCDs and every panel was
-    // fetched from HBM / Infinity Cache up to 8 times: the kernel ran at memory speed, 16.8 GB per product).
-    // The Hermitian modes launch the lower-triangle tiles ONLY (zgemm_tiles): a workgroup that exits at once still
-    // costs a dispatch slot, and at ~1 workgroup per microsecond and XCD the dispatcher - not the matrix pipe - set
-    // the pace: with 6 of 16 workgroups idle the two Hermitian products took as long as the full ones (4.7 ms).
-    const int ntx = (n + MT - 1) / MT, ntile = zgemm_tiles(n, MODE == 2 || MODE == 3);
-    const int lin = blockIdx.x, slot = lin >> 3;
-    const int b = (slot / ntile) * 8 + (lin & 7), tt = slot % ntile;
-    int by, bx;
-    if (MODE == 2 || MODE == 3) {
-        by = 0;
-        while ((by + 1) * (by + 2) / 2 <= tt) ++by;
-        bx = tt - by * (by + 1) / 2;
-    } else {
-        by = tt / ntx;
-        bx = tt - by * ntx;
-    }
-    if (b >= nbatch) return;
-    const size_t pidx = (size_t)b * ntile + tt;
     const int ti = by * MT, tj = bx * MT;
     const cd* Ab = A + (size_t)b * sA;
     const cd* Bb = B + (size_t)b * sB;
@@ -266,6 +245,43 @@ __global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const c
                     if (MODE == 3 && bx < by) Cb[(size_t)gj * n + gi] = make_double2(v.x, -v.y);
                 }
             }
+}
+
+// XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs, so id % 8 picks the XCD and all tiles of
+// one matrix get ids that are congruent mod 8 and consecutive in that XCD's order: the A / B panels the tiles share
+// meet in ONE L2 (with a 3-D grid the 16 tiles of a 256 x 256 matrix landed on all 8 XCDs and every panel was
+// fetched from HBM / Infinity Cache up to 8 times: the kernel ran at memory speed, 16.8 GB per product).
+// The dispatcher hands out about one workgroup per microsecond and XCD, and a 64 x 64 x 256 tile is 28 us of matrix
+// work on a CU that holds three of them: with one tile per workgroup the DISPATCHER set the pace (the Hermitian modes
+// took as long as the full product while 6 of their 16 workgroups exited at once).  So the Hermitian modes launch
+// the lower-triangle tiles only (zgemm_tiles), and every workgroup works through ZGEMM_TPW tiles.
+constexpr int ZGEMM_TPW = 2;
+__host__ __device__ inline int zgemm_groups(int n, bool hermitian) { return (zgemm_tiles(n, hermitian) + ZGEMM_TPW - 1) / ZGEMM_TPW; }
+
+template <int MODE>
+__global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB,
+                                                         long long sC, int opB, int addI, const cd* Badd, const cd* Ref,
+                                                         double* part, int nbatch) {
+    constexpr bool HERM = MODE == 2 || MODE == 3;
+    const int ntx = (n + MT - 1) / MT, ntile = zgemm_tiles(n, HERM), ngrp = zgemm_groups(n, HERM);
+    const int lin = blockIdx.x, slot = lin >> 3;
+    const int b = (slot / ngrp) * 8 + (lin & 7), grp = slot % ngrp;
+    if (b >= nbatch) return;
+    for (int rep = 0; rep < ZGEMM_TPW; ++rep) {
+        const int tt = grp * ZGEMM_TPW + rep;
+        if (tt >= ntile) break;
+        int by, bx;
+        if (HERM) {
+            by = 0;
+            while ((by + 1) * (by + 2) / 2 <= tt) ++by;
+            bx = tt - by * (by + 1) / 2;
+        } else {
+            by = tt / ntx;
+            bx = tt - by * ntx;
+        }
+        zgemm_tile<MODE>(A, B, Cm, n, sA, sB, sC, opB, addI, Badd, Ref, part, b, by, bx, (size_t)b * ntile + tt);
+        __syncthreads();
+    }
 }
 
 // S = triu(g0) - triu(g0)^H (wilson_sf.py:97-98) and g0 + S, both n x n
