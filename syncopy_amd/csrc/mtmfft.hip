@@ -294,6 +294,10 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
                       p->log2n, p->G, mode);
         p->kernel_name = buf;
     } else if (!std::getenv("SPYHIP_NO_MIXED") && !std::getenv("SPYHIP_FORCE_GENERIC") && !std::getenv("SPYHIP_FORCE_LONG") &&
+               // (one taper and a Bluestein length M <= 4096 - sliding Hann windows of 500 samples, say: the chirp-z
+               // kernel keeps the segment in registers and wins by 10-20 %; from two tapers on, and for M = 8192,
+               // the mixed-radix engine is ahead)
+               !(ntaper == 1 && 2 * nfft - 1 <= 4096 && !std::getenv("SPYHIP_FORCE_MIXED")) &&
                spyfft::mix_schedule(nfft, (nchan + 3) / 4, &p->mix, &p->mix_threads, &p->lds_bytes) &&
                p->lds_bytes <= ctx->lds_per_block) {
         // 5-smooth lengths (2000, 3000, 5000, 500 ...): the packed mixed-radix engine

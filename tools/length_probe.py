@@ -11,7 +11,7 @@ from scipy.signal import windows  # noqa: E402
 
 from syncopy_amd import backend as be  # noqa: E402
 
-C, K = 256, 7
+C, K = 256, int(os.environ.get("LP_K", "7"))
 for N in [int(a) for a in sys.argv[1:]] or [1000, 2000, 3000, 4096, 5000, 8192, 10000, 16384]:
     T = max(8, min(200, (1 << 28) // (N * C)))
     data = torch.randn((T * N, C), device="cuda", dtype=torch.float32)
