@@ -195,7 +195,7 @@ def test_csd_mfma_kernel(C, F, R, tpw):
         assert_parity(E.coh_normalize(acc, output), O.normalize_csd(acc, output), what=output)
 
 
-@pytest.mark.parametrize("C,F,R", [(256, 3, 7), (256, 3, 19), (128, 5, 9), (64, 7, 9), (32, 11, 6), (192, 2, 6), (96, 5, 6), (320, 3, 6)])
+@pytest.mark.parametrize("C,F,R", [(256, 2, 7), (128, 5, 9), (64, 6, 9), (192, 2, 6), (320, 1, 6)])
 def test_csd_3m_kernel(C, F, R):
     """csd3m_kernel (3-multiplication complex product, 16 x 16 sub-tiles, two workgroups per frequency, rows global ->
     LDS by DMA): all 136 sub-tiles land where they belong, ragged last chunks are zero-filled, the accumulation
@@ -210,7 +210,7 @@ def test_csd_3m_kernel(C, F, R):
     spec = ((rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C)) + 2.0 * common) * gain).astype(np.complex64)
     acc = np.zeros((F, C, C), np.complex64)
     assert E.csd_accumulate(spec[:R // 2], acc) == code and E.csd_accumulate(spec[R // 2:], acc) == code
-    if R == 19:                                  # the two-workgroups-per-frequency variant: same sums, same order
+    if C == 256:                                 # the two-workgroups-per-frequency variant: same sums, same order
         E.lib().emu_set_m3_wpg(4)
         try:
             alt = np.zeros((F, C, C), np.complex64)
