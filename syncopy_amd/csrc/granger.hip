@@ -110,6 +110,15 @@ int invert_one(spyhip_ctx* ctx, cd* dst, const cd* src, int n, int* inf) {
 }
 
 int cholesky(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d) {
+    static const bool old_chol = std::getenv("SPYHIP_CHOL_OLD") != nullptr;
+    const size_t plds = ((size_t)n * (spywil::CHP + 1) + spywil::CHP * (spywil::CHP + 1)) * sizeof(cd);
+    if (!old_chol && n <= 256 && n >= 2 * spywil::CHP && plds <= ctx->lds_per_block) {      // panels of 32 columns
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::zchol_panel_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+        hipLaunchKernelGGL(spywil::zchol_panel_kernel, dim3(batch), dim3(256), plds, ctx->stream, M, n, info_d);
+        SPY_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(spywil::zchol_kernel, dim3(batch), dim3(256), (size_t)n * sizeof(cd), ctx->stream, M, n, info_d);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;

@@ -650,6 +650,11 @@ void emu_w_inv_mfma(double* M, int n, int batch, int* info) {
                 [&] { spywil::zinv_mfma_kernel(reinterpret_cast<cd*>(M), reinterpret_cast<const cd*>(src.data()), n, info); });
 }
 void emu_w_chol(double* M, int n, int batch, int* info) {
+    if (n <= 256 && n >= 2 * spywil::CHP) {       // as granger.hip: the panel kernel
+        const size_t plds = ((size_t)n * (spywil::CHP + 1) + spywil::CHP * (spywil::CHP + 1)) * 16;
+        emu::launch(dim3(batch), dim3(256), plds, [&] { spywil::zchol_panel_kernel(reinterpret_cast<cd*>(M), n, info); });
+        return;
+    }
     emu::launch(dim3(batch), dim3(256), (size_t)n * 16, [&] { spywil::zchol_kernel(reinterpret_cast<cd*>(M), n, info); });
 }
 void emu_w_gamma0(const double* A, int F, int n, double* out) {

@@ -443,6 +443,20 @@ def test_wilson_building_blocks():
     assert abs(E.w_cond(P[:1, :9, :9].copy(), iters=40) / np.linalg.cond(P[0, :9, :9]) - 1) < 5e-2
 
 
+@pytest.mark.parametrize("n", [64, 70])
+def test_panel_cholesky(n):
+    """zchol_panel_kernel (n >= 64: left-looking panels of 32 columns; 70: a ragged last panel of 6): the factor, the
+    zeroed strict upper triangle, and the flag for a matrix that is not positive definite."""
+    rng = np.random.default_rng(n)
+    X = rng.normal(size=(3, n, n)) + 1j * rng.normal(size=(3, n, n))
+    P = X @ X.conj().transpose(0, 2, 1) + 0.5 * n * np.eye(n)
+    P[2, 40, 40] = -1.0                                        # third matrix: indefinite
+    Lc, info = E.w_chol(P)
+    assert list(info) == [0, 0, 1]
+    np.testing.assert_allclose(Lc[:2], np.linalg.cholesky(P[:2]), rtol=1e-10, atol=1e-10)
+    assert np.all(np.triu(Lc[:2], 1) == 0)
+
+
 @pytest.mark.skipif(not __import__("os").environ.get("SPY_EMU_SLOW"),
                     reason="~5 min of thread emulation; set SPY_EMU_SLOW=1 (the GPU suite covers the same chain)")
 def test_wilson_granger_small_vs_oracle():
