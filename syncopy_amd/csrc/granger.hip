@@ -30,15 +30,15 @@ struct Dev {
 int gemm(spyhip_ctx* ctx, const cd* A, const cd* B, cd* C, int n, int batch, long long sA, long long sB, long long sC,
          int opB, int addI, const cd* Badd = nullptr, const cd* Ref = nullptr, double* part = nullptr) {
     if (n >= 48) {      // fp64 matrix cores, 64 x 64 tiles
-        const bool herm = part || (!Badd && opB == 1 && A == B && sA == sB);
-        dim3 grid((unsigned)(spywil::zgemm_groups(n, herm) * ((batch + 7) / 8) * 8));      // XCD-aware 1-D grid, see the kernel
-        if (!part && !Badd && opB == 1 && A == B && sA == sB)               // X X^H: Hermitian product
+        const int mode = part ? 2 : (Badd ? 1 : ((opB == 1 && A == B && sA == sB) ? 3 : 0));     // 3: X X^H, Hermitian product
+        dim3 grid((unsigned)(spywil::zgemm_groups(n, mode) * ((batch + 7) / 8) * 8));            // XCD-aware 1-D grid, see the kernel
+        if (mode == 3)
             hipLaunchKernelGGL(spywil::zgemm_mfma_kernel<3>, grid, dim3(256), 0, ctx->stream, A, B, C, n, sA, sB, sC, opB, addI,
                                Badd, Ref, part, batch);
-        else if (part)
+        else if (mode == 2)
             hipLaunchKernelGGL(spywil::zgemm_mfma_kernel<2>, grid, dim3(256), 0, ctx->stream, A, B, C, n, sA, sB, sC, opB, addI,
                                Badd, Ref, part, batch);
-        else if (Badd)
+        else if (mode == 1)
             hipLaunchKernelGGL(spywil::zgemm_mfma_kernel<1>, grid, dim3(256), 0, ctx->stream, A, B, C, n, sA, sB, sC, opB, addI,
                                Badd, Ref, part, batch);
         else

@@ -254,16 +254,22 @@ __device__ __forceinline__ void zgemm_tile(const cd* A, const cd* B, cd* Cm, int
 // The dispatcher hands out about one workgroup per microsecond and XCD, and a 64 x 64 x 256 tile is 28 us of matrix
 // work on a CU that holds three of them: with one tile per workgroup the DISPATCHER set the pace (the Hermitian modes
 // took as long as the full product while 6 of their 16 workgroups exited at once).  So the Hermitian modes launch
-// the lower-triangle tiles only (zgemm_tiles), and every workgroup works through ZGEMM_TPW tiles.
-constexpr int ZGEMM_TPW = 2;
-__host__ __device__ inline int zgemm_groups(int n, bool hermitian) { return (zgemm_tiles(n, hermitian) + ZGEMM_TPW - 1) / ZGEMM_TPW; }
+// the lower-triangle tiles only (zgemm_tiles), and every workgroup works through zgemm_tpw(MODE) tiles.
+// (measured per mode at 2049 x 256 x 256: the plain product - whose four tiles of a row share the A panel - likes 4
+// tiles per workgroup, 3.66 -> 2.84 ms with the triangular factor; the others are best with 2)
+__host__ __device__ constexpr int zgemm_tpw(int mode) { return mode == 0 ? 4 : 2; }
+__host__ __device__ inline int zgemm_groups(int n, int mode) {
+    const int tpw = zgemm_tpw(mode);
+    return (zgemm_tiles(n, mode == 2 || mode == 3) + tpw - 1) / tpw;
+}
 
 template <int MODE>
 __global__ void __launch_bounds__(256) SPY_ZGEMM_KATTR zgemm_mfma_kernel(const cd* A, const cd* B, cd* Cm, int n, long long sA, long long sB,
                                                          long long sC, int opB, int addI, const cd* Badd, const cd* Ref,
                                                          double* part, int nbatch) {
     constexpr bool HERM = MODE == 2 || MODE == 3;
-    const int ntx = (n + MT - 1) / MT, ntile = zgemm_tiles(n, HERM), ngrp = zgemm_groups(n, HERM);
+    constexpr int ZGEMM_TPW = zgemm_tpw(MODE);
+    const int ntx = (n + MT - 1) / MT, ntile = zgemm_tiles(n, HERM), ngrp = zgemm_groups(n, MODE);
     const int lin = blockIdx.x, slot = lin >> 3;
     const int b = (slot / ngrp) * 8 + (lin & 7), grp = slot % ngrp;
     if (b >= nbatch) return;

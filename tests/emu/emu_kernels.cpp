@@ -602,7 +602,7 @@ void emu_w_widen(const float* in, double* out, int C, long long n, double eps) {
 void emu_w_gemm(const double* A, const double* B, double* Cm, int n, int batch, long long sA, long long sB, long long sC, int opB, int addI) {
     if (n >= 48) {      // as granger.hip: fp64 MFMA tiles
         const bool herm = opB == 1 && A == B && sA == sB;
-        dim3 g(spywil::zgemm_groups(n, herm) * ((batch + 7) / 8) * 8);
+        dim3 g(spywil::zgemm_groups(n, herm ? 3 : 0) * ((batch + 7) / 8) * 8);
         if (herm)     // as granger.hip: X X^H takes the Hermitian instance (lower-triangle tiles only)
             emu::launch(g, dim3(256), 0, [&] { spywil::zgemm_mfma_kernel<3>(reinterpret_cast<const cd*>(A), reinterpret_cast<const cd*>(B), reinterpret_cast<cd*>(Cm), n, sA, sB, sC, opB, addI, nullptr, nullptr, nullptr, batch); });
         else
@@ -616,7 +616,7 @@ void emu_w_gemm(const double* A, const double* B, double* Cm, int n, int batch, 
 double emu_w_gemm_fused(const double* A, const double* B, double* Cm, int n, int batch, long long sB, int opB, const double* Badd,
                         const double* Ref) {
     const int ntile = spywil::zgemm_tiles(n, Ref != nullptr);
-    dim3 g(spywil::zgemm_groups(n, Ref != nullptr) * ((batch + 7) / 8) * 8);
+    dim3 g(spywil::zgemm_groups(n, Ref ? 2 : 1) * ((batch + 7) / 8) * 8);
     std::vector<double> part((size_t)ntile * batch, -1.0);
     emu::launch(g, dim3(256), 0, [&] {
         if (Ref)
