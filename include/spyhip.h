@@ -171,6 +171,14 @@ const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* plan);
  * diagonal, 32x32 tile granularity) is maintained until spyhip_csd_finalize. */
 int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
                           void* acc_d);
+/* Arithmetic of the accumulation.  Default (0): the 3-multiplication complex product where a kernel is built for the
+ * channel count: re = P1 + P2, im = P3 - P1 + P2 from three fp32 row sums.  Its imaginary part carries an ABSOLUTE
+ * error of ~6e-8 * sqrt(nrows) * |Re acc| (three independently rounded sums are subtracted): within rtol 1e-5 of
+ * the complex value and of abs / pow / real outputs, but not of the imaginary part or the phase of strongly
+ * coherent channel pairs near zero lag.  on = 1: the 4-multiplication kernels everywhere, whose imaginary part is
+ * summed directly like the reference's complex64 products (connectivity/csd.py:98-102) - what the front ends select
+ * for output = "imag" / "angle".  Per context; costs ~25 % of K4's throughput at 256 channels. */
+int spyhip_csd_set_phase_exact(spyhip_ctx* ctx, int on);
 /* same accumulation from spectra in the channel-blocked layout of spyhip_fft_plan_set_blocked:
  * spec_d = (nrows, ceil(nchan/4), nfreq, 4) complex64.  Bit-identical results. */
 int spyhip_csd_accumulate_blocked(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "spyhip_fft_plan_kernel_name": (C.c_char_p, [vp]),
     "spyhip_fft_plan_set_blocked": (C.c_int, [vp, C.c_int]),
     "spyhip_csd_accumulate": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    "spyhip_csd_set_phase_exact": (C.c_int, [vp, C.c_int]),
     "spyhip_csd_accumulate_blocked": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "spyhip_coh_from_accumulator": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]),
     "spyhip_ppc_accumulate": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

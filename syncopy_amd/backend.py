@@ -317,6 +317,29 @@ class CWTPlan:
             pass
 
 
+class csd_phase_exact:
+    """`with backend.csd_phase_exact(on):` - K4 arithmetic of the current device's context for the block
+    (include/spyhip.h: spyhip_csd_set_phase_exact).  The 3-multiplication kernels keep complex values, moduli and real
+    parts within rtol 1e-5 but subtract three independently rounded row sums for the imaginary part; coherence
+    outputs that ARE the imaginary part or the phase ("imag", "angle") take the 4-multiplication kernels, whose
+    imaginary part is summed directly like the reference's complex64 products (connectivity/csd.py:98-102)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            ctx = context()
+            check(ctx.lib.spyhip_csd_set_phase_exact(ctx.handle, 1), "spyhip_csd_set_phase_exact")
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            ctx = context()
+            check(ctx.lib.spyhip_csd_set_phase_exact(ctx.handle, 0), "spyhip_csd_set_phase_exact")
+        return False
+
+
 def csd_accumulate(spec, acc, blocked=False):
     """acc[f,i,j] += sum_r spec[r,f,i] conj(spec[r,f,j]) on the lower triangle (MFMA).
     spec: (..., F, C) complex64 (leading dims flattened to rows), or with blocked=True the hand-over layout

@@ -302,7 +302,18 @@ def _ppc(data, classes, st, compute_method, log_dict):
 
 
 def _run_stages(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict):
-    """ST stage (single-trial cross spectra, trial-averaged unless kept) -> AV stage, plus the jackknife."""
+    """ST stage (single-trial cross spectra, trial-averaged unless kept) -> AV stage, plus the jackknife.
+    Coherence outputs that are the imaginary part or the phase run K4 with directly summed imaginary parts
+    (backend.csd_phase_exact): the default 3-multiplication kernels subtract three rounded row sums there."""
+    exact = method == "coh" and output in ("imag", "angle") and compute_method in (None, "hip")
+    if exact:
+        from .. import backend
+        with backend.csd_phase_exact(True):
+            return _run_stages_impl(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
+    return _run_stages_impl(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
+
+
+def _run_stages_impl(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict):
     if method == "ppc":
         return _ppc(data, classes, st, compute_method, log_dict)
     if method == "coh":

@@ -13,6 +13,24 @@
 // per 16 keeps the radix-16 scatter conflict free for ds_write_b64 lane groups).
 #pragma once
 #include "fft_device.h"
+#ifndef SPYFFT_ABL
+#define SPYFFT_ABL 0
+#endif
+
+// development timeline probe (tools/fft_stamp_probe.hip): s_memtime stamps of one lane per wave, off in the library
+#ifdef SPYFFT_STAMPS
+#define SPY_STAMP(sn) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x >= SPYFFT_STAMP_B0 && blockIdx.x < SPYFFT_STAMP_B0 + 8 * SPYFFT_STAMP_NB && (blockIdx.x & 7) == 0) \
+            spy_stamp_buf[((((blockIdx.x - SPYFFT_STAMP_B0) >> 3) * 16 + (threadIdx.x >> 6)) << 10) + (sn)] = __builtin_readcyclecounter(); \
+        ++(sn); } while (0)
+#define SPY_STAMP_PARAM , int& sn
+#define SPY_STAMP_ARG , sn
+__device__ unsigned long long* spy_stamp_buf;
+#else
+#define SPY_STAMP(sn) do { } while (0)
+#define SPY_STAMP_PARAM
+#define SPY_STAMP_ARG
+#endif
 
 namespace spyfft {
 
@@ -151,7 +169,7 @@ __device__ __forceinline__ void apply_tw(C2 (&v)[16], const Tw6& t) {
 // before the reads; there is NO barrier after the last reads: a caller that writes the planes itself
 // must put a __syncthreads() in front of its writes.
 template <int LOG2N, int G>
-__device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h, const float2* __restrict__ tw) {
+__device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h, const float2* __restrict__ tw SPY_STAMP_PARAM) {
     using C = Cfg2<LOG2N, G>;
     v2f* const im = re + C::PLANE;
     const int rb = C::rbase(j, h);
@@ -163,6 +181,7 @@ __device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h,
         const int k = j & (Ns - 1);
         if (p > 0) apply_tw(v, tnext);
         dft16p(v);
+        SPY_STAMP(sn);
         if (p + 1 < C::NP16) {
             const int Ns1 = Ns * 16;
             const int k1 = j & (Ns1 - 1);
@@ -175,18 +194,29 @@ __device__ __forceinline__ void fft2_forward(C2 (&v)[16], v2f* re, int j, int h,
             const int ws = (p == 0) ? G : (Ns + (C::PAD ? Ns / 16 : 0)) * G;
             // write-after-read barrier placed HERE, behind this pass's butterflies, instead of right after the
             // previous reads: a wave that is done reading starts computing at once and meets the others later
-            __syncthreads();
+            if (!(SPYFFT_ABL & 16)) __syncthreads();
+            SPY_STAMP(sn);
+            if (!(SPYFFT_ABL & 8)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                re[wb + r * ws] = v[r].r;
-                im[wb + r * ws] = v[r].i;
+                for (int r = 0; r < 16; ++r) {
+                    re[wb + r * ws] = v[r].r;
+                    im[wb + r * ws] = v[r].i;
+                }
             }
-            __syncthreads();
+            SPY_STAMP(sn);
+            if (!(SPYFFT_ABL & 16)) __syncthreads();
+            SPY_STAMP(sn);
+            if (!(SPYFFT_ABL & 32)) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                v[e].r = re[rb + e * C::ESTRIDE];
-                v[e].i = im[rb + e * C::ESTRIDE];
+                for (int e = 0; e < 16; ++e) {
+                    v[e].r = re[rb + e * C::ESTRIDE];
+                    v[e].i = im[rb + e * C::ESTRIDE];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const C2 t = v[e]; v[e].r = t.i * 0.5f; v[e].i = t.r; }
             }
+            SPY_STAMP(sn);
         }
     }
     if constexpr (C::RLAST > 1) {
@@ -215,7 +245,10 @@ template <int LOG2N, int G>
 __device__ __forceinline__ void fft2_inverse(C2 (&v)[16], v2f* re, int j, int h, const float2* __restrict__ tw) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e].i = -v[e].i;
-    fft2_forward<LOG2N, G>(v, re, j, h, tw);
+#ifdef SPYFFT_STAMPS
+    int sn = 1000;
+#endif
+    fft2_forward<LOG2N, G>(v, re, j, h, tw SPY_STAMP_ARG);
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e].i = -v[e].i;
 }

@@ -29,6 +29,10 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
 
     const int tid = threadIdx.x;
     const int h = tid % G, j0 = tid / G;
+#ifdef SPYFFT_STAMPS
+    int sn = 0;
+#endif
+    SPY_STAMP(sn);
 
     // XCD-aware block -> (segment, quad group): the S workgroups that share 128-byte lines of the
     // (time x channel) rows get ids congruent mod 8 (same XCD / L2) and adjacent in dispatch order.
@@ -154,6 +158,10 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         }
     }
 
+#ifdef SPYFFT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SPY_STAMP(sn);
     // accumulators for the taper mean (bins e<8 plus the Nyquist bin on j == 0):
     // real outputs: ma.r = sum conv(X(c0,c1)), ma.i = sum conv(X(c2,c3)); complex: ma = X(c0,c1), mb = X(c2,c3)
     C2 ma[MEAN ? 9 : 1], mb[(MEAN && CPLX) ? 9 : 1];
@@ -219,10 +227,13 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
             }
         }
 
-        fft2_forward<LOG2N, G>(v, lds, j, h, a.tw);
+        SPY_STAMP(sn);
+        fft2_forward<LOG2N, G>(v, lds, j, h, a.tw SPY_STAMP_ARG);
+        SPY_STAMP(sn);
 
         // ---- separate the real channels: partner bin N-f lives in the upper half
         __syncthreads();              // the FFT's last reads of the planes are done everywhere
+        SPY_STAMP(sn);
         {
             const int wb = C::rbase(j, h);
 #pragma unroll
@@ -231,7 +242,9 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                 lim[wb + e * C::ESTRIDE] = v[e].i;
             }
         }
+        SPY_STAMP(sn);
         __syncthreads();
+        SPY_STAMP(sn);
         // output slab of (segment b, taper k): wave-uniform base, 32-bit lane offsets
         char* const slab = reinterpret_cast<char*>(a.out) +
                            ((size_t)b * kout + (MEAN ? 0 : k)) * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
@@ -336,6 +349,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
             }
         }
         // no barrier here: the next taper's first LDS write sits behind one (fft2_forward / block_sum)
+        SPY_STAMP(sn);
     }
 
     if (MEAN) {

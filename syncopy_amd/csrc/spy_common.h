@@ -28,6 +28,7 @@ struct spyhip_ctx {
     void* comm_buf = nullptr;       // packed lower triangle travelling through spyhip_allreduce_csd
     size_t comm_buf_bytes = 0;
 #endif
+    int csd_phase_exact = 0;        // spyhip_csd_set_phase_exact: 4-multiplication K4 kernels only (csd.hip)
     int granger_iters = 0;          // Wilson iterations of the last spyhip_granger call on this context
     int num_cu = 256;
     size_t lds_per_block = 160 * 1024;
