@@ -21,6 +21,18 @@ torch = pytest.importorskip("torch")
 
 FSEL = (0, 1, 2, 255, 256, 257, 1023, 1024, 1025, 1500, 2040, 2044, 2045, 2046, 2047, 2048)
 
+# Imaginary part / phase of a coherency are projections of a complex number of modulus <= 1: the absolute floor of the
+# criterion refers to THAT scale, not to the largest imaginary part (which is ~0.007 here - a floor of 1e-6 of it, 7e-9,
+# is below the rounding noise of any float32 accumulation over 7000 rows, the reference's own complex64 sums included:
+# half an ulp of the partial sums times sqrt(7000) is ~5e-5 on |S| ~ 7600, i.e. ~7e-9 of the normalisation).
+IMAG_ATOL = 1e-7
+
+
+def excess_abs(a, b, rtol=1e-5, atol=IMAG_ATOL):
+    err = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
+    assert np.isfinite(err).all()
+    return float((err / (rtol * np.abs(b) + atol)).max())
+
 
 @pytest.fixture(scope="module")
 def be():
@@ -94,17 +106,15 @@ def test_imaginary_part_needs_phase_exact_kernels(be):
         worst = 0.0
         for f in FSEL:
             ref = _reference(spec, f)
-            worst = max(worst, excess(acc[f].cpu().numpy().imag[il], ref.imag[il].astype(np.float32)))
-            if exact:
-                d = np.sqrt(np.real(np.diag(ref)))
-                cref = ref / np.outer(d, d)
-                for output, r in (("imag", cref.imag), ("angle", np.angle(cref))):
-                    got = be.coh_from_accumulator(acc, 1.0 / R, output)[f].cpu().numpy()
-                    assert_parity(got[il], r[il].astype(np.float32), what=f"coh {output} f={f} (phase-exact)")
+            d = np.sqrt(np.real(np.diag(ref)))
+            cref = ref / np.outer(d, d)
+            for output, r in (("imag", cref.imag), ("angle", np.angle(cref))):
+                got = be.coh_from_accumulator(acc, 1.0 / R, output)[f].cpu().numpy()
+                worst = max(worst, excess_abs(got[il], r[il]))
         res[exact] = worst
         del acc
-    print(f"[depth] imaginary part, coherent pairs: default kernels err/tol = {res[False]:.3g}, "
-          f"phase-exact kernels {res[True]:.3g}")
+    print(f"[depth] coherence imag / angle of coherent pairs (|d| <= 1e-5 |b| + {IMAG_ATOL:g}): default kernels err/tol = "
+          f"{res[False]:.3g}, phase-exact kernels {res[True]:.3g}")
     assert res[True] <= 1.0, res
     assert res[False] > 1.0, ("the 3-multiplication kernels now meet the criterion on imaginary parts: "
                               "drop the phase-exact routing", res)
