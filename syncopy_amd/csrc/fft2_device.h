@@ -82,7 +82,9 @@ __device__ __forceinline__ void dft8p(C2 (&t)[8]) {
         t[k + 4] = csub(a[k], b[k]);
     }
 }
-__device__ __forceinline__ void dft16p(C2 (&t)[16]) {
+// 16-point DFT in two halves (the pipelined kernel puts a workgroup barrier between them): a = four 4-point DFTs
+// over n1 + the internal twiddles, b = four 4-point DFTs over n2 + the index transposition
+__device__ __forceinline__ void dft16p_a(C2 (&t)[16]) {
     // n = 4*n1 + n2, k = k1 + 4*k2
     const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
     const float h = 0.70710678118654752440f;
@@ -98,6 +100,8 @@ __device__ __forceinline__ void dft16p(C2 (&t)[16]) {
     t[4 * 1 + 3] = cmul_s(t[4 * 1 + 3], make_float2(s1, -c1));
     t[4 * 2 + 3] = C2{(t[4 * 2 + 3].i - t[4 * 2 + 3].r) * h, (t[4 * 2 + 3].r + t[4 * 2 + 3].i) * -h};
     t[4 * 3 + 3] = cmul_s(t[4 * 3 + 3], make_float2(-c1, s1));
+}
+__device__ __forceinline__ void dft16p_b(C2 (&t)[16]) {
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) dft4(t[4 * k1], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3]);
     // t[4*k1 + k2] = X[k1 + 4*k2]: transpose the 4x4 register tile (pure renaming once unrolled)
@@ -110,6 +114,10 @@ __device__ __forceinline__ void dft16p(C2 (&t)[16]) {
             t[4 * k2 + k1] = tmp;
         }
     }
+}
+__device__ __forceinline__ void dft16p(C2 (&t)[16]) {
+    dft16p_a(t);
+    dft16p_b(t);
 }
 
 template <int LOG2N, int G>

@@ -15,6 +15,8 @@
 #include "mtmfft_mixed_plan.h"
 
 namespace spyfft {
+int pipe_launch(hipStream_t stream, const MtmArgs& a, int log2n, unsigned grid, int outk, bool mean);
+int pipe_max_tapers_demean();
 int mixed_launch(hipStream_t stream, const MtmArgs& a, const MixPlan& g, int threads, size_t lds, unsigned grid, int outk,
                  bool mean);
 }
@@ -28,6 +30,7 @@ struct spyhip_fft_plan {
     int detrend = -1, demean_taper = 0;
     float scale = 1.f;
     bool pow2 = false;
+    bool pipe = false;          // pipelined two-quad kernel (mtmfft_pipe_kernel.h): N = 1024, 2048, 4096
     bool mixed = false;         // packed mixed-radix engine for 5-smooth lengths (mtmfft_mixed.h)
     spyfft::MixPlan mix{};
     int mix_threads = 0;
@@ -288,10 +291,17 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         // CU) write 64 contiguous bytes per bin row and are 13 % faster; everything else prefers two independent
         // 256-thread workgroups per CU
         if (p->log2n == 12 && output == SPYHIP_OUT_FOURIER && p->keeptapers) p->G = 2;
+        // N = 1024 ... 4096: the pipelined kernel (two quads per workgroup in opposite phases, lane-exchange channel
+        // separation) is an OPT-IN experiment (SPYHIP_FFT_PIPE=1): measured 8.9 vs 7.2 us/trial at c2 - a wave that is
+        // alone on its SIMD while its partner waits on LDS issues one vector instruction per 7+ cycles
+        p->pipe = p->log2n >= 10 && p->log2n <= 12 && std::getenv("SPYHIP_FFT_PIPE") &&
+                  !(p->demean_taper && ntaper > spyfft::pipe_max_tapers_demean()) &&
+                  !(output == SPYHIP_OUT_FOURIER && !p->keeptapers);      // (complex taper mean: 72 accumulator registers)
         if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
         char buf[128];
-        std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
-                      p->log2n, p->G, mode);
+        if (p->pipe) std::snprintf(buf, sizeof buf, "mtmfft_pipe_kernel<%d, %s>", p->log2n, mode);
+        else std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
+                           p->log2n, p->G, mode);
         p->kernel_name = buf;
     } else if (!std::getenv("SPYHIP_NO_MIXED") && !std::getenv("SPYHIP_FORCE_GENERIC") && !std::getenv("SPYHIP_FORCE_LONG") &&
                // (one taper and a Bluestein length M <= 4096 - sliding Hann windows of 500 samples, say: the chirp-z
@@ -500,7 +510,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     if (p->pow2) {
         // work items per segment: channel quads (packed kernel) or channel pairs (2^14)
         const bool quad = p->log2n <= 13;
-        const int G = p->G;
+        const int G = p->pipe ? 2 : p->G;
         const int nitem = quad ? (p->nchan + 3) / 4 : npairs;
         a.npg = (nitem + G - 1) / G;
         int S = (quad ? 8 : 16) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;   // workgroups sharing 128-byte rows
@@ -510,6 +520,9 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         const long long grid = ((nclusters + 7) / 8) * S * 8;
         if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
         const unsigned g = (unsigned)grid;
+        if (p->pipe)
+            return spyfft::pipe_launch(p->ctx->stream, a, p->log2n, g, p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1),
+                                       !p->keeptapers);
         switch (p->log2n) {
             case 8: return launch_quad_mode<8, 16>(p, a, g);
             case 9: return launch_quad_mode<9, 8>(p, a, g);

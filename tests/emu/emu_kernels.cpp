@@ -21,6 +21,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/ccov_kernel.h"
 #include "../../syncopy_amd/csrc/jack_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
+#include "../../syncopy_amd/csrc/mtmfft_pipe_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_mixed.h"
 #include "../../syncopy_amd/csrc/mtmfft_long.h"
@@ -72,6 +73,20 @@ void run_quad_mode(const MtmArgs& a, unsigned grid, int outk, int mean, long onl
         case 3: run_quad<LOG2N, G, 1, true>(a, grid, only_block); break;
         case 4: run_quad<LOG2N, G, 2, false>(a, grid, only_block); break;
         default: run_quad<LOG2N, G, 2, true>(a, grid, only_block); break;
+    }
+}
+
+template <int LOG2N>
+void run_pipe_mode(const MtmArgs& a, unsigned grid, int outk, int mean) {
+    using P = spyfft::CfgP<LOG2N>;
+    auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(P::NTHREADS), P::LDS_BYTES, fn); };
+    switch (outk * 2 + mean) {
+        case 0: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 0, false>(a); }); break;
+        case 1: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 0, true>(a); }); break;
+        case 2: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 1, false>(a); }); break;
+        case 3: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 1, true>(a); }); break;
+        case 4: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 2, false>(a); }); break;
+        default: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 2, true>(a); }); break;
     }
 }
 
@@ -164,6 +179,8 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     a.out_kind = out_kind; a.out = out;
     a.means = g_means;
     a.blocked = g_blocked;
+    const bool pipe = G >= 100;          // G = 102: the pipelined kernel (two quads per workgroup, mtmfft_pipe_kernel.h)
+    if (pipe) G -= 100;
     const bool quad = log2n <= 13;
     const int nitem = quad ? (nchan + 3) / 4 : (nchan + 1) / 2;
     a.npg = (nitem + G - 1) / G;
@@ -174,6 +191,15 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     const unsigned grid = (unsigned)(((nclusters + 7) / 8) * S * 8);
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
     const int mean = keeptapers ? 0 : 1;
+    if (pipe) {
+        if (G != 2) return -1;
+        switch (log2n) {
+            case 10: run_pipe_mode<10>(a, grid, outk, mean); return 0;
+            case 11: run_pipe_mode<11>(a, grid, outk, mean); return 0;
+            case 12: run_pipe_mode<12>(a, grid, outk, mean); return 0;
+            default: return -1;
+        }
+    }
     switch (log2n * 100 + G) {
         case 816: run_quad_mode<8, 16>(a, grid, outk, mean, -1); break;
         case 908: run_quad_mode<9, 8>(a, grid, outk, mean, -1); break;

@@ -525,3 +525,26 @@ def test_offset_channels_match_the_reference_next_to_dc(nsig, nfft, kw):
     plain = E.fft_exec(x, [0], [0], [nsig], nsig, nfft, tap, sc, detrend=0, output="fourier", keeptapers=True, **kw)[0]
     if nsig >= 1000:                         # (short sums happen to round well)
         assert excess(plain[:, :, 1], ref[:, :, 1]) > 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K1p: the pipelined two-quad kernel (mtmfft_pipe_kernel.h) - folded column order of the last pass, lane-exchange
+# separation (columns 0 and T/2 through LDS), anti-phased halves, lane-pair 32-byte stores
+@pytest.mark.parametrize("log2n,nchan,K,output,keeptapers,detrend,demean", [
+    (10, 8, 2, "fourier", True, 0, False),      # one wave per half; fast store path with the lane-pair trick
+    (10, 5, 3, "pow", False, 1, False),         # ragged: the second half has one channel; taper mean; linear detrend
+    (10, 3, 1, "abs", True, -1, False),         # second half empty
+    (11, 8, 2, "pow", True, 0, True),           # radix-8 last pass, demean_taper through the LDS tail
+    (11, 12, 2, "fourier", True, -1, False),    # two workgroups per segment
+    (12, 8, 2, "fourier", True, 0, False),      # four waves per half, three radix-16 passes
+    (12, 6, 2, "pow", False, 0, True),
+])
+def test_pipe_kernel_vs_oracle(log2n, nchan, K, output, keeptapers, detrend, demean):
+    n = 1 << log2n
+    _fft_case(n, n, nchan, K, output, keeptapers, detrend, demean_taper=demean, G=102, nseg=2 if log2n < 12 else 1)
+
+
+def test_pipe_kernel_selection_and_padding():
+    # frequency selection, channel selection, zero padding (nsig < nfft) on the general store path
+    _fft_case(700, 1024, 7, 2, "pow", True, 0, G=102, freq_idx=np.array([0, 3, 511, 512, 17]), chan_idx=np.array([6, 0, 3, 3, 1]))
+    _fft_case(1500, 2048, 8, 2, "fourier", True, 1, G=102, freq_idx=np.arange(5, 900, 7))

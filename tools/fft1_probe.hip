@@ -10,6 +10,7 @@
     type* name = reinterpret_cast<type*>(name##_raw)
 #include "../include/spyhip.h"
 #include "../syncopy_amd/csrc/mtmfft2_kernel.h"
+#include "../syncopy_amd/csrc/mtmfft_pipe_kernel.h"
 #ifndef PG
 #define PG 1
 #endif
@@ -21,6 +22,9 @@
 #endif
 #ifndef PQUAD
 #define PQUAD 0
+#endif
+#ifndef PPIPE
+#define PPIPE 0
 #endif
 using namespace spyfft;
 __global__ void fillr(float* p, size_t n) {
@@ -47,7 +51,12 @@ int main(int argc, char** argv) {
     MtmArgs a{};
     a.data = data; a.ld = C; a.seg_start = st; a.seg_lo = st; a.seg_hi = hi; a.nseg = B; a.nsig = N;
     a.nchan = C; a.ntaper = K; a.tapers = tap; a.tw = tw; a.scale = 0.001f; a.detrend = 0; a.nfsel = F; a.out_kind = 0; a.out = out;
-#if PQUAD
+#if PPIPE
+    using Cf = CfgP<LOG2N, PPIPE>;
+    const int nitem = C / 4;
+    a.npg = (nitem + PPIPE - 1) / PPIPE; int S = 8 / PPIPE; if (S > a.npg) S = a.npg;
+    auto kern = mtmfft_pipe_kernel<LOG2N, POUTK, (bool)PMEAN, PPIPE>;
+#elif PQUAD
     using Cf = Cfg2<LOG2N, G>;
     const int nitem = C / 4;
     a.npg = (nitem + G - 1) / G; int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
@@ -70,7 +79,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3; ++i) kern<<<grid, Cf::NTHREADS, Cf::LDS_BYTES>>>(a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
-    printf("quad=%d G=%d outk=%d mean=%d regs=%d lds=%zu blocks/CU=%d : %.3f ms / %d trials = %.2f us/trial (%s)\n", PQUAD, G, POUTK, PMEAN,
+    printf("pipe=%d quad=%d G=%d outk=%d mean=%d regs=%d lds=%zu blocks/CU=%d : %.3f ms / %d trials = %.2f us/trial (%s)\n", PPIPE, PQUAD, G, POUTK, PMEAN,
            fa.numRegs, (size_t)Cf::LDS_BYTES, occ, ms, B, 1e3 * ms / B, hipGetErrorString(hipGetLastError()));
     return 0;
 }

@@ -1,19 +1,14 @@
 #!/bin/bash
-# K1 investigation session on the GPU box.  Output: gpurun_out/k1_session.txt
 set -u
 mkdir -p gpurun_out/k1s
 out=gpurun_out/k1_session.txt; : > $out
 FL="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -Wno-unused-value"
-b() { hipcc $FL "$@" 2>gpurun_out/k1s/err.txt || { echo "BUILD FAILED: $*" >> $out; tail -5 gpurun_out/k1s/err.txt >> $out; return 1; }; }
-for abl in 0 8 16 24 32 40 56 7 63; do
-  echo -n "[quad abl=$abl] " >> $out
-  b -DPQUAD=1 -DSPYFFT_ABL=$abl tools/fft1_probe.hip -o gpurun_out/k1s/q && timeout 120 gpurun_out/k1s/q 500 >> $out 2>&1
+b() { hipcc $FL "$@" 2>gpurun_out/k1s/err.txt || { echo "BUILD FAILED: $*" >> $out; tail -3 gpurun_out/k1s/err.txt >> $out; return 1; }; }
+mode="-DPOUTK=0 -DPMEAN=1"
+i=0
+for opt in "" "-mllvm -amdgpu-enable-max-ilp-scheduling-strategy=1" "-mllvm -amdgpu-sched-strategy=max-ilp" "-mllvm -amdgpu-sched-strategy=max-memory-clause" "-mllvm -amdgpu-schedule-metric-bias=0" "-mllvm -misched-topdown" "-mllvm -misched-bottomup" "-mllvm -enable-post-misched=0" "-mllvm -amdgpu-use-amdgpu-trackers=1" "-mllvm -amdgpu-igrouplp=0" "-ffast-math" "-O2" "-mllvm -amdgpu-early-inline-all=true" ; do
+  echo -n "[quad G=1 '$opt'] " >> $out
+  b -DPQUAD=1 $mode $opt tools/fft1_probe.hip -o gpurun_out/k1s/q && timeout 120 gpurun_out/k1s/q 500 >> $out 2>&1
 done
-for abl in 0 7; do
-  echo -n "[pair abl=$abl] " >> $out
-  b -DPQUAD=0 -DSPYFFT_ABL=$abl tools/fft1_probe.hip -o gpurun_out/k1s/p && timeout 120 gpurun_out/k1s/p 500 >> $out 2>&1
-done
-b -DPQUAD=0 tools/fft1_probe.hip -o gpurun_out/k1s/p
-bash tools/pmc_probe.sh pair gpurun_out/k1s/p 500 >> $out 2>&1
 rm -rf gpurun_out/k1s
 cat $out
