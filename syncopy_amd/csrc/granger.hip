@@ -202,6 +202,38 @@ bool plus_plan(int L, spywil::PlusPlan* pl) {
     return true;
 }
 
+// [g]^+ for nent entries over F rfft bins: the radix-16 LDS kernel for power-of-two lag-domain lengths 256 ... 4096,
+// the generic LDS kernel while two length-L arrays fit LDS, global scratch beyond (any length)
+int plus_any(spyhip_ctx* ctx, int L, const spywil::PlusPlan& pl, const cd* g, int F, long long nent, const cd* tw, cd* gp, cd* g0,
+             bool use_plus4 = true) {
+    const int prc = use_plus4 ? plus4(ctx, L, g, F, nent, tw, gp, g0) : 1;
+    if (prc <= 0) return prc;
+    const size_t lds = (size_t)2 * L * sizeof(cd);
+    if (lds <= ctx->lds_per_block) {
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::plus_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(spywil::plus_kernel, dim3((unsigned)nent), dim3(256), lds, ctx->stream, g, F, nent, pl, tw, gp, g0);
+        SPY_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    // entries per launch: scratch of at most 1 GiB (at least one workgroup per CU if that is more)
+    long long chunk = std::max<long long>(ctx->num_cu, ((size_t)1 << 30) / lds);
+    if (chunk > nent) chunk = nent;
+    const size_t need = (size_t)chunk * lds;
+    if (need > ctx->scratch_bytes) {
+        if (ctx->scratch) { SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+        SPY_HIP_CHECK(hipMalloc(&ctx->scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    for (long long e0 = 0; e0 < nent; e0 += chunk) {
+        const long long ne = std::min(chunk, nent - e0);
+        hipLaunchKernelGGL(spywil::plus_long_kernel, dim3((unsigned)ne), dim3(256), 0, ctx->stream, g, F, nent, pl, tw, gp, g0,
+                           reinterpret_cast<cd*>(ctx->scratch), e0);
+    }
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, double rtol, int niter,
@@ -213,9 +245,8 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
     const int F = nfreq, n = nchan, L = 2 * (F - 1);
     const size_t nn = (size_t)n * n, tot = (size_t)F * nn;
     spywil::PlusPlan pl;
-    if (!plus_plan(L, &pl) || (size_t)2 * L * sizeof(cd) > ctx->lds_per_block) {
-        spy::set_error("granger: %d frequencies (lag-domain length %d) exceed the LDS FFT of the plus operator "
-                       "(the reference documents its defaults for up to 5000 samples)", F, L);
+    if (!plus_plan(L, &pl)) {
+        spy::set_error("granger: no radix schedule for the lag-domain length %d (%d frequencies)", L, F);
         return -3;
     }
     Dev dev;
@@ -272,8 +303,6 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
     if (cholesky(ctx, scr, n, 1, inf)) return -2;
     if (int rc = check_info(ctx, inf, 1, "Cholesky factorisation of gamma_0 (not positive definite)")) return rc;
     hipLaunchKernelGGL(spywil::transpose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, scr, psi0, n);
-    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::plus_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * L * sizeof(cd))));
     SPY_HIP_CHECK(hipMemcpyAsync(scr2, psi0, nn * sizeof(cd), hipMemcpyDeviceToDevice, ctx->stream));   // keep psi0 of iteration 0
     bool converged = false;
     double err = INFINITY;
@@ -295,13 +324,7 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
         SPY_HIP_CHECK(hipMemcpyAsync(hinf.data(), inf, F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         if (gemm(ctx, T1, U, T2, n, F, nn, nn, nn, 0, n >= 48 ? 2 : 0)) return -2;          // psi^-1 U (U lower triangular)
         if (gemm(ctx, T2, T2, T1, n, F, nn, nn, nn, 1, 1)) return -2;                      // g + I
-        {                                                                                   // T2 = [g+I]^+
-            const int prc = use_plus4 ? plus4(ctx, L, T1, F, (long long)nn, tw, T2, g0) : 1;
-            if (prc < 0) return prc;
-            if (prc > 0)
-                hipLaunchKernelGGL(spywil::plus_kernel, dim3((unsigned)nn), dim3(256), 2 * L * sizeof(cd), ctx->stream,
-                                   T1, F, (long long)nn, pl, tw, T2, g0);
-        }
+        if (int prc = plus_any(ctx, L, pl, T1, F, (long long)nn, tw, T2, g0, use_plus4)) return prc;      // T2 = [g+I]^+
         const bool fused = n >= 48;               // the matrix-core gemm takes S and the error check along
         if (fused) {
             hipLaunchKernelGGL(spywil::skew_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, g0, scr, g0S, n);
@@ -461,8 +484,8 @@ extern "C" int spyhip_wilson_plus(spyhip_ctx* ctx, const void* g_d, int nftot, i
     SPY_HIP_CHECK(hipSetDevice(ctx->device));
     const int L = 2 * (nftot - 1);
     spywil::PlusPlan pl;
-    if (!plus_plan(L, &pl) || (size_t)2 * L * sizeof(cd) > ctx->lds_per_block) {
-        spy::set_error("wilson_plus: lag-domain length %d exceeds the LDS FFT of the plus operator", L);
+    if (!plus_plan(L, &pl)) {
+        spy::set_error("wilson_plus: no radix schedule for the lag-domain length %d", L);
         return -3;
     }
     Tmp t;
@@ -471,17 +494,9 @@ extern "C" int spyhip_wilson_plus(spyhip_ctx* ctx, const void* g_d, int nftot, i
     std::vector<cd> h(L);
     for (int m = 0; m < L; ++m) { const double a = -2.0 * PI * m / L; h[m] = make_double2(std::cos(a), std::sin(a)); }
     SPY_HIP_CHECK(hipMemcpyAsync(tw, h.data(), L * sizeof(cd), hipMemcpyHostToDevice, ctx->stream));
-    const int prc = plus4(ctx, L, reinterpret_cast<const cd*>(g_d), nftot, (long long)nent, tw, reinterpret_cast<cd*>(gp_d),
-                          reinterpret_cast<cd*>(g0_d));
-    if (prc < 0) return prc;
-    if (prc > 0) {
-        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::plus_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * L * sizeof(cd))));
-        hipLaunchKernelGGL(spywil::plus_kernel, dim3((unsigned)nent), dim3(256), 2 * L * sizeof(cd), ctx->stream,
-                           reinterpret_cast<const cd*>(g_d), nftot, (long long)nent, pl, tw, reinterpret_cast<cd*>(gp_d),
-                           reinterpret_cast<cd*>(g0_d));
-        SPY_HIP_CHECK(hipGetLastError());
-    }
+    if (int prc = plus_any(ctx, L, pl, reinterpret_cast<const cd*>(g_d), nftot, (long long)nent, tw, reinterpret_cast<cd*>(gp_d),
+                           reinterpret_cast<cd*>(g0_d)))
+        return prc;
     SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));        // tw is freed on return
     return 0;
 }

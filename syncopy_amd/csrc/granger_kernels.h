@@ -875,14 +875,10 @@ __device__ __forceinline__ void po_pass_any(const cd* in, cd* out, int L, int R,
     else po_pass(in, out, L, R, Ns, tw, sign, tid);
 }
 
-// nent = entries per frequency row (n^2 for the whole matrix, fewer for an entry shard of the sharded factorisation)
-__global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, long long nent, PlusPlan pl, const cd* tw, cd* gp, cd* g0) {
-    SPY_DYN_SMEM(cd, buf);          // 2 x L
-    const int L = pl.L, tid = threadIdx.x;
-    const int e = blockIdx.x;       // entry i*n + j
-    cd* a = buf;
-    cd* b = buf + L;
-    const size_t fs = (size_t)nent;
+// body of the plus operator for entry e with the two length-L working arrays a, b (LDS or global scratch)
+__device__ __forceinline__ void plus_entry(const cd* g, int F, size_t fs, long long e, const PlusPlan& pl, const cd* tw, cd* gp,
+                                           cd* g0, cd* a, cd* b, int tid) {
+    const int L = pl.L;
     for (int f = tid; f < F; f += 256) {
         const cd v = g[(size_t)f * fs + e];
         a[f] = v;
@@ -915,6 +911,22 @@ __global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, long long
         cd* t = a; a = b; b = t;
     }
     for (int f = tid; f < F; f += 256) gp[(size_t)f * fs + e] = a[f];
+}
+
+// nent = entries per frequency row (n^2 for the whole matrix, fewer for an entry shard of the sharded factorisation)
+__global__ void __launch_bounds__(256) plus_kernel(const cd* g, int F, long long nent, PlusPlan pl, const cd* tw, cd* gp, cd* g0) {
+    SPY_DYN_SMEM(cd, buf);          // 2 x L
+    plus_entry(g, F, (size_t)nent, blockIdx.x, pl, tw, gp, g0, buf, buf + pl.L, threadIdx.x);
+}
+
+// The same operator for lag-domain lengths whose working arrays (2 x L complex128) do not fit LDS - trials longer than
+// 5120 samples (wilson_sf.py:154-184 has no length limit): the arrays live in global scratch, 2 L entries per workgroup
+// (512 KiB at L = 16384: L2-resident while the workgroup works on them; the passes are the same Stockham passes, the
+// workgroup barrier orders its own global stores and loads).  One workgroup per entry e0 + blockIdx.x.
+__global__ void __launch_bounds__(256) plus_long_kernel(const cd* g, int F, long long nent, PlusPlan pl, const cd* tw, cd* gp, cd* g0,
+                                                        cd* scr, long long e0) {
+    cd* const a = scr + (size_t)blockIdx.x * 2 * (size_t)pl.L;
+    plus_entry(g, F, (size_t)nent, e0 + blockIdx.x, pl, tw, gp, g0, a, a + pl.L, threadIdx.x);
 }
 
 // S = triu(g0) - triu(g0)^H ; out_b[f] = gp[f] + S (all f) ; out0 = g0 + S
