@@ -186,7 +186,7 @@ def test_granger_long_trials_through_the_front_end():
     adj = np.zeros((8, 8))
     adj[0, 1] = adj[3, 5] = 0.3
     for nSamples, pad in ((16384, "maxperlen"), (5000, "nextpow2")):
-        data = spy.synthdata.ar2_network(AdjMat=adj, nSamples=nSamples, nTrials=3, seed=3)
+        data = spy.synthdata.ar2_network(AdjMat=adj, nSamples=nSamples, nTrials=12, seed=3)
         kw = dict(method="granger", tapsmofrq=3, pad=pad)
         got = spy.connectivityanalysis(data, **kw)
         ref = spy.connectivityanalysis(data, compute_method="sequential", routine_classes=ORACLE_CONN, **kw)
