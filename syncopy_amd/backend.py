@@ -370,7 +370,7 @@ def csd_kernel_name(nchan, blocked=False):
     import os
     if nchan == 256 and not os.environ.get("SPYHIP_CSD_4M"):
         return "spycsd::csd3m_kernel<256, 8>"
-    if nchan in (32, 64, 96, 128, 160, 192, 224, 320, 384, 512) and not blocked and not os.environ.get("SPYHIP_CSD_4M"):
+    if nchan % 16 == 0 and 16 <= nchan <= 512 and not blocked and not os.environ.get("SPYHIP_CSD_4M"):
         return "spycsd::csd3m_kernel<%d, 8>" % nchan
     if not blocked and nchan <= 256:
         return "spycsd::csd_accum_kernel<5, 4, %d>" % (1 if nchan == 256 else 2)

@@ -7,6 +7,9 @@ int m3_launch_b(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
 int m3_launch_c(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
 int m3_launch_d(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
 int m3_launch_e(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
+int m3_launch_f(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
+int m3_launch_g(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
+int m3_launch_h(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
 
 int m3_launch(int nchan, hipStream_t stream, CsdArgs a, long long nprow) {
     int rc;
@@ -15,24 +18,12 @@ int m3_launch(int nchan, hipStream_t stream, CsdArgs a, long long nprow) {
     if ((rc = m3_launch_c(nchan, stream, a, nprow)) != -100) return rc;
     if ((rc = m3_launch_d(nchan, stream, a, nprow)) != -100) return rc;
     if ((rc = m3_launch_e(nchan, stream, a, nprow)) != -100) return rc;
+    if ((rc = m3_launch_f(nchan, stream, a, nprow)) != -100) return rc;
+    if ((rc = m3_launch_g(nchan, stream, a, nprow)) != -100) return rc;
+    if ((rc = m3_launch_h(nchan, stream, a, nprow)) != -100) return rc;
     return -100;
 }
 
-bool m3_available(int nchan) {
-    switch (nchan) {
-        case 32:
-        case 64:
-        case 96:
-        case 128:
-        case 160:
-        case 192:
-        case 224:
-        case 256:
-        case 320:
-        case 384:
-        case 512:
-            return true;
-        default: return false;
-    }
-}
+// every multiple of 16 up to 512 channels is built (M3Tab generates the sub-tile tables at compile time)
+bool m3_available(int nchan) { return nchan >= 16 && nchan <= 512 && nchan % 16 == 0; }
 }  // namespace spycsd

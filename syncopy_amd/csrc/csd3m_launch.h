@@ -18,8 +18,7 @@ inline int m3_parts(int nchan) {
 // build has no instance for `nchan`
 int m3_launch(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
 
-// channel counts this build instantiates: the multiples of 32 up to 256, 320, 384, 512 (any multiple of 16 up to 512
-// works - M3Tab generates the tables - but every count is a minute of compile time)
+// channel counts this build instantiates: every multiple of 16 up to 512 (csd3m_{a..h}.hip)
 bool m3_available(int nchan);
 
 }  // namespace spycsd

@@ -232,7 +232,12 @@ def test_csd_tail_row_split(be):
                                    (128, 131, 20), (64, 1027, 9), (192, 300, 12),   # lean path, several f per row
                                    # 3M kernel with generated sub-tile tables: partial last packed rows, its tail
                                    (160, 259, 10), (224, 6, 13), (96, 515, 9), (32, 2051, 5), (320, 131, 9), (384, 87, 10),
-                                   (48, 1283, 9), (240, 258, 10),     # (4-multiplication lean path: no 3M instance)
+                                   (48, 1283, 9), (240, 258, 10),
+                                   # every other multiple of 16 up to 512 (generated tables; NP = 2 ... 5 workgroups per
+                                   # frequency above 256 channels)
+                                   (16, 300, 12), (80, 200, 9), (112, 77, 10), (144, 130, 9), (176, 50, 12), (208, 33, 9),
+                                   (272, 40, 9), (288, 9, 20), (304, 17, 9), (336, 12, 9), (352, 9, 9), (368, 8, 10),
+                                   (400, 9, 9), (416, 7, 9), (432, 10, 9), (448, 10, 9), (464, 5, 12), (480, 9, 12), (496, 6, 9),
                                    (384, 7, 40), (512, 65, 20), (300, 130, 10),     # wide variant (+ its tail)
                                    (255, 270, 9), (63, 33, 14), (127, 3, 40), (301, 5, 12)])   # odd channel counts
 def test_csd_accumulate_vs_oracle(be, C, F, R):
