@@ -447,8 +447,8 @@ def main():
         fft_bytes = sum(nb * (N * C * 4 + K * F * C * 8) for _, _, nb in ev_fft)
         # matrix flops the 3-multiplication kernel really issues: 136 sub-tiles x 3 MFMAs of 16x16x4 per 4 rows
         # (every multiple of 16 up to 256 channels: floor(256 / C) frequencies per workgroup, nb (nb + 1) / 2 sub-tiles each)
-        is3m = (C == 256 or (C % 16 == 0 and 16 <= C <= 512 and not blocked)) and not os.environ.get("SPYHIP_CSD_4M")
-        nsub = (C // 16) * (C // 16 + 1) // 2
+        is3m = (C == 256 or (C <= 512 and not blocked)) and not os.environ.get("SPYHIP_CSD_4M")
+        nsub = ((C + 15) // 16) * ((C + 15) // 16 + 1) // 2
         executed = ((rows[0] + 3) // 4) * F * nsub * 3 * 2048.0 if is3m else None
         value = world * T * args.steps / el
         coll = {"executed": bool(dist_on), "backend": "nccl (RCCL)" if dist_on else None}

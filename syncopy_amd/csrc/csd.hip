@@ -94,7 +94,7 @@ long long m3_main_rows(spyhip_ctx* ctx, long long nprow, int np) {
 }  // namespace
 
 static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan, void* acc_d,
-                               int blocked);
+                               int blocked, bool only_4m = false);
 
 extern "C" int spyhip_csd_set_phase_exact(spyhip_ctx* ctx, int on) {
     if (!ctx) { spy::set_error("csd_set_phase_exact: null context"); return -1; }
@@ -113,7 +113,7 @@ extern "C" int spyhip_csd_accumulate_blocked(spyhip_ctx* ctx, const void* spec_d
 }
 
 static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan, void* acc_d,
-                               int blocked) {
+                               int blocked, bool only_4m) {
     if (!ctx || !spec_d || !acc_d) { spy::set_error("csd_accumulate: null argument"); return -1; }
     if (nrows < 0 || nfreq < 1 || nchan < 1) { spy::set_error("csd_accumulate: bad shape"); return -1; }
     if (nrows == 0) return 0;
@@ -141,7 +141,7 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
     // SPYHIP_CSD_4M=1 keeps the 4-multiplication kernels everywhere (A/B measurements, cross-checks).
     // spyhip_csd_set_phase_exact selects them per context (imag / angle outputs, see include/spyhip.h).
     static const bool env_4m = std::getenv("SPYHIP_CSD_4M") != nullptr;
-    const bool force_4m = env_4m || ctx->csd_phase_exact != 0;
+    const bool force_4m = env_4m || ctx->csd_phase_exact != 0 || only_4m;
     const bool wide3m = !force_4m && nchan > 256 && spycsd::m3_available(nchan);
     if (!blocked && nchan > 256 && nchan <= 512 && !wide3m) {
         a.fast_nwgf = (a.ntiles + 39) / 40;
@@ -165,18 +165,28 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
         if (rc || f_main == nfreq) return rc;
         return launch_tail(ctx, a, f_main * a.ntiles, nrows, nfreq, nchan);
     }
-    // the other channel counts the 3M kernel is built for (csd3m_launch.h), row-major spectra: below 256 channels
-    // floor(256 / C) frequencies per workgroup (the last packed row may be partial; hand-made sub-tile tables for
-    // 128 / 64 / 32, generated ones for the rest); 320 / 384 / 512 channels: 512-element LDS rows, several
-    // workgroups per frequency
+    // every other channel count up to 512, row-major spectra: the 3M kernel instance of the next multiple of 16 with
+    // the narrower rows padded inside its LDS image (csd3m_kernel.h, EXACT = false).  Below 256 (padded) channels
+    // floor(256 / CHp) frequencies per workgroup (the last packed row may be partial); above, 512-element LDS rows and
+    // several workgroups per frequency.  Odd channel counts: the last row of spectra goes to the 4-multiplication
+    // kernels (the 16-byte copy of the last channel reaches 8 bytes beyond its frequency).
     if (nchan != 256 && !blocked && !force_4m && spycsd::m3_available(nchan)) {
-        const int fpr = nchan < 256 ? 256 / nchan : 1;
-        const long long nprow = (nfreq + fpr - 1) / fpr;
-        const long long p_main = m3_main_rows(ctx, nprow, spycsd::m3_parts(nchan));
-        const int rc = spycsd::m3_launch(nchan, ctx->stream, a, p_main);
-        if (rc == -100) { spy::set_error("csd_accumulate: no 3M kernel for %d channels", nchan); return -1; }
-        if (rc || p_main == nprow) return rc;
-        return launch_tail(ctx, a, fpr * p_main * a.ntiles, nrows, nfreq, nchan);
+        const int chp = spycsd::m3_padded(nchan);
+        const int64_t nrows3 = (nchan & 1) ? nrows - 1 : nrows;
+        if (nrows3 > 0) {
+            CsdArgs b = a;
+            b.nrows = nrows3;
+            const int fpr = chp < 256 ? 256 / chp : 1;
+            const long long nprow = (nfreq + fpr - 1) / fpr;
+            const long long p_main = m3_main_rows(ctx, nprow, spycsd::m3_parts(nchan));
+            int rc = spycsd::m3_launch(nchan, ctx->stream, b, p_main);
+            if (rc == -100) { spy::set_error("csd_accumulate: no 3M kernel for %d channels", nchan); return -1; }
+            if (rc) return rc;
+            if (p_main < nprow && (rc = launch_tail(ctx, b, fpr * p_main * a.ntiles, nrows3, nfreq, nchan))) return rc;
+        }
+        if (nrows3 == nrows) return 0;
+        return csd_accumulate_impl(ctx, reinterpret_cast<const float2*>(spec_d) + (size_t)nrows3 * nfreq * nchan, 1, nfreq, nchan,
+                                   acc_d, 0, true);
     }
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
     if (fast || a.ntiles >= 21) {

@@ -1,12 +1,12 @@
-// 3-multiplication cross-spectral kernels for 304, 320, 336 channels (see csd3m_launch.h)
+// 3-multiplication cross-spectral kernels for up to 320, 336 channels per instance, any channel count below an instance's
+// (rows narrower than the LDS image: csd3m_kernel<CH, 8, false>; see csd3m_launch.h)
 #include "csd3m_launch_impl.h"
 
 namespace spycsd {
-int m3_launch_d(int nchan, hipStream_t stream, CsdArgs a, long long nprow) {
-    switch (nchan) {
-        case 304: return m3_launch_one<304>(stream, a, nprow);
-        case 320: return m3_launch_one<320>(stream, a, nprow);
-        case 336: return m3_launch_one<336>(stream, a, nprow);
+int m3_launch_d(int chp, hipStream_t stream, CsdArgs a, long long nprow) {
+    switch (chp) {
+        case 320: return m3_launch_one<320, false>(stream, a, nprow);
+        case 336: return m3_launch_one<336, false>(stream, a, nprow);
         default: return -100;
     }
 }

@@ -293,7 +293,12 @@ inline void m3_glds16(const void* gsrc, char* lds_wave_base) {
 
 // G: which 17 sub-tiles; WPG: waves per workgroup (8: one workgroup per frequency, two waves per SIMD; 4: two
 // workgroups per frequency, one wave per SIMD); wave WV of the workgroup stages rows (16 / WPG) WV ... of every chunk
-template <int CH, int G, int WPG>
+// EXACT = false: the spectra carry a.C <= CH channels per frequency (any count, odd ones included); the LDS image keeps
+// its CH-channel geometry - every lane fetches the 16 bytes of ITS two LDS elements from wherever they sit in the
+// narrower rows (8-byte aligned sources for odd a.C), lanes of the padding channels a.C ... CH - 1 copy nothing (what
+// the padding holds only reaches accumulator rows / columns >= a.C, which are not stored).  For odd a.C the lane of
+// channel a.C - 1 reads 8 bytes past its frequency: the host keeps the very last row of a launch away from this kernel.
+template <int CH, int G, int WPG, bool EXACT>
 __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int lane) {
     using TAB = M3Tab<CH>;
     constexpr int M3_NT = TAB::NT, M3_NB = TAB::NB;
@@ -305,7 +310,8 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     constexpr int NPW = KB * PPR / WPG;              // pieces a wave stages per chunk
     constexpr int RG = 4 * ROWLEN * 8;               // bytes per group of four rows
     const int l15 = lane & 15, lq = lane >> 4;
-    const size_t rowstride = (size_t)a.F * CH;                      // float2 elements between rows
+    const int C = EXACT ? CH : a.C;                                 // channels per frequency in memory
+    const size_t rowstride = (size_t)a.F * C;                       // float2 elements between rows
     const size_t rowbytes = rowstride * 8;
     // source of this lane's 16 bytes of (row 0, piece p): row-major spectra (r, f, c): 16 consecutive bytes of the
     // row; channel-quad-blocked spectra (r, c/4, f, 4) (spyhip_fft_plan_set_blocked, 256 channels only): lanes
@@ -315,6 +321,15 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     const size_t piecestep = a.blocked ? (size_t)32 * a.F * 32 : 1024;    // from piece p (128 channels) to piece p + 1
     // valid bytes of this packed row: its FPR frequencies (fewer in the last one), CH channels each
     const int vbytes = ((a.F - f * FPR) < FPR ? (a.F - f * FPR) : FPR) * CH * 8;
+    // EXACT = false: byte offset of this lane's two elements of piece p inside a row of spectra, or -1 (padding / no
+    // such frequency)
+    long long poff[PPR];
+#pragma unroll
+    for (int p = 0; p < PPR; ++p) {
+        const int e0 = p * 128 + 2 * lane, d = e0 / CH, c = e0 % CH;
+        poff[p] = (!EXACT && c < C && f * FPR + d < a.F) ? ((long long)(f * FPR + d) * C + c) * 8 : -1;
+    }
+    const char* const sbase = reinterpret_cast<const char*>(a.spec);
     const long long nrows = a.nrows;
     const long long nchunk = (nrows + KB - 1) / KB;
 
@@ -331,7 +346,10 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
             // behind it belong to the next row of spectra, or to nobody, and are not copied: those lanes sit the copy
             // out and leave stale LDS behind, which only sub-tiles of missing frequencies read - never stored)
             if (row < rleft) {                                          // wave-uniform
-                if ((FPR == 1 && CH == ROWLEN) || piece * 1024 + lane * 16 < vbytes)
+                if (!EXACT) {
+                    if (poff[piece] >= 0)
+                        m3_glds16(sbase + (size_t)(r0 + row) * rowbytes + poff[piece], dst + row * (ROWLEN * 8) + piece * 1024);
+                } else if ((FPR == 1 && CH == ROWLEN) || piece * 1024 + lane * 16 < vbytes)
                     m3_glds16(gbase + (size_t)(r0 + row) * rowbytes + piece * piecestep, dst + row * (ROWLEN * 8) + piece * 1024);
             } else {
                 *reinterpret_cast<float4*>(dst + row * (ROWLEN * 8) + piece * 1024 + lane * 16) =
@@ -424,14 +442,25 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
         static_assert(bi / BPF == bj / BPF && bi >= bj, "a sub-tile lies inside one frequency, on or below the diagonal");
         const int fr = f * FPR + bi / BPF;           // this sub-tile's frequency
         if (t < TAB::cnt(G) && fr < a.F) {           // wave-uniform
-            float2* const pb = a.acc + (size_t)fr * CH * CH + (size_t)((bi % BPF) * 16 + 4 * lq) * CH + (bj % BPF) * 16 + l15;
-            float2 old[4];
+            if constexpr (EXACT) {
+                float2* const pb = a.acc + (size_t)fr * CH * CH + (size_t)((bi % BPF) * 16 + 4 * lq) * CH + (bj % BPF) * 16 + l15;
+                float2 old[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) old[r] = pb[(size_t)r * CH];
+                for (int r = 0; r < 4; ++r) old[r] = pb[(size_t)r * CH];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                pb[(size_t)r * CH] =
-                    make_float2(old[r].x + (p1[t][r] + p2[t][r]), old[r].y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+                for (int r = 0; r < 4; ++r)
+                    pb[(size_t)r * CH] =
+                        make_float2(old[r].x + (p1[t][r] + p2[t][r]), old[r].y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+            } else {
+                const int row0 = (bi % BPF) * 16 + 4 * lq, colj = (bj % BPF) * 16 + l15;
+                float2* const pb = a.acc + (size_t)fr * C * C + (size_t)row0 * C + colj;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < C && colj < C) {
+                        const float2 old = pb[(size_t)r * C];
+                        pb[(size_t)r * C] = make_float2(old.x + (p1[t][r] + p2[t][r]), old.y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+                    }
+            }
         }
     });
 }
@@ -439,14 +468,14 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 // WPG = 8: one workgroup of 8 waves per frequency (block b -> frequency item_base / 36 + b);
 // WPG = 4: two workgroups of 4 waves per frequency (block b -> frequency ... + b / 2, sub-tile sets of half b % 2).
 // run-time wave index -> compile-time sub-tile set
-template <int CH, int WPG, int G0, int G1>
+template <int CH, int WPG, bool EXACT, int G0, int G1>
 __device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, int f, int lane) {
     if constexpr (G0 + 1 == G1) {
-        m3_wave<CH, G0, WPG>(a, Xb, f, lane);
+        m3_wave<CH, G0, WPG, EXACT>(a, Xb, f, lane);
     } else {
         constexpr int GM = (G0 + G1) / 2;
-        if (g < GM) m3_dispatch<CH, WPG, G0, GM>(g, a, Xb, f, lane);
-        else m3_dispatch<CH, WPG, GM, G1>(g, a, Xb, f, lane);
+        if (g < GM) m3_dispatch<CH, WPG, EXACT, G0, GM>(g, a, Xb, f, lane);
+        else m3_dispatch<CH, WPG, EXACT, GM, G1>(g, a, Xb, f, lane);
     }
 }
 
@@ -455,7 +484,7 @@ __device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, i
 // (slot / NP) * 8 + XCD, part slot % NP - all parts of a frequency run on ONE XCD, one after the other in its
 // dispatch order, so the rows they all stage are fetched from HBM once and found in that XCD's L2 afterwards.
 // WPG = 4 (256 channels only): two workgroups of 4 waves per frequency, one wave per SIMD (the measured dead end).
-template <int CH, int WPG>
+template <int CH, int WPG, bool EXACT = true>
 __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdArgs a) {
     static_assert(CH == 256 || WPG == 8, "the two-workgroup split exists for 256 channels only");
     constexpr int NP = M3Tab<CH>::NP;
@@ -484,7 +513,7 @@ __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdAr
     }
     f += (int)(a.item_base / M3_TILES_PER_F);
     if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
-    m3_dispatch<CH, WPG, 0, (WPG == 4 ? 8 : M3Tab<CH>::NW)>(g, a, Xb, f, lane);
+    m3_dispatch<CH, WPG, EXACT, 0, (WPG == 4 ? 8 : M3Tab<CH>::NW)>(g, a, Xb, f, lane);
 }
 
 }  // namespace spycsd

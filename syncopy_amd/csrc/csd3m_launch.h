@@ -7,18 +7,25 @@
 
 namespace spycsd {
 
+// channel count of the kernel instance that serves `nchan` channels: the next multiple of 16 (the LDS image of a
+// narrower row is padded, csd3m_kernel.h)
+inline int m3_padded(int nchan) { return (nchan + 15) & ~15; }
+
 // workgroups per packed row (csd3m_kernel.h: M3Tab<CH>::NP): 1 up to 256 channels, ceil(sub-tiles / 112) above
 inline int m3_parts(int nchan) {
-    if (nchan <= 256) return 1;
-    const int nb = nchan / 16;
+    const int chp = m3_padded(nchan);
+    if (chp <= 256) return 1;
+    const int nb = chp / 16;
     return (nb * (nb + 1) / 2 + 111) / 112;
 }
 
-// launch csd3m_kernel<nchan, 8> over the packed rows [0, nprow); 0, a negative spyhip error code, or -100 if this
-// build has no instance for `nchan`
+// launch the kernel instance for `nchan` channels (a.C = nchan; csd3m_kernel<256, 8, true> for exactly 256,
+// csd3m_kernel<m3_padded(nchan), 8, false> otherwise) over the packed rows [0, nprow); 0, a negative spyhip error code,
+// or -100 if this build has no such instance.  Odd channel counts: the caller must keep the last row of spectra out of
+// a.nrows (the lane of the last channel reads 8 bytes beyond its frequency).
 int m3_launch(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
 
-// channel counts this build instantiates: every multiple of 16 up to 512 (csd3m_{a..h}.hip)
+// channel counts served: 1 ... 512 (instances for every multiple of 16, csd3m_{a..h}.hip + csd3m_x.hip)
 bool m3_available(int nchan);
 
 }  // namespace spycsd

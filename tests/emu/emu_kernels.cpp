@@ -422,7 +422,8 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     a.item_base = 0; a.item_end = a.nitems;
     unsigned grid = (unsigned)((a.nitems + per - 1) / per);
     const unsigned T = spycsd::CSD_THREADS;
-    const bool wide3m = !g_force_4m && (C == 320 || C == 384);        // (csd.hip: 320 / 384 / 448 / 512)
+    const int chp_w = (C + 15) & ~15;
+    const bool wide3m = !g_force_4m && (chp_w == 304 || chp_w == 320 || chp_w == 384);   // (csd.hip: every count up to 512)
     if (force_tpw == 0 && !g_blocked && C > 256 && C <= 512 && !wide3m) {      // as csd.hip: the wide variant
         a.fast_nwgf = (a.ntiles + 39) / 40;
         a.fast_per = (a.ntiles + a.fast_nwgf - 1) / a.fast_nwgf;
@@ -442,25 +443,39 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
             emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8>(a); });
         return 8;
     }
-    if (force_tpw == 0 && C % 16 == 0 && (C < 256 || C == 320 || C == 384) && !g_force_4m) {
-        // as csd.hip: the 3-multiplication kernel with floor(256 / C) frequencies per workgroup, or (above 256
-        // channels) NP workgroups per frequency in XCD-aware order
-        const int fpr = C < 256 ? 256 / C : 1;
+    // (the emulator instantiates a sample of the 3M channel counts; the others take the 4-multiplication kernels here)
+    const int chp_emu = (C + 15) & ~15;
+    const bool have3m = chp_emu == 16 || chp_emu == 32 || chp_emu == 48 || chp_emu == 64 || chp_emu == 96 || chp_emu == 128 ||
+                        chp_emu == 192 || chp_emu == 240 || chp_emu == 256 || chp_emu == 304 || chp_emu == 320 || chp_emu == 384;
+    if (force_tpw == 0 && C != 256 && C <= 512 && !g_blocked && !g_force_4m && have3m) {
+        // as csd.hip: the 3-multiplication kernel instance of the next multiple of 16 with narrower rows padded inside
+        // its LDS image; floor(256 / CHp) frequencies per workgroup, or (above 256 channels) NP workgroups per
+        // frequency in XCD-aware order; odd channel counts: the last row through the 4-multiplication kernels
+        const int chp = (C + 15) & ~15;
+        const int fpr = chp < 256 ? 256 / chp : 1;
         const long long nprow = (F + fpr - 1) / fpr;
+        const long long nrows3 = (C & 1) ? nrows - 1 : nrows;
         a.item_end = nprow * spycsd::M3_TILES_PER_F;
+        a.nrows = nrows3;
         const dim3 b(512);
 #define EMU_M3(CH)                                                                                                      \
     case CH: {                                                                                                          \
         const int np = spycsd::M3Tab<CH>::NP;                                                                           \
         const dim3 g((unsigned)(np == 1 ? nprow : ((nprow + 7) / 8) * 8 * np));                                          \
-        emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<CH, 8>(a); });                                \
+        if (nrows3 > 0) emu::launch(g, b, spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<CH, 8, false>(a); });          \
         break;                                                                                                          \
     }
-        switch (C) {
-            EMU_M3(16) EMU_M3(32) EMU_M3(48) EMU_M3(64) EMU_M3(96) EMU_M3(128) EMU_M3(192) EMU_M3(240) EMU_M3(320) EMU_M3(384)
+        switch (chp) {
+            EMU_M3(16) EMU_M3(32) EMU_M3(48) EMU_M3(64) EMU_M3(96) EMU_M3(128) EMU_M3(192) EMU_M3(240) EMU_M3(256) EMU_M3(304) EMU_M3(320) EMU_M3(384)
             default: return -1;            // (the emulator instantiates a sample of the channel counts)
         }
 #undef EMU_M3
+        if (nrows3 < nrows) {
+            const int keep = g_force_4m;
+            g_force_4m = 1;
+            emu_csd_accumulate(spec + (size_t)nrows3 * F * C * 2, 1, F, C, acc, 0);
+            g_force_4m = keep;
+        }
         return 9;
     }
     if (fast && C == 256) emu::launch(dim3(grid), dim3(T), lds, [&] { spycsd::csd_accum_kernel<5, 4, 1>(a); });

@@ -195,7 +195,10 @@ def test_csd_mfma_kernel(C, F, R, tpw):
         assert_parity(E.coh_normalize(acc, output), O.normalize_csd(acc, output), what=output)
 
 
-@pytest.mark.parametrize("C,F,R", [(256, 2, 7), (128, 5, 9), (64, 6, 9), (192, 2, 6), (320, 1, 6)])
+@pytest.mark.parametrize("C,F,R", [(256, 2, 7), (128, 5, 9), (64, 6, 9), (192, 2, 6), (320, 1, 6),
+                                   # rows narrower than the kernel's LDS image: odd counts (last row through the
+                                   # 4-multiplication kernels, 8-byte aligned copies), even non-multiples of 16
+                                   (37, 9, 7), (63, 5, 9), (90, 3, 6), (255, 2, 7), (301, 1, 6), (14, 20, 5)])
 def test_csd_3m_kernel(C, F, R):
     """csd3m_kernel (3-multiplication complex product, 16 x 16 sub-tiles, two workgroups per frequency, rows global ->
     LDS by DMA): all 136 sub-tiles land where they belong, ragged last chunks are zero-filled, the accumulation
