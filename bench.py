@@ -65,8 +65,12 @@ def _cpu_model():
 
 
 def _cpu_worker(args):
-    """One process of the one-process-per-core baseline: `n` trials of cross_spectra_cF, BLAS/FFT threads = 1."""
-    nchan, nsamp, n, faithful, seed = args
+    """One process of the one-process-per-core baseline: `n` trials of the coherence ST stage, BLAS/FFT threads = 1.
+    mode "faithful": cross_spectra_cF as the reference runs it (materialises the (K,F,C,C) product, csd.py:98);
+    "einsum": the oracle's accumulation without that temporary; "blas": best-effort CPU - the same mtmfft, then one
+    complex64 matrix product per frequency through BLAS (np.matmul on (F, C, K) x (F, K, C), 64 frequencies at a
+    time, accumulated in place into the trial sum)."""
+    nchan, nsamp, n, mode, seed = args
     os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
     try:
         from threadpoolctl import threadpool_limits
@@ -80,9 +84,21 @@ def _cpu_worker(args):
     acc = None
     t0 = time.perf_counter()
     for _ in range(n):
-        r, _ = O.cross_spectra_cF(x.copy(), samplerate=1000.0, nSamples=nsamp, foi=None, taper="dpss", taper_opt=topt,
-                                  polyremoval=0, faithful=faithful)
-        acc = r if acc is None else acc.__iadd__(r)      # the trial sum of compute_sequential (:1022-1032)
+        if mode == "blas":
+            specs, _ = O.mtmfft(O.detrend(x.copy(), 0), 1000.0, nsamp, "dpss", topt)        # (K, F, C) complex64
+            A = np.ascontiguousarray(specs.transpose(1, 2, 0))                               # (F, C, K)
+            B = np.ascontiguousarray(specs.conj().transpose(1, 0, 2))                        # (F, K, C)
+            if acc is None:
+                acc = np.zeros((A.shape[0], nchan, nchan), dtype=np.complex64)
+            inv = np.float32(1.0 / specs.shape[0])
+            for f0 in range(0, A.shape[0], 64):
+                blk = np.matmul(A[f0:f0 + 64], B[f0:f0 + 64])
+                blk *= inv
+                acc[f0:f0 + 64] += blk
+        else:
+            r, _ = O.cross_spectra_cF(x.copy(), samplerate=1000.0, nSamples=nsamp, foi=None, taper="dpss", taper_opt=topt,
+                                      polyremoval=0, faithful=(mode == "faithful"))
+            acc = r if acc is None else acc.__iadd__(r)      # the trial sum of compute_sequential (:1022-1032)
     return time.perf_counter() - t0
 
 
@@ -96,10 +112,12 @@ def cpu_baseline(nchan, nsamp):
     """BASELINE.md section 4.2 on the GPU box's host: the reference's per-trial coherence ST stage
     (mtmfft + outer product + taper mean, csd.py:94-102) as restated by the oracle,
       (a) one process, one trial at a time = compute_sequential (computational_routine.py:944);
-      (b) one process per physical core over disjoint trials = the Dask LocalCluster trial map (:926), BLAS threads
-          = 1, inputs in RAM, worker start-up not timed; as many processes as half the free memory allows;
-    each as "reference-faithful" (materialises the (K,F,C,C) product like csd.py:98, 8.6 GB per process at
-    256 x 4096) and as "best-effort CPU" (einsum accumulation, no temporary).
+      (b) one process per PHYSICAL core over disjoint trials = the Dask LocalCluster trial map (:926), BLAS threads
+          = 1, inputs in RAM, worker start-up not timed; as many processes as half of the usable memory allows
+          (cgroup limit respected; the per-process footprints below are measured peaks, rounded up);
+    as "reference-faithful" (materialises the (K,F,C,C) product like csd.py:98: ~15 GB per process at 256 x 4096),
+    "einsum" (the oracle's accumulation without that temporary, ~3.2 GB) and "best-effort BLAS" (one cgemm per
+    frequency, accumulated in place: ~1.4 GB, so every physical core gets a process).
     `value` is (a)-faithful: the reference's own code path on one core."""
     import multiprocessing as mp
     try:
@@ -116,60 +134,83 @@ def cpu_baseline(nchan, nsamp):
                 avail = min(avail, int(lim))
         except OSError:
             pass
-    budget = avail // 4                       # never more than a quarter of it, whatever the core count
+    budget = avail // 2
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else phys
     ncore = max(1, min(phys, usable))
-    t_f = _cpu_worker((nchan, nsamp, 1, True, 0))
-    t_e = _cpu_worker((nchan, nsamp, 1, False, 0))
+    t_f = _cpu_worker((nchan, nsamp, 1, "faithful", 0))
+    t_e = _cpu_worker((nchan, nsamp, 1, "einsum", 0))
+    t_b = _cpu_worker((nchan, nsamp, 1, "blas", 0))
     res_bytes = (nsamp // 2 + 1) * nchan * nchan * 8
     variants = {
         "faithful_1core": {"value": 1.0 / t_f, "cores": 1, "s_per_trial": t_f},
-        "best_effort_einsum_1core": {"value": 1.0 / t_e, "cores": 1, "s_per_trial": t_e},
+        "einsum_1core": {"value": 1.0 / t_e, "cores": 1, "s_per_trial": t_e},
+        "best_effort_blas_1core": {"value": 1.0 / t_b, "cores": 1, "s_per_trial": t_b},
     }
     ctx = mp.get_context("spawn")
-    for name, faithful, per_proc in (("faithful_process_per_core", True, 14 * res_bytes),
-                                     ("best_effort_einsum_process_per_core", False, 3 * res_bytes)):
-        nproc = int(min(ncore, 32, budget // max(per_proc, 1)))      # 32 processes bound the run time and the risk
+    for name, mode, per_proc, ntr in (("faithful_process_per_core", "faithful", 14 * res_bytes, 1),
+                                      ("einsum_process_per_core", "einsum", 3 * res_bytes, 1),
+                                      ("best_effort_blas_process_per_core", "blas", int(1.3 * res_bytes), 2)):
+        nproc = int(min(ncore, budget // max(per_proc, 1)))
         if nproc < 2:
             variants[name] = {"value": None, "cores": 0, "note": "skipped: not enough memory for two processes"}
             continue
         with ctx.Pool(nproc) as pool:
             pool.map(_cpu_noop, range(nproc), chunksize=1)
             t0 = time.perf_counter()
-            pool.map(_cpu_worker, [(nchan, nsamp, 1, faithful, 100 + i) for i in range(nproc)], chunksize=1)
+            pool.map(_cpu_worker, [(nchan, nsamp, ntr, mode, 100 + i) for i in range(nproc)], chunksize=1)
             t_all = time.perf_counter() - t0
-        variants[name] = {"value": nproc / t_all, "cores": nproc, "trials": nproc, "wall_s": t_all}
+        variants[name] = {"value": nproc * ntr / t_all, "cores": nproc, "cores_available": ncore, "trials": nproc * ntr,
+                          "wall_s": t_all, "GB_per_process_budgeted": per_proc / 1e9}
+    best = max((v for v in variants.values() if v.get("value")), key=lambda v: v["value"])
     return {
         "value": 1.0 / t_f, "unit": "trials/s", "cores": 1, "kind": "port",
         "sample": f"1 trial of {nchan} ch x {nsamp} samples, cross_spectra_cF reference-faithful (mtmfft + (K,F,C,C) outer "
                   f"product + taper mean, as csd.py:94-102), {t_f:.1f} s on one host core",
         "cpu_model": _cpu_model(), "physical_cores": phys, "usable_cores": usable,
         "usable_memory_GB": avail / 1e9, "memory_budget_GB": budget / 1e9,
+        "best_cpu_trials_per_s": best["value"], "best_cpu_cores": best["cores"],
         "variants": variants,
-        "note": "process-per-core variants: one trial per process, BLAS threads = 1, inputs in RAM, worker start-up "
-                "excluded, processes limited so that their arrays stay within a quarter of the usable memory "
-                "(cgroup limit respected)",
+        "note": "process-per-core variants: BLAS threads = 1, inputs in RAM, worker start-up excluded; one process per "
+                "physical core unless half of the usable memory (cgroup limit respected) holds fewer",
     }
 
 
 # ----------------------------------------------------------------------------------------------------------------
+def k4_sources_sha():
+    """Hash of the K4 kernel sources: written into the PMC summary by tools/pmc_run.sh, compared here - counters taken on
+    other kernel code are not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("csd3m_kernel.h", "csd3m_launch_impl.h", "csd.hip", "csd_kernel.h", "csd_args.h"):
+        with open(os.path.join(ROOT, "syncopy_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(nrows, nfreq, nchan):
-    """HBM bytes per CSD launch from the committed counter passes (profiles/r*_pmc_counters_final.txt:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/pmc_harness.cpp, same launch
-    shape).  Units are KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM) prescribes for 16-byte
-    per-lane streaming reads on gfx950.  Counters are only valid for the shape they were taken on
-    (first line of the file)."""
-    for name in ("r2_pmc_counters_final.txt", "r1_pmc_counters_final.txt"):
+    """HBM bytes per CSD launch from the committed counter passes (profiles/r*_pmc_counters_final.txt: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of tools/pmc_harness.cpp, same launch shape; rocprofv3 counter collection
+    crashes inside torch's own kernels, so the passes cannot run inside this process).  Units are KiB; FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md (HBM) prescribes for 16-byte per-lane streaming reads on gfx950.  Returns
+    (bytes or None, provenance): the counters are only reported for the launch shape AND the kernel sources they were
+    taken on (first line of the file: shape and `k4_sources_sha`)."""
+    sha = k4_sources_sha()
+    for name in ("r3_pmc_counters_final.txt", "r2_pmc_counters_final.txt", "r1_pmc_counters_final.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
     else:
-        return None
+        return None, {"from_profile": None}
+    prov = {"from_profile": "profiles/" + name, "k4_sources_sha": sha}
     total, cur = 0.0, None
     for ln in open(path):
         if ln.startswith("#"):
             if f"rows={nrows} F={nfreq} C={nchan} " not in ln:
-                return None
+                prov["refused"] = "profile taken on another launch shape"
+                return None, prov
+            if f"k4_sources_sha={sha}" not in ln:
+                prov["refused"] = "profile taken on other K4 kernel sources (stale)"
+                return None, prov
             continue
         if not ln.startswith(" "):
             cur = ln.strip()
@@ -181,7 +222,7 @@ def pmc_traffic(nrows, nfreq, nchan):
             total += 2.0 * 1024.0 * float(rest)
         elif name == "WRITE_SIZE":
             total += 1024.0 * float(rest)
-    return total or None
+    return (total or None), prov
 
 
 class _QuietStdout:
@@ -291,6 +332,30 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
                 "bound": "max(hbm at keeptrials accounting, fft-flop lower estimate)", "bytes_per_trial": byt,
                 "flop_per_trial": flop_lo, "bound_us_per_trial": bound_us, "frac": bound_us / (1e3 * ms / T4)})
     del res, plan, d4
+    # ---- headline through the front end: spy.connectivityanalysis(method="coh") on host-resident AnalogData.  First
+    # call = PCIe-inclusive (trial queue uploaded host -> HBM, plans and tapers built); warm call = front-end inclusive
+    # (argument checks, dry run, plan lookup, kernels, copy of the 0.54 GB result to the host), queue resident
+    import syncopy_amd as spy
+    host = data.cpu().numpy()
+    trl = np.stack([np.arange(T) * N, np.arange(1, T + 1) * N, np.zeros(T)], axis=1)
+    adata = spy.AnalogData(host, samplerate=1000.0, trialdefinition=trl)
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = spy.connectivityanalysis(adata, method="coh", tapsmofrq=1, polyremoval=0)
+        shape = list(res.data.shape)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        del res
+    out.append({"name": "headline through the front end: spy.connectivityanalysis(method='coh', tapsmofrq=1) on %d ch x %d samp x %d trials of host-resident AnalogData" % (C, N, T),
+                "value": T / min(ts[1:]), "unit": "trials/s", "warm_call_s": min(ts[1:]), "first_call_s": ts[0],
+                "pcie_inclusive_trials_per_s": T / ts[0], "result_shape": shape,
+                "note": "value = front-end inclusive with the trial queue resident in HBM (result copied to the host); "
+                        "first_call_s additionally uploads the %.1f GB trial queue over PCIe and builds plans / tapers"
+                        % (host.nbytes / 1e9)})
+    del adata, host
+    spy.release_device_buffers()
     # ---- c5: Wilson / Granger AV stage on the CSD of the resident trials (demean_taper as method='granger' sets it)
     plan = be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, True, None, "fourier", True, reference_mean=refmean)
     acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
@@ -435,6 +500,51 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
 
+    # one more analysis, fenced on both sides: the un-pipelined latency of a single analysis (the timed steps above
+    # overlap the collective / coherence tail of step i with the transforms of step i + 1 when N > 1)
+    fence()
+    t1 = time.perf_counter()
+    coh = step(False)
+    fence()
+    latency = time.perf_counter() - t1
+
+    selfcheck = None
+    if rank == 0 and not blocked and B == T:
+        # parity at the depth that was timed (K * T rows): raw accumulator and coherence of a handful of frequencies
+        # against complex128 products of the spectra of the last step (still in `spec`), criterion of tests/parity.py
+        fsel = sorted({0, 1, 2, F // 4, F // 2, F - 3, F - 2, F - 1})
+        acc = accs[(nstep[0] - 1) % len(accs)]
+        spec3 = spec.reshape(-1, F, C)
+        tril = torch.tril(torch.ones(C, C, dtype=torch.bool, device="cuda"))
+        worst_csd = worst_coh = 0.0
+        for f in fsel:
+            x = spec3[:, f, :].to(torch.complex128)
+            ref = x.T @ x.conj()
+            if dist_on:
+                dist.all_reduce(torch.view_as_real(ref))          # the accumulator holds the sum over ranks
+            got = acc[f].to(torch.complex128)
+            tol = 1e-5 * ref.abs() + 1e-6 * ref.abs().max()
+            worst_csd = max(worst_csd, float((((got - ref).abs() / tol)[tril]).max()))
+            d = torch.sqrt(torch.diagonal(ref).real)
+            cref = ref.abs() / torch.outer(d, d)
+            tolc = 1e-5 * cref + 1e-6 * cref.max()
+            worst_coh = max(worst_coh, float(((coh[f].to(torch.float64) - cref).abs() / tolc).max()))
+        # the transform itself: trial 0, float64 taper + rfft of the detrended float32 trial (mtmfft.py:96-127)
+        x0 = data[:N].to(torch.float64)
+        x0 = x0 - x0.mean(0, keepdim=True)
+        ref = torch.fft.rfft(x0[None] * torch.from_numpy(tapers).cuda()[:, :, None], dim=1) * scale      # (K, F, C)
+        got = spec3[:K].to(torch.complex128)
+        tol = 1e-5 * ref.abs() + 1e-6 * ref.abs().max()
+        worst_fft = float(((got - ref).abs() / tol).max())
+        selfcheck = {"max_err_over_tol": max(worst_csd, worst_coh, worst_fft), "csd": worst_csd, "coherence": worst_coh,
+                     "fft": worst_fft, "rows": int(K * T), "frequencies": fsel,
+                     "criterion": "|a-b| <= 1e-5 |b| + 1e-6 max|b| against complex128 / float64 references of the same inputs"}
+        assert selfcheck["max_err_over_tol"] <= 1.0, selfcheck
+    elif dist_on and not blocked and B == T:
+        for f in sorted({0, 1, 2, F // 4, F // 2, F - 3, F - 2, F - 1}):     # the reference sum needs every rank's spectra
+            x = spec.reshape(-1, F, C)[:, f, :].to(torch.complex128)
+            dist.all_reduce(torch.view_as_real(x.T @ x.conj()))
+
     if rank == 0:
         assert bool(torch.isfinite(coh).all()), "non-finite coherence"
         diag = coh[:, torch.arange(C), torch.arange(C)]
@@ -454,6 +564,7 @@ def main():
         coll = {"executed": bool(dist_on), "backend": "nccl (RCCL)" if dist_on else None}
         if ev_coll:
             coll.update({"bytes": ev_coll[0][2], "pack_allreduce_unpack_ms": float(np.mean([a.elapsed_time(b) for a, b, _ in ev_coll]))})
+        traffic, traffic_prov = pmc_traffic(rows[0], F, C)
         line = {
             "metric": "trials/sec for mtmfft+coherence (256 ch x 4096 samples, 7 DPSS tapers, full CSD)",
             "value": value,
@@ -462,6 +573,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps,
+            "analysis_latency_ms": 1e3 * latency,
+            "selfcheck": selfcheck,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -497,7 +610,8 @@ def main():
                 # spectra once + read-modify-write of the accumulator's lower triangle (16 x 16 sub-tiles for the
                 # 3-multiplication kernel, 32 x 32 tiles otherwise)
                 "algorithmic_hbm_bytes_per_launch": rows[0] * F * C * 8 + (2 * F * nsub * 256 * 8 if is3m else 2 * F * (((C + 31) // 32) * ((C + 31) // 32 + 1) // 2) * 1024 * 8),
-                "traffic": pmc_traffic(rows[0], F, C),
+                "traffic": traffic,
+                "traffic_source": traffic_prov,
             },
         }
         if world == 1 and not args.no_secondary:

@@ -62,7 +62,27 @@ def _ptr(t):
 
 
 _PIN_BYTES = 256 << 20
+_D2H_CHUNK = 64 << 20
 _pin = {}
+_copy_pool = None
+
+
+def _host_copy(dst, src):
+    """dst[:] = src for large byte arrays, split over four threads (NumPy releases the GIL in its copy loops): one
+    thread moves ~10 GB/s into freshly allocated pageable memory (page faults included), which made the drain of the
+    pinned staging buffer - not the bus - the slow half of a large result's way to the host."""
+    global _copy_pool
+    n = dst.shape[0]
+    if n < (8 << 20):
+        dst[:] = src
+        return
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="spyhip-copy")
+    step = (n + 3) // 4
+    futs = [_copy_pool.submit(np.copyto, dst[o:o + step], src[o:o + step]) for o in range(0, n, step)]
+    for f in futs:
+        f.result()
 
 
 def to_host(t):
@@ -80,18 +100,18 @@ def to_host(t):
     stage = _staging()
     stream = torch.cuda.current_stream(t.device)
     pending = None                                   # (event, staging buffer, offset, length) of the copy in flight
-    for k, off in enumerate(range(0, nbytes, _PIN_BYTES)):
-        n = min(_PIN_BYTES, nbytes - off)
+    for k, off in enumerate(range(0, nbytes, _D2H_CHUNK)):
+        n = min(_D2H_CHUNK, nbytes - off)
         buf = stage[k & 1]
         buf[:n].copy_(flat[off:off + n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(stream)
         if pending is not None:                      # drain the previous chunk while this one is on the bus
             pending[0].synchronize()
-            dst[pending[2]:pending[2] + pending[3]] = pending[1][:pending[3]].numpy()
+            _host_copy(dst[pending[2]:pending[2] + pending[3]], pending[1][:pending[3]].numpy())
         pending = (ev, buf, off, n)
     pending[0].synchronize()
-    dst[pending[2]:pending[2] + pending[3]] = pending[1][:pending[3]].numpy()
+    _host_copy(dst[pending[2]:pending[2] + pending[3]], pending[1][:pending[3]].numpy())
     return out
 
 

@@ -27,7 +27,10 @@ import sys
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 BLK = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 with open("gpurun_out/pmc/summary.txt", "w") as out:
-    out.write(f"# shape: trials={B} rows={B * 7} F=2049 C=256 blocked={BLK} (per-dispatch means over the repeated launches)\n")
+    sys.path.insert(0, ".")
+    import bench
+    out.write(f"# shape: trials={B} rows={B * 7} F=2049 C=256 blocked={BLK} k4_sources_sha={bench.k4_sources_sha()} "
+              f"(per-dispatch means over the repeated launches)\n")
     for k, d in agg.items():
         out.write(k + "\n")
         for c, v in sorted(d.items()):
