@@ -100,7 +100,16 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m syncopy_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     # A host that uses PyTorch has libamdhip64 loaded already and ours binds to that runtime; a NumPy-only host
-    # (syncopy_amd/abi.py) gets the runtime through the library's own dependencies.  torch is never imported here.
+    # (syncopy_amd/abi.py) gets the runtime through the library's own dependencies.  Loading order matters when both
+    # are used in one process: if torch is imported AFTER this library, torch binds to the system libamdhip64 this
+    # library pulled in (same SONAME) instead of the runtime bundled with its wheel.  So: torch already imported ->
+    # nothing to do; torch importable and not opted out (SPY_NO_TORCH=1, what the NumPy-only tests set) -> import it
+    # first; otherwise the process is NumPy-only by declaration.
+    import sys
+    if "torch" not in sys.modules and not os.environ.get("SPY_NO_TORCH"):
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -10,6 +10,14 @@ hands back NumPy arrays.
 
 The PyTorch-backed front ends (`spy.freqanalysis`, `spy.connectivityanalysis`) call the very same entry points with
 tensor pointers; nothing here is a second implementation of any arithmetic.
+
+A process that really is NumPy-only sets SPY_NO_TORCH=1 before the first use: otherwise `_lib.load()` imports an
+installed torch FIRST, so that a later `import torch` in the same process does not bind to the system libamdhip64 this
+library brings in (same SONAME as the runtime bundled with the torch wheel).
+
+`reference_mean` (the per-channel mean in the reference's float32 summation order, K0) reproduces NumPy bit for bit
+for dimord time x channel; for channel x time data the reference averages a transposed view with pairwise summation
+and the result agrees to float32 rounding only.
 """
 import ctypes as C
 

@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <mutex>
+#include <string>
 
 #include "spy_common.h"
 
@@ -28,6 +29,7 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_once;
+std::string g_dlerr;            // dlerror() of the failed dlopen, captured where it happened
 
 void load_rccl() {
     void* h = nullptr;
@@ -36,7 +38,11 @@ void load_rccl() {
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return;
+    if (!h) {
+        const char* e = dlerror();          // one call: it clears the state it reports
+        g_dlerr = e ? e : "dlopen failed";
+        return;
+    }
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
@@ -48,7 +54,7 @@ void load_rccl() {
 int need_rccl() {
     std::call_once(g_once, load_rccl);
     if (!g_rccl.ok) {
-        spy::set_error("RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+        spy::set_error("RCCL (librccl.so.1) could not be loaded: %s", g_dlerr.empty() ? "symbols missing" : g_dlerr.c_str());
         return -5;
     }
     return 0;

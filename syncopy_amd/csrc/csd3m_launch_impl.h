@@ -13,12 +13,9 @@ int m3_launch_one(hipStream_t stream, CsdArgs a, long long nprow) {
     a.item_base = 0;
     a.item_end = nprow * M3_TILES_PER_F;
     auto kern = csd3m_kernel<CH, 8, EXACT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          M3_LDS_BYTES));
-        attr_set = true;
-    }
+    // (the attribute is per device and the call is cheap: no process-wide "already set" flag)
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      M3_LDS_BYTES));
     // XCD-aware groups of 8 frequencies (NP > 1) / of 32 for the channel-quad-blocked layout (the kernel permutes them)
     const long long grid = NP > 1 ? ((nprow + 7) / 8) * 8 * NP : (a.blocked ? ((nprow + 31) / 32) * 32 : nprow);
     if (grid > 0x7fffffffLL) { spy::set_error("csd_accumulate: grid too large"); return -1; }

@@ -169,12 +169,9 @@ template <int LOG2L>
 int launch_plus4(spyhip_ctx* ctx, const cd* g, int F, long long nent, const cd* tw, cd* gp, cd* g0) {
     using C = spywil::PCfg<LOG2L>;
     auto kern = spywil::plus4_kernel<LOG2L>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    // (per device, cheap: set at every launch)
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3((unsigned)((nent + 3) / 4)), dim3(C::T), C::LDS_BYTES, ctx->stream, g, F, nent, tw, gp, g0);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;

@@ -88,12 +88,9 @@ template <int LOG2N, int G, int OUTK, bool MEAN>
 int launch_pow2(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     using C = spyfft::Cfg<LOG2N, G>;
     auto kern = spyfft::mtmfft_pow2_kernel<LOG2N, G, OUTK, MEAN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    // (per device, cheap: set at every launch)
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
@@ -117,12 +114,9 @@ template <int LOG2N, int G, int OUTK, bool MEAN>
 int launch_quad(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     using C = spyfft::Cfg2<LOG2N, G>;
     auto kern = spyfft::mtmfft_quad_kernel<LOG2N, G, OUTK, MEAN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    // (per device, cheap: set at every launch)
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
@@ -146,12 +140,9 @@ template <int LOG2N, int G, int OUTK, bool MEAN>
 int launch_blue(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     using C = spyfft::Cfg2<LOG2N, G>;
     auto kern = spyfft::mtmfft_blue_kernel<LOG2N, G, OUTK, MEAN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    // (per device, cheap: set at every launch)
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;

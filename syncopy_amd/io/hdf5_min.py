@@ -16,6 +16,8 @@ attributes: the subset libhdf5 of any version (and therefore unmodified Syncopy 
 Layout follows the HDF5 File Format Specification version 1.1/2.0 (III.A-E, IV.A.1-2); no code of the reference or
 of libhdf5 is involved.
 """
+import mmap
+import os
 import struct
 
 import numpy as np
@@ -28,14 +30,48 @@ class HDF5FormatError(Exception):
     pass
 
 
+# a version-1 object header message carries its size as uint16: one attribute holds < 64 KiB (HDF5 itself has the same
+# limit for attributes kept in the object header; h5py then raises RuntimeError, save_spy_container.py:263-272)
+MAX_ATTRIBUTE_BYTES = 65528
+
+
+class AttributeTooLarge(HDF5FormatError):
+    def __init__(self, name, size):
+        super().__init__(f"attribute '{name}' needs {size} bytes, more than the {MAX_ATTRIBUTE_BYTES} an object header "
+                         f"message holds")
+        self.name, self.size = name, size
+
+
 # ======================================================================================================== reader
 class _Reader:
     def __init__(self, path):
+        # the metadata is a few KB anywhere in the file: map it read-only instead of reading a multi-GB recording
+        # into host memory (slicing, .index and np.frombuffer work on an mmap); close() drops the mapping once the
+        # datasets are resolved - contiguous datasets come back as their own np.memmap
         self.path = path
-        with open(path, "rb") as fh:
-            self.buf = fh.read()
+        self._fh = open(path, "rb")
+        size = os.fstat(self._fh.fileno()).st_size
+        if size == 0:
+            self._fh.close()
+            raise HDF5FormatError(f"{path}: empty file")
+        self.buf = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
         self.base = 0
-        self._superblock()
+        try:
+            self._superblock()
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        if getattr(self, "buf", None) is not None:
+            try:
+                self.buf.close()
+            except BufferError:      # an array built with np.frombuffer still points into the mapping: leave it to the GC
+                pass
+            self.buf = None
+        if getattr(self, "_fh", None) is not None:
+            self._fh.close()
+            self._fh = None
 
     # ---- primitives
     def u(self, off, size):
@@ -156,7 +192,7 @@ class _Reader:
             for k in range(n):
                 e = a + 8 + 40 * k
                 noff, hdr = self.u(e, 8), self.u(e + 8, 8)
-                end = self.buf.index(b"\0", seg + noff)
+                end = self.buf.find(b"\0", seg + noff)
                 out[self.buf[seg + noff:end].decode("utf-8")] = hdr
             return
         if self.buf[a:a + 4] != b"TREE" or self.buf[a + 4] != 0:
@@ -185,7 +221,7 @@ class _Reader:
             q = p + 8
             names, offs, types = [], [], []
             for _ in range(nmemb):
-                end = self.buf.index(b"\0", q)
+                end = self.buf.find(b"\0", q)
                 name = self.buf[q:end].decode("ascii")
                 if ver < 3:
                     q += (end - q + 8) // 8 * 8
@@ -282,17 +318,20 @@ def read_datasets(path, names=None):
     """{name: (array, file offset of the first element or None)} of the datasets in the root group of `path`.
     Contiguous datasets come back as read-only np.memmap."""
     r = _Reader(path)
-    links = r.links(r.root)
-    out = {}
-    for name, addr in links.items():
-        if names is not None and name not in names:
-            continue
-        out[name] = r.dataset(addr)
-    if names is not None:
-        for n in names:
-            if n not in out:
-                raise KeyError(f"{path}: no dataset named '{n}' in the root group (has: {sorted(links)})")
-    return out
+    try:
+        links = r.links(r.root)
+        out = {}
+        for name, addr in links.items():
+            if names is not None and name not in names:
+                continue
+            out[name] = r.dataset(addr)
+        if names is not None:
+            for n in names:
+                if n not in out:
+                    raise KeyError(f"{path}: no dataset named '{n}' in the root group (has: {sorted(links)})")
+        return out
+    finally:
+        r.close()
 
 
 # ======================================================================================================== writer
@@ -370,7 +409,10 @@ def _attribute(name, value):
     nm = name.encode("utf-8") + b"\0"
     dt, sp = _type_message(arr.dtype), _space_message(arr.shape)
     body = struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(sp)) + _pad8(nm) + _pad8(dt) + _pad8(sp)
-    return _message(0x0C, body + np.ascontiguousarray(arr).tobytes())
+    raw = np.ascontiguousarray(arr).tobytes()
+    if len(body) + len(raw) + 8 > MAX_ATTRIBUTE_BYTES:
+        raise AttributeTooLarge(name, len(body) + len(raw))
+    return _message(0x0C, body + raw)
 
 
 def write_file(path, datasets, attrs=None):

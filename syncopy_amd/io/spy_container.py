@@ -173,7 +173,23 @@ def save(out, container=None, tag=None, filename=None, overwrite=False):
             attrs[key] = np.asarray(v)
         else:
             attrs[key] = v
-    offsets = hdf5_min.write_file(data_file, {"data": np.asarray(data), "trialdefinition": trl}, attrs)
+    while True:
+        try:
+            offsets = hdf5_min.write_file(data_file, {"data": np.asarray(data), "trialdefinition": trl}, attrs)
+            break
+        except hdf5_min.AttributeTooLarge as exc:
+            # an HDF5 attribute holds < 64 KiB: shorten it as the reference does when h5py refuses it
+            # (save_spy_container.py:263-272); the full value stays in the .info side-car
+            v = attrs[exc.name]
+            if isinstance(v, str):
+                short = "... " + v[-(32 << 10):]
+            elif isinstance(v, (list, tuple, np.ndarray)) and len(v) > 2:
+                short = [str(v[0]), "...", str(v[-1])]
+            else:
+                raise
+            SPYWarning(f"attribute '{exc.name}' is too large for the HDF5 container ({exc.size} bytes): stored "
+                       f"truncated, complete in {info_file}")
+            attrs[exc.name] = short
     meta["data_offset"], meta["trl_offset"] = offsets["data"], offsets["trialdefinition"]
     meta["_hdfFileDatasetProperties"] = ["data"]
     meta["file_checksum"] = hash_file(data_file)

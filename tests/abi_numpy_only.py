@@ -5,6 +5,8 @@ rank per visible GPU ... here one rank) and the trial queue's exact-indexing che
 import os
 import sys
 
+os.environ["SPY_NO_TORCH"] = "1"       # a NumPy-only host by declaration: syncopy_amd/_lib.py must not import torch
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

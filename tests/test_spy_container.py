@@ -183,3 +183,32 @@ def test_unmodified_reference_loads_what_we_save(tmp_path):
     r = subprocess.run(["bash", os.path.join(HERE, "..", "oracle", "make_golden.sh"), "--check-container", cont],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_large_attributes_are_truncated_not_fatal(tmp_path):
+    """An HDF5 root attribute holds < 64 KiB (object header message size is uint16): a long `_log` or channel list is
+    stored truncated with a warning, as the reference does when h5py refuses it (save_spy_container.py:263-272); the
+    .info side-car keeps the full value and load() reads that."""
+    import warnings
+    x = np.zeros((16, 2), dtype=np.float32)
+    obj = spy.AnalogData(x, samplerate=100.0, trialdefinition=np.array([[0, 16, 0]]))
+    obj.log = "line of history\n" * 6000                       # ~96 kB
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        spy.save(obj, filename=str(tmp_path / "biglog"))
+    assert any("too large" in str(x.message) for x in w)
+    back = spy.load(str(tmp_path / "biglog.analog"))
+    assert np.array_equal(np.asarray(back.data), x) and back.log.count("line of history") == 6000
+
+
+def test_reader_maps_instead_of_reading(tmp_path):
+    """load() must not pull the data file into host memory to find a few KB of metadata."""
+    from syncopy_amd.io import hdf5_min
+    x = np.arange(4096 * 8, dtype=np.float32).reshape(4096, 8)
+    hdf5_min.write_file(str(tmp_path / "m.h5"), {"data": x, "trialdefinition": np.zeros((1, 3))}, {"k": "v"})
+    r = hdf5_min._Reader(str(tmp_path / "m.h5"))
+    import mmap
+    assert isinstance(r.buf, mmap.mmap)
+    r.close()
+    d = hdf5_min.read_datasets(str(tmp_path / "m.h5"))
+    assert isinstance(d["data"][0], np.memmap) and np.array_equal(d["data"][0], x)
