@@ -353,6 +353,15 @@ int spyhip_granger_last_iterations(const spyhip_ctx* ctx);
 /* ---- utilities on the in-HBM trial queue ---------------------------------- */
 /* out[r, :] = alpha * sum_t in[t, r, :]  (trial mean of (T, n) float32) */
 int spyhip_trial_mean_f32(spyhip_ctx* ctx, const float* in_d, float* out_d, int64_t ntrials, int64_t n);
+/* the same for (T, n) complex64: sums per component, then the reference's complex division by the real count - a
+ * multiplication by the float32 reciprocal 1/T (NumPy's Smith division, summary_stats.py:426) */
+int spyhip_trial_mean_c64(spyhip_ctx* ctx, const void* in_d, void* out_d, int64_t ntrials, int64_t n);
+/* spy.mean(data, dim=<axis label>) for one trial (statistics/summary_stats.py:24, statistics/compRoutines.py:22-57:
+ * np.nanmean(trial, axis, keepdims=True)): x_d (outer, n, inner) float32 or complex64 -> out_d (outer, inner); NaN
+ * elements are skipped; float32 sums in NumPy's order (rows in order for an axis that is not the last, pairwise
+ * blocks for the last one), one division in float64. */
+int spyhip_axis_nanmean(spyhip_ctx* ctx, const void* x_d, int64_t outer, int64_t n, int64_t inner, int is_complex,
+                        void* out_d);
 
 #ifdef __cplusplus
 }

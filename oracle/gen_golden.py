@@ -239,6 +239,35 @@ tfa("slt_adaptive_fourier", method="superlet", order_max=4, adaptive=True, foi=n
     output="fourier")
 save("superlet_variants", **kw)
 
+# ---------------------------------------------------------------- spy.mean (statistics/summary_stats.py:24-318)
+kw = {}
+md = synthdata.ar2_network(nTrials=6, nSamples=300, AdjMat=np.zeros((5, 5)), seed=7)
+md = md + 0                                   # in-memory arithmetic copy: a plain AnalogData we may modify
+md_tr = trials_of(md)
+kw["data"] = np.stack(md_tr)
+kw["samplerate"] = np.array(md.samplerate)
+kw["trialdefinition"] = np.array(md.trialdefinition)
+for name, opts in (("analog_trials", dict(dim="trials")), ("analog_time", dict(dim="time")),
+                   ("analog_time_avg", dict(dim="time", keeptrials=False)), ("analog_channel", dict(dim="channel")),
+                   ("analog_trials_sel", dict(dim="trials", select={"trials": [0, 2, 3], "channel": [0, 3]}))):
+    r = spy.mean(md, **opts)
+    kw[name] = np.array(r.data)
+    kw[name + "_trldef"] = np.array(r.trialdefinition)
+msp = spy.freqanalysis(md, method="mtmfft", tapsmofrq=10, keeptapers=True, output="fourier")
+kw["spec"] = np.array(msp.data)
+kw["spec_trldef"] = np.array(msp.trialdefinition)
+for name, opts in (("spec_trials", dict(dim="trials")), ("spec_freq", dict(dim="freq")), ("spec_taper", dict(dim="taper")),
+                   ("spec_channel_avg", dict(dim="channel", keeptrials=False))):
+    r = spy.mean(msp, **opts)
+    kw[name] = np.array(r.data)
+mpw = spy.freqanalysis(md, method="mtmfft", tapsmofrq=10, output="pow")
+kw["pow"] = np.array(mpw.data)
+r = spy.mean(mpw, dim="trials")               # (keep the object alive while reading its HDF5 file)
+kw["pow_trials"] = np.array(r.data)
+r = spy.mean(mpw, dim="freq", keeptrials=False)
+kw["pow_freq_avg"] = np.array(r.data)
+save("mean_variants", **kw)
+
 # ---------------------------------------------------------------- backend-level vectors
 kw = {}
 # harmonic known-answer signal (tests/backend/test_timefreq.py:351-404)

@@ -744,3 +744,23 @@ def white_noise(n_samples, n_channels, n_trials, seed=None):
     """synthdata/analog.py:20-48 under collect_trials."""
     seeds = trial_seeds(seed, n_trials)
     return [np.random.default_rng(s).normal(size=(n_samples, n_channels)).astype("f4") for s in seeds]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# spy.mean (statistics/summary_stats.py:24-52, 205-318; statistics/compRoutines.py:22-57)
+def trial_mean(trials):
+    """Sequential trial average in the data's dtype: `result += trl` for every trial, then ONE division
+    (summary_stats.py:321-340, 408-428)."""
+    out = np.zeros(trials[0].shape, dtype=trials[0].dtype)
+    for trl in trials:
+        out += trl
+    out /= len(trials)
+    return out
+
+
+def axis_mean(trl, axis):
+    """npstats_cF with operation='mean' (compRoutines.py:22-57): np.nanmean(trl, axis, keepdims=True)."""
+    return np.nanmean(trl, axis=axis, keepdims=True)
+
+
+STAT_OPS = {"trial_mean": trial_mean, "axis_mean": axis_mean}

@@ -16,7 +16,8 @@ from .shared.kwarg_decorators import StructDict, get_defaults  # noqa: F401
 
 # The front ends keep their tensors in PyTorch (device memory, streams, torch.distributed) and are imported on first
 # use; `syncopy_amd.abi` drives the same library with NumPy + ctypes only and never pulls torch in.
-_LAZY = {"freqanalysis": ".specest.freqanalysis", "connectivityanalysis": ".connectivity.connectivity_analysis"}
+_LAZY = {"freqanalysis": ".specest.freqanalysis", "connectivityanalysis": ".connectivity.connectivity_analysis",
+         "mean": ".statistics.summary_stats"}
 
 
 def release_device_buffers():

@@ -83,6 +83,8 @@ SIGNATURES = {
     "spyhip_wilson_update": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, c_f64p]),
     "spyhip_wilson_finish": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "spyhip_trial_mean_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64]),
+    "spyhip_trial_mean_c64": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64]),
+    "spyhip_axis_nanmean": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, vp]),
 }
 
 

@@ -622,13 +622,34 @@ def granger_stats(device=None):
     return {"iterations": int(ctx.lib.spyhip_granger_last_iterations(ctx.handle))}
 
 
-def trial_mean(x):
-    """Sequential float32 sum over axis 0 followed by one division (trial averaging order of the reference)."""
-    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-    T = x.shape[0]
-    n = x.numel() // T
-    out = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
+def axis_nanmean(x, axis):
+    """np.nanmean(x, axis, keepdims=True) of one trial array (float32 / complex64) on the device, in NumPy's summation
+    order (statistics/compRoutines.py:22-57)."""
+    assert x.is_cuda and x.dtype in (torch.float32, torch.complex64) and x.is_contiguous()
+    axis = axis % x.dim()
+    outer = int(np.prod(x.shape[:axis], dtype=np.int64))
+    n = int(x.shape[axis])
+    inner = int(np.prod(x.shape[axis + 1:], dtype=np.int64))
+    shape = list(x.shape)
+    shape[axis] = 1
+    out = torch.empty(shape, dtype=x.dtype, device=x.device)
     ctx = context(x.device)
     ctx.bind_stream()
-    check(ctx.lib.spyhip_trial_mean_f32(ctx.handle, _ptr(x), _ptr(out), T, n), "spyhip_trial_mean_f32")
+    check(ctx.lib.spyhip_axis_nanmean(ctx.handle, _ptr(x), outer, n, inner, int(x.is_complex()), _ptr(out)),
+          "spyhip_axis_nanmean")
+    return out
+
+
+def trial_mean(x):
+    """Sequential float32 sum over axis 0 followed by one division (trial averaging order of the reference)."""
+    assert x.is_cuda and x.dtype in (torch.float32, torch.complex64) and x.is_contiguous()
+    T = x.shape[0]
+    n = x.numel() // T
+    out = torch.empty(x.shape[1:], dtype=x.dtype, device=x.device)
+    ctx = context(x.device)
+    ctx.bind_stream()
+    if x.is_complex():          # complex64: the reference's complex division by the count (1/T as a float32 factor)
+        check(ctx.lib.spyhip_trial_mean_c64(ctx.handle, _ptr(x), _ptr(out), T, n), "spyhip_trial_mean_c64")
+    else:
+        check(ctx.lib.spyhip_trial_mean_f32(ctx.handle, _ptr(x), _ptr(out), T, n), "spyhip_trial_mean_f32")
     return out

@@ -175,15 +175,20 @@ extern "C" int spyhip_queue_segments(const spyhip_queue* q, const int64_t** star
 }
 
 // ---- elementwise helpers for keeptrials=False accumulation ---------------------------------
+// RECIP: the components of complex64 data - NumPy divides a complex array by a real count with Smith's algorithm, which
+// for a real divisor is a MULTIPLICATION by the float32 reciprocal 1/T (loops.c.src, CFLOAT_divide: rat = 0, scl = 1/T,
+// out = in * scl), not a division: the last bit differs
+template <bool RECIP>
 __global__ void trial_mean_kernel(const float* __restrict__ in, float* __restrict__ out, long long ntrials,
                                   long long n) {
     // sequential sum over trials in float32, one division at the end: the order of
     // ComputationalRoutine.compute_sequential (computational_routine.py:1022-1032)
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const float scl = __fdiv_rn(1.0f, (float)ntrials);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float s = 0.f;
-        for (long long t = 0; t < ntrials; ++t) s += in[t * n + i];
-        out[i] = s / (float)ntrials;
+        for (long long t = 0; t < ntrials; ++t) s = __fadd_rn(s, in[t * n + i]);
+        out[i] = RECIP ? __fmul_rn(s, scl) : __fdiv_rn(s, (float)ntrials);
     }
 }
 
@@ -193,8 +198,126 @@ extern "C" int spyhip_trial_mean_f32(spyhip_ctx* ctx, const float* in_d, float* 
     SPY_HIP_CHECK(hipSetDevice(ctx->device));
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(trial_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in_d, out_d,
+    hipLaunchKernelGGL(trial_mean_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in_d, out_d,
                        (long long)ntrials, (long long)n);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int spyhip_trial_mean_c64(spyhip_ctx* ctx, const void* in_d, void* out_d, int64_t ntrials, int64_t n) {
+    if (!ctx || !in_d || !out_d || ntrials < 1) { spy::set_error("trial_mean: bad argument"); return -1; }
+    if (n <= 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    long long blocks = (2 * n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(trial_mean_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const float*>(in_d), reinterpret_cast<float*>(out_d), (long long)ntrials, (long long)(2 * n));
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- np.nanmean along one axis of a trial array (statistics/compRoutines.py:22-57: NumpyStatDim / npstats_cF) -----
+// element k of a run with NaNs replaced by zero as np.nanmean does before it sums (pofs != 0: complex data - the element
+// counts as NaN if either component is)
+__device__ __forceinline__ float nan0(const float* a, long long idx, long long pofs) {
+    const float v = a[idx];
+    if (pofs == 0) return (v != v) ? 0.f : v;
+    const float w = a[idx + pofs];
+    return ((v != v) || (w != w)) ? 0.f : v;
+}
+
+// NumPy's float32 sum of n values that are contiguous in memory (pairwise_sum_FLOAT: eight running sums over blocks of
+// at most 128 values, halves of longer runs added recursively) - followed literally so that means over the LAST axis
+// agree with the reference to the last bit whenever its divide does
+__device__ float np_pairwise_sum(const float* a, long long n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (long long i = 0; i < n; ++i) res = __fadd_rn(res, nan0(a, i, 0));
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = nan0(a, j, 0);
+        long long i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], nan0(a, i + j, 0));
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                              __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (; i < n; ++i) res = __fadd_rn(res, nan0(a, i, 0));
+        return res;
+    }
+    long long n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(np_pairwise_sum(a, n2), np_pairwise_sum(a + n2, n - n2));
+}
+
+// one component of m complex values (interleaved floats): pairwise_sum_CFLOAT on 2m floats - fewer than 4 complex: plain
+// loop; up to 64: this component's four running sums r[c], r[c+2], r[c+4], r[c+6]; longer: halves (multiples of 4)
+__device__ float np_pairwise_sum_c(const float* a, long long m, long long pofs) {
+    if (m < 4) {
+        float r = 0.f;
+        for (long long k = 0; k < m; ++k) r = __fadd_rn(r, nan0(a, 2 * k, pofs));
+        return r;
+    }
+    if (m <= 64) {
+        float r[4];
+        for (int j = 0; j < 4; ++j) r[j] = nan0(a, 2 * j, pofs);
+        long long k = 4;
+        for (; k < m - (m % 4); k += 4)
+            for (int j = 0; j < 4; ++j) r[j] = __fadd_rn(r[j], nan0(a, 2 * (k + j), pofs));
+        float res = __fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3]));
+        for (; k < m; ++k) res = __fadd_rn(res, nan0(a, 2 * k, pofs));
+        return res;
+    }
+    long long m2 = m / 2;
+    m2 -= m2 % 4;
+    return __fadd_rn(np_pairwise_sum_c(a, m2, pofs), np_pairwise_sum_c(a + 2 * m2, m - m2, pofs));
+}
+
+// x (outer, n, inner) float32 (complex64 = inner doubled by the caller: components are independent except for the NaN
+// test, which takes the complex element) -> out (outer, inner): NaNs skipped, sum in float32 in NumPy's order
+// (axis not last: one accumulator per output walking the n rows in order; last axis: pairwise), division in float64
+__global__ void axis_nanmean_kernel(const float* __restrict__ x, long long outer, long long n, long long inner, int cplx,
+                                    float* __restrict__ out) {
+    const long long tot = outer * inner, stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
+        const long long o = e / inner, i = e - o * inner;
+        const float* p = x + o * n * inner + i;
+        const long long partner = cplx ? ((i & 1) ? -1 : 1) : 0;       // the other component of a complex element
+        long long cnt = 0;
+        bool anynan = false;
+        for (long long k = 0; k < n; ++k) {
+            const float v = p[k * inner], w = cplx ? p[k * inner + partner] : 0.f;
+            const bool bad = (v != v) || (w != w);
+            anynan |= bad;
+            cnt += bad ? 0 : 1;
+        }
+        float s;
+        (void)anynan;
+        if (inner == (cplx ? 2 : 1)) {
+            // contiguous run (complex: NumPy sums the interleaved floats with the same eight accumulators, i.e. this
+            // component with stride 2 over blocks of 64 complex values)
+            s = cplx ? np_pairwise_sum_c(p, n, partner) : np_pairwise_sum(p, n);
+        } else {
+            s = 0.f;
+            for (long long k = 0; k < n; ++k) {
+                const float v = p[k * inner], w = cplx ? p[k * inner + partner] : 0.f;
+                s = __fadd_rn(s, ((v != v) || (w != w)) ? 0.f : v);
+            }
+        }
+        out[e] = (float)((double)s / (double)cnt);
+    }
+}
+
+extern "C" int spyhip_axis_nanmean(spyhip_ctx* ctx, const void* x_d, int64_t outer, int64_t n, int64_t inner, int is_complex,
+                                   void* out_d) {
+    if (!ctx || !x_d || !out_d || outer < 1 || n < 1 || inner < 1) { spy::set_error("axis_nanmean: bad argument"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long in2 = is_complex ? 2 * inner : inner;
+    long long blocks = (outer * in2 + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(axis_nanmean_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const float*>(x_d),
+                       (long long)outer, (long long)n, in2, is_complex ? 1 : 0, reinterpret_cast<float*>(out_d));
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }
