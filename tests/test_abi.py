@@ -67,10 +67,11 @@ def test_package_never_imports_the_oracle():
 
 def test_numpy_only_host_does_not_pull_torch_in():
     """`syncopy_amd.abi` (the NumPy + ctypes host of INTEGRATION.md) and the package itself import without PyTorch;
-    on a box without a GPU the context creation fails loudly."""
+    on a box without a GPU the context creation fails loudly.  A NumPy-only host declares itself with SPY_NO_TORCH=1
+    (otherwise _lib.load() imports an installed torch first, for the load order of libamdhip64 - ADVICE r2)."""
     import subprocess
     import sys
-    code = ("import sys; sys.path.insert(0, %r)\n"
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['SPY_NO_TORCH'] = '1'\n"
             "import syncopy_amd as spy\n"
             "from syncopy_amd import abi\n"
             "from syncopy_amd.specest.tapers import taper_table\n"
@@ -80,4 +81,13 @@ def test_numpy_only_host_does_not_pull_torch_in():
             "assert 'torch' not in sys.modules\n"
             "print('ok')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    # without the declaration the library loads torch BEFORE itself when torch is installed
+    code2 = ("import sys; sys.path.insert(0, %r)\n"
+             "from syncopy_amd import _lib\n"
+             "assert 'torch' not in sys.modules\n"
+             "_lib.load()\n"
+             "assert 'torch' in sys.modules\n"
+             "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
