@@ -5,6 +5,7 @@ torch, their raw device pointers are handed to the HIP library, and all kernels
 are enqueued on torch's current stream.  There is no CPU code path here.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -401,10 +402,45 @@ def csd_kernel_name(nchan, blocked=False):
     return "spycsd::csd_accum_kernel<3, 2, 0>" if ntiles >= 6 else "spycsd::csd_accum_kernel<1, 1, 0>"
 
 
+_lib_comm = {}          # device index -> True once the library's own RCCL communicator is up
+
+
+def _library_comm(ctx):
+    """The library's RCCL communicator on this context (include/spyhip.h: spyhip_comm_*), created once per process:
+    rank 0 draws the unique id, the existing process group carries its 128 bytes to the others (the only use of
+    torch.distributed on this path), every rank joins.  Collective: all ranks arrive here together - at the first
+    sum over ranks of an analysis."""
+    import torch.distributed as dist
+    if _lib_comm.get(ctx.device):
+        return
+    rank, size = dist.get_rank(), dist.get_world_size()
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_ubyte * 128)()
+        check(ctx.lib.spyhip_comm_unique_id(buf), "spyhip_comm_unique_id")
+        uid = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+    uid = uid.cuda(ctx.device)
+    dist.broadcast(uid, src=0)
+    raw = (C.c_ubyte * 128).from_buffer_copy(uid.cpu().numpy().tobytes())
+    check(ctx.lib.spyhip_comm_init(ctx.handle, raw, rank, size), "spyhip_comm_init")
+    _lib_comm[ctx.device] = True
+
+
+def shutdown_library_comm():
+    """Destroy the library's RCCL communicators (before the process group that bootstrapped them goes away)."""
+    for dev in list(_lib_comm):
+        ctx = _contexts.get(dev)
+        if ctx is not None:
+            check(ctx.lib.spyhip_comm_destroy(ctx.handle), "spyhip_comm_destroy")
+        _lib_comm.pop(dev, None)
+
+
 def csd_allreduce_(acc):
-    """Sum the (lower-triangle) CSD accumulator over all ranks in place: the ONE collective of the coherence path.
-    Only the lower triangle carries data before csd_finalize, so it is packed to (F, C(C+1)/2), all-reduced over
-    RCCL and unpacked (half the bytes on xGMI).  No-op for a single process."""
+    """Sum the (lower-triangle) CSD accumulator over all ranks in place: the ONE collective of the coherence path
+    (the reference's mutex-guarded `+=`, kwarg_decorators.py:723-735).  Only the lower triangle carries data before
+    csd_finalize: `spyhip_allreduce_csd` packs it to (F, C(C+1)/2), sums it with the library's own RCCL communicator
+    over xGMI in a fixed rank order and unpacks it (half the bytes).  No-op for a single process; under a gloo group
+    (the CPU tests never get here) the packed triangle goes through torch.distributed instead."""
     from . import parallel
     if not parallel.collective_active():
         return acc
@@ -412,6 +448,12 @@ def csd_allreduce_(acc):
     F, Cn, _ = acc.shape
     ctx = context(acc.device)
     ctx.bind_stream()
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl" and not os.environ.get("SPY_TORCH_COLLECTIVE"):
+        _library_comm(ctx)
+        ctx.bind_stream()
+        check(ctx.lib.spyhip_allreduce_csd(ctx.handle, _ptr(acc), F, Cn), "spyhip_allreduce_csd")
+        return acc
     packed = torch.empty((F, Cn * (Cn + 1) // 2), dtype=torch.complex64, device=acc.device)
     check(ctx.lib.spyhip_csd_tril_pack(ctx.handle, _ptr(acc), F, Cn, _ptr(packed)), "spyhip_csd_tril_pack")
     parallel.allreduce_sum_(packed)

@@ -52,12 +52,24 @@ def main(out_path):
         same = torch.equal(torch.view_as_real(acc[:, ii, jj].contiguous()),
                            torch.view_as_real((before[:, ii, jj] * world).contiguous()))
         res["pack_allreduce_unpack_bit_exact"] = np.array(same)
+        # the product's ONE collective path: backend.csd_allreduce_ = spyhip_allreduce_csd on the library's own RCCL
+        # communicator (bootstrapped through this process group); same bits as the torch.distributed sum above
+        acc2 = before.clone()
+        be.csd_allreduce_(acc2)
+        res["library_allreduce_bit_exact"] = np.array(torch.equal(
+            torch.view_as_real(acc2[:, ii, jj].contiguous()), torch.view_as_real(acc[:, ii, jj].contiguous())))
+        res["library_comm_up"] = np.array(bool(be._lib_comm))
         res["world"] = np.array(world)
         torch.cuda.synchronize()
         if dist.get_rank() == 0:
             np.savez(out_path, **res)
     finally:
-        dist.destroy_process_group()
+        try:
+            from syncopy_amd import backend
+            torch.cuda.synchronize()
+            backend.shutdown_library_comm()
+        finally:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,7 @@ def test_front_ends_under_nccl_group(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     z = np.load(out)
     assert int(z["world"]) == n and bool(z["pack_allreduce_unpack_bit_exact"])
+    assert bool(z["library_comm_up"]) and bool(z["library_allreduce_bit_exact"])
     adj = np.zeros((37, 37))
     adj[0, 1] = adj[5, 30] = 0.3
     data = spy.synthdata.ar2_network(AdjMat=adj, nSamples=1024, nTrials=11, seed=3, samplerate=500)
