@@ -146,6 +146,12 @@ int spyhip_fft_exec(spyhip_fft_plan* plan, const float* data_d, int64_t ld,
  * so that every wave stores whole 2-KiB runs.  Channels beyond nchan in the last quad are written as 0.
  * Returns -3 for plans that cannot use it (other outputs, nfft not a power of two in 256..8192). */
 int spyhip_fft_plan_set_blocked(spyhip_fft_plan* plan, int on);
+/* Precision of the transform.  reference = 0 (default): taper product and FFT in float32 - error ~1e-7 of a
+ * channel's largest bin, inside the parity criterion |a-b| <= 1e-5 |b| + 1e-6 max|b|.  reference = 1: float64 taper
+ * product and float64 FFT, the spectrum rounded to complex64 and scaled in float32 exactly where
+ * specest/mtmfft.py:104-127 does it - every bin to ~1e-7 of ITSELF (pure rtol 1e-5 also 60 dB below the peak), at
+ * about five times the cost; power-of-two nfft 256 ... 4096, standard layout (-3 otherwise). */
+int spyhip_fft_plan_set_precision(spyhip_fft_plan* plan, int reference);
 /* Constant detrending (detrend = SPYHIP_DETREND_CONSTANT) with the per-channel mean taken EXACTLY as the reference
  * takes it for whole trials: scipy.signal.detrend on the float32 (time x channel) array is data - np.mean(data, 0),
  * and NumPy sums the slow axis sequentially in ONE float32 accumulator per channel (then one float32 division).

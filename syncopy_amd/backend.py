@@ -223,6 +223,11 @@ class FFTPlan:
         if self.reference_mean:
             check(self.ctx.lib.spyhip_fft_plan_set_reference_mean(self.handle, 1), "spyhip_fft_plan_set_reference_mean")
 
+    def set_precision(self, reference=True):
+        """`reference=True`: float64 taper product and FFT, rounded to complex64 where the reference rounds
+        (spyhip_fft_plan_set_precision; power-of-two nfft 256 ... 4096).  Returns False if this plan cannot."""
+        return self.ctx.lib.spyhip_fft_plan_set_precision(self.handle, int(bool(reference))) == 0
+
     def set_blocked(self, on=True):
         """Channel-quad-blocked hand-over layout (nseg*ntaper, ceil(nchan/4), nfsel, 4) for csd_accumulate(...,
         blocked=True); returns False (layout unchanged) when the plan cannot use it."""

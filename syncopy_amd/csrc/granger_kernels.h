@@ -10,16 +10,9 @@
 // non-negative frequencies only and the lag-domain step uses the conjugate-symmetric extension
 // (real(ifft(full)) == irfft(half) exactly).
 #pragma once
+#include "cd_math.h"
 
 namespace spywil {
-
-typedef double2 cd;
-
-__device__ __forceinline__ cd cmul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ cd cmulc(cd a, cd b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
-__device__ __forceinline__ cd cadd(cd a, cd b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cd csub(cd a, cd b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double cabs2(cd a) { return a.x * a.x + a.y * a.y; }
 
 // ---- complex64 (F,C,C) -> complex128, + eps on the diagonal (regularize_csd: CSD + eps*I)
 __global__ void __launch_bounds__(256) widen_kernel(const float2* in, cd* out, int C, long long n, double eps) {

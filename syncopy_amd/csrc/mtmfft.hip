@@ -15,6 +15,13 @@
 #include "mtmfft_mixed_plan.h"
 
 namespace spyfft {
+struct F64Args {              // mtmfft_f64_kernel.h (kept out of this translation unit: it pulls in the Wilson kernels)
+    MtmArgs m;
+    const double* tapers64;
+    const double2* tw64;
+    double scale64;
+};
+int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean);
 int pipe_launch(hipStream_t stream, const MtmArgs& a, int log2n, unsigned grid, int outk, bool mean);
 int pipe_max_tapers_demean();
 int mixed_launch(hipStream_t stream, const MtmArgs& a, const MixPlan& g, int threads, size_t lds, unsigned grid, int outk,
@@ -50,6 +57,10 @@ struct spyhip_fft_plan {
     spy::DevBuf<int> fpos;
     bool identity_freq = true;
     bool blocked = false;
+    bool precision64 = false;   // float64 taper product + FFT, complex64 rounding where the reference rounds (mtmfft_f64_kernel.h)
+    spy::DevBuf<double> tapers64;
+    spy::DevBuf<double2> tw64;
+    std::string fp32_kernel_name;
     bool ref_mean = false;      // constant detrending with the reference's float32 row-order means (seq_mean_kernel)
     spy::DevBuf<float> means;
     size_t means_cap = 0;
@@ -253,6 +264,10 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
     std::vector<float> tf((size_t)ntaper * nsig);
     for (size_t i = 0; i < tf.size(); ++i) tf[i] = (float)tapers[i];
     if (p->tapers.upload(tf, ctx->stream)) { delete p; return -2; }
+    {   // the windows as the reference holds them (float64), for spyhip_fft_plan_set_precision
+        std::vector<double> td(tapers, tapers + (size_t)ntaper * nsig);
+        if (p->tapers64.upload(td, ctx->stream)) { delete p; return -2; }
+    }
 
     // frequency selection -> inverse map bin -> output slot
     p->identity_freq = (freq_idx == nullptr);
@@ -441,12 +456,43 @@ extern "C" int spyhip_fft_plan_destroy(spyhip_fft_plan* p) {
 
 extern "C" int spyhip_fft_plan_set_blocked(spyhip_fft_plan* p, int on) {
     if (!p) { spy::set_error("fft_plan_set_blocked: null plan"); return -1; }
+    if (on && p->precision64) { spy::set_error("fft_plan_set_blocked: not with the reference-precision kernel"); return -3; }
     if (on && !(p->pow2 && p->log2n <= 13 && p->output == SPYHIP_OUT_FOURIER && p->keeptapers)) {
         spy::set_error("fft_plan_set_blocked: the channel-blocked layout needs output=FOURIER, keeptapers=1 and a "
                        "power-of-two nfft in 256..8192");
         return -3;
     }
     p->blocked = on != 0;
+    return 0;
+}
+
+extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) {
+    if (!p) { spy::set_error("fft_plan_set_precision: null plan"); return -1; }
+    if (!reference) {
+        if (p->precision64) p->kernel_name = p->fp32_kernel_name;
+        p->precision64 = false;
+        return 0;
+    }
+    if (!(p->pow2 && p->log2n >= 8 && p->log2n <= 12) || p->blocked) {
+        spy::set_error("fft_plan_set_precision: the reference-precision kernel serves power-of-two nfft 256 ... 4096 in "
+                       "the standard layout (nfft = %d)", p->nfft);
+        return -3;
+    }
+    if (!p->tw64.p) {
+        std::vector<double2> t(p->nfft);
+        for (int m = 0; m < p->nfft; ++m) {
+            const double ang = -2.0 * PI * (double)m / (double)p->nfft;
+            t[m] = make_double2(std::cos(ang), std::sin(ang));
+        }
+        SPY_HIP_CHECK(hipSetDevice(p->ctx->device));
+        if (p->tw64.upload(t, p->ctx->stream)) return -2;
+    }
+    if (!p->precision64) p->fp32_kernel_name = p->kernel_name;
+    p->precision64 = true;
+    char buf[96];
+    std::snprintf(buf, sizeof buf, "mtmfft_f64_kernel<%d, %d, %s>", p->log2n,
+                  p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
+    p->kernel_name = buf;
     return 0;
 }
 
@@ -498,6 +544,17 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         a.means = p->means.p;
     }
     const int npairs = (p->nchan + 1) / 2;
+    if (p->precision64) {
+        spyfft::F64Args fa{};
+        fa.m = a;
+        fa.tapers64 = p->tapers64.p;
+        fa.tw64 = p->tw64.p;
+        fa.scale64 = (double)p->scale;
+        const long long grid = (long long)nseg * npairs;
+        if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
+        return spyfft::f64_launch(p->ctx->stream, fa, p->log2n, (unsigned)grid,
+                                  p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), !p->keeptapers);
+    }
     if (p->pow2) {
         // work items per segment: channel quads (packed kernel) or channel pairs (2^14)
         const bool quad = p->log2n <= 13;

@@ -19,6 +19,7 @@
 // add_S (S = triu(g0) - triu(g0)^H added to every frequency, wilson_sf.py:97-98) is NOT fused: g0 of all entries is
 // only known when this kernel has finished.
 #pragma once
+#include "cd_math.h"
 
 #ifndef SPY_PLUS_KATTR
 #ifndef SPY_HOST_EMU

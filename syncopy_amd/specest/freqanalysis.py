@@ -32,11 +32,19 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
                  polyremoval=0, taper="hann", demean_taper=False, taper_opt=None, tapsmofrq=None, nTaper=None,
                  keeptapers=False, toi="all", t_ftimwin=None, wavelet="Morlet", width=6, order=None, order_max=None,
                  order_min=1, c_1=3, adaptive=False, ft_compat=False, select=None, compute_method=None,
-                 routine_classes=None, **kwargs):
+                 routine_classes=None, precision="float32", **kwargs):
     """Spectral estimation of AnalogData on MI355X.  Arguments as spy.freqanalysis
     (freqanalysis.py:62-90).  `compute_method`: None/'hip' (batched from the in-HBM trial
     queue) or 'sequential' (the reference's per-trial loop over the same kernels).
-    `routine_classes` lets tests substitute compute classes (e.g. bound to the CPU oracle)."""
+    `routine_classes` lets tests substitute compute classes (e.g. bound to the CPU oracle).
+    `precision` (not a reference argument): "float32" (default) transforms in float32 - ~1e-7 of a channel's largest
+    bin; "reference" runs the taper product and the FFT in float64 and rounds to complex64 where the reference does
+    (mtmfft.py:96-127): every bin to 1e-5 of itself, ~5x the time; methods 'mtmfft' / 'mtmconvol' / 'welch' with a
+    power-of-two transform length 256 ... 4096 (e.g. pad='nextpow2')."""
+    if precision not in ("float32", "reference"):
+        raise SPYValueError("'float32' or 'reference'", varname="precision", actual=str(precision))
+    if precision == "reference" and method not in ("mtmfft", "mtmconvol", "welch"):
+        raise SPYValueError("method 'mtmfft', 'mtmconvol' or 'welch' for precision='reference'", varname="method", actual=method)
     if not isinstance(data, AnalogData) or data.data is None:
         raise SPYTypeError(data, varname="data", expected="non-empty AnalogData")
     classes = {"mtmfft": MultiTaperFFT, "mtmconvol": MultiTaperFFTConvol}
@@ -62,6 +70,12 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
         polyremoval = int(polyremoval)
 
     with attached_selection(data, select):
+        if precision == "reference":
+            from . import hip_spectral as hs
+            with hs.precision("reference"):
+                return _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval,
+                                     taper, demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin,
+                                     wavelet, width, ft_compat, compute_method, (order_max, order_min, c_1, adaptive))
         return _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
                              demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin, wavelet, width,
                              ft_compat, compute_method, (order_max, order_min, c_1, adaptive))

@@ -7,6 +7,7 @@ Used by the compute functions in compRoutines.py both for one trial at a time
 import numpy as np
 import torch
 from .. import backend
+from ..shared.errors import SPYValueError
 from .tapers import spec_scale, taper_table  # noqa: F401
 
 _plan_cache = {}
@@ -29,6 +30,27 @@ def _cache_hit(cache, key):
     return value
 
 
+_precision = ["float32"]        # arithmetic of the tapered FFT plans created inside `with precision(...)`
+
+
+class precision:
+    """`with hs.precision("reference"):` - tapered-FFT plans requested inside the block transform in float64 and round
+    to complex64 where the reference does (mtmfft.py:96-127; spyhip_fft_plan_set_precision).  Default "float32"."""
+
+    def __init__(self, kind):
+        if kind not in ("float32", "reference"):
+            raise SPYValueError("'float32' or 'reference'", varname="precision", actual=str(kind))
+        self.kind = kind
+
+    def __enter__(self):
+        _precision.append(self.kind)
+        return self
+
+    def __exit__(self, *exc):
+        _precision.pop()
+        return False
+
+
 def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_taper, freq_idx, output, keeptapers,
              device, blocked=False, whole_trials=True):
     """Cached FFTPlan; `blocked` asks for the channel-blocked hand-over layout of the CSD path (the plan's
@@ -39,13 +61,17 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
     fkey = None if freq_idx is None else np.asarray(freq_idx, dtype=np.int32).tobytes()
     key = (int(nsig), int(nfft), int(nchan), taper, tuple(sorted((taper_opt or {}).items())), int(nnorm),
            float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device), bool(blocked),
-           bool(whole_trials))
+           bool(whole_trials), _precision[-1])
     plan = _cache_hit(_plan_cache, key)
     if plan is None:
         tp = taper_table(taper, nsig, nnorm, taper_opt)
         plan = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
                                keeptapers, device=device, reference_mean=whole_trials and detrend == 0)
-        if blocked:
+        if _precision[-1] == "reference":
+            if not plan.set_precision(True):
+                raise SPYValueError("a power-of-two transform length 256 ... 4096 (e.g. pad='nextpow2') for "
+                                    "precision='reference'", varname="precision", actual=f"nfft = {int(nfft)}")
+        elif blocked:
             plan.set_blocked(True)
         _bounded_put(_plan_cache, key, plan)
     return plan

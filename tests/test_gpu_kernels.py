@@ -396,3 +396,86 @@ def test_blocked_tail_starts_inside_a_frequency(be):
         x = spec[:, f, :].to(torch.complex128)
         ref = (x.T @ x.conj() / R).cpu().numpy()
         assert_parity(a_blk[f].cpu().numpy(), ref.astype(np.complex64), what=f"blocked csd f={f}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K1 at the reference's precision (spyhip_fft_plan_set_precision): float64 taper product + FFT, complex64 rounding
+def _harmonic_fixture(N=4096):
+    """Harmonics + a noise floor 60 dB below them (tools/precision_report.py): the dynamic range the float32 transform
+    cannot resolve bin by bin."""
+    t = np.arange(N) / 1000.0
+    rng = np.random.default_rng(0)
+    harm = np.stack([np.cos(2 * np.pi * f * t) for f in (40.0, 100.0, 7.3, 333.0)], axis=1)
+    return (harm + 1e-3 * rng.normal(size=harm.shape)).astype(np.float32)
+
+
+def test_reference_precision_resolves_60dB(be):
+    x = _harmonic_fixture()
+    N, C = x.shape
+    tap = O.taper_table("hann", N, N, {})
+    sc = O.spec_scale(N, N)
+    ref, _ = O.mtmfft(O.detrend(x.copy(), 0), 1000.0, N, "hann", {})
+    ref = ref.astype(np.complex128)
+    dev = torch.from_numpy(x).cuda()
+    starts = torch.zeros(1, dtype=torch.int64, device="cuda")
+    frac = {}
+    for prec in ("float32", "reference"):
+        plan = be.FFTPlan(N, N, C, tap, sc, 0, False, None, "fourier", True, reference_mean=True)
+        if prec == "reference":
+            assert plan.set_precision(True) and "f64" in plan.kernel_name
+        got = plan.execute(dev, starts).cpu().numpy()[0].astype(np.complex128)
+        err = np.abs(got - ref)
+        frac[prec] = float((err <= 1e-5 * np.abs(ref)).mean())
+        assert_parity(got.astype(np.complex64), ref.astype(np.complex64), what=prec)
+    print(f"bins within PURE rtol 1e-5 of the float64 reference: float32 {100 * frac['float32']:.1f} %, "
+          f"reference precision {100 * frac['reference']:.2f} %")
+    assert frac["reference"] >= 0.99 and frac["float32"] < 0.5
+
+
+@pytest.mark.parametrize("case", [dict(nsig=4096, nfft=4096, K=7, output="pow", keeptapers=False, detrend=0, nchan=5),
+                                  dict(nsig=700, nfft=1024, K=3, output="fourier", keeptapers=True, detrend=1, nchan=4),
+                                  dict(nsig=256, nfft=256, K=2, output="abs", keeptapers=True, detrend=-1, nchan=3,
+                                       demean=True),
+                                  dict(nsig=2048, nfft=2048, K=4, output="fourier", keeptapers=False, detrend=0, nchan=2,
+                                       freq_idx=[0, 5, 1024, 77])])
+def test_reference_precision_options(be, case):
+    """Every option of the plan through the float64 kernel: padding, detrending modes, demean_taper, taper mean,
+    conversions, frequency selection, odd channel counts - vs the oracle, which now agrees to complex64 rounding."""
+    rng = np.random.default_rng(3)
+    nsig, nfft, K, C = case["nsig"], case["nfft"], case["K"], case["nchan"]
+    # offsets only where the reference's own float32 detrending is reproduced exactly (the sequential mean, K0); its
+    # float32 least-squares line (scipy.signal.detrend -> LAPACK sgelsd) leaves ~1e-7 x offset of its own noise next to DC
+    x = (rng.normal(size=(nsig + 7, C)) + np.arange(C) * (10.0 if case["detrend"] == 0 else 0.0)).astype(np.float32)
+    taper, topt = ("dpss", {"NW": (K + 1) / 2, "Kmax": K})
+    tap = O.taper_table(taper, nsig, nfft, topt)
+    fi = case.get("freq_idx")
+    plan = be.FFTPlan(nsig, nfft, C, tap, O.spec_scale(nsig, nfft), None if case["detrend"] < 0 else case["detrend"],
+                      case.get("demean", False), fi, case["output"], case["keeptapers"], reference_mean=case["detrend"] == 0)
+    assert plan.set_precision(True)
+    got = plan.execute(torch.from_numpy(x).cuda(), torch.tensor([3], dtype=torch.int64, device="cuda")).cpu().numpy()[0]
+    freqs = np.fft.rfftfreq(nfft, 1e-3)
+    ref, _ = O.mtmfft_cF(np.array(x[3:3 + nsig]), foi=freqs if fi is None else freqs[fi], keeptapers=case["keeptapers"],
+                         polyremoval=None if case["detrend"] < 0 else case["detrend"], output=case["output"],
+                         method_kwargs=dict(samplerate=1000.0, taper=taper, taper_opt=topt, nSamples=nfft,
+                                            demean_taper=case.get("demean", False)))
+    assert_parity(got, ref[0], what=str(case))
+    if case["output"] == "fourier":
+        # bin by bin to complex64 rounding (the float32 scale multiplies rounded values on both sides)
+        err = np.abs(got.astype(np.complex128) - ref[0])
+        rt = 1e-5 if case["detrend"] == 1 else 4e-7           # (the line fit: the reference's own float32 lstsq noise)
+        assert np.all(err <= rt * np.abs(ref[0]) + 1e-12 * np.abs(ref[0]).max()), float((err / np.abs(ref[0])).max())
+
+
+def test_reference_precision_through_freqanalysis():
+    import syncopy_amd as spy
+    from syncopy_amd.shared.errors import SPYValueError
+    x = _harmonic_fixture()
+    data = spy.AnalogData(x, samplerate=1000.0)
+    a = spy.freqanalysis(data, method="mtmfft", taper="hann", output="fourier", precision="reference")
+    ref, _ = O.mtmfft(O.detrend(x.copy(), 0), 1000.0, 4096, "hann", {})
+    err = np.abs(a.data[0].astype(np.complex128) - ref)
+    assert (err <= 1e-5 * np.abs(ref)).mean() >= 0.99
+    with pytest.raises(SPYValueError):
+        spy.freqanalysis(spy.AnalogData(x[:2000], samplerate=1000.0), method="mtmfft", precision="reference")
+    with pytest.raises(SPYValueError):
+        spy.freqanalysis(data, method="wavelet", precision="reference")
