@@ -22,6 +22,11 @@ struct F64Args {              // mtmfft_f64_kernel.h (kept out of this translati
     double scale64;
 };
 int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean);
+int dec_launch_a(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
+int dec_launch_b(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
+int dec_launch_c(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
+int dec_launch_d(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
+int dec_launch_c2(hipStream_t stream, const MtmArgs& a, int nquads);
 int pipe_launch(hipStream_t stream, const MtmArgs& a, int log2n, unsigned grid, int outk, bool mean);
 int pipe_max_tapers_demean();
 int mixed_launch(hipStream_t stream, const MtmArgs& a, const MixPlan& g, int threads, size_t lds, unsigned grid, int outk,
@@ -38,6 +43,7 @@ struct spyhip_fft_plan {
     float scale = 1.f;
     bool pow2 = false;
     bool pipe = false;          // pipelined two-quad kernel (mtmfft_pipe_kernel.h): N = 1024, 2048, 4096
+    bool dec = false;           // compile-time radix schedules for decimal lengths (mtmfft_dec_kernel.h)
     bool mixed = false;         // packed mixed-radix engine for 5-smooth lengths (mtmfft_mixed.h)
     spyfft::MixPlan mix{};
     int mix_threads = 0;
@@ -308,6 +314,14 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         if (p->pipe) std::snprintf(buf, sizeof buf, "mtmfft_pipe_kernel<%d, %s>", p->log2n, mode);
         else std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
                            p->log2n, p->G, mode);
+        p->kernel_name = buf;
+    } else if ((nfft == 200 || nfft == 500 || nfft == 1000 || nfft == 2000 || nfft == 2500 || nfft == 5000) && !std::getenv("SPYHIP_NO_DEC") && !std::getenv("SPYHIP_FORCE_GENERIC") &&
+               !std::getenv("SPYHIP_FORCE_LONG") && !std::getenv("SPYHIP_FORCE_MIXED")) {
+        // decimal trial lengths (1 kHz x 0.2 ... 5 s): radix schedules fixed at compile time, 10 values per thread
+        p->dec = true;
+        if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "mtmfft_dec_kernel<N = %d, %s>", nfft, mode);
         p->kernel_name = buf;
     } else if (!std::getenv("SPYHIP_NO_MIXED") && !std::getenv("SPYHIP_FORCE_GENERIC") && !std::getenv("SPYHIP_FORCE_LONG") &&
                // (one taper and a Bluestein length M <= 4096 - sliding Hann windows of 500 samples, say: the chirp-z
@@ -581,6 +595,19 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             case 14: return launch_pow2_mode<14, 1>(p, a, g);
             default: spy::set_error("no kernel for log2n=%d", p->log2n); return -1;
         }
+    }
+    if (p->dec) {
+        const int nquads = (p->nchan + 3) / 4;
+        const bool mean = !p->keeptapers;
+        const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+        if (p->nfft == 2000 && outk == 2 && !mean && nquads >= 2) return spyfft::dec_launch_c2(p->ctx->stream, a, nquads);
+        int rc;
+        if ((rc = spyfft::dec_launch_a(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_b(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_c(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_d(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
+        spy::set_error("fft_exec: no decimal-length kernel for nfft = %d", p->nfft);
+        return -1;
     }
     if (p->mixed) {
         const int G = p->G;

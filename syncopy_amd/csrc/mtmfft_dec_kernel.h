@@ -1,0 +1,398 @@
+// K1d: the packed tapered FFT with COMPILE-TIME radix schedules and V values per thread - decimal trial lengths
+// (1000 = 10 x 10 x 10, 2000 = 10 x 10 x 10 x 2, 5000 = 10 x 10 x 10 x 5: 1 kHz x 1 / 2 / 5 s; BASELINE config 1 is
+// N = 2000) and, with V = 8, a high-occupancy variant of the power-of-two lengths.
+//
+// Reference semantics: specest/mtmfft.py:16-129 + specest/compRoutines.py:169-189 (and specest/stft.py:101-154 when one
+// segment = one STFT frame) - the same argument block, options and output layouts as mtmfft_quad_kernel.
+//
+// Structure of the packed power-of-two kernel (mtmfft2_kernel.h) with its radix-16 network generalised: N = V R1 R2 R3,
+// T = N / V threads per channel quad; thread j keeps the samples n = j + T e (e < V) of its FOUR channels in registers
+// across all tapers; every Stockham pass of radix R (R divides V, V / R butterflies per thread) reads in[j + T e] and
+// writes out[(b / Ns) Ns R + b % Ns + r Ns] - with immediates instead of the run-time index arithmetic of the
+// mixed-radix engine (mtmfft_mixed.h: 2.1x the vector instructions and 2.9x the LDS cycles of the power-of-two kernel
+// per sample, profiles/r2_pmc_mixed2000_*); the first pass takes the tapered samples straight from the registers and
+// the last pass leaves bin j + T e in register e, so a transform of P passes makes P - 1 exchanges through LDS
+// (the mixed-radix engine: 2 P + 3 array passes).  With V = 10 a thread holds 40 + 40 data registers instead of the
+// 64 + 64 of the radix-16 kernel: four waves per SIMD instead of two.
+#pragma once
+#include "fft2_device.h"
+#include "mtmfft_kernel.h"
+#include "mtmfft_mixed.h"      // dft3p / dft5p / dft_pq: the composite butterflies
+
+namespace spyfft {
+
+template <int R>
+__device__ __forceinline__ void dec_dft(C2 (&t)[R]) {
+    if constexpr (R == 2) dft2p(t);
+    else if constexpr (R == 4) dft4p(t);
+    else if constexpr (R == 5) dft5p(t);
+    else if constexpr (R == 8) dft8p(t);
+    else if constexpr (R == 10) dft_pq<2, 5>(t);
+    else if constexpr (R == 16) dft16p(t);
+    else if constexpr (R == 20) dft_pq<4, 5>(t);
+    else static_assert(R == 2, "radix of the compile-time schedules: 2, 4, 5, 8, 10, 16, 20");
+}
+
+template <int V_, int R1_, int R2_, int R3_, int G_>
+struct CfgD {
+    static constexpr int V = V_, R1 = R1_, R2 = R2_, R3 = R3_, G = G_;
+    static constexpr int N = V * R1 * R2 * R3;
+    static constexpr int T = N / V;                          // threads per channel quad
+    static constexpr int NPASS = 2 + (R2 > 1 ? 1 : 0) + (R3 > 1 ? 1 : 0);
+    static constexpr int NTHREADS = ((T * G + 63) / 64) * 64;
+    static constexpr int PLANE = N + N / V + 1;              // float4 units per quad: one pad per V values
+    static constexpr int ESTRIDE = (T + T / V) * G;          // LDS distance of e -> e + 1
+    static constexpr size_t LDS_BYTES = (size_t)PLANE * G * 16;
+    static_assert(R1 > 1 && V % R1 == 0 && V % R2 == 0 && V % R3 == 0, "every radix divides the values per thread");
+    static_assert(T % V == 0, "T multiple of V: idx(j + T e) stays affine in e");
+    static_assert(NTHREADS <= 1024 && (64 % G) == 0, "workgroup shape");
+    __device__ static __forceinline__ int idx(int i, int h) { return (i + i / V) * G + h; }
+};
+
+// One pass.  In: v[e] = in[j + T e] (pass 0: the tapered samples).  Out: LAST - v[e] = X[j + T e] in registers;
+// otherwise the outputs go through LDS and v[e] = out[j + T e] comes back.
+template <class C, int R, int Ns, bool FIRST, bool LAST>
+__device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int h, bool active,
+                                         const float2* __restrict__ tw) {
+    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, MB = V / R;
+    int wbase[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int b = j + T * m;
+        const int q = b / Ns, k = b - q * Ns;
+        C2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = v[m + MB * r];
+        if (!FIRST) {
+            const unsigned kb = (unsigned)(k * (N / (Ns * R))) * 8u;          // byte offset of tw[k N / (Ns R)]
+#pragma unroll
+            for (int r = 1; r < R; ++r) u[r] = cmul_s(u[r], ldg<float2>(tw, kb * (unsigned)r));
+        }
+        dec_dft<R>(u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[m + MB * r] = u[r];
+        // LDS slot of output r: idx(q Ns R + k + r Ns); Ns is 1 (first pass, R = V) or a multiple of V
+        wbase[m] = FIRST ? (b * (V + 1)) * G + h : (q * (Ns * R + Ns * R / V) + k + k / V) * G + h;
+    }
+    if (LAST) return;
+    constexpr int WS = FIRST ? G : (Ns + Ns / V) * G;
+    __syncthreads();              // (write-after-read: earlier reads of the buffer by any thread are done)
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const C2 t = v[m + MB * r];
+                lds[wbase[m] + r * WS] = make_float4(t.r[0], t.r[1], t.i[0], t.i[1]);
+            }
+    }
+    __syncthreads();
+    const int rb = C::idx(j, h);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const float4 t = lds[rb + e * C::ESTRIDE];
+        v[e].r = v2f{t.x, t.y};
+        v[e].i = v2f{t.z, t.w};
+    }
+}
+
+// OUTK: 0 = power (inlined), 1 = any other real conversion, 2 = complex; MEAN: average over tapers
+template <class C, int OUTK, bool MEAN>
+__global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(MtmArgs a) {
+    constexpr bool CPLX = (OUTK == 2);
+    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, HV = V / 2;
+    SPY_DYN_SMEM(float4, lds);
+
+    const int tid = threadIdx.x;
+    const int h = tid % G, jt = tid / G;
+    const bool active = jt < T;                   // the workgroup is padded to whole waves
+    const int j0 = active ? jt : 0;
+
+    // XCD-aware block -> (segment, quad group), as mtmfft_quad_kernel
+    const long long id = blockIdx.x;
+    const int xcd = (int)(id & 7);
+    const long long y = id >> 3;
+    const long long nclt = (long long)a.nseg * a.ncl, chunk = (nclt + 7) >> 3;
+    const long long cidx = (long long)xcd * chunk + y / a.S;
+    const int q = (int)(y % a.S);
+    if (cidx >= nclt) return;
+    const int b = (int)(cidx / a.ncl);
+    const int pg = (int)(cidx % a.ncl) * a.S + q;
+    if (pg >= a.npg) return;
+
+    const int c0 = 4 * (pg * G + h);
+    bool has[4];
+    unsigned col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        has[i] = active && c0 + i < a.nchan;
+        col[i] = has[i] ? (unsigned)(a.chan_idx ? a.chan_idx[c0 + i] : c0 + i) : 0u;
+    }
+    const bool full = has[3];
+    const long long start = a.seg_start[b];
+    const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
+    const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
+    const int rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
+    const unsigned rowb = (unsigned)a.ld * 4u;        // bytes per row
+    const float* seg = a.data + start * a.ld;         // wave-uniform; only rows in [rlo, rhi) are dereferenced
+
+    // ---- load the segment once: x[e] = sample n = j + T*e; r = (c0, c1), i = (c2, c3)
+    C2 x[V];
+    if (rhi > rlo) {
+        const bool vec4 = (a.chan_idx == nullptr) && full && ((a.ld & 3) == 0) &&
+                          ((reinterpret_cast<size_t>(a.data) & 15) == 0);
+        if (vec4) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int n = j0 + T * e;
+                const int nc = min(max(n, rlo), rhi - 1);
+                const float4 t = ldg<float4>(seg, (unsigned)nc * rowb + col[0] * 4u);
+                const bool ok = (n == nc);
+                x[e].r = v2f{ok ? t.x : 0.f, ok ? t.y : 0.f};
+                x[e].i = v2f{ok ? t.z : 0.f, ok ? t.w : 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int n = j0 + T * e;
+                const int nc = min(max(n, rlo), rhi - 1);
+                float u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = ldg<float>(seg, (unsigned)nc * rowb + col[i] * 4u);
+                    u[i] = (n == nc && has[i]) ? t : 0.f;
+                }
+                x[e].r = v2f{u[0], u[1]};
+                x[e].i = v2f{u[2], u[3]};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) x[e].r = x[e].i = splat(0.f);
+    }
+
+    // ---- polynomial removal over the nsig samples (float64 sums, branch-free; constant: the reference-order means)
+    if (a.detrend == 0 && a.means) {
+        const float* mp = a.means + (size_t)b * a.nchan + c0;
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = has[i] ? mp[i] : 0.f;
+        const v2f mr = v2f{f[0], f[1]}, mi = v2f{f[2], f[3]};
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const bool in = j0 + T * e < a.nsig;
+            x[e].r -= in ? mr : splat(0.f);
+            x[e].i -= in ? mi : splat(0.f);
+        }
+    } else if (a.detrend >= 0) {
+        const float mid = 0.5f * (float)(a.nsig - 1);
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int n = j0 + T * e;
+            const float m = (active && n < a.nsig) ? 1.f : 0.f;
+            const float u[4] = {m * x[e].r[0], m * x[e].r[1], m * x[e].i[0], m * x[e].i[1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += (double)u[i];
+            if (a.detrend == 1) {
+                const double dn = (double)(m * ((float)n - mid));   // exact: half-integers < 2^23
+                s[4] += dn * x[e].r[0];
+                s[5] += dn * x[e].r[1];
+                s[6] += dn * x[e].i[0];
+                s[7] += dn * x[e].i[1];
+            }
+        }
+        block_sum<C::NTHREADS, G, 8>(s, reinterpret_cast<double*>(lds), tid, h);
+        const double inv = 1.0 / a.nsig;
+        if (a.detrend == 1 && a.nsig > 1) {
+            const double den = 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0));
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int n = j0 + T * e;
+                const double dn = (double)((float)n - mid);
+                const bool in = n < a.nsig;
+                float t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = in ? (float)(s[i] * inv + s[4 + i] * den * dn) : 0.f;
+                x[e].r -= v2f{t[0], t[1]};
+                x[e].i -= v2f{t[2], t[3]};
+            }
+        } else {
+            const v2f mr = v2f{(float)(s[0] * inv), (float)(s[1] * inv)};
+            const v2f mi = v2f{(float)(s[2] * inv), (float)(s[3] * inv)};
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const bool in = j0 + T * e < a.nsig;
+                x[e].r -= in ? mr : splat(0.f);
+                x[e].i -= in ? mi : splat(0.f);
+            }
+        }
+    }
+
+    // accumulators for the taper mean (bins e < V/2 plus the Nyquist bin on j == 0)
+    C2 ma[MEAN ? HV + 1 : 1], mb[(MEAN && CPLX) ? HV + 1 : 1];
+    if (MEAN) {
+#pragma unroll
+        for (int e = 0; e <= HV; ++e) {
+            ma[e].r = ma[e].i = splat(0.f);
+            if (CPLX) mb[e].r = mb[e].i = splat(0.f);
+        }
+    }
+    const int kout = MEAN ? 1 : a.ntaper;
+    const float hs = 0.5f * a.scale;
+    const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
+    constexpr unsigned OSZ = CPLX ? 8u : 4u;   // bytes per output element
+    const bool fast = full && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) &&
+                      ((a.nchan & (CPLX ? 1 : 3)) == 0);
+
+    for (int k = 0; k < a.ntaper; ++k) {
+        const int j = opaque(j0);
+        const float* w = a.tapers + (size_t)k * a.nsig;   // wave-uniform
+        C2 v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const unsigned n = (unsigned)(j + T * e);
+            const float wl = ldg<float>(w, min(n, nsig_m1) * 4u);
+            const float wn = (n <= nsig_m1) ? wl : 0.f;
+            v[e].r = x[e].r * wn;
+            v[e].i = x[e].i * wn;
+        }
+        if (a.demean_taper) {
+            __syncthreads();          // block_sum writes its scratch into the buffer other waves may still be reading
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                s[0] += v[e].r[0];
+                s[1] += v[e].r[1];
+                s[2] += v[e].i[0];
+                s[3] += v[e].i[1];
+            }
+            if (!active) s[0] = s[1] = s[2] = s[3] = 0.0;
+            block_sum<C::NTHREADS, G, 4>(s, reinterpret_cast<double*>(lds), tid, h);
+            const v2f mr = v2f{(float)(s[0] / a.nsig), (float)(s[1] / a.nsig)};
+            const v2f mi = v2f{(float)(s[2] / a.nsig), (float)(s[3] / a.nsig)};
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const bool in = j + T * e < a.nsig;
+                v[e].r -= in ? mr : splat(0.f);
+                v[e].i -= in ? mi : splat(0.f);
+            }
+        }
+
+        // ---- the passes: radix V from the registers, then R1 (R2, R3); the last one leaves v[e] = Z[j + T e]
+        dec_pass<C, V, 1, true, false>(v, lds, j, h, active, a.tw);
+        dec_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, a.tw);
+        if constexpr (C::NPASS >= 3) dec_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, a.tw);
+        if constexpr (C::NPASS >= 4) dec_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, a.tw);
+
+        // ---- separate the real channels: partner bin N - f lives in the upper half
+        __syncthreads();              // the FFT's last reads of the buffer are done everywhere
+        if (active) {
+            const int wb = C::idx(j, h);
+#pragma unroll
+            for (int e = HV; e < V; ++e) lds[wb + e * C::ESTRIDE] = make_float4(v[e].r[0], v[e].r[1], v[e].i[0], v[e].i[1]);
+        }
+        __syncthreads();
+        char* const slab = reinterpret_cast<char*>(a.out) +
+                           ((size_t)b * kout + (MEAN ? 0 : k)) * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
+#pragma unroll
+        for (int e = 0; e <= HV; ++e) {
+            C2 xa, xb;   // xa = X(c0, c1), xb = X(c2, c3)
+            int f;
+            if (e < HV) {
+                if (!active) break;
+                f = j + T * e;
+                const C2 z = v[e];
+                C2 zp = z;
+                if (f != 0) {
+                    const float4 t = lds[C::idx(N - f, h)];
+                    zp.r = v2f{t.x, t.y};
+                    zp.i = v2f{t.z, t.w};
+                }
+                xa.r = (z.r + zp.r) * hs;
+                xa.i = (z.i - zp.i) * hs;
+                xb.r = (z.i + zp.i) * hs;
+                xb.i = (zp.r - z.r) * hs;
+            } else {
+                if (j != 0 || !active) break;
+                f = N / 2;
+                xa.r = v[HV].r * a.scale;
+                xb.r = v[HV].i * a.scale;
+                xa.i = xb.i = splat(0.f);
+            }
+            if (MEAN) {
+                if (CPLX) {
+                    ma[e] = cadd(ma[e], xa);
+                    mb[e] = cadd(mb[e], xb);
+                } else if (OUTK == 0) {
+                    ma[e].r += xa.r * xa.r + xa.i * xa.i;
+                    ma[e].i += xb.r * xb.r + xb.i * xb.i;
+                } else {
+                    ma[e].r += v2f{convert_real_slow(make_float2(xa.r[0], xa.i[0]), a.out_kind),
+                                   convert_real_slow(make_float2(xa.r[1], xa.i[1]), a.out_kind)};
+                    ma[e].i += v2f{convert_real_slow(make_float2(xb.r[0], xb.i[0]), a.out_kind),
+                                   convert_real_slow(make_float2(xb.r[1], xb.i[1]), a.out_kind)};
+                }
+                continue;
+            }
+            if (fast) {
+                const unsigned o = ((unsigned)f * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+                if (CPLX) {
+                    stg<float4>(slab, o, make_float4(xa.r[0], xa.i[0], xa.r[1], xa.i[1]));
+                    stg<float4>(slab, o + 16u, make_float4(xb.r[0], xb.i[0], xb.r[1], xb.i[1]));
+                } else if (OUTK == 0) {
+                    const v2f pa = xa.r * xa.r + xa.i * xa.i, pb2 = xb.r * xb.r + xb.i * xb.i;
+                    stg<float4>(slab, o, make_float4(pa[0], pa[1], pb2[0], pb2[1]));
+                } else {
+                    stg<float4>(slab, o, make_float4(convert_real_slow(make_float2(xa.r[0], xa.i[0]), a.out_kind),
+                                                     convert_real_slow(make_float2(xa.r[1], xa.i[1]), a.out_kind),
+                                                     convert_real_slow(make_float2(xb.r[0], xb.i[0]), a.out_kind),
+                                                     convert_real_slow(make_float2(xb.r[1], xb.i[1]), a.out_kind)));
+                }
+            } else {
+                const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
+                if (fi >= 0) {
+                    const float2 X[4] = {make_float2(xa.r[0], xa.i[0]), make_float2(xa.r[1], xa.i[1]),
+                                         make_float2(xb.r[0], xb.i[0]), make_float2(xb.r[1], xb.i[1])};
+                    const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!has[i]) continue;
+                        if (CPLX) stg<float2>(slab, o + i * OSZ, X[i]);
+                        else stg<float>(slab, o + i * OSZ, convert_real<OUTK>(X[i], a.out_kind));
+                    }
+                }
+            }
+        }
+        // no barrier here: the next taper's first LDS write sits behind one (dec_pass / block_sum)
+    }
+
+    if (MEAN) {
+        char* const slab = reinterpret_cast<char*>(a.out) + (size_t)b * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
+        const float nt = (float)a.ntaper;
+#pragma unroll
+        for (int e = 0; e <= HV; ++e) {
+            if (!active || (e == HV && j0 != 0)) break;
+            const int f = (e < HV) ? j0 + T * e : N / 2;
+            const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
+            if (fi < 0) continue;
+            const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+            if (CPLX) {
+                const float2 X[4] = {make_float2(ma[e].r[0] / nt, ma[e].i[0] / nt), make_float2(ma[e].r[1] / nt, ma[e].i[1] / nt),
+                                     make_float2(mb[e].r[0] / nt, mb[e].i[0] / nt), make_float2(mb[e].r[1] / nt, mb[e].i[1] / nt)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (has[i]) stg<float2>(slab, o + i * OSZ, X[i]);
+            } else if (fast) {
+                stg<float4>(slab, o, make_float4(ma[e].r[0] / nt, ma[e].r[1] / nt, ma[e].i[0] / nt, ma[e].i[1] / nt));
+            } else {
+                const float X[4] = {ma[e].r[0] / nt, ma[e].r[1] / nt, ma[e].i[0] / nt, ma[e].i[1] / nt};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (has[i]) stg<float>(slab, o + i * OSZ, X[i]);
+            }
+        }
+    }
+}
+
+}  // namespace spyfft

@@ -48,8 +48,9 @@ OUT_KINDS = {"pow": 0, "abs": 1, "fourier": 2, "complex": 2, "real": 3, "imag": 
 
 def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
              freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False,
-             force_long=False, reference_mean=False, no_mixed=False, mixed_nostage=False):
-    """`reference_mean`: constant detrending with the means of seq_mean_kernel (spyhip_fft_plan_set_reference_mean)."""
+             force_long=False, reference_mean=False, no_mixed=False, mixed_nostage=False, dec=None):
+    """`reference_mean`: constant detrending with the means of seq_mean_kernel (spyhip_fft_plan_set_reference_mean).
+    `dec`: id of a compile-time schedule of mtmfft_dec_kernel (emu_kernels.cpp)."""
     if reference_mean and detrend == 0:
         d32 = np.ascontiguousarray(data, dtype=np.float32)
         nch = d32.shape[1] if chan_idx is None else len(chan_idx)
@@ -59,11 +60,11 @@ def fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend
         try:
             return fft_exec(d32, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend, demean_taper, freq_idx,
                             output, keeptapers, chan_idx, G, force_generic, blocked, force_long, False, no_mixed,
-                            mixed_nostage)
+                            mixed_nostage, dec)
         finally:
             lib().emu_set_means(None)
     return _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend, demean_taper, freq_idx,
-                     output, keeptapers, chan_idx, G, force_generic, blocked, force_long, no_mixed, mixed_nostage)
+                     output, keeptapers, chan_idx, G, force_generic, blocked, force_long, no_mixed, mixed_nostage, dec)
 
 
 def seq_mean(data, seg_start, seg_lo, seg_hi, nsig, chan_idx=None):
@@ -86,7 +87,7 @@ LAST_MIXED = {}
 
 def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
               freq_idx=None, output="pow", keeptapers=True, chan_idx=None, G=None, force_generic=False, blocked=False,
-              force_long=False, no_mixed=False, mixed_nostage=False):
+              force_long=False, no_mixed=False, mixed_nostage=False, dec=None):
     """Emulated spyhip_fft_exec.  data: (rows, ld) float32; tapers: (K, nsig) float64.
     blocked: channel-blocked hand-over layout (nseg*K, ceil(nchan/4), nfsel, 4) (fourier, keeptapers)."""
     data = np.ascontiguousarray(data, dtype=np.float32)
@@ -113,6 +114,16 @@ def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detren
     if blocked:
         assert kind == 2 and keeptapers
         out = np.full((nseg * kout, (nchan + 3) // 4, nfsel, 4), np.nan, dtype=np.complex64)
+    if dec is not None:
+        # mtmfft_dec_kernel: the compile-time schedule `dec` (emu_kernels.cpp: emu_mtmfft_dec)
+        rc = lib().emu_mtmfft_dec(
+            C.c_int(int(dec)), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
+            _p(ss, C.c_longlong), _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg),
+            C.c_int(nsig), C.c_int(nchan), C.c_int(K), _p(tp, C.c_float), _p(twiddles(nfft), C.c_float),
+            C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), _p(fpos, C.c_int),
+            C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0, f"no emulated decimal kernel {dec}"
+        return out
     pow2 = (nfft & (nfft - 1)) == 0 and 256 <= nfft <= 16384 and not force_generic
     if pow2:
         log2n = int(np.log2(nfft))

@@ -22,6 +22,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/jack_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_pipe_kernel.h"
+#include "../../syncopy_amd/csrc/mtmfft_dec_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_mixed.h"
 #include "../../syncopy_amd/csrc/mtmfft_long.h"
@@ -124,6 +125,29 @@ int run_long(const spyfft::LongArgs& a, int l, int stage, long long items) {
 
 }  // namespace
 
+// mtmfft_dec_kernel (compile-time radix schedules): id = 1000 / 2000 / 5000 (V = 10), 2001 (20 x 10 x 10), 4096 / 512 (V = 8)
+template <class Cf>
+static void run_dec_mode(const MtmArgs& a0, int nseg, int nchan, int outk, int mean) {
+    MtmArgs a = a0;
+    const int G = Cf::G;
+    const int nitem = (nchan + 3) / 4;
+    a.npg = (nitem + G - 1) / G;
+    int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+    a.S = S;
+    a.ncl = (a.npg + S - 1) / S;
+    const long long nclusters = (long long)nseg * a.ncl;
+    const unsigned grid = (unsigned)(((nclusters + 7) / 8) * S * 8);
+    auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(Cf::NTHREADS), Cf::LDS_BYTES, fn); };
+    switch (outk * 2 + mean) {
+        case 0: go([&] { spyfft::mtmfft_dec_kernel<Cf, 0, false>(a); }); break;
+        case 1: go([&] { spyfft::mtmfft_dec_kernel<Cf, 0, true>(a); }); break;
+        case 2: go([&] { spyfft::mtmfft_dec_kernel<Cf, 1, false>(a); }); break;
+        case 3: go([&] { spyfft::mtmfft_dec_kernel<Cf, 1, true>(a); }); break;
+        case 4: go([&] { spyfft::mtmfft_dec_kernel<Cf, 2, false>(a); }); break;
+        default: go([&] { spyfft::mtmfft_dec_kernel<Cf, 2, true>(a); }); break;
+    }
+}
+
 static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD entry points
 static int g_force_4m = 0;  // SPYHIP_CSD_4M: 256 channels on the 4-multiplication kernel
 static int g_m3_wpg = 8;    // waves per workgroup of the 3-multiplication kernel
@@ -209,6 +233,33 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
         case 1202: if (outk != 2 || mean) return -1; run_quad<12, 2, 2, false>(a, grid, -1); break;
         case 1301: run_quad_mode<13, 1>(a, grid, outk, mean, -1); break;
         case 1401: run_pow2_mode<14, 1>(a, grid, outk, mean, -1); break;
+        default: return -1;
+    }
+    return 0;
+}
+
+int emu_mtmfft_dec(int id, const float* data, long long ld, const int* chan_idx,
+                   const long long* seg_start, const long long* seg_lo, const long long* seg_hi, int nseg,
+                   int nsig, int nchan, int ntaper, const float* tapers, const float* tw, float scale,
+                   int detrend, int demean_taper, const int* fpos, int nfsel, int out_kind, int keeptapers,
+                   void* out) {
+    MtmArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
+    a.tapers = tapers; a.tw = reinterpret_cast<const float2*>(tw); a.scale = scale;
+    a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
+    a.out_kind = out_kind; a.out = out;
+    a.means = g_means;
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    const int mean = keeptapers ? 0 : 1;
+    switch (id) {
+        case 1000: run_dec_mode<spyfft::CfgD<10, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;
+        case 2000: run_dec_mode<spyfft::CfgD<10, 10, 10, 2, 1>>(a, nseg, nchan, outk, mean); break;
+        case 2001: run_dec_mode<spyfft::CfgD<20, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;
+        case 5000: run_dec_mode<spyfft::CfgD<10, 10, 10, 5, 1>>(a, nseg, nchan, outk, mean); break;
+        case 512: run_dec_mode<spyfft::CfgD<8, 8, 8, 1, 4>>(a, nseg, nchan, outk, mean); break;
+        case 4096: run_dec_mode<spyfft::CfgD<8, 8, 8, 8, 1>>(a, nseg, nchan, outk, mean); break;
         default: return -1;
     }
     return 0;

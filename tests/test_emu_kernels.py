@@ -11,7 +11,7 @@ from parity import assert_parity, excess
 
 
 def _fft_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=False, G=None, generic=False,
-              freq_idx=None, chan_idx=None, nseg=2, seed=1, long=False, no_mixed=False, nostage=False):
+              freq_idx=None, chan_idx=None, nseg=2, seed=1, long=False, no_mixed=False, nostage=False, dec=None):
     rng = np.random.default_rng(seed)
     data = rng.normal(size=(nsig * nseg + 9, nchan)).astype("f4")
     ss = np.array([4 + i * nsig for i in range(nseg)])
@@ -19,7 +19,7 @@ def _fft_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=Fa
     tapers = O.taper_table(taper, nsig, nfft, topt)
     out = E.fft_exec(data, ss, ss, ss + nsig, nsig, nfft, tapers, O.spec_scale(nsig, nfft), detrend, demean_taper,
                      freq_idx, output, keeptapers, chan_idx=chan_idx, G=G, force_generic=generic, force_long=long,
-                     no_mixed=no_mixed, mixed_nostage=nostage)
+                     no_mixed=no_mixed, mixed_nostage=nostage, dec=dec)
     freqs = np.fft.rfftfreq(nfft, 1e-3)
     foi = freqs if freq_idx is None else freqs[freq_idx]
     for b in range(nseg):
@@ -551,3 +551,25 @@ def test_pipe_kernel_selection_and_padding():
     # frequency selection, channel selection, zero padding (nsig < nfft) on the general store path
     _fft_case(700, 1024, 7, 2, "pow", True, 0, G=102, freq_idx=np.array([0, 3, 511, 512, 17]), chan_idx=np.array([6, 0, 3, 3, 1]))
     _fft_case(1500, 2048, 8, 2, "fourier", True, 1, G=102, freq_idx=np.arange(5, 900, 7))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K1d: compile-time radix schedules (mtmfft_dec_kernel.h)
+@pytest.mark.parametrize("dec,nfft,nchan,K,output,keeptapers,detrend,demean", [
+    (1000, 1000, 8, 2, "fourier", True, 0, False),     # 10 x 10 x 10, two quads per workgroup, fast stores
+    (1000, 1000, 5, 3, "pow", False, 1, True),         # ragged channels, taper mean, linear detrend, demean_taper
+    (2000, 2000, 4, 2, "pow", True, 0, False),         # 10 x 10 x 10 x 2: BASELINE config 1's length
+    (2000, 2000, 3, 2, "fourier", False, -1, False),
+    (2001, 2000, 8, 2, "abs", True, 0, False),         # 20 x 10 x 10
+    (5000, 5000, 4, 1, "fourier", True, 0, False),     # 10 x 10 x 10 x 5
+    (512, 512, 16, 2, "pow", True, 0, False),          # V = 8: 8 x 8 x 8
+    (4096, 4096, 4, 2, "fourier", True, 0, False),     # 8 x 8 x 8 x 8
+])
+def test_dec_kernel_vs_oracle(dec, nfft, nchan, K, output, keeptapers, detrend, demean):
+    _fft_case(nfft, nfft, nchan, K, output, keeptapers, detrend, demean_taper=demean, nseg=2 if nfft <= 1000 else 1, dec=dec)
+
+
+def test_dec_kernel_padding_and_selection():
+    _fft_case(1700, 2000, 6, 2, "pow", True, 0, dec=2000, nseg=1, freq_idx=np.array([0, 1, 999, 1000, 37]),
+              chan_idx=np.array([5, 0, 2, 2]))
+    _fft_case(900, 1000, 4, 2, "fourier", True, 1, dec=1000, nseg=2)

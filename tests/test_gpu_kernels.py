@@ -154,12 +154,16 @@ def test_blocked_handover_layout_is_bit_identical(be, C, N, B, K):
     # what consumers read is the lower triangle (the rest of a diagonal tile is never looked at)
     be.csd_finalize(a_std, 1.0)
     be.csd_finalize(a_blk, 1.0)
-    if C == 256:
-        # 256 channels: the standard layout takes the variant whose diagonal tiles are summed four rows at a time on
-        # 16 x 16 x 4 matrix instructions - same products, different order of the float32 additions
-        assert_parity(a_std.cpu().numpy(), a_blk.cpu().numpy(), what="blocked vs standard layout")
-    else:
-        assert torch.equal(torch.view_as_real(a_std), torch.view_as_real(a_blk))
+    # the standard layout takes the 3-multiplication kernels (every channel count up to 512 since round 3), the blocked
+    # one the 4-multiplication kernels (256 channels: the 3M kernel with gathering copies): same products, different
+    # float32 addition order
+    assert_parity(a_std.cpu().numpy(), a_blk.cpu().numpy(), what="blocked vs standard layout")
+    with be.csd_phase_exact(True):             # the same kernel family on both layouts: bit-identical accumulators
+        a4 = torch.zeros_like(a_std)
+        be.csd_accumulate(s_std, a4)
+        be.csd_finalize(a4, 1.0)
+        if C != 256:
+            assert torch.equal(torch.view_as_real(a4), torch.view_as_real(a_blk))
     assert not be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, False, None, "pow", True).set_blocked(True)
 
 
