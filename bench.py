@@ -556,8 +556,11 @@ def main():
         fft_bytes = sum(nb * (N * C * 4 + K * F * C * 8) for _, _, nb in ev_fft)
         # matrix flops the 3-multiplication kernel really issues: 136 sub-tiles x 3 MFMAs of 16x16x4 per 4 rows
         # (every multiple of 16 up to 256 channels: floor(256 / C) frequencies per workgroup, nb (nb + 1) / 2 sub-tiles each)
-        is3m = (C == 256 or (C <= 512 and not blocked)) and not os.environ.get("SPYHIP_CSD_4M")
+        is3m = (C == 256 or not blocked) and not os.environ.get("SPYHIP_CSD_4M")
         nsub = ((C + 15) // 16) * ((C + 15) // 16 + 1) // 2
+        if C > 512:       # 256-channel blocks: Hermitian product per block, a 256-sub-tile rectangle per pair of blocks
+            blocks = [min(256, C - 256 * i) for i in range((C + 255) // 256)]
+            nsub = sum(((b + 15) // 16) * ((b + 15) // 16 + 1) // 2 for b in blocks) + 256 * (len(blocks) * (len(blocks) - 1) // 2)
         executed = ((rows[0] + 3) // 4) * F * nsub * 3 * 2048.0 if is3m else None
         value = world * T * args.steps / el
         coll = {"executed": bool(dist_on), "backend": "RCCL, library communicator (spyhip_allreduce_csd)" if dist_on else None}

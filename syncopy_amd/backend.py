@@ -398,6 +398,8 @@ def csd_kernel_name(nchan, blocked=False):
         return "spycsd::csd3m_kernel<256, 8, true>"
     if nchan <= 512 and not blocked and not os.environ.get("SPYHIP_CSD_4M"):
         return "spycsd::csd3m_kernel<%d, 8, false>" % ((nchan + 15) // 16 * 16)
+    if nchan > 512 and not blocked and not os.environ.get("SPYHIP_CSD_4M"):
+        return "spycsd::csd3m_kernel<512, 8, false, true> (+ csd3m_kernel<256, 8, false> per 256-channel block)"
     if not blocked and nchan <= 256:
         return "spycsd::csd_accum_kernel<5, 4, %d>" % (1 if nchan == 256 else 2)
     if not blocked and nchan <= 512:

@@ -84,6 +84,22 @@ int launch_tail(spyhip_ctx* ctx, CsdArgs a, long long first, int64_t nrows, int 
     return 0;
 }
 
+// acc[f, i, j] += x[f, i] conj(x[f, j]) (i >= j) for ONE row of spectra: the last row of an odd channel count above 512
+// (the 3M kernels' 16-byte copies would read 8 bytes past the end of the spectra there)
+__global__ void __launch_bounds__(256) csd_rank1_kernel(const float2* __restrict__ x, int F, int C, float2* __restrict__ acc) {
+    const long long per = (long long)C * C, tot = (long long)F * per, stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
+        const long long f = e / per, r = e - f * per;
+        const int i = (int)(r / C), j = (int)(r - (long long)i * C);
+        if (j > i) continue;
+        const float2 a = x[f * C + i], b = x[f * C + j];
+        float2 o = acc[e];
+        o.x += a.x * b.x + a.y * b.y;
+        o.y += a.y * b.x - a.x * b.y;
+        acc[e] = o;
+    }
+}
+
 // packed rows to give the 3M kernel when the workgroups beyond the last full round of the chip go to the re-cut tail
 long long m3_main_rows(spyhip_ctx* ctx, long long nprow, int np) {
     const long long nwg = nprow * np, rem = nwg % ctx->num_cu;
@@ -187,6 +203,41 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
         if (nrows3 == nrows) return 0;
         return csd_accumulate_impl(ctx, reinterpret_cast<const float2*>(spec_d) + (size_t)nrows3 * nfreq * nchan, 1, nfreq, nchan,
                                    acc_d, 0, true);
+    }
+    // more than 512 channels, row-major spectra: the lower triangle in blocks of 256 channels - the Hermitian product of
+    // every block with itself (the 3M instance of its width, reading its channel range out of the wide rows) and the
+    // rectangle of every pair of blocks (csd3m_kernel<512, 8, false, true>: the two ranges side by side in one
+    // 512-element LDS image, the 256 sub-tiles of the off-diagonal quadrant shared by three workgroups per frequency).
+    // No channel count is too wide for LDS any more: a launch never stages more than 512 channels.
+    if (nchan > 512 && !blocked && !force_4m) {
+        const int64_t nrows3 = (nchan & 1) ? nrows - 1 : nrows;
+        const int nb = (nchan + 255) / 256;
+        if (nrows3 > 0) {
+            CsdArgs b = a;
+            b.nrows = nrows3;
+            b.ctot = nchan;
+            for (int I = 0; I < nb; ++I) {
+                const int nI = std::min(256, nchan - 256 * I);
+                b.ch0 = 256 * I; b.n0 = nI; b.ch1 = 0; b.n1 = 0;
+                const int chp = spycsd::m3_padded(nI);
+                const int fpr = chp < 256 ? 256 / chp : 1;
+                int rc = spycsd::m3_launch_padded(chp, ctx->stream, b, (nfreq + fpr - 1) / fpr);
+                if (rc == -100) { spy::set_error("csd_accumulate: no 3M kernel for a block of %d channels", nI); return -1; }
+                if (rc) return rc;
+                for (int J = 0; J < I; ++J) {
+                    b.ch0 = 256 * J; b.n0 = 256; b.ch1 = 256 * I; b.n1 = nI;
+                    if ((rc = spycsd::m3_launch_rect(ctx->stream, b, nfreq))) return rc;
+                }
+            }
+        }
+        if (nrows3 < nrows) {
+            const long long tot = (long long)nfreq * nchan * nchan;
+            hipLaunchKernelGGL(csd_rank1_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 65535)), dim3(256), 0,
+                               ctx->stream, reinterpret_cast<const float2*>(spec_d) + (size_t)nrows3 * nfreq * nchan, nfreq, nchan,
+                               reinterpret_cast<float2*>(acc_d));
+            SPY_HIP_CHECK(hipGetLastError());
+        }
+        return 0;
     }
     // tiles per wave (waves 0-3, waves 4-7): (5,4) packs the 36 tiles of C=256 into one workgroup per frequency
     if (fast || a.ntiles >= 21) {

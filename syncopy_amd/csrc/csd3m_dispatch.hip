@@ -14,7 +14,10 @@ int m3_launch_h(int chp, hipStream_t stream, CsdArgs a, long long nprow);
 
 int m3_launch(int nchan, hipStream_t stream, CsdArgs a, long long nprow) {
     if (nchan == 256) return m3_launch_exact256(stream, a, nprow);
-    const int chp = m3_padded(nchan);
+    return m3_launch_padded(m3_padded(nchan), stream, a, nprow);
+}
+
+int m3_launch_padded(int chp, hipStream_t stream, CsdArgs a, long long nprow) {
     int rc;
     if ((rc = m3_launch_a(chp, stream, a, nprow)) != -100) return rc;
     if ((rc = m3_launch_b(chp, stream, a, nprow)) != -100) return rc;

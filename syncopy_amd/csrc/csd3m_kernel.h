@@ -64,15 +64,19 @@ constexpr int M3_TILES_PER_F = 36;                   // 32 x 32 tiles per freque
 // row): the sub-tiles are listed frequency by frequency, 4 x 4 super-tile by super-tile (so that consecutive ones share
 // channel blocks) and cut into 8 runs of NT; wave g's run may be shorter (CNT[g]).  Hand-made tables below for the
 // counts that matter most.
-template <int CH>
+// RECT (CH = 512 only): the 16 x 16 sub-tiles of the off-diagonal RECTANGLE blocks 16 ... 31 (rows) x 0 ... 15 (columns)
+// of a 512-element image whose two halves hold two different 256-channel ranges of a wider recording: the piece of the
+// lower triangle between two channel blocks (more than 512 channels, csd.hip).
+template <int CH, bool RECT = false>
 struct M3Tab {
     static_assert(CH % 16 == 0 && CH >= 16 && CH <= 512, "channel count of the generated 3M tables");
+    static_assert(!RECT || CH == 512, "the rectangle tables are those of the 512-element image");
     // up to 256 channels: 256-element LDS rows holding 256 / CH frequencies, 16-row chunks, one workgroup per packed
     // row; 272 ... 512 channels: 512-element rows (one frequency), 8-row chunks (the same 32 KiB per buffer), and the
     // sub-tiles of a frequency shared by NP workgroups that each stage the whole rows (<= 14 sub-tiles per wave there:
     // the fragments of up to 16 distinct channel blocks need registers too)
     static constexpr int ROWLEN = CH <= 256 ? 256 : 512, KB = CH <= 256 ? 16 : 8;
-    static constexpr int BPF = CH / 16, FPR = ROWLEN / CH, NSUB = BPF * (BPF + 1) / 2, NTOT = FPR * NSUB;
+    static constexpr int BPF = CH / 16, FPR = ROWLEN / CH, NSUB = RECT ? 256 : BPF * (BPF + 1) / 2, NTOT = FPR * NSUB;
     static constexpr int NP = CH <= 256 ? 1 : (NTOT + 111) / 112;
     static constexpr int NW = 8 * NP;
     static constexpr int NT = (NTOT + NW - 1) / NW;
@@ -89,8 +93,8 @@ struct M3Tab {
         int seq_r[NTOT > 0 ? NTOT : 1] = {}, seq_c[NTOT > 0 ? NTOT : 1] = {};
         int n = 0;
         for (int d = 0; d < FPR; ++d)
-            for (int I = 0; I < (BPF + 3) / 4; ++I)
-                for (int J = 0; J <= I; ++J)
+            for (int I = (RECT ? 4 : 0); I < (BPF + 3) / 4; ++I)
+                for (int J = 0; J <= (RECT ? 3 : I); ++J)
                     for (int r = 4 * I; r < 4 * I + 4 && r < BPF; ++r)
                         for (int c = 4 * J; c < 4 * J + 4 && c <= r; ++c) {
                             seq_r[n] = d * BPF + r;
@@ -255,16 +259,16 @@ struct M3Tab<32> {
     static constexpr int cnt(int) { return NT; }
 };
 
-template <int CH>
+template <class TAB>
 __host__ __device__ constexpr bool m3_is_row(int g, int i) {      // block i of wave g is the row block of some sub-tile
-    for (int t = 0; t < M3Tab<CH>::cnt(g); ++t)
-        if (M3Tab<CH>::ta(g, t) == i) return true;
+    for (int t = 0; t < TAB::cnt(g); ++t)
+        if (TAB::ta(g, t) == i) return true;
     return false;
 }
-template <int CH>
+template <class TAB>
 __host__ __device__ constexpr bool m3_is_col(int g, int i) {
-    for (int t = 0; t < M3Tab<CH>::cnt(g); ++t)
-        if (M3Tab<CH>::tb(g, t) == i) return true;
+    for (int t = 0; t < TAB::cnt(g); ++t)
+        if (TAB::tb(g, t) == i) return true;
     return false;
 }
 
@@ -298,9 +302,12 @@ inline void m3_glds16(const void* gsrc, char* lds_wave_base) {
 // narrower rows (8-byte aligned sources for odd a.C), lanes of the padding channels a.C ... CH - 1 copy nothing (what
 // the padding holds only reaches accumulator rows / columns >= a.C, which are not stored).  For odd a.C the lane of
 // channel a.C - 1 reads 8 bytes past its frequency: the host keeps the very last row of a launch away from this kernel.
-template <int CH, int G, int WPG, bool EXACT>
+// Channel sub-ranges (a.ctot > 0, more than 512 channels): the image's channels are a.n0 channels from a.ch0 of rows
+// that are a.ctot channels wide (Hermitian block of one range) or, RECT, the two halves of the 512-element image are
+// ranges (a.ch0, a.n0) and (a.ch1, a.n1) and the wave's sub-tiles are those of the rectangle range 1 x range 0.
+template <int CH, int G, int WPG, bool EXACT, bool RECT>
 __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int lane) {
-    using TAB = M3Tab<CH>;
+    using TAB = M3Tab<CH, RECT>;
     constexpr int M3_NT = TAB::NT, M3_NB = TAB::NB;
     constexpr int ROWLEN = TAB::ROWLEN, KB = TAB::KB;  // LDS row length (elements), rows per chunk: 32 KiB per buffer
     static_assert(KB * ROWLEN * 8 == M3_CHUNK_BYTES, "chunk geometry");
@@ -310,7 +317,14 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     constexpr int NPW = KB * PPR / WPG;              // pieces a wave stages per chunk
     constexpr int RG = 4 * ROWLEN * 8;               // bytes per group of four rows
     const int l15 = lane & 15, lq = lane >> 4;
-    const int C = EXACT ? CH : a.C;                                 // channels per frequency in memory
+    const int C = EXACT ? CH : (a.ctot ? a.ctot : a.C);             // channels per frequency in memory
+    const int ch0 = (!EXACT && a.ctot) ? a.ch0 : 0, n0 = EXACT ? CH : (a.ctot ? a.n0 : a.C);
+    const int ch1 = RECT ? a.ch1 : 0, n1 = RECT ? a.n1 : 0;
+    // image channel c -> channel of the rows in memory, or -1 (padding)
+    auto gchan = [&](int c) -> int {
+        if (RECT) return c < 256 ? (c < n0 ? ch0 + c : -1) : (c - 256 < n1 ? ch1 + c - 256 : -1);
+        return c < n0 ? ch0 + c : -1;
+    };
     const size_t rowstride = (size_t)a.F * C;                       // float2 elements between rows
     const size_t rowbytes = rowstride * 8;
     // source of this lane's 16 bytes of (row 0, piece p): row-major spectra (r, f, c): 16 consecutive bytes of the
@@ -327,7 +341,8 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 #pragma unroll
     for (int p = 0; p < PPR; ++p) {
         const int e0 = p * 128 + 2 * lane, d = e0 / CH, c = e0 % CH;
-        poff[p] = (!EXACT && c < C && f * FPR + d < a.F) ? ((long long)(f * FPR + d) * C + c) * 8 : -1;
+        const int gc = EXACT ? -1 : gchan(c);
+        poff[p] = (gc >= 0 && f * FPR + d < a.F) ? ((long long)(f * FPR + d) * C + gc) * 8 : -1;
     }
     const char* const sbase = reinterpret_cast<const char*>(a.spec);
     const long long nrows = a.nrows;
@@ -402,8 +417,8 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
         for (int st = 0; st < KB / 4; ++st) {
             m3_for<0, M3_NB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                sm[i] = m3_is_row<CH>(G, i) ? x[i].x + x[i].y : 0.f;
-                df[i] = m3_is_col<CH>(G, i) ? x[i].x - x[i].y : 0.f;
+                sm[i] = m3_is_row<TAB>(G, i) ? x[i].x + x[i].y : 0.f;
+                df[i] = m3_is_col<TAB>(G, i) ? x[i].x - x[i].y : 0.f;
             });
             float re[M3_NB], im[M3_NB];
             m3_for<0, M3_NB>([&](auto ic) { constexpr int i = decltype(ic)::value; re[i] = x[i].x; im[i] = x[i].y; });
@@ -452,14 +467,16 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
                     pb[(size_t)r * CH] =
                         make_float2(old[r].x + (p1[t][r] + p2[t][r]), old[r].y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
             } else {
-                const int row0 = (bi % BPF) * 16 + 4 * lq, colj = (bj % BPF) * 16 + l15;
-                float2* const pb = a.acc + (size_t)fr * C * C + (size_t)row0 * C + colj;
+                const int row0 = (bi % BPF) * 16 + 4 * lq, gcol = gchan((bj % BPF) * 16 + l15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < C && colj < C) {
-                        const float2 old = pb[(size_t)r * C];
-                        pb[(size_t)r * C] = make_float2(old.x + (p1[t][r] + p2[t][r]), old.y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = gchan(row0 + r);
+                    if (grow >= 0 && gcol >= 0) {
+                        float2* const pe = a.acc + (size_t)fr * C * C + (size_t)grow * C + gcol;
+                        const float2 old = *pe;
+                        *pe = make_float2(old.x + (p1[t][r] + p2[t][r]), old.y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
                     }
+                }
             }
         }
     });
@@ -468,14 +485,14 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 // WPG = 8: one workgroup of 8 waves per frequency (block b -> frequency item_base / 36 + b);
 // WPG = 4: two workgroups of 4 waves per frequency (block b -> frequency ... + b / 2, sub-tile sets of half b % 2).
 // run-time wave index -> compile-time sub-tile set
-template <int CH, int WPG, bool EXACT, int G0, int G1>
+template <int CH, int WPG, bool EXACT, bool RECT, int G0, int G1>
 __device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, int f, int lane) {
     if constexpr (G0 + 1 == G1) {
-        m3_wave<CH, G0, WPG, EXACT>(a, Xb, f, lane);
+        m3_wave<CH, G0, WPG, EXACT, RECT>(a, Xb, f, lane);
     } else {
         constexpr int GM = (G0 + G1) / 2;
-        if (g < GM) m3_dispatch<CH, WPG, EXACT, G0, GM>(g, a, Xb, f, lane);
-        else m3_dispatch<CH, WPG, EXACT, GM, G1>(g, a, Xb, f, lane);
+        if (g < GM) m3_dispatch<CH, WPG, EXACT, RECT, G0, GM>(g, a, Xb, f, lane);
+        else m3_dispatch<CH, WPG, EXACT, RECT, GM, G1>(g, a, Xb, f, lane);
     }
 }
 
@@ -484,10 +501,11 @@ __device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, i
 // (slot / NP) * 8 + XCD, part slot % NP - all parts of a frequency run on ONE XCD, one after the other in its
 // dispatch order, so the rows they all stage are fetched from HBM once and found in that XCD's L2 afterwards.
 // WPG = 4 (256 channels only): two workgroups of 4 waves per frequency, one wave per SIMD (the measured dead end).
-template <int CH, int WPG, bool EXACT = true>
+template <int CH, int WPG, bool EXACT = true, bool RECT = false>
 __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdArgs a) {
     static_assert(CH == 256 || WPG == 8, "the two-workgroup split exists for 256 channels only");
-    constexpr int NP = M3Tab<CH>::NP;
+    static_assert(!RECT || !EXACT, "rectangles come with channel sub-ranges");
+    constexpr int NP = M3Tab<CH, RECT>::NP;
     SPY_DYN_SMEM(char, Xb);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -513,7 +531,7 @@ __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdAr
     }
     f += (int)(a.item_base / M3_TILES_PER_F);
     if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
-    m3_dispatch<CH, WPG, EXACT, 0, (WPG == 4 ? 8 : M3Tab<CH>::NW)>(g, a, Xb, f, lane);
+    m3_dispatch<CH, WPG, EXACT, RECT, 0, (WPG == 4 ? 8 : M3Tab<CH, RECT>::NW)>(g, a, Xb, f, lane);
 }
 
 }  // namespace spycsd

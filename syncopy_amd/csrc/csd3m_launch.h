@@ -25,6 +25,14 @@ inline int m3_parts(int nchan) {
 // a.nrows (the lane of the last channel reads 8 bytes beyond its frequency).
 int m3_launch(int nchan, hipStream_t stream, CsdArgs a, long long nprow);
 
+// the instance csd3m_kernel<chp, 8, false> (chp a multiple of 16 up to 512) whatever the channel count: channel
+// sub-ranges of wider rows (a.ctot, a.ch0, a.n0)
+int m3_launch_padded(int chp, hipStream_t stream, CsdArgs a, long long nprow);
+
+// the rectangle of the lower triangle between two channel blocks (a.ch1, a.n1 <= 256: rows) x (a.ch0, a.n0 <= 256:
+// columns) of rows that are a.ctot channels wide, all `nfreq` frequencies
+int m3_launch_rect(hipStream_t stream, CsdArgs a, long long nfreq);
+
 // channel counts served: 1 ... 512 (instances for every multiple of 16, csd3m_{a..h}.hip + csd3m_x.hip)
 bool m3_available(int nchan);
 

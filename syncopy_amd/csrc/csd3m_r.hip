@@ -1,0 +1,7 @@
+// 3-multiplication cross-spectral kernel for the rectangle between two 256-channel blocks of a recording with more than
+// 512 channels (csd3m_kernel<512, 8, false, true>; see csd3m_launch.h)
+#include "csd3m_launch_impl.h"
+
+namespace spycsd {
+int m3_launch_rect(hipStream_t stream, CsdArgs a, long long nfreq) { return m3_launch_one<512, false, true>(stream, a, nfreq); }
+}  // namespace spycsd

@@ -30,6 +30,9 @@ struct CsdArgs {
     int blocked;                // spec = (nrows, ceil(C/4), F, 4): channel quads contiguous in frequency
     int fast_per;               // FAST path: items per workgroup = (frequencies per 256-element LDS row) * ntiles
     int fast_nwgf;              // FAST == 3: workgroups per frequency (each owns <= fast_per of its ntiles tiles)
+    // channel sub-ranges of the 3-multiplication kernel (more than 512 channels; 0 = the whole rows): rows are `ctot`
+    // channels wide, the launch works on n0 channels from ch0 (and, for a rectangle, n1 channels from ch1)
+    int ctot, ch0, n0, ch1, n1;
 };
 
 }  // namespace spycsd

@@ -573,3 +573,20 @@ def test_dec_kernel_padding_and_selection():
     _fft_case(1700, 2000, 6, 2, "pow", True, 0, dec=2000, nseg=1, freq_idx=np.array([0, 1, 999, 1000, 37]),
               chan_idx=np.array([5, 0, 2, 2]))
     _fft_case(900, 1000, 4, 2, "fourier", True, 1, dec=1000, nseg=2)
+
+
+def test_csd_3m_more_than_512_channels():
+    """More than 512 channels (csd.hip): Hermitian 3M products of the 256-channel blocks + the rectangle kernel
+    (csd3m_kernel<512, 8, false, true>: two channel ranges side by side in one LDS image) for every pair of blocks; an odd
+    count sends its last row through the rank-1 update.  520 channels = blocks of 256, 256, 8."""
+    C, F, R = 521, 1, 6
+    rng = np.random.default_rng(3)
+    spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)
+    acc = np.zeros((F, C, C), np.complex64)
+    assert E.csd_accumulate(spec[:2], acc) == 10 and E.csd_accumulate(spec[2:], acc) == 10
+    ref = np.einsum("rfi,rfj->fij", spec.astype(np.complex128), spec.conj().astype(np.complex128))
+    ii, jj = np.tril_indices(C)
+    assert_parity(acc[:, ii, jj], ref[:, ii, jj].astype(np.complex64), what="wide csd, lower triangle")
+    iu, ju = np.triu_indices(C, 1)
+    off = iu // 16 != ju // 16                           # (a diagonal 16 x 16 tile is stored whole, as for <= 512)
+    assert not acc[:, iu[off], ju[off]].any()            # nothing else lands above the diagonal

@@ -243,7 +243,10 @@ def test_csd_tail_row_split(be):
                                    (272, 40, 9), (288, 9, 20), (304, 17, 9), (336, 12, 9), (352, 9, 9), (368, 8, 10),
                                    (400, 9, 9), (416, 7, 9), (432, 10, 9), (448, 10, 9), (464, 5, 12), (480, 9, 12), (496, 6, 9),
                                    (384, 7, 40), (512, 65, 20), (300, 130, 10),     # wide variant (+ its tail)
-                                   (255, 270, 9), (63, 33, 14), (127, 3, 40), (301, 5, 12)])   # odd channel counts
+                                   (255, 270, 9), (63, 33, 14), (127, 3, 40), (301, 5, 12),    # odd channel counts
+                                   # more than 512 channels: 3M products per 256-channel block + rectangle kernel
+                                   (640, 5, 9), (768, 3, 10), (1024, 2, 9), (700, 4, 9), (513, 3, 9), (1025, 2, 5),
+                                   (528, 70, 8)])
 def test_csd_accumulate_vs_oracle(be, C, F, R):
     rng = np.random.default_rng(C + F)
     spec = (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C))).astype(np.complex64)
