@@ -208,8 +208,10 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
     // every block with itself (the 3M instance of its width, reading its channel range out of the wide rows) and the
     // rectangle of every pair of blocks (csd3m_kernel<512, 8, false, true>: the two ranges side by side in one
     // 512-element LDS image, the 256 sub-tiles of the off-diagonal quadrant shared by three workgroups per frequency).
-    // No channel count is too wide for LDS any more: a launch never stages more than 512 channels.
-    if (nchan > 512 && !blocked && !force_4m) {
+    // No channel count is too wide for LDS any more: a launch never stages more than 512 channels.  Phase-exact
+    // accumulation (force_4m) takes the same walk with the 4-multiplication instances of the tiled kernel (the 32 x 32-tile
+    // kernels below cannot stage rows this wide).
+    if (nchan > 512 && !blocked) {
         const int64_t nrows3 = (nchan & 1) ? nrows - 1 : nrows;
         const int nb = (nchan + 255) / 256;
         if (nrows3 > 0) {
@@ -219,14 +221,16 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
             for (int I = 0; I < nb; ++I) {
                 const int nI = std::min(256, nchan - 256 * I);
                 b.ch0 = 256 * I; b.n0 = nI; b.ch1 = 0; b.n1 = 0;
-                const int chp = spycsd::m3_padded(nI);
+                const int chp = force_4m ? 256 : spycsd::m3_padded(nI);
                 const int fpr = chp < 256 ? 256 / chp : 1;
-                int rc = spycsd::m3_launch_padded(chp, ctx->stream, b, (nfreq + fpr - 1) / fpr);
+                int rc = force_4m ? spycsd::m4_launch_block(ctx->stream, b, nfreq)
+                                  : spycsd::m3_launch_padded(chp, ctx->stream, b, (nfreq + fpr - 1) / fpr);
                 if (rc == -100) { spy::set_error("csd_accumulate: no 3M kernel for a block of %d channels", nI); return -1; }
                 if (rc) return rc;
                 for (int J = 0; J < I; ++J) {
                     b.ch0 = 256 * J; b.n0 = 256; b.ch1 = 256 * I; b.n1 = nI;
-                    if ((rc = spycsd::m3_launch_rect(ctx->stream, b, nfreq))) return rc;
+                    if ((rc = force_4m ? spycsd::m4_launch_rect(ctx->stream, b, nfreq) : spycsd::m3_launch_rect(ctx->stream, b, nfreq)))
+                        return rc;
                 }
             }
         }

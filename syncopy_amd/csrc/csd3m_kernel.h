@@ -305,7 +305,10 @@ inline void m3_glds16(const void* gsrc, char* lds_wave_base) {
 // Channel sub-ranges (a.ctot > 0, more than 512 channels): the image's channels are a.n0 channels from a.ch0 of rows
 // that are a.ctot channels wide (Hermitian block of one range) or, RECT, the two halves of the 512-element image are
 // ranges (a.ch0, a.n0) and (a.ch1, a.n1) and the wave's sub-tiles are those of the rectangle range 1 x range 0.
-template <int CH, int G, int WPG, bool EXACT, bool RECT>
+// M4: the 4-multiplication product in the same tiling (p3 accumulates Im = Xi Yr - Xr Yi directly instead of the third
+// product of the 3M scheme, whose imaginary part is a difference of large terms): spyhip_csd_set_phase_exact on more
+// than 512 channels, where the 32 x 32-tile kernels of csd_kernel.h do not fit a row into LDS.
+template <int CH, int G, int WPG, bool EXACT, bool RECT, bool M4>
 __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int lane) {
     using TAB = M3Tab<CH, RECT>;
     constexpr int M3_NT = TAB::NT, M3_NB = TAB::NB;
@@ -417,8 +420,12 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
         for (int st = 0; st < KB / 4; ++st) {
             m3_for<0, M3_NB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                sm[i] = m3_is_row<TAB>(G, i) ? x[i].x + x[i].y : 0.f;
-                df[i] = m3_is_col<TAB>(G, i) ? x[i].x - x[i].y : 0.f;
+                if constexpr (M4) {
+                    df[i] = m3_is_col<TAB>(G, i) ? -x[i].y : 0.f;            // (sm is not used)
+                } else {
+                    sm[i] = m3_is_row<TAB>(G, i) ? x[i].x + x[i].y : 0.f;
+                    df[i] = m3_is_col<TAB>(G, i) ? x[i].x - x[i].y : 0.f;
+                }
             });
             float re[M3_NB], im[M3_NB];
             m3_for<0, M3_NB>([&](auto ic) { constexpr int i = decltype(ic)::value; re[i] = x[i].x; im[i] = x[i].y; });
@@ -428,8 +435,14 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
             // overwrite x) only after the P1 / P2 products, which come last
             m3_for<0, M3_NT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                if constexpr (t < TAB::cnt(G))
-                    p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[TAB::ta(G, t)], df[TAB::tb(G, t)], p3[t], 0, 0, 0);
+                if constexpr (t < TAB::cnt(G)) {
+                    if constexpr (M4) {
+                        p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(im[TAB::ta(G, t)], re[TAB::tb(G, t)], p3[t], 0, 0, 0);
+                        p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(re[TAB::ta(G, t)], df[TAB::tb(G, t)], p3[t], 0, 0, 0);
+                    } else {
+                        p3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[TAB::ta(G, t)], df[TAB::tb(G, t)], p3[t], 0, 0, 0);
+                    }
+                }
             });
             m3_for<0, M3_NT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
@@ -465,7 +478,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     pb[(size_t)r * CH] =
-                        make_float2(old[r].x + (p1[t][r] + p2[t][r]), old[r].y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+                        make_float2(old[r].x + (p1[t][r] + p2[t][r]), old[r].y + (M4 ? p3[t][r] : (p3[t][r] - p1[t][r]) + p2[t][r]));
             } else {
                 const int row0 = (bi % BPF) * 16 + 4 * lq, gcol = gchan((bj % BPF) * 16 + l15);
 #pragma unroll
@@ -474,7 +487,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
                     if (grow >= 0 && gcol >= 0) {
                         float2* const pe = a.acc + (size_t)fr * C * C + (size_t)grow * C + gcol;
                         const float2 old = *pe;
-                        *pe = make_float2(old.x + (p1[t][r] + p2[t][r]), old.y + ((p3[t][r] - p1[t][r]) + p2[t][r]));
+                        *pe = make_float2(old.x + (p1[t][r] + p2[t][r]), old.y + (M4 ? p3[t][r] : (p3[t][r] - p1[t][r]) + p2[t][r]));
                     }
                 }
             }
@@ -485,14 +498,14 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
 // WPG = 8: one workgroup of 8 waves per frequency (block b -> frequency item_base / 36 + b);
 // WPG = 4: two workgroups of 4 waves per frequency (block b -> frequency ... + b / 2, sub-tile sets of half b % 2).
 // run-time wave index -> compile-time sub-tile set
-template <int CH, int WPG, bool EXACT, bool RECT, int G0, int G1>
+template <int CH, int WPG, bool EXACT, bool RECT, bool M4, int G0, int G1>
 __device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, int f, int lane) {
     if constexpr (G0 + 1 == G1) {
-        m3_wave<CH, G0, WPG, EXACT, RECT>(a, Xb, f, lane);
+        m3_wave<CH, G0, WPG, EXACT, RECT, M4>(a, Xb, f, lane);
     } else {
         constexpr int GM = (G0 + G1) / 2;
-        if (g < GM) m3_dispatch<CH, WPG, EXACT, RECT, G0, GM>(g, a, Xb, f, lane);
-        else m3_dispatch<CH, WPG, EXACT, RECT, GM, G1>(g, a, Xb, f, lane);
+        if (g < GM) m3_dispatch<CH, WPG, EXACT, RECT, M4, G0, GM>(g, a, Xb, f, lane);
+        else m3_dispatch<CH, WPG, EXACT, RECT, M4, GM, G1>(g, a, Xb, f, lane);
     }
 }
 
@@ -501,7 +514,7 @@ __device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, i
 // (slot / NP) * 8 + XCD, part slot % NP - all parts of a frequency run on ONE XCD, one after the other in its
 // dispatch order, so the rows they all stage are fetched from HBM once and found in that XCD's L2 afterwards.
 // WPG = 4 (256 channels only): two workgroups of 4 waves per frequency, one wave per SIMD (the measured dead end).
-template <int CH, int WPG, bool EXACT = true, bool RECT = false>
+template <int CH, int WPG, bool EXACT = true, bool RECT = false, bool M4 = false>
 __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdArgs a) {
     static_assert(CH == 256 || WPG == 8, "the two-workgroup split exists for 256 channels only");
     static_assert(!RECT || !EXACT, "rectangles come with channel sub-ranges");
@@ -531,7 +544,7 @@ __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdAr
     }
     f += (int)(a.item_base / M3_TILES_PER_F);
     if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
-    m3_dispatch<CH, WPG, EXACT, RECT, 0, (WPG == 4 ? 8 : M3Tab<CH, RECT>::NW)>(g, a, Xb, f, lane);
+    m3_dispatch<CH, WPG, EXACT, RECT, M4, 0, (WPG == 4 ? 8 : M3Tab<CH, RECT>::NW)>(g, a, Xb, f, lane);
 }
 
 }  // namespace spycsd

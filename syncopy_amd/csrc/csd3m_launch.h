@@ -32,6 +32,10 @@ int m3_launch_padded(int chp, hipStream_t stream, CsdArgs a, long long nprow);
 // the rectangle of the lower triangle between two channel blocks (a.ch1, a.n1 <= 256: rows) x (a.ch0, a.n0 <= 256:
 // columns) of rows that are a.ctot channels wide, all `nfreq` frequencies
 int m3_launch_rect(hipStream_t stream, CsdArgs a, long long nfreq);
+// the same tiling with the 4-multiplication product (csd3m_kernel<..., M4 = true>): rectangle, and one Hermitian block of
+// up to 256 channels (padded inside the 256-channel image)
+int m4_launch_rect(hipStream_t stream, CsdArgs a, long long nfreq);
+int m4_launch_block(hipStream_t stream, CsdArgs a, long long nfreq);
 
 // channel counts served: 1 ... 512 (instances for every multiple of 16, csd3m_{a..h}.hip + csd3m_x.hip)
 bool m3_available(int nchan);

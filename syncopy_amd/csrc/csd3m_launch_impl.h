@@ -6,13 +6,13 @@
 
 namespace spycsd {
 
-template <int CH, bool EXACT = true, bool RECT = false>
+template <int CH, bool EXACT = true, bool RECT = false, bool M4 = false>
 int m3_launch_one(hipStream_t stream, CsdArgs a, long long nprow) {
     if (nprow <= 0) return 0;
     constexpr int NP = M3Tab<CH, RECT>::NP;            // workgroups per packed row (> 1 above 256 channels)
     a.item_base = 0;
     a.item_end = nprow * M3_TILES_PER_F;
-    auto kern = csd3m_kernel<CH, 8, EXACT, RECT>;
+    auto kern = csd3m_kernel<CH, 8, EXACT, RECT, M4>;
     // (the attribute is per device and the call is cheap: no process-wide "already set" flag)
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       M3_LDS_BYTES));

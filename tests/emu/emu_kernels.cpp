@@ -494,7 +494,7 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
             emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8>(a); });
         return 8;
     }
-    if (force_tpw == 0 && C > 512 && !g_blocked && !g_force_4m) {
+    if (force_tpw == 0 && C > 512 && !g_blocked) {
         // as csd.hip: blocks of 256 channels - Hermitian product per block (instances 16 / 256 here), rectangle per pair
         const long long nrows3 = (C & 1) ? nrows - 1 : nrows;
         const int nb = (C + 255) / 256;
@@ -504,18 +504,23 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
         for (int I = 0; I < nb && nrows3 > 0; ++I) {
             const int nI = std::min(256, C - 256 * I);
             b.ch0 = 256 * I; b.n0 = nI; b.ch1 = 0; b.n1 = 0;
-            const int chp = (nI + 15) & ~15, fpr = chp < 256 ? 256 / chp : 1;
+            const int chp = g_force_4m ? 256 : (nI + 15) & ~15, fpr = chp < 256 ? 256 / chp : 1;
             const long long nprow = (F + fpr - 1) / fpr;
             b.item_base = 0; b.item_end = nprow * spycsd::M3_TILES_PER_F;
-            if (chp == 256) emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8, false>(b); });
+            if (g_force_4m) emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8, false, false, true>(b); });
+            else if (chp == 256) emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8, false>(b); });
             else if (chp == 16) emu::launch(dim3((unsigned)nprow), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<16, 8, false>(b); });
             else return -1;
             for (int J = 0; J < I; ++J) {
                 b.ch0 = 256 * J; b.n0 = 256; b.ch1 = 256 * I; b.n1 = nI;
                 b.item_base = 0; b.item_end = (long long)F * spycsd::M3_TILES_PER_F;
                 constexpr int NPR = spycsd::M3Tab<512, true>::NP;
-                emu::launch(dim3((unsigned)(((F + 7) / 8) * 8 * NPR)), dim3(512), spycsd::M3_LDS_BYTES,
-                            [&] { spycsd::csd3m_kernel<512, 8, false, true>(b); });
+                if (g_force_4m)
+                    emu::launch(dim3((unsigned)(((F + 7) / 8) * 8 * NPR)), dim3(512), spycsd::M3_LDS_BYTES,
+                                [&] { spycsd::csd3m_kernel<512, 8, false, true, true>(b); });
+                else
+                    emu::launch(dim3((unsigned)(((F + 7) / 8) * 8 * NPR)), dim3(512), spycsd::M3_LDS_BYTES,
+                                [&] { spycsd::csd3m_kernel<512, 8, false, true>(b); });
             }
         }
         if (nrows3 < nrows) {                    // csd_rank1_kernel of csd.hip, on the host
@@ -529,7 +534,7 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
                         o.y += u.y * v.x - u.x * v.y;
                     }
         }
-        return 10;
+        return g_force_4m ? 11 : 10;
     }
     // (the emulator instantiates a sample of the 3M channel counts; the others take the 4-multiplication kernels here)
     const int chp_emu = (C + 15) & ~15;

@@ -590,3 +590,13 @@ def test_csd_3m_more_than_512_channels():
     iu, ju = np.triu_indices(C, 1)
     off = iu // 16 != ju // 16                           # (a diagonal 16 x 16 tile is stored whole, as for <= 512)
     assert not acc[:, iu[off], ju[off]].any()            # nothing else lands above the diagonal
+    # phase-exact accumulation: the same walk with the 4-multiplication instances (csd3m_kernel<..., M4 = true>)
+    acc4 = np.zeros((F, C, C), np.complex64)
+    assert E.csd_accumulate(spec, acc4, force_4m=True) == 11
+    assert_parity(acc4[:, ii, jj], ref[:, ii, jj].astype(np.complex64), what="wide csd, 4 multiplications")
+    # its imaginary part is a sum of products, not a difference of the three 3M products: error ~ eps * |Im| terms only
+    coherent = np.repeat(spec[:, :, :1], C, axis=2) * (1 + 1e-3 * rng.normal(size=(1, 1, C))).astype(np.float32)
+    acc4[:] = 0
+    E.csd_accumulate(coherent.astype(np.complex64), acc4, force_4m=True)
+    scale = np.abs(acc4[0, 0, 0])
+    assert np.abs(acc4[:, ii, jj].imag).max() <= 1e-6 * scale       # real multiples of one signal: Im = 0 up to rounding

@@ -270,6 +270,29 @@ def test_csd_accumulate_vs_oracle(be, C, F, R):
             assert_parity(coh, cref, what=f"coh {output}")
 
 
+@pytest.mark.parametrize("C,F,R", [(640, 3, 200), (513, 2, 101), (1030, 1, 64)])
+def test_csd_phase_exact_more_than_512_channels(be, C, F, R):
+    """spyhip_csd_set_phase_exact above 512 channels: the tiled kernel's 4-multiplication instances
+    (csd3m_kernel<..., M4 = true>).  Channels that are real multiples of one signal plus a little noise: the imaginary
+    part of every cross spectrum is tiny against its modulus, which the 3M product cannot resolve and this one does."""
+    rng = np.random.default_rng(C)
+    common = rng.normal(size=(R, F, 1)) + 1j * rng.normal(size=(R, F, 1))
+    spec = (common * (1 + 0.1 * rng.normal(size=(1, 1, C))) + 1e-3 * (rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C)))).astype(np.complex64)
+    ref = np.einsum("rfi,rfj->fij", spec.astype(np.complex128), spec.conj().astype(np.complex128))
+    s = torch.from_numpy(spec).cuda()
+    ii, jj = np.tril_indices(C, -1)
+    err = {}
+    for exact in (False, True):
+        acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+        with be.csd_phase_exact(exact):
+            be.csd_accumulate(s[: R // 2].contiguous(), acc)
+            be.csd_accumulate(s[R // 2:].contiguous(), acc)
+        got = acc.cpu().numpy()
+        assert_parity(got[:, ii, jj], ref[:, ii, jj].astype(np.complex64), what=f"wide csd (phase exact {exact})")
+        err[exact] = np.abs(got[:, ii, jj].imag - ref[:, ii, jj].imag).max() / np.abs(ref[:, ii, jj]).max()
+    assert err[True] < 2e-7 and err[True] < 0.5 * err[False], err
+
+
 @pytest.mark.parametrize("C,F,T,K", [(5, 33, 6, 3), (40, 17, 9, 1), (70, 9, 12, 7), (256, 3, 40, 7)])
 def test_ppc_vs_oracle(be, C, F, T, K):
     """K7 (phasor sums + closed form) against the oracle's walk over all trial pairs; both entry points; accumulation
