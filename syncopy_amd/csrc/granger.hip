@@ -67,6 +67,16 @@ int check_info(spyhip_ctx* ctx, int* info_d, int batch, const char* what) {
 // `src`: invert src into M (out of place) instead of M in place
 int invert(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d, bool blocked = false, const cd* src = nullptr) {
     static const bool old_inverse = std::getenv("SPYHIP_INVERSE_OLD") != nullptr;
+    // 64-row blocks (half the sweeps over the matrices) where they pad no more than the 32-row blocks would
+    static const bool no_inv64 = std::getenv("SPYHIP_INVERSE_32") != nullptr;
+    if (blocked && n >= 2 * spywil::ZW && (n + 63) / 64 * 64 == (n + 31) / 32 * 32 && !old_inverse && !no_inv64) {
+        const size_t lds = (size_t)2 * spywil::ZW * (spywil::ZW + 1) * sizeof(cd);
+        SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::zinv64_mfma_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(spywil::zinv64_mfma_kernel, dim3(batch), dim3(spywil::ZT), lds, ctx->stream, M, src, n, info_d);
+        SPY_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (blocked && n >= 2 * spywil::ZM && !old_inverse) {      // matrix-core block Gauss-Jordan
         const int npad = ((n + spywil::ZM - 1) / spywil::ZM) * spywil::ZM;
         const size_t lds = ((size_t)spywil::ZM * (npad + 1) + spywil::ZM * (spywil::ZM + 1)) * sizeof(cd);
@@ -172,7 +182,7 @@ int launch_plus4(spyhip_ctx* ctx, const cd* g, int F, long long nent, const cd* 
     // (per device, cheap: set at every launch)
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)C::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3((unsigned)((nent + 3) / 4)), dim3(C::T), C::LDS_BYTES, ctx->stream, g, F, nent, tw, gp, g0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)spywil::plus4_grid(nent)), dim3(C::T), C::LDS_BYTES, ctx->stream, g, F, nent, tw, gp, g0);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }

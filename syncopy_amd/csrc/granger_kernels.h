@@ -596,6 +596,195 @@ __global__ void __launch_bounds__(ZT) zinv_mfma_kernel(cd* M, const cd* src, int
     if (bad) info[blockIdx.x] = 2;
 }
 
+// ---- the same block Gauss-Jordan with blocks of ZW = 64 rows: FOUR sweeps over a 256 x 256 matrix instead of eight
+// (the 32-row kernel moves 8 x 2 MB per matrix at ~2.8 TB/s: it is bound by those sweeps, not by its 8 n^3 flops).
+// A 64-row R panel does not fit LDS next to D, so a block step walks the matrix in column QUARTERS of 64:
+//   for every quarter q (the quarter of block k itself LAST):
+//       R_q = D A_k,q on the matrix cores -> LDS (q = k: R_q = D, no copy)
+//       A_i,q <- (q = k ? 0 : A_i,q) - A_i,k R_q   for the row tiles i outside block k   (A_i,k re-read per quarter:
+//                                                  64 KB from L2; nobody writes column block k before its own quarter)
+//       A_k,q <- R_q
+// LDS: D and R_q, 64 x 65 complex128 each (133 KB).  Pivots inside the diagonal block only, in order; info = 2 flags a
+// (relatively) tiny pivot exactly as the other blocked kernels do.
+constexpr int ZW = 64;
+__global__ void __launch_bounds__(ZT) zinv64_mfma_kernel(cd* M, const cd* src, int n, int* info) {
+    SPY_DYN_SMEM(char, raw);
+    constexpr int LDD = ZW + 1;
+    cd* const D = reinterpret_cast<cd*>(raw);        // ZW x LDD
+    cd* const Rq = D + (size_t)ZW * LDD;             // ZW x LDD
+    __shared__ double s_scale;
+    const int npad = ((n + ZW - 1) / ZW) * ZW, nq = npad / ZW, ntile = npad / 16;
+    cd* A = M + (size_t)blockIdx.x * n * n;
+    const cd* S0 = src ? src + (size_t)blockIdx.x * n * n : A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int dr = tid >> 3, dc0 = tid & 7;          // diagonal block: row dr, columns dc0 + 8 q
+    int bad = 0;
+    for (int kb = 0; kb < nq; ++kb) {
+        const int k0 = kb * ZW;
+        const cd* S = kb == 0 ? S0 : A;              // where this sweep reads the matrix
+        // (a) D = A_kk (identity padding beyond n), inverted by in-block Gauss-Jordan.  A thread OWNS row dr, columns
+        // dc0 + 8 q in registers for all 64 pivots; a pivot step only publishes pivot row and pivot column in LDS
+        // (two buffers in turn: one barrier per pivot) - 10 LDS reads per thread and pivot instead of 18 + 8 writes
+        cd own[8];
+        double m2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = k0 + dr, j = k0 + dc0 + 8 * q;
+            own[q] = (i < n && j < n) ? S[(size_t)i * n + j] : make_double2(i == j ? 1.0 : 0.0, 0.0);
+            m2 = fmax(m2, cabs2(own[q]));
+        }
+        {                                            // largest |entry|^2 of the block (pivot threshold)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off));
+            double* const red = reinterpret_cast<double*>(Rq);
+            if (lane == 0) red[wave] = m2;
+            __syncthreads();
+            if (tid == 0) {
+                double m = red[0];
+                for (int w = 1; w < ZT / 64; ++w) m = fmax(m, red[w]);
+                s_scale = m;
+            }
+            __syncthreads();
+        }
+        const double thresh = 1e-26 * s_scale;
+        __syncthreads();                             // (everybody has read s_scale / red before Rq is reused)
+        // publication buffers in Rq (free until the first quarter): [buf][0..63] pivot row, [buf][64..127] pivot column
+        cd* const pub = Rq;
+#pragma unroll
+        for (int pq = 0; pq < 8; ++pq) {             // pivot p = pr + 8 pq: held in own[pq] by the threads with dc0 = pr
+#pragma unroll 1
+            for (int pr = 0; pr < 8; ++pr) {
+                const int p = pr + 8 * pq;
+                cd* const pb = pub + (p & 1) * 2 * ZW;
+                if (dr == p) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) pb[dc0 + 8 * q] = own[q];
+                }
+                if (dc0 == pr) pb[ZW + dr] = own[pq];
+                __syncthreads();
+                const cd piv = pb[p], pcol = pb[ZW + dr];
+                const double d = cabs2(piv);
+                if (!(d > thresh)) bad = 1;
+                const cd pinv = d > 0.0 ? make_double2(piv.x / d, -piv.y / d) : make_double2(0.0, 0.0);
+                const cd f = cmul(pcol, pinv);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = dc0 + 8 * q;
+                    const cd prow = pb[c];
+                    cd v;
+                    if (dr == p) v = (c == p) ? pinv : cmul(prow, pinv);
+                    else v = (c == p) ? make_double2(-f.x, -f.y) : csub(own[q], cmul(f, prow));
+                    own[q] = v;
+                }
+            }
+        }
+        __syncthreads();                             // the last publication has been read: Rq is free
+#pragma unroll
+        for (int q = 0; q < 8; ++q) D[dr * LDD + dc0 + 8 * q] = own[q];
+        __syncthreads();
+        for (int qi = 0; qi < nq; ++qi) {
+            const int q = qi + 1 < nq ? (qi < kb ? qi : qi + 1) : kb;    // the quarters != kb in order, then kb
+            const int c0 = q * ZW;
+            const bool own_q = q == kb;
+            const cd* const R = own_q ? D : Rq;
+            // (b) R_q = D A_k,q: wave -> column tile (wave >> 1) of the quarter, row tiles 2 (wave & 1) + {0, 1}
+            if (!own_q) {
+                const int jt = wave >> 1, u0 = 2 * (wave & 1);
+                const int j = c0 + 16 * jt + l15;
+                f64x4 cr[2], ci[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { cr[u][r] = 0.0; ci[u][r] = 0.0; }
+                cd bb[ZW / 4];
+#pragma unroll
+                for (int ks = 0; ks < ZW / 4; ++ks) {
+                    const int gk = k0 + 4 * ks + l4;
+                    bb[ks] = (gk < n && j < n) ? S[(size_t)gk * n + j] : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < ZW / 4; ++ks) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const cd a = D[(16 * (u0 + u) + l15) * LDD + 4 * ks + l4];
+                        cr[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bb[ks].x, cr[u], 0, 0, 0);
+                        ci[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bb[ks].y, ci[u], 0, 0, 0);
+                        cr[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, bb[ks].y, cr[u], 0, 0, 0);
+                        ci[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bb[ks].x, ci[u], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Rq[(16 * (u0 + u) + l4 + 4 * r) * LDD + 16 * jt + l15] = make_double2(cr[u][r], ci[u][r]);
+                __syncthreads();
+            }
+            // (c) row tiles outside block k (one per wave and pass), the four column tiles of the quarter:
+            //     A_ij <- (q = kb ? 0 : A_ij) + (-A_i,blockk) R_kj
+            for (int it = wave; it < ntile; it += ZT / 64) {
+                if (16 * it >= k0 && 16 * it < k0 + ZW) continue;       // wave-uniform
+                const int gi = 16 * it + l15;
+                f64x4 cr[4], ci[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int j = c0 + 16 * v + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + l4 + 4 * r;
+                        const cd c = (!own_q && i < n && j < n) ? S[(size_t)i * n + j] : make_double2(0.0, 0.0);
+                        cr[v][r] = c.x;
+                        ci[v][r] = c.y;
+                    }
+                }
+                cd ta[ZW / 4];                                           // -A[gi][k0 + 4 ks + l4]
+#pragma unroll
+                for (int ks = 0; ks < ZW / 4; ++ks) {
+                    const int gk = k0 + 4 * ks + l4;
+                    const cd t = (gi < n && gk < n) ? S[(size_t)gi * n + gk] : make_double2(0.0, 0.0);
+                    ta[ks] = make_double2(-t.x, -t.y);
+                }
+#pragma unroll
+                for (int ks = 0; ks < ZW / 4; ++ks) {
+                    cd bb[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) bb[v] = R[(4 * ks + l4) * LDD + 16 * v + l15];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        cr[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks].x, bb[v].x, cr[v], 0, 0, 0);
+                        ci[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks].x, bb[v].y, ci[v], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        cr[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ta[ks].y, bb[v].y, cr[v], 0, 0, 0);
+                        ci[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks].y, bb[v].x, ci[v], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int j = c0 + 16 * v + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + l4 + 4 * r;
+                        if (i < n && j < n) A[(size_t)i * n + j] = make_double2(cr[v][r], ci[v][r]);
+                    }
+                }
+            }
+            // (d) rows of block k, columns of the quarter
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const int i = k0 + dr, j = c0 + dc0 + 8 * qq;
+                if (i < n && j < n) A[(size_t)i * n + j] = R[dr * LDD + dc0 + 8 * qq];
+            }
+            __syncthreads();                         // R_q is free for the next quarter, D for the next block
+        }
+    }
+    if (tid == 0) info[blockIdx.x] = 0;
+    __syncthreads();
+    if (bad) info[blockIdx.x] = 2;
+}
+
 // ---- batched in-place inverse: Gauss-Jordan with partial pivoting, one workgroup per matrix.
 // `info[b]` = 1 if a zero pivot was met.
 __global__ void __launch_bounds__(256) zinv_kernel(cd* M, int n, int* info) {

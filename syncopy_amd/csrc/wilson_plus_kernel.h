@@ -227,11 +227,12 @@ __device__ __forceinline__ void p_pair(cd (&ga)[8], cd (&gb)[8], cd& gn_a, cd& g
     }
 }
 
-// grid = ceil(nent / 4) workgroups of T threads; g, gp: (F, nent) complex128 (nent = n^2 for a whole matrix, fewer for
-// an entry shard of the frequency-sharded factorisation); g0: (nent).  The two pairs of a
-// workgroup are loaded, transformed and stored one after the other (one pair = 32 bytes per frequency row; the second
-// pair finds its half of the 64-byte pieces in the L2 / Infinity Cache): 64 data registers instead of 128, two
-// workgroups per CU.
+// grid = plus4_grid(nent) workgroups of T threads, ONE entry pair each (32 bytes of every frequency row); g, gp:
+// (F, nent) complex128 (nent = n^2 for a whole matrix, fewer for an entry shard of the frequency-sharded factorisation);
+// g0: (nent).  Four consecutive pairs share the 128-byte lines of every row, so they are dealt to four workgroups that
+// the dispatcher places on the SAME XCD one after the other (block b -> XCD b % 8): the line is fetched from HBM once
+// and found in that XCD's L2 by the other three.  64 data registers, two workgroups per CU.
+__host__ __device__ inline long long plus4_grid(long long nent) { return (((nent + 1) / 2 + 31) / 32) * 32; }
 template <int LOG2L>
 __global__ void __launch_bounds__((PCfg<LOG2L>::T)) SPY_PLUS_KATTR plus4_kernel(const cd* g, int F, long long nent, const cd* tw, cd* gp, cd* g0) {
     using C = PCfg<LOG2L>;
@@ -239,39 +240,37 @@ __global__ void __launch_bounds__((PCfg<LOG2L>::T)) SPY_PLUS_KATTR plus4_kernel(
     SPY_DYN_SMEM(cd, lds);
     const int j = threadIdx.x;
     const size_t nn = (size_t)nent;          // entries per frequency row
-#pragma unroll 1
-    for (int pair = 0; pair < 2; ++pair) {
-        const size_t e0 = (size_t)blockIdx.x * 4 + 2 * pair;
-        if (e0 >= nn) break;                                      // workgroup-uniform
-        const bool two = e0 + 1 < nn;
-        cd xa[8], xb[8], na = make_double2(0.0, 0.0), nb = na;
+    const size_t b = blockIdx.x;
+    const size_t e0 = 2 * ((b / 32) * 32 + (b % 8) * 4 + (b / 8) % 4);
+    if (e0 >= nn) return;                                         // workgroup-uniform
+    const bool two = e0 + 1 < nn;
+    cd xa[8], xb[8], na = make_double2(0.0, 0.0), nb = na;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const cd* row = g + (size_t)(j + T * e) * nn + e0;
-            xa[e] = row[0];
-            xb[e] = two ? row[1] : make_double2(0.0, 0.0);
-        }
-        if (j == 0) {
-            const cd* row = g + (size_t)half * nn + e0;
-            na = row[0];
-            nb = two ? row[1] : make_double2(0.0, 0.0);
-        }
-        double z0a = 0.0, z0b = 0.0;
-        p_pair<LOG2L>(xa, xb, na, nb, lds, j, tw, z0a, z0b);
+    for (int e = 0; e < 8; ++e) {
+        const cd* row = g + (size_t)(j + T * e) * nn + e0;
+        xa[e] = row[0];
+        xb[e] = two ? row[1] : make_double2(0.0, 0.0);
+    }
+    if (j == 0) {
+        const cd* row = g + (size_t)half * nn + e0;
+        na = row[0];
+        nb = two ? row[1] : make_double2(0.0, 0.0);
+    }
+    double z0a = 0.0, z0b = 0.0;
+    p_pair<LOG2L>(xa, xb, na, nb, lds, j, tw, z0a, z0b);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            cd* row = gp + (size_t)(j + T * e) * nn + e0;
-            row[0] = xa[e];
-            if (two) row[1] = xb[e];
-        }
-        if (j == 0) {
-            cd* row = gp + (size_t)half * nn + e0;
-            row[0] = na;
-            g0[e0] = make_double2(z0a, 0.0);
-            if (two) {
-                row[1] = nb;
-                g0[e0 + 1] = make_double2(z0b, 0.0);
-            }
+    for (int e = 0; e < 8; ++e) {
+        cd* row = gp + (size_t)(j + T * e) * nn + e0;
+        row[0] = xa[e];
+        if (two) row[1] = xb[e];
+    }
+    if (j == 0) {
+        cd* row = gp + (size_t)half * nn + e0;
+        row[0] = na;
+        g0[e0] = make_double2(z0a, 0.0);
+        if (two) {
+            row[1] = nb;
+            g0[e0 + 1] = make_double2(z0b, 0.0);
         }
     }
     (void)F;

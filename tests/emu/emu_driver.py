@@ -438,7 +438,8 @@ def w_inv(M, blocked=False):
     M = np.array(M, dtype=np.complex128, order="C")
     batch, n = (M.shape[0], M.shape[1]) if M.ndim == 3 else (1, M.shape[0])
     info = np.zeros(batch, dtype=np.int32)
-    fn = {False: lib().emu_w_inv, True: lib().emu_w_inv_blocked, "mfma": lib().emu_w_inv_mfma}[blocked]
+    fn = {False: lib().emu_w_inv, True: lib().emu_w_inv_blocked, "mfma": lib().emu_w_inv_mfma,
+          "mfma64": lib().emu_w_inv_mfma64}[blocked]
     fn(_dp(M), C.c_int(n), C.c_int(batch), _dp(info))
     return M, info
 

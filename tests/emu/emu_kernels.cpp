@@ -164,7 +164,7 @@ static void emu_launch_ccov(const spyfft::CcovArgs& a) {
 template <int LOG2L>
 void run_plus4(const double* g, int F, int n, const double* tw, double* gp, double* g0) {
     using C = spywil::PCfg<LOG2L>;
-    emu::launch(dim3((unsigned)((n * n + 3) / 4)), dim3(C::T), C::LDS_BYTES, [&] {
+    emu::launch(dim3((unsigned)spywil::plus4_grid((long long)n * n)), dim3(C::T), C::LDS_BYTES, [&] {
         spywil::plus4_kernel<LOG2L>(reinterpret_cast<const spywil::cd*>(g), F, (long long)n * n, reinterpret_cast<const spywil::cd*>(tw),
                                     reinterpret_cast<spywil::cd*>(gp), reinterpret_cast<spywil::cd*>(g0)); });
 }
@@ -782,6 +782,12 @@ void emu_w_inv_mfma(double* M, int n, int batch, int* info) {
     std::fill(M, M + (size_t)batch * n * n * 2, -777.0);
     emu::launch(dim3(batch), dim3(spywil::ZT), ((size_t)spywil::ZM * (npad + 1) + spywil::ZM * (spywil::ZM + 1)) * 16,
                 [&] { spywil::zinv_mfma_kernel(reinterpret_cast<cd*>(M), reinterpret_cast<const cd*>(src.data()), n, info); });
+}
+void emu_w_inv_mfma64(double* M, int n, int batch, int* info) {
+    std::vector<double> src(M, M + (size_t)batch * n * n * 2);
+    std::fill(M, M + (size_t)batch * n * n * 2, -777.0);
+    emu::launch(dim3(batch), dim3(spywil::ZT), (size_t)2 * spywil::ZW * (spywil::ZW + 1) * 16,
+                [&] { spywil::zinv64_mfma_kernel(reinterpret_cast<cd*>(M), reinterpret_cast<const cd*>(src.data()), n, info); });
 }
 void emu_w_chol(double* M, int n, int batch, int* info) {
     if (n <= 256 && n >= 2 * spywil::CHP) {       // as granger.hip: the panel kernel

@@ -354,6 +354,23 @@ def test_blocked_inverse_on_f64_matrix_cores(n):
     assert info[0] == 2
 
 
+@pytest.mark.parametrize("n", [128, 100, 192, 64])
+def test_blocked_inverse_with_64_row_blocks(n):
+    """zinv64_mfma_kernel (64 x 64 diagonal blocks, the matrix walked in column quarters through a 64 x 64 R panel in
+    LDS, the quarter of the block itself last): ragged sizes, asymmetric complex matrices, out of place, the tiny-pivot
+    flag."""
+    rng = np.random.default_rng(n)
+    B = 2
+    A = rng.normal(size=(B, n, n)) + 1j * rng.normal(size=(B, n, n)) + 3 * np.sqrt(n) * np.eye(n)
+    inv, info = E.w_inv(A, blocked="mfma64")
+    assert not info.any()
+    np.testing.assert_allclose(inv, np.linalg.inv(A), rtol=1e-9, atol=1e-11)
+    P = np.zeros((1, n, n), complex)
+    P[0] = np.eye(n)[::-1]
+    _, info = E.w_inv(P, blocked="mfma64")
+    assert info[0] == 2
+
+
 @pytest.mark.parametrize("F", [9, 17, 11, 8])       # L = 16 (4*4), 32 (4*4*2), 20 (4*5), 14 (2*7)
 def test_plus_operator(F):
     rng = np.random.default_rng(F)
