@@ -598,14 +598,16 @@ __global__ void __launch_bounds__(ZT) zinv_mfma_kernel(cd* M, const cd* src, int
 
 // ---- the same block Gauss-Jordan with blocks of ZW = 64 rows: FOUR sweeps over a 256 x 256 matrix instead of eight
 // (the 32-row kernel moves 8 x 2 MB per matrix at ~2.8 TB/s: it is bound by those sweeps, not by its 8 n^3 flops).
-// A 64-row R panel does not fit LDS next to D, so a block step walks the matrix in column QUARTERS of 64:
-//   for every quarter q (the quarter of block k itself LAST):
-//       R_q = D A_k,q on the matrix cores -> LDS (q = k: R_q = D, no copy)
-//       A_i,q <- (q = k ? 0 : A_i,q) - A_i,k R_q   for the row tiles i outside block k   (A_i,k re-read per quarter:
-//                                                  64 KB from L2; nobody writes column block k before its own quarter)
-//       A_k,q <- R_q
-// LDS: D and R_q, 64 x 65 complex128 each (133 KB).  Pivots inside the diagonal block only, in order; info = 2 flags a
-// (relatively) tiny pivot exactly as the other blocked kernels do.
+// A 64-row R panel does not fit LDS next to D - it does not have to: a wave owns a COLUMN tile (16 columns), computes
+// its 64 x 16 piece of R = D A_k* into registers (64 VGPRs) and keeps it there for the whole block step; what
+// passes through LDS is the column block k of the other rows (the A operand of the trailing update), 64 rows at a time.
+// LDS: D and that panel, 64 x 65 complex128 each (133 KB) whatever n is.  Pivots inside the diagonal block only, in
+// order; info = 2 flags a (relatively) tiny pivot exactly as the other blocked kernels do.
+// Measured at 2049 x 256 x 256 (profiles/r3_wilson_inverse_variants.txt): 32-row blocks 12.2 ms; 64-row blocks with the
+// matrix walked in column quarters through an R panel in LDS 10.2; + register-resident diagonal-block inversion 8.9;
+// this version 7.5 (its parts ADD UP - memory skeleton 3.4 + diagonal blocks 1.6 + MFMA phases 3.0 - one workgroup per
+// CU runs them one after the other); two 4-wave workgroups per CU (R pieces parked in the rows of block k, D's LDS
+// reused for the panel) 9.2: 512 matrices in flight no longer fit the 256 MB Infinity Cache between sweeps.
 constexpr int ZW = 64;
 __global__ void __launch_bounds__(ZT) zinv64_mfma_kernel(cd* M, const cd* src, int n, int* info) {
     SPY_DYN_SMEM(char, raw);
@@ -666,7 +668,8 @@ __global__ void __launch_bounds__(ZT) zinv64_mfma_kernel(cd* M, const cd* src, i
                 const cd piv = pb[p], pcol = pb[ZW + dr];
                 const double d = cabs2(piv);
                 if (!(d > thresh)) bad = 1;
-                const cd pinv = d > 0.0 ? make_double2(piv.x / d, -piv.y / d) : make_double2(0.0, 0.0);
+                const double rd = d > 0.0 ? 1.0 / d : 0.0;         // (one division on the pivot chain instead of two)
+                const cd pinv = make_double2(piv.x * rd, -piv.y * rd);
                 const cd f = cmul(pcol, pinv);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -683,18 +686,26 @@ __global__ void __launch_bounds__(ZT) zinv64_mfma_kernel(cd* M, const cd* src, i
 #pragma unroll
         for (int q = 0; q < 8; ++q) D[dr * LDD + dc0 + 8 * q] = own[q];
         __syncthreads();
-        for (int qi = 0; qi < nq; ++qi) {
-            const int q = qi + 1 < nq ? (qi < kb ? qi : qi + 1) : kb;    // the quarters != kb in order, then kb
-            const int c0 = q * ZW;
-            const bool own_q = q == kb;
-            const cd* const R = own_q ? D : Rq;
-            // (b) R_q = D A_k,q: wave -> column tile (wave >> 1) of the quarter, row tiles 2 (wave & 1) + {0, 1}
-            if (!own_q) {
-                const int jt = wave >> 1, u0 = 2 * (wave & 1);
-                const int j = c0 + 16 * jt + l15;
-                f64x4 cr[2], ci[2];
+        // (b) - (d): a wave owns ONE column tile per pass of 8 tiles (the tiles of block k last: nobody reads column block
+        // k from memory after it has been overwritten).  Its R fragment - R_k,jt = D A_k,jt, 64 x 16 - is computed
+        // into registers and never leaves them: the accumulator layout of the four 16 x 16 products IS the B-operand
+        // layout of the trailing update (lane (l15, l4) holds rows 4 ks + l4, ks = 4 u + r, of column l15).  The
+        // (negated) column block k of the other rows passes through LDS, 64 rows at a time.
+        const int nout = ntile - 4;
+        for (int e0 = 0; e0 < ntile; e0 += ZT / 64) {
+            const int e = e0 + wave;
+            const bool have = e < ntile;                                  // wave-uniform
+            const int jt = !have ? 0 : (e < nout ? (e < 4 * kb ? e : e + 4) : 4 * kb + (e - nout));
+            const bool own_t = have && e >= nout;                         // a tile of block k itself: R = D
+            const int j = 16 * jt + l15;
+            cd Rf[ZW / 4];
+            if (own_t) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int ks = 0; ks < ZW / 4; ++ks) Rf[ks] = D[(4 * ks + l4) * LDD + 16 * (jt - 4 * kb) + l15];
+            } else if (have) {
+                f64x4 cr[4], ci[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { cr[u][r] = 0.0; ci[u][r] = 0.0; }
                 cd bb[ZW / 4];
@@ -706,8 +717,8 @@ __global__ void __launch_bounds__(ZT) zinv64_mfma_kernel(cd* M, const cd* src, i
 #pragma unroll
                 for (int ks = 0; ks < ZW / 4; ++ks) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const cd a = D[(16 * (u0 + u) + l15) * LDD + 4 * ks + l4];
+                    for (int u = 0; u < 4; ++u) {
+                        const cd a = D[(16 * u + l15) * LDD + 4 * ks + l4];
                         cr[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bb[ks].x, cr[u], 0, 0, 0);
                         ci[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bb[ks].y, ci[u], 0, 0, 0);
                         cr[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, bb[ks].y, cr[u], 0, 0, 0);
@@ -715,69 +726,85 @@ __global__ void __launch_bounds__(ZT) zinv64_mfma_kernel(cd* M, const cd* src, i
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        Rq[(16 * (u0 + u) + l4 + 4 * r) * LDD + 16 * jt + l15] = make_double2(cr[u][r], ci[u][r]);
+                    for (int r = 0; r < 4; ++r) Rf[4 * u + r] = make_double2(cr[u][r], ci[u][r]);
+            }
+            // (d) rows of block k of this column tile
+            if (have) {
+#pragma unroll
+                for (int ks = 0; ks < ZW / 4; ++ks) {
+                    const int i = k0 + 4 * ks + l4;
+                    if (i < n && j < n) A[(size_t)i * n + j] = Rf[ks];
+                }
+            }
+            // (c) the other block rows: A_i,jt <- (tile of block k ? 0 : A_i,jt) + (-A_i,k) R_k,jt
+            auto fetch = [&](int it0, cd (&c)[2][4]) {                   // accumulator start of row tiles it0, it0 + 1
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * (it0 + t) + l4 + 4 * r;
+                        c[t][r] = (have && !own_t && i < n && j < n) ? S[(size_t)i * n + j] : make_double2(0.0, 0.0);
+                    }
+            };
+            cd cn[2][4];
+            if (nq > 1) fetch(4 * (kb == 0 ? 1 : 0), cn);
+            for (int cb = 0; cb < nq; ++cb) {
+                if (cb == kb) continue;
+                __syncthreads();                                         // the previous panel has been read
+                // (prefetching the next panel into registers across the MFMAs was measured: no gain, 34 more spills)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = ZW * cb + dr, jj = k0 + dc0 + 8 * q;
+                    const cd t = (i < n && jj < n) ? S[(size_t)i * n + jj] : make_double2(0.0, 0.0);
+                    Rq[dr * LDD + dc0 + 8 * q] = make_double2(-t.x, -t.y);
+                }
                 __syncthreads();
-            }
-            // (c) row tiles outside block k (one per wave and pass), the four column tiles of the quarter:
-            //     A_ij <- (q = kb ? 0 : A_ij) + (-A_i,blockk) R_kj
-            for (int it = wave; it < ntile; it += ZT / 64) {
-                if (16 * it >= k0 && 16 * it < k0 + ZW) continue;       // wave-uniform
-                const int gi = 16 * it + l15;
-                f64x4 cr[4], ci[4];
+#pragma unroll 1
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int it0 = 4 * cb + 2 * pr;
+                    f64x4 cr[2], ci[2];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int j = c0 + 16 * v + l15;
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * it + l4 + 4 * r;
-                        const cd c = (!own_q && i < n && j < n) ? S[(size_t)i * n + j] : make_double2(0.0, 0.0);
-                        cr[v][r] = c.x;
-                        ci[v][r] = c.y;
+                        for (int r = 0; r < 4; ++r) { cr[t][r] = cn[t][r].x; ci[t][r] = cn[t][r].y; }
+                    // the next pair's tiles are requested before the MFMAs of this one
+                    int nxt = pr == 0 ? it0 + 2 : -1;
+                    if (pr == 1) {
+                        int cbn = cb + 1;
+                        if (cbn == kb) ++cbn;
+                        if (cbn < nq) nxt = 4 * cbn;
                     }
-                }
-                cd ta[ZW / 4];                                           // -A[gi][k0 + 4 ks + l4]
+                    if (nxt >= 0) fetch(nxt, cn);
+                    if (have) {
 #pragma unroll
-                for (int ks = 0; ks < ZW / 4; ++ks) {
-                    const int gk = k0 + 4 * ks + l4;
-                    const cd t = (gi < n && gk < n) ? S[(size_t)gi * n + gk] : make_double2(0.0, 0.0);
-                    ta[ks] = make_double2(-t.x, -t.y);
-                }
+                        for (int ks = 0; ks < ZW / 4; ++ks) {
+                            cd aa[2];
 #pragma unroll
-                for (int ks = 0; ks < ZW / 4; ++ks) {
-                    cd bb[4];
+                            for (int t = 0; t < 2; ++t) aa[t] = Rq[(16 * (2 * pr + t) + l15) * LDD + 4 * ks + l4];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) bb[v] = R[(4 * ks + l4) * LDD + 16 * v + l15];
+                            for (int t = 0; t < 2; ++t) {
+                                cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[t].x, Rf[ks].x, cr[t], 0, 0, 0);
+                                ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[t].x, Rf[ks].y, ci[t], 0, 0, 0);
+                            }
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        cr[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks].x, bb[v].x, cr[v], 0, 0, 0);
-                        ci[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks].x, bb[v].y, ci[v], 0, 0, 0);
-                    }
+                            for (int t = 0; t < 2; ++t) {
+                                cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aa[t].y, Rf[ks].y, cr[t], 0, 0, 0);
+                                ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[t].y, Rf[ks].x, ci[t], 0, 0, 0);
+                            }
+                        }
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        cr[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ta[ks].y, bb[v].y, cr[v], 0, 0, 0);
-                        ci[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks].y, bb[v].x, ci[v], 0, 0, 0);
-                    }
-                }
+                        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int j = c0 + 16 * v + l15;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * it + l4 + 4 * r;
-                        if (i < n && j < n) A[(size_t)i * n + j] = make_double2(cr[v][r], ci[v][r]);
+                            for (int r = 0; r < 4; ++r) {
+                                const int i = 16 * (it0 + t) + l4 + 4 * r;
+                                if (i < n && j < n) A[(size_t)i * n + j] = make_double2(cr[t][r], ci[t][r]);
+                            }
                     }
                 }
             }
-            // (d) rows of block k, columns of the quarter
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) {
-                const int i = k0 + dr, j = c0 + dc0 + 8 * qq;
-                if (i < n && j < n) A[(size_t)i * n + j] = R[dr * LDD + dc0 + 8 * qq];
-            }
-            __syncthreads();                         // R_q is free for the next quarter, D for the next block
+            __syncthreads();                         // panel and D are free (next pass of tiles / next block)
         }
     }
     if (tid == 0) info[blockIdx.x] = 0;
