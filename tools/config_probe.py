@@ -242,8 +242,8 @@ if "h2d" in which:
     print("h2d", res["h2d_upload"], flush=True)
     del pinned, host
 
-if "granger" in which:
-    for C, N, T in ((64, 1024, 700), (256, 4096, 300)):
+if "granger" in which or "granger256" in which:
+    for C, N, T in (((64, 1024, 700), (256, 4096, 300)) if "granger" in which else ((256, 4096, 300),)):
         data = synthdata.ar2_uncoupled_fast(C, N, T, seed=4)
         K = 7
         F = N // 2 + 1

@@ -1,6 +1,8 @@
 // Torch-free driver of the C ABI for rocprofv3 counter passes (PMC collection crashes inside
 // torch's own kernels on this image).  Runs the coherence front half on synthetic trials:
-//   spyhip_fft_exec (fourier, all tapers) -> spyhip_csd_accumulate[_blocked], `reps` times.
+//   spyhip_fft_exec (fourier, all tapers) -> spyhip_csd_accumulate[_blocked], `reps` times;
+//   which & 4: the trials are 64 distinct AR(2) realisations (alphas 0.55, -0.8 as synthdata.ar2_network), and the
+//   averaged CSD goes through spyhip_granger afterwards (K6 at 256 channels x 2049 frequencies).
 // build: hipcc -O2 tools/pmc_harness.cpp -Iinclude -Lsyncopy_amd -lspyhip -Wl,-rpath,$PWD/syncopy_amd -o gpurun_out/pmc_harness
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -15,7 +17,7 @@
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 500, reps = argc > 2 ? atoi(argv[2]) : 2;
-    const int which = argc > 3 ? atoi(argv[3]) : 3;   // bit 0: fft, bit 1: csd
+    const int which = argc > 3 ? atoi(argv[3]) : 3;   // bit 0: fft, bit 1: csd, bit 2: granger on the result
     const int blocked = argc > 4 ? atoi(argv[4]) : 0; // 1: channel-blocked hand-over layout (bench.py --blocked)
     const int C = 256, N = 4096, K = 7, F = N / 2 + 1;
     spyhip_ctx* ctx;
@@ -23,10 +25,19 @@ int main(int argc, char** argv) {
     std::mt19937 rng(1);
     std::normal_distribution<float> nd(0.f, 1.f);
     // one random trial, replicated on the device (counter collection does not care about the values)
-    std::vector<float> h((size_t)N * C);
+    const int ndistinct = (which & 4) ? (B < 64 ? B : 64) : 1;
+    std::vector<float> h((size_t)ndistinct * N * C);
     for (auto& v : h) v = nd(rng);
-    float* data; CK(hipMalloc(&data, (size_t)B * h.size() * 4));
-    for (int b = 0; b < B; ++b) CK(hipMemcpy(data + (size_t)b * h.size(), h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    if (which & 4)
+        for (int t = 0; t < ndistinct; ++t)
+            for (int n = 2; n < N; ++n)
+                for (int c = 0; c < C; ++c) {
+                    float* x = h.data() + (size_t)t * N * C;
+                    x[(size_t)n * C + c] += 0.55f * x[(size_t)(n - 1) * C + c] - 0.8f * x[(size_t)(n - 2) * C + c];
+                }
+    const size_t tl = (size_t)N * C;
+    float* data; CK(hipMalloc(&data, (size_t)B * tl * 4));
+    for (int b = 0; b < B; ++b) CK(hipMemcpy(data + (size_t)b * tl, h.data() + (size_t)(b % ndistinct) * tl, tl * 4, hipMemcpyHostToDevice));
     std::vector<int64_t> st(B), hi(B);
     for (int b = 0; b < B; ++b) { st[b] = (int64_t)b * N; hi[b] = st[b] + N; }
     int64_t *dst, *dhi; CK(hipMalloc(&dst, B * 8)); CK(hipMalloc(&dhi, B * 8));
@@ -49,6 +60,14 @@ int main(int argc, char** argv) {
         if (which & 1) SK(spyhip_fft_exec(plan, data, C, nullptr, dst, dst, dhi, B, spec));
         if (which & 2) SK(blocked ? spyhip_csd_accumulate_blocked(ctx, spec, (int64_t)B * K, F, C, acc)
                                : spyhip_csd_accumulate(ctx, spec, (int64_t)B * K, F, C, acc));
+    }
+    if (which & 4) {
+        SK(spyhip_csd_finalize(ctx, acc, F, C, 1.0 / ((double)B * K * reps)));
+        void* gr; CK(hipMalloc(&gr, (size_t)F * C * C * 4));
+        double info[4];
+        SK(spyhip_granger(ctx, acc, F, C, 5e-6, 100, 1e4, 1e-1, gr, nullptr, nullptr, info));
+        printf("granger: converged %g, max rel. err %g, reg. factor %g, initial cond. num %g, %d iterations\n", info[0], info[1],
+               info[2], info[3], spyhip_granger_last_iterations(ctx));
     }
     SK(spyhip_ctx_synchronize(ctx));
     printf("kernel %s; done B=%d reps=%d\n", spyhip_fft_plan_kernel_name(plan), B, reps);
