@@ -25,6 +25,25 @@ def _deps():
     return deps
 
 
+def _fresh(obj):
+    """True if `obj` is newer than every file its compiler-written dependency list (obj.d) names."""
+    dep = obj + ".d"
+    if not (os.path.exists(obj) and os.path.exists(dep)):
+        return False
+    t = os.path.getmtime(obj)
+    try:
+        with open(dep) as fh:
+            names = fh.read().replace("\\\n", " ").split()
+    except OSError:
+        return False
+    for n in names[1:]:
+        if n.endswith(":"):
+            continue
+        if not os.path.exists(n) or os.path.getmtime(n) > t:
+            return False
+    return True
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -44,7 +63,9 @@ def build(force=False, verbose=False):
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
+        if not force and _fresh(obj):
+            continue
+        cmd = [hipcc()] + flags + ["-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

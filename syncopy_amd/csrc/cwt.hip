@@ -14,6 +14,7 @@ using spyfft::CwtArgs;
 // blocks (less FFT work per output sample, two workgroups per CU) instead of on the block the longest one needs
 struct CwtGroup {
     int log2n = 0, G = 1, V = 0, halo = 0, nblocks = 0, nscales = 0;
+    int long_idx = -1, piece = 0;  // long_idx >= 0: piece `piece` of the long_idx-th scale whose kernel exceeds a block
     spy::DevBuf<float2> tw, hspec;
     spy::DevBuf<int> cshift, sidx;
 };
@@ -28,11 +29,16 @@ struct spyhip_cwt_plan {
     size_t trend_cap = 0;
     spy::DevBuf<char> stage;      // time-contiguous staging of one chunk of segments
     int chunk = 0;                // segments per chunk the staging buffer holds
+    std::vector<int> long_scales; // scales whose trimmed kernel has more than CWT_PIECE - 1 taps: run piece by piece
+    spy::DevBuf<int> lidx;        // their scale indices on the device
+    spy::DevBuf<float2> stage_long;   // (chunk, long scale, channel, time) complex sums of the pieces (real outputs)
+    int chunk_long = 0;
     ~spyhip_cwt_plan() { for (auto* g : groups) delete g; }
 };
 
 namespace {
 const double PI = 3.14159265358979323846264338327950288;
+constexpr int CWT_PIECE = 8192;   // taps per piece of a long kernel: a 16384-point block then yields 8193 outputs
 
 template <int LOG2N, int G, int OUTK>
 int launch_cwt(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
@@ -148,6 +154,10 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
         while (NB < 4 * (Lt + 1) && NB < 8192) NB <<= 1;
         while (NB < 2 * (Lt + 1) && NB < 16384) NB <<= 1;
         need[s] = NB;
+        if (2 * (Lt + 1) > 16384) {                 // longer than one block can serve: cut into pieces (below)
+            need[s] = 0;
+            p->long_scales.push_back(s);
+        }
     }
     for (int NB = 1024; NB <= 16384; NB <<= 1) {
         std::vector<int> ids;
@@ -194,6 +204,40 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
             return -2;
         }
     }
+    // ---- kernels longer than a block: h = sum_p h_p (pieces of CWT_PIECE taps), y = sum_p h_p * x.  Piece p is an
+    // overlap-save convolution of its own: taps [p PL, p PL + Lp), centre c_p = c - p PL (may be negative or beyond the
+    // piece), input window from o0 - halo_p with halo_p = Lp - 1 - c_p, output n of block o0 at q = n - o0 + Lp - 1.
+    for (size_t li = 0; li < p->long_scales.size(); ++li) {
+        const int sc = p->long_scales[li];
+        const int Lt = (int)kers[sc].re.size();
+        const int NB = 16384;
+        for (int pc = 0; pc * CWT_PIECE < Lt; ++pc) {
+            const int m0 = pc * CWT_PIECE, Lp = std::min(CWT_PIECE, Lt - m0);
+            auto* g = new CwtGroup();
+            p->groups.push_back(g);
+            g->log2n = 14; g->G = 1; g->nscales = 1; g->long_idx = (int)li; g->piece = pc;
+            g->V = NB - (Lp - 1);
+            g->halo = Lp - 1 - (kers[sc].c - m0);
+            g->nblocks = (nsig + g->V - 1) / g->V;
+            std::vector<float2> tw(NB), hs(NB);
+            for (int m = 0; m < NB; ++m) {
+                const double ang = -2.0 * PI * m / NB;
+                tw[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            }
+            std::vector<double> re(NB, 0.0), im(NB, 0.0);
+            for (int m = 0; m < Lp; ++m) { re[m] = kers[sc].re[m0 + m]; im[m] = kers[sc].im[m0 + m]; }
+            spy::fft_host(re, im);
+            for (int k = 0; k < NB; ++k) hs[k] = make_float2((float)(re[k] / NB), (float)(im[k] / NB));
+            // complex outputs add up in the staging rows of the scale itself, real ones in the complex side buffer
+            std::vector<int> cshift{Lp - 1}, ids{output == SPYHIP_OUT_FOURIER ? sc : (int)li};
+            if (g->tw.upload(tw, ctx->stream) || g->hspec.upload(hs, ctx->stream) || g->cshift.upload(cshift, ctx->stream) ||
+                g->sidx.upload(ids, ctx->stream)) {
+                delete p;
+                return -2;
+            }
+        }
+    }
+    if (!p->long_scales.empty() && p->lidx.upload(p->long_scales, ctx->stream)) { delete p; return -2; }
     p->identity_time = (tpos == nullptr);
     p->ntime_out = tpos ? ntime_out : nsig;
     if (tpos) {
@@ -255,6 +299,13 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
     }
     chunk = p->chunk;
     a.stage = p->stage.p;
+    const int nlong = (int)p->long_scales.size();
+    const bool long_side = nlong > 0 && esz == 4;      // real outputs: the pieces are summed as complex numbers first
+    if (long_side && chunk > p->chunk_long) {
+        if (p->stage_long.p) { (void)hipFree(p->stage_long.p); p->stage_long.p = nullptr; }
+        if (p->stage_long.alloc((size_t)chunk * nlong * p->nchan * p->nsig)) return -2;
+        p->chunk_long = chunk;
+    }
     for (int s0 = 0; s0 < nseg; s0 += chunk) {
         const int ns = std::min(chunk, nseg - s0);
         CwtArgs c = a;
@@ -271,6 +322,10 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
             k.sidx = gr->sidx.p;
             k.tw = gr->tw.p; k.hspec = gr->hspec.p; k.cshift = gr->cshift.p;
             k.V = gr->V; k.halo = gr->halo; k.nblocks = gr->nblocks;
+            if (gr->long_idx >= 0) {
+                k.stage_add = gr->piece > 0;
+                if (long_side) { k.stage = p->stage_long.p; k.nscales_total = nlong; }
+            }
             const long long nunit = gr->log2n <= 13 ? (p->nchan + 1) / 2 : p->nchan;   // channel pairs / channels
             const long long ngrp = (nunit + gr->G - 1) / gr->G;
             const long long grid = (long long)ns * ngrp * gr->nblocks;
@@ -282,10 +337,16 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
                 case 11: rc = launch_cwt2_out<11, 2>(p, k, g); break;
                 case 12: rc = launch_cwt2_out<12, 1>(p, k, g); break;
                 case 13: rc = launch_cwt2_out<13, 1>(p, k, g); break;
-                case 14: rc = launch_cwt_out<14, 1>(p, k, g); break;
+                case 14: rc = gr->long_idx >= 0 ? launch_cwt<14, 1, 2>(p, k, g) : launch_cwt_out<14, 1>(p, k, g); break;
                 default: spy::set_error("cwt_exec: unsupported block length 2^%d", gr->log2n); return -1;
             }
             if (rc) return rc;
+        }
+        if (long_side) {
+            const long long tot = (long long)ns * nlong * p->nchan * p->nsig;
+            hipLaunchKernelGGL(spyfft::cwt_long_convert_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                               p->ctx->stream, p->stage_long.p, p->lidx.p, nlong, ns, p->nscales, p->nchan, p->nsig,
+                               p->output, reinterpret_cast<float*>(p->stage.p));
         }
         const dim3 sg((p->nsig + 63) / 64, p->nscales, accumulate == 2 ? 1 : ns);
         if (esz == 8) hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float2>, sg, dim3(256), 0, p->ctx->stream, c);

@@ -44,6 +44,7 @@ struct CwtArgs {
     int seg0;                     // first segment of the chunk being processed
     const int* sidx;              // scale s of this launch -> scale index of the plan (nullptr = identity): scales
     int nscales_total;            // are grouped by the block length their kernel support needs (0 = nscales)
+    int stage_add;                // 1: add to the staging values (later pieces of a kernel longer than one block)
 };
 
 // per (segment, channel): mean and least-squares slope over the trial rows [lo, hi), in two
@@ -165,8 +166,12 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) cwt_kernel(CwtArgs 
         for (int e = 0; e < 16; ++e) {
             const int n = j + T * e - sh + o0;
             if (!has || n < o0 || n >= nend) continue;
-            if (CPLX) reinterpret_cast<float2*>(a.stage)[rowo + n] = v[e];
-            else reinterpret_cast<float*>(a.stage)[rowo + n] = convert_real<OUTK>(v[e], a.out_kind);
+            if (CPLX) {
+                float2* const d = reinterpret_cast<float2*>(a.stage) + rowo + n;
+                *d = a.stage_add ? cadd(*d, v[e]) : v[e];
+            } else {
+                reinterpret_cast<float*>(a.stage)[rowo + n] = convert_real<OUTK>(v[e], a.out_kind);
+            }
         }
     }
 }
@@ -254,6 +259,21 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArg
             }
         }
     }
+}
+
+// Kernels longer than one block (more than 8191 taps after trimming) are cut into pieces of <= 8192 taps: each piece
+// is an overlap-save convolution of its own (own launch, own halo), the complex results of the pieces add up in a
+// complex side buffer (segment, long scale, channel, time); this kernel converts the sums into the staging rows of
+// those scales.
+__global__ void __launch_bounds__(256) cwt_long_convert_kernel(const float2* lng, const int* lidx, int nlong, int nseg,
+                                                               int nscales, int nchan, int nsig, int out_kind,
+                                                               float* stage) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per = (long long)nchan * nsig;
+    if (i >= (long long)nseg * nlong * per) return;
+    const long long r = i % per, q = i / per;
+    const int li = (int)(q % nlong), b = (int)(q / nlong);
+    stage[((long long)b * nscales + lidx[li]) * per + r] = convert_real_slow(lng[i], out_kind);
 }
 
 // staging (segment, scale, channel, time) -> out (segment, slot(time), scale, channel), 64 x 64 tiles
