@@ -402,6 +402,27 @@ def test_cwt_trial_sum_mode(be):
     assert_parity(total.cpu().numpy(), ref.cpu().numpy(), what="cwt trial sum")
 
 
+@pytest.mark.parametrize("output", ["pow", "fourier"])
+def test_cwt_kernels_longer_than_one_block(be, output):
+    """Morlet kernels of more than 8191 taps (transform.py:96-103 samples 10 s / dt of them and convolves in full,
+    whatever the signal length): the plan cuts them into pieces of 8192 taps, every piece is its own overlap-save
+    convolution on 16384-point blocks and the complex results add up before the output conversion.  20000 samples
+    at 1 kHz: 0.3 Hz -> 32210 taps (4 pieces), 0.5 Hz -> 19326 (3), 1.5 Hz -> 6442 (one 16384-point block),
+    20 Hz -> 483 (2048-point blocks); 3 channels exercise the padded pair of the packed kernel."""
+    rng = np.random.default_rng(5)
+    nsig, C, T = 20000, 3, 2
+    x = (rng.normal(size=(T * nsig, C)) + np.sin(2 * np.pi * 0.4e-3 * np.arange(T * nsig))[:, None]).astype(np.float32)
+    freqs = np.array([0.3, 0.5, 1.5, 20.0])
+    scales = (1 / freqs) * (6 + np.sqrt(38)) / (4 * np.pi)
+    plan = be.CWTPlan(nsig, C, scales, 1e-3, 6.0, 0, output)
+    st = torch.arange(T, device="cuda", dtype=torch.int64) * nsig
+    got = plan.execute(torch.from_numpy(x).cuda(), st, st, st + nsig).cpu().numpy()
+    for t in range(T):
+        trl = O.detrend(x[t * nsig:(t + 1) * nsig], 0)
+        ref = O.convert_output(O.cwt(trl, 1000.0, scales).transpose(1, 0, 2), output)
+        assert_parity(got[t], ref, what=f"long cwt kernels, {output}, trial {t}")
+
+
 def test_blocked_tail_starts_inside_a_frequency(be):
     """the (5,4) path of the blocked hand-over layout cuts work into 36-tile items whatever ntiles is, so
     the re-cut tail can start in the middle of a frequency (C = 192: 21 tiles).  The row-split reduction only covers
