@@ -59,6 +59,7 @@ struct spyhip_fft_plan {
     GenPlan gen{};
     size_t lds_bytes = 0;
     spy::DevBuf<float> tapers;
+    spy::DevBuf<float> tapers_half;   // tapers * scale / 2 (mtmfft_quad_kernel: no scaling left in its epilogue)
     spy::DevBuf<float2> tw, chirp, bhat;
     spy::DevBuf<int> fpos;
     bool identity_freq = true;
@@ -134,7 +135,10 @@ int launch_quad(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     // (per device, cheap: set at every launch)
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
+    MtmArgs b = a;
+    b.tapers = p->tapers_half.p;          // this kernel expects the scale / 2 folded into the window
+    if (!b.tapers) { spy::set_error("fft_exec: plan without the pre-scaled taper table"); return -1; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, b);
     SPY_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -270,6 +274,10 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
     std::vector<float> tf((size_t)ntaper * nsig);
     for (size_t i = 0; i < tf.size(); ++i) tf[i] = (float)tapers[i];
     if (p->tapers.upload(tf, ctx->stream)) { delete p; return -2; }
+    if (spy::is_pow2((unsigned)nfft) && nfft >= 256 && nfft <= 8192) {
+        for (size_t i = 0; i < tf.size(); ++i) tf[i] = (float)(tapers[i] * (0.5 * scale));
+        if (p->tapers_half.upload(tf, ctx->stream)) { delete p; return -2; }
+    }
     {   // the windows as the reference holds them (float64), for spyhip_fft_plan_set_precision
         std::vector<double> td(tapers, tapers + (size_t)ntaper * nsig);
         if (p->tapers64.upload(td, ctx->stream)) { delete p; return -2; }

@@ -11,6 +11,10 @@
 // Separation afterwards:  X(c0,c1)[f] = (Z[f] + conj(Z[N-f]))/2,  X(c2,c3)[f] = (Z[f] - conj(Z[N-f]))/(2i).
 // The segment is read from HBM exactly once (kept in registers across tapers); the spectra never
 // leave registers/LDS before the output conversion.
+// `a.tapers` of THIS kernel carry the factor scale/2 already (the plan uploads w * scale/2 rounded from float64):
+// the separation X = (Z[f] +- conj Z[N-f]) * scale/2 then needs no multiplication at all (32 packed
+// instructions per thread and taper).  When the window fills the transform (nsig == N, every c2/c3-type
+// call) the taper weights are fetched without the zero-padding clamps (64 of ~950 vector instructions).
 #pragma once
 #include "fft2_device.h"
 #include "mtmfft_kernel.h"
@@ -173,8 +177,8 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         }
     }
     const int kout = MEAN ? 1 : a.ntaper;
-    const float hs = 0.5f * a.scale;
     const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
+    const bool wfull = (a.nsig == N);     // uniform: no zero padding behind the window
     constexpr unsigned OSZ = CPLX ? 8u : 4u;   // bytes per output element
     // straight-line epilogue: all four channels present, every bin kept, 16-byte aligned rows
     const bool fast = full && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) &&
@@ -182,11 +186,16 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
 
     // taper weights of the first taper; later tapers are prefetched while the previous FFT runs
     float wn[16];
+    if (wfull) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const unsigned n = (unsigned)(j0 + T * e);
-        const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(a.tapers, min(n, nsig_m1) * 4u);
-        wn[e] = (n <= nsig_m1) ? wl : 0.f;
+        for (int e = 0; e < 16; ++e) wn[e] = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(a.tapers, (unsigned)(j0 + T * e) * 4u);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned n = (unsigned)(j0 + T * e);
+            const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(a.tapers, min(n, nsig_m1) * 4u);
+            wn[e] = (n <= nsig_m1) ? wl : 0.f;
+        }
     }
 
     for (int k = 0; k < a.ntaper; ++k) {
@@ -199,11 +208,16 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         }
         if (k + 1 < a.ntaper) {
             const float* w = a.tapers + (size_t)(k + 1) * a.nsig;   // wave-uniform
+            if (wfull) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned n = (unsigned)(j + T * e);
-                const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, min(n, nsig_m1) * 4u);
-                wn[e] = (n <= nsig_m1) ? wl : 0.f;
+                for (int e = 0; e < 16; ++e) wn[e] = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, (unsigned)(j + T * e) * 4u);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned n = (unsigned)(j + T * e);
+                    const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, min(n, nsig_m1) * 4u);
+                    wn[e] = (n <= nsig_m1) ? wl : 0.f;
+                }
             }
         }
         if (a.demean_taper) {
@@ -261,15 +275,15 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                 zp.r = lre[pb + (7 - e) * C::ESTRIDE];
                 zp.i = lim[pb + (7 - e) * C::ESTRIDE];
                 if (f == 0) zp = z;
-                xa.r = (z.r + zp.r) * hs;
-                xa.i = (z.i - zp.i) * hs;
-                xb.r = (z.i + zp.i) * hs;
-                xb.i = (zp.r - z.r) * hs;
+                xa.r = z.r + zp.r;          // (the tapers carry scale / 2)
+                xa.i = z.i - zp.i;
+                xb.r = z.i + zp.i;
+                xb.i = zp.r - z.r;
             } else {
                 if (j != 0) break;
                 f = N / 2;
-                xa.r = v[8].r * a.scale;
-                xb.r = v[8].i * a.scale;
+                xa.r = v[8].r * 2.f;
+                xb.r = v[8].i * 2.f;
                 xa.i = xb.i = splat(0.f);
             }
             if (MEAN) {

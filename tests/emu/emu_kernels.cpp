@@ -206,6 +206,13 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     const bool pipe = G >= 100;          // G = 102: the pipelined kernel (two quads per workgroup, mtmfft_pipe_kernel.h)
     if (pipe) G -= 100;
     const bool quad = log2n <= 13;
+    // mtmfft_quad_kernel expects the window times scale / 2 (the plan uploads that table, mtmfft.hip)
+    std::vector<float> th;
+    if (quad && !pipe) {
+        th.resize((size_t)ntaper * nsig);
+        for (size_t i = 0; i < th.size(); ++i) th[i] = (float)((double)tapers[i] * (0.5 * (double)scale));
+        a.tapers = th.data();
+    }
     const int nitem = quad ? (nchan + 3) / 4 : (nchan + 1) / 2;
     a.npg = (nitem + G - 1) / G;
     int S = (quad ? 8 : 16) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
