@@ -31,3 +31,21 @@ def excess(a, b, rtol=RTOL, atol_rel=ATOL_REL):
 def assert_parity(a, b, rtol=RTOL, atol_rel=ATOL_REL, what=""):
     e = excess(a, b, rtol, atol_rel)
     assert e <= 1.0, f"{what}: parity violated, max err/tol = {e:.3g} (rtol={rtol}, atol_rel={atol_rel})"
+
+
+def jackknife_tolerances(est, var, T, ulps=8.0):
+    """Per-element error bounds of the jackknife statistics when every leave-one-out replicate r_t and the direct
+    estimate carry an independent absolute error eps = ulps * 2^-24 * |estimate| (float32 results of the AV stage):
+
+      var  = (T-1)/T sum_t (r_t - mean r)^2     ->  |d var|  <= 2 sqrt((T-1) var) eps      (Cauchy-Schwarz over t)
+      bias = (T-1) (mean_t r_t - direct)        ->  |d bias| <= (T-1) (1 + 1/sqrt(T)) eps
+
+    on top of the shared criterion rtol*|b| + atol_rel*max|b|.  The replicates of a 20-trial coherence differ from the
+    direct estimate by 1e-3 ... 1e-2 of it, so var ~ 1e-6 est^2: the float32 rounding of the estimates IS 1e-3 of such a
+    variance - which is what a flat rtol of 3e-3 used to stand for, now stated element by element."""
+    est = np.abs(np.asarray(est)).astype(np.float64)
+    var = np.abs(np.asarray(var)).astype(np.float64)
+    eps = ulps * 2.0 ** -24 * est
+    tol_var = RTOL * var + ATOL_REL * var.max() + 2.0 * np.sqrt((T - 1) * var) * eps
+    tol_bias = (T - 1) * (1.0 + 1.0 / np.sqrt(T)) * eps
+    return tol_var, tol_bias
