@@ -533,14 +533,11 @@ def ppc(st_csd):
 def cross_covariance(x, samplerate=1, polyremoval=0, norm=False):
     """connectivity/ST_compRoutines.py:466-584, line by line: (N, C) -> ((nLags, 1, C, C) float64, lags).
     Note the reversed "same" crop of the upper triangle: for an even number of samples it starts one lag late."""
-    from scipy.signal import detrend as sp_detrend, fftconvolve
+    from scipy.signal import fftconvolve
     dat = np.array(x)
     n, c = dat.shape
     lags = np.arange(0, n // 2) if n % 2 == 0 else np.arange(0, n // 2 + 1)
-    if polyremoval == 0:
-        dat = sp_detrend(dat, type="constant", axis=0)
-    elif polyremoval == 1:
-        dat = sp_detrend(dat, type="linear", axis=0)
+    dat = detrend(dat, polyremoval)      # scipy.signal.detrend(type="constant" | "linear", axis=0), :496-499
     norm_overlap = np.arange(n, n // 2, step=-1)
     CC = np.empty((len(lags), 1, c, c))
     for i in range(c):

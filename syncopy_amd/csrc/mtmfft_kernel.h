@@ -63,6 +63,36 @@ struct MtmArgs {
 // is what the bins next to DC are made of - so it is reproduced literally: one thread per (segment, channel), a
 // serial chain of v_add_f32 over the rows (loads batched 16 rows ahead; lanes = adjacent channels: coalesced).
 // Rows outside [seg_lo, seg_hi) count as +0 and leave the sum as it is.
+//
+// ONE channel is the exception: the reference's trial is then an (nSamples, 1) array, contiguous along the axis that is
+// reduced, and NumPy sums such a run PAIRWISE (pairwise_sum_FLOAT: eight running sums over blocks of at most 128
+// values, halves of longer runs recursively) - np_pairwise_rows below follows that order.
+__device__ inline float np_pairwise_rows(const float* p, long long ld, int i0, int n, int rlo, int rhi) {
+    auto at = [&](int i) { return (i >= rlo && i < rhi) ? p[(long long)i * ld] : 0.f; };
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res = __fadd_rn(res, at(i0 + i));
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = at(i0 + j);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], at(i0 + i + j));
+        }
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                              __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (; i < n; ++i) res = __fadd_rn(res, at(i0 + i));
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(np_pairwise_rows(p, ld, i0, n2, rlo, rhi), np_pairwise_rows(p, ld, i0 + n2, n - n2, rlo, rhi));
+}
+
 static __global__ void __launch_bounds__(64) seq_mean_kernel(MtmArgs a, float* means) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     const int b = blockIdx.y;
@@ -72,6 +102,10 @@ static __global__ void __launch_bounds__(64) seq_mean_kernel(MtmArgs a, float* m
     const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
     const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
     const int rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
+    if (a.nchan == 1) {
+        means[b] = __fdiv_rn(np_pairwise_rows(a.data + start * a.ld + col, a.ld, 0, a.nsig, rlo, rhi), (float)a.nsig);
+        return;
+    }
     const float* p = a.data + (start + rlo) * a.ld + col;
     float s = 0.f;
     int n = rlo;

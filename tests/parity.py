@@ -35,7 +35,8 @@ def assert_parity(a, b, rtol=RTOL, atol_rel=ATOL_REL, what=""):
 
 def jackknife_tolerances(est, var, T, ulps=8.0):
     """Per-element error bounds of the jackknife statistics when every leave-one-out replicate r_t and the direct
-    estimate carry an independent absolute error eps = ulps * 2^-24 * |estimate| (float32 results of the AV stage):
+    estimate carry an independent absolute error eps = ulps * 2^-24 * max|estimate| (float32 results of the AV stage;
+    a coherency S_ij / sqrt(S_ii S_jj) is rounded at the scale of its unit diagonal, not of |C_ij|):
 
       var  = (T-1)/T sum_t (r_t - mean r)^2     ->  |d var|  <= 2 sqrt((T-1) var) eps      (Cauchy-Schwarz over t)
       bias = (T-1) (mean_t r_t - direct)        ->  |d bias| <= (T-1) (1 + 1/sqrt(T)) eps
@@ -45,7 +46,7 @@ def jackknife_tolerances(est, var, T, ulps=8.0):
     variance - which is what a flat rtol of 3e-3 used to stand for, now stated element by element."""
     est = np.abs(np.asarray(est)).astype(np.float64)
     var = np.abs(np.asarray(var)).astype(np.float64)
-    eps = ulps * 2.0 ** -24 * est
+    eps = ulps * 2.0 ** -24 * (est.max() if est.size else 0.0)
     tol_var = RTOL * var + ATOL_REL * var.max() + 2.0 * np.sqrt((T - 1) * var) * eps
     tol_bias = (T - 1) * (1.0 + 1.0 / np.sqrt(T)) * eps
     return tol_var, tol_bias

@@ -522,6 +522,17 @@ def test_reference_order_mean_is_numpy_bit_for_bit():
     # the float64 block sums differ from this by up to ~1e-6 of the offset - that is the whole point
     exact = x[:4096].astype(np.float64).mean(axis=0)
     assert np.abs(np.mean(x[:4096], axis=0) - exact).max() > 1e-5
+    # ONE channel: the trial is an (nSamples, 1) array, contiguous along the reduced axis, which NumPy sums pairwise
+    # (pairwise_sum_FLOAT) - a different rounding sequence from the row-by-row one above
+    for n in (5, 8, 100, 128, 129, 1000, 4096, 4100, 4999):
+        for src in (np.ascontiguousarray(x[:n, 3:4]), x):                      # a one-channel recording / one selected column
+            ci = None if src.shape[1] == 1 else [3]
+            got = E.seq_mean(src, [0], [0], [n], n, chan_idx=ci)
+            assert np.array_equal(got[0], np.mean(np.ascontiguousarray(x[:n, 3:4]), axis=0)), n
+    seq = np.float32(0)
+    for v in x[:4096, 3]:
+        seq = np.float32(seq + v)
+    assert seq / np.float32(4096) != np.mean(np.ascontiguousarray(x[:4096, 3:4]), axis=0)[0]    # (the orders do differ)
 
 
 @pytest.mark.parametrize("nsig,nfft,kw", [(4096, 4096, {}), (1000, 1024, {}), (2000, 2000, {}),

@@ -126,7 +126,8 @@ def test_jackknife(golden_dir, name):
     if name == "granger":
         check_jackknife(out, z, name, rtol=3e-3, atol_rel=3e-4)     # (the reference's own Granger tolerance: atol 1e-2)
         return
-    # element-wise bounds from the float32 rounding of the replicates (tests/parity.py:jackknife_tolerances, 8 ulp)
+    # element-wise bounds from the float32 rounding of the replicates (tests/parity.py:jackknife_tolerances: 8 ulp at
+    # the unit scale of a coherency)
     from parity import jackknife_tolerances
     assert_parity(out.data, z[name], what=name)
     tol_var, tol_bias = jackknife_tolerances(z[name], z[name + "_jack_var"], T=20)

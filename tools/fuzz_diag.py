@@ -1,0 +1,26 @@
+"""Where does a case of tests/test_gpu_fuzz.py disagree?  python tools/fuzz_diag.py mtmfft 5 9 25 ... (development aid)."""
+import sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import pytest, types
+import test_gpu_fuzz as T
+import parity
+
+kind = sys.argv[1]
+fn = {"mtmfft": T.test_mtmfft_random_options, "conn": T.test_connectivity_random_options,
+      "tf": T.test_timefrequency_random_options}[kind]
+def report(a, b, rtol=parity.RTOL, atol_rel=parity.ATOL_REL, what=""):
+    a = np.asarray(a); b = np.asarray(b)
+    tol = rtol * np.abs(b) + atol_rel * np.abs(b).max()
+    err = np.abs(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64) - b)
+    r = err / np.where(tol == 0, 1e-38, tol)
+    i = np.unravel_index(np.argmax(r), r.shape)
+    nbad = int((r > 1).sum())
+    bad_f = sorted(set(np.argwhere(r > 1)[:, -2].tolist()))[:12] if r.ndim >= 2 else []
+    print(f"  {what}\n    shape {a.shape} max err/tol {r.max():.3g} at {tuple(int(x) for x in i)} got {a[i]} ref {b[i]} max|b| {np.abs(b).max():.4g}; "
+          f"{nbad} elements over; axis -2 indices over: {bad_f}")
+T.assert_parity = report
+for s in sys.argv[2:]:
+    print("seed", s)
+    fn(int(s))
