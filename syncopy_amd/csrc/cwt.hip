@@ -281,10 +281,16 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         }
         a.trend = p->trend.p;
         if (nseg > 65535) { spy::set_error("cwt_exec: more than 65535 segments per call"); return -1; }
-        hipLaunchKernelGGL(spyfft::cwt_trend_partial_kernel, dim3((p->nchan + 63) / 64, spyfft::CWT_TREND_SPLITS, nseg),
-                           dim3(256), 0, p->ctx->stream, a, p->trend_part.p);
-        hipLaunchKernelGGL(spyfft::cwt_trend_final_kernel, dim3((unsigned)(((size_t)nseg * p->nchan + 255) / 256)), dim3(256),
-                           0, p->ctx->stream, a, p->trend_part.p, p->trend.p);
+        if (p->detrend == 0) {
+            // the reference's float32 mean in its own summation order (one thread per segment and channel)
+            hipLaunchKernelGGL(spyfft::cwt_mean_np_kernel, dim3((p->nchan + 63) / 64, nseg), dim3(64), 0, p->ctx->stream, a,
+                               p->trend.p);
+        } else {
+            hipLaunchKernelGGL(spyfft::cwt_trend_partial_kernel, dim3((p->nchan + 63) / 64, spyfft::CWT_TREND_SPLITS, nseg),
+                               dim3(256), 0, p->ctx->stream, a, p->trend_part.p);
+            hipLaunchKernelGGL(spyfft::cwt_trend_final_kernel, dim3((unsigned)(((size_t)nseg * p->nchan + 255) / 256)), dim3(256),
+                               0, p->ctx->stream, a, p->trend_part.p, p->trend.p);
+        }
         SPY_HIP_CHECK(hipGetLastError());
     }
     // staging buffer: as many segments per chunk as fit ~4 GiB (at least one): enough workgroups per launch that

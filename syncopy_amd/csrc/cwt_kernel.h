@@ -104,6 +104,61 @@ __global__ void __launch_bounds__(256) cwt_trend_final_kernel(CwtArgs a, const d
     trend[i * 2 + 1] = (a.detrend == 1 && n > 1.0) ? t1 * 12.0 / (n * (n * n - 1.0)) : 0.0;
 }
 
+// Constant detrending (polyremoval = 0): the mean scipy.signal.detrend(type="constant") subtracts is NumPy's float32
+// mean over the rows of the trial - one float32 accumulator per channel in time order, PAIRWISE for a one-channel
+// trial (mtmfft_kernel.h: seq_mean_kernel) - and its rounding (~1e-6 of a channel's offset) is what the first and last
+// samples of a wavelet transform are made of (the kernel has zero mean, the truncated convolution at the edges has
+// not).  Reproduced literally; one thread per (segment, channel).
+__global__ void __launch_bounds__(64) cwt_mean_np_kernel(CwtArgs a, double* trend) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= a.nchan) return;
+    const long long col = a.chan_idx ? a.chan_idx[c] : c;
+    const long long lo = a.trial_lo[b], n = a.trial_hi[b] - lo;
+    const float* p = a.data + lo * a.ld + col;
+    float s = 0.f;
+    if (a.nchan == 1) {
+        s = np_pairwise_rows(p, a.ld, 0, (int)n, 0, (int)n);
+    } else {
+        // few threads (segments x channels), long trials: the next 32 rows are in flight while the current 32 are added
+        // (two register sets in turn, no copies), rows addressed as a wave-uniform row pointer + this lane's column so
+        // that the loads take the scalar-base form: the time is the dependent chain of 16384 additions
+        constexpr int D = 32;
+        const unsigned colb = (unsigned)col * 4u;
+        const char* row = reinterpret_cast<const char*>(a.data + lo * a.ld);       // wave-uniform
+        const long long rstride = a.ld * 4;                                          // bytes per row (uniform)
+        float t[D], u[D];
+        long long k = 0;
+        auto fetch = [&](float (&d)[D], const char* r) {
+#pragma unroll
+            for (int e = 0; e < D; ++e) d[e] = ldg<float>(r + (long long)e * rstride, colb);
+        };
+        auto add = [&](const float (&d)[D]) {
+#pragma unroll
+            for (int e = 0; e < D; ++e) s = __fadd_rn(s, d[e]);
+        };
+        if (n >= D) fetch(t, row);
+        while (k + D <= n) {
+            row += D * rstride;
+            if (k + 2 * D <= n) fetch(u, row);
+            add(t);
+            k += D;
+            if (k + D > n) break;
+            row += D * rstride;
+            if (k + 2 * D <= n) fetch(t, row);
+            add(u);
+            k += D;
+        }
+        for (; k < n; ++k) {
+            s = __fadd_rn(s, ldg<float>(row, colb));
+            row += rstride;
+        }
+    }
+    double* o = trend + ((size_t)b * a.nchan + c) * 2;
+    o[0] = (double)__fdiv_rn(s, (float)n);
+    o[1] = 0.0;
+}
+
 template <int LOG2N, int G, int OUTK>
 __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) cwt_kernel(CwtArgs a) {
     using C = Cfg<LOG2N, G>;

@@ -693,7 +693,9 @@ int emu_cwt(int log2n, int G, const float* data, long long ld, const int* chan_i
     a.ntime_out = ntime_out; a.out = out; a.accumulate = accumulate;
     std::vector<double> trend((size_t)nseg * nchan * 2, 0.0);
     a.trend = trend.data();
-    if (detrend >= 0) {
+    if (detrend == 0) {                      // as cwt.hip: the reference-order float32 mean
+        emu::launch(dim3((nchan + 63) / 64, nseg), dim3(64), 0, [&] { spyfft::cwt_mean_np_kernel(a, trend.data()); });
+    } else if (detrend > 0) {
         std::vector<double> part(trend.size() * spyfft::CWT_TREND_SPLITS, 0.0);
         emu::launch(dim3((nchan + 63) / 64, spyfft::CWT_TREND_SPLITS, nseg), dim3(256), 0,
                     [&] { spyfft::cwt_trend_partial_kernel(a, part.data()); });

@@ -2,6 +2,8 @@
 lengths 3 ... 6000 (every transform-length class: powers of two, decimal, 5-smooth, Bluestein, primes, long), channel
 counts 1 ... 40, ragged trials, every padding / taper / output / detrending combination the path supports.  A case
 that the front end itself rejects must be rejected identically by both sides."""
+import os
+
 import numpy as np
 import pytest
 import scipy.signal as sps
@@ -22,6 +24,7 @@ def _gpu():
     backend.require_gpu()
 
 
+SCALE = int(os.environ.get("SPY_FUZZ_SCALE", "1"))      # SPY_FUZZ_SCALE=10: ten times the seeds (exploration runs)
 LENGTHS = [3, 7, 16, 30, 64, 100, 127, 128, 200, 250, 256, 257, 360, 500, 512, 729, 1000, 1009, 1024, 1500, 2000, 2048,
            2500, 3000, 3001, 4096, 4100, 5000, 6000]
 
@@ -89,7 +92,7 @@ def _run_both(fn, data, classes, kw):
     return got, ref, exact
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(48 * SCALE))
 def test_mtmfft_random_options(seed):
     rng = np.random.default_rng(1000 + seed)
     ragged, polyremoval = bool(rng.integers(0, 2)), [None, 0, 1][int(rng.integers(0, 3))]
@@ -121,7 +124,7 @@ def test_mtmfft_random_options(seed):
         _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {data.data.shape[1]}")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_connectivity_random_options(seed):
     rng = np.random.default_rng(2000 + seed)
     polyremoval = [None, 0, 1][int(rng.integers(0, 3))]
@@ -145,15 +148,21 @@ def test_connectivity_random_options(seed):
         floor = {"ppc": 5e-6, "corr": 1e-5}.get(method, 1e-6)       # (the floors of these two methods)
         if method == "ppc":
             # the worst of M = (frequencies x channel pairs x trials) single-trial cross spectra comes within ~1/sqrt(M) of
-            # zero (|S| is Rayleigh-like: P(|S| < r sigma) ~ r^2); its phase then carries the float32 rounding 1e-7
-            # amplified by sqrt(M), and a trial weighs 2/T in the pair average: that element of the result is uncertain
-            # by ~2e-7 sqrt(M) 2/T in the reference's complex64 arithmetic and here alike
+            # zero (|S| is Rayleigh-like: P(|S| < r sigma) ~ r^2).  The float32 transform leaves an ABSOLUTE error of
+            # ~5e-7 of the rms bin in every spectrum (the reference transforms in float64 and is exact there), so the
+            # phase of that element is off by ~1e-6 sqrt(M), and a trial weighs 2/T in the pair average
             T = len(lengths)
-            floor = max(floor, 2e-7 * np.sqrt(ref.data.size / 2 * T) * 2 / T)
+            floor = max(floor, 1e-6 * np.sqrt(ref.data.size / 2 * T) * 2 / T)
+        if method == "coh" and kw.get("output") == "imag":
+            # Im of a channel's coherence with itself: exactly 0 here, rounding residue of 0 in the reference's
+            # complex64 arithmetic (with ONE channel the whole reference result is that residue): not compared
+            for arr in (got.data, ref.data) + ((exact.data,) if exact is not None else ()):
+                idx = np.arange(arr.shape[-1])
+                arr[..., idx, idx] = 0
         _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {data.data.shape[1]}", atol_rel=floor)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_timefrequency_random_options(seed):
     rng = np.random.default_rng(3000 + seed)
     ragged, polyremoval = bool(rng.integers(0, 2)), [None, 0, 1][int(rng.integers(0, 3))]
