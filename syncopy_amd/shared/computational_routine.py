@@ -116,7 +116,10 @@ class ComputationalRoutine(ABC):
         arr = data.data[a:b] if tax == 0 else data.data[:, a:b]
         if chans is not None:
             arr = arr[:, chans] if tax == 0 else arr[chans, :]
-        return np.array(arr)   # fresh copy, as the reference hands the cF (computational_routine.py:1001)
+        # fresh C-ordered copy, as the reference hands the cF (computational_routine.py:1001: h5py reads a selection into
+        # a new C-contiguous array).  NumPy's own `arr[:, list]` is laid out column by column, and np.mean(axis=0) - the
+        # detrending of every cF - then sums each column PAIRWISE instead of row by row: a different float32 rounding
+        return np.array(arr, order="C")
 
     def my_trials(self):
         """Trial indices of this rank (all trials without a process group; parallel.py)."""

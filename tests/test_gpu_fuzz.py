@@ -181,3 +181,81 @@ def test_timefrequency_random_options(seed):
     got, ref, exact = _run_both(spy.freqanalysis, data, ORACLE_FREQ, kw)
     if got is not None:
         _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {data.data.shape[1]}")
+
+
+@pytest.mark.parametrize("seed", range(32 * SCALE))
+def test_mtmfft_selections_and_window_options(seed):
+    """foi lists, in-place selections (trials / channels / latency), explicit taper counts, Kaiser windows,
+    demean_taper, ft_compat, padding in seconds, and channels whose offset is 100 x their fluctuations (constant
+    detrending then lives or dies by the ORDER of the float32 mean)."""
+    rng = np.random.default_rng(4000 + seed)
+    ragged = bool(rng.integers(0, 2))
+    polyremoval = [0, 0, 1, None][int(rng.integers(0, 4))]
+    data, lengths = _make(rng, ragged, offsets=False)
+    if polyremoval == 0:
+        data.data[...] += (rng.normal(size=data.data.shape[1]) * 100).astype(np.float32)[None, :]
+    elif polyremoval == 1:
+        data.data[...] += (rng.normal(size=data.data.shape[1]) * 3).astype(np.float32)[None, :]
+    nchan, ntr, nmin = data.data.shape[1], len(lengths), min(lengths)
+    kw = dict(method="mtmfft", polyremoval=polyremoval, output=str(rng.choice(["pow", "abs", "fourier"])))
+    kw["keeptrials"] = bool(rng.integers(0, 2)) or kw["output"] == "fourier"
+    w = int(rng.integers(0, 4))
+    if w == 0:
+        kw["taper"] = "kaiser"
+        kw["taper_opt"] = {"beta": float(rng.choice([2.0, 8.6, 14.0]))}
+    elif w == 1:
+        kw["tapsmofrq"] = float(rng.choice([4.0, 12.0]))
+        kw["nTaper"] = int(rng.integers(1, 5))
+        kw["keeptapers"] = bool(rng.integers(0, 2)) and kw["keeptrials"]
+    elif w == 2:
+        kw["taper"] = str(rng.choice(["hann", "hamming", "blackman", "bartlett"]))
+    else:
+        kw["taper"] = None
+    if kw["output"] == "fourier":
+        kw["keeptapers"] = True
+    kw["demean_taper"] = bool(rng.integers(0, 2))
+    kw["ft_compat"] = bool(rng.integers(0, 2))
+    pad = int(rng.integers(0, 3))
+    kw["pad"] = ["maxperlen", "nextpow2", float(np.ceil(max(lengths) * 1.25) / 1000.0)][pad]
+    if rng.integers(0, 2):
+        nyq = 500.0
+        kw["foi"] = np.sort(rng.uniform(0, nyq, size=int(rng.integers(1, 12))))
+    sel = {}
+    if rng.integers(0, 2) and ntr > 1:
+        sel["trials"] = sorted(rng.choice(ntr, size=int(rng.integers(1, ntr + 1)), replace=False).tolist())
+    if rng.integers(0, 2) and nchan > 1:
+        sel["channel"] = rng.choice(nchan, size=int(rng.integers(1, nchan + 1)), replace=False).tolist()
+    if rng.integers(0, 3) == 0 and nmin >= 40:
+        t0 = float(rng.uniform(0, 0.3 * nmin)) / 1000.0
+        sel["latency"] = [t0, t0 + float(rng.uniform(0.3 * nmin, 0.6 * nmin)) / 1000.0]
+    if sel:
+        kw["select"] = sel
+    got, ref, exact = _run_both(spy.freqanalysis, data, ORACLE_FREQ, kw)
+    if got is not None:
+        _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {nchan}")
+
+
+@pytest.mark.parametrize("seed", range(12 * SCALE))
+def test_welch_and_superlet_random_options(seed):
+    rng = np.random.default_rng(5000 + seed)
+    polyremoval = [None, 0, 1][int(rng.integers(0, 3))]
+    data, lengths = _make(rng, ragged=False, offsets=polyremoval is not None)
+    n = lengths[0]
+    if rng.integers(0, 2):
+        win = max(8, min(int(rng.choice([32, 100, 128, 256, 500])), n))
+        kw = dict(method="welch", t_ftimwin=win / 1000.0, toi=float(rng.choice([0.0, 0.25, 0.5])),
+                  keeptrials=bool(rng.integers(0, 2)))
+        if rng.integers(0, 2):
+            kw["taper"] = "hann"
+        else:
+            kw["tapsmofrq"] = float(rng.choice([10.0, 25.0]))
+    else:
+        kw = dict(method="superlet", order_max=int(rng.integers(2, 6)), order_min=1, c_1=int(rng.integers(1, 4)),
+                  adaptive=bool(rng.integers(0, 2)), foi=np.sort(rng.uniform(20, 300, size=int(rng.integers(2, 5)))),
+                  toi="all", output=str(rng.choice(["pow", "abs"])), keeptrials=True)
+    kw["polyremoval"] = polyremoval
+    got, ref, exact = _run_both(spy.freqanalysis, data, ORACLE_FREQ, kw)
+    if got is not None:
+        # superlets: a root of a small modulus amplifies the transform's absolute error (DESIGN section 7: floor 5e-6)
+        _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {data.data.shape[1]}",
+               atol_rel=5e-6 if kw["method"] == "superlet" else ATOL_REL)

@@ -9,10 +9,13 @@ import parity
 
 kind = sys.argv[1]
 fn = {"mtmfft": T.test_mtmfft_random_options, "conn": T.test_connectivity_random_options,
-      "tf": T.test_timefrequency_random_options}[kind]
-def report(a, b, rtol=parity.RTOL, atol_rel=parity.ATOL_REL, what=""):
-    a = np.asarray(a); b = np.asarray(b)
+      "tf": T.test_timefrequency_random_options, "sel": T.test_mtmfft_selections_and_window_options,
+      "welch": T.test_welch_and_superlet_random_options}[kind]
+def report(got, ref, exact, what="", atol_rel=parity.ATOL_REL, rtol=parity.RTOL):
+    a = np.asarray(got.data); b = np.asarray(ref.data)
     tol = rtol * np.abs(b) + atol_rel * np.abs(b).max()
+    if exact is not None:
+        tol = tol + 2 * np.abs(b - np.asarray(exact.data))
     err = np.abs(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64) - b)
     r = err / np.where(tol == 0, 1e-38, tol)
     i = np.unravel_index(np.argmax(r), r.shape)
@@ -20,7 +23,7 @@ def report(a, b, rtol=parity.RTOL, atol_rel=parity.ATOL_REL, what=""):
     bad_f = sorted(set(np.argwhere(r > 1)[:, -2].tolist()))[:12] if r.ndim >= 2 else []
     print(f"  {what}\n    shape {a.shape} max err/tol {r.max():.3g} at {tuple(int(x) for x in i)} got {a[i]} ref {b[i]} max|b| {np.abs(b).max():.4g}; "
           f"{nbad} elements over; axis -2 indices over: {bad_f}")
-T.assert_parity = report
+T._check = report
 for s in sys.argv[2:]:
     print("seed", s)
     fn(int(s))
