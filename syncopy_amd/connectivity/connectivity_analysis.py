@@ -22,9 +22,17 @@ from .ST_compRoutines import CrossCovariance, CrossSpectra, SpectralDyadicProduc
 @unwrap_cfg
 def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi=None, foilim=None, pad="maxperlen",
                          polyremoval=0, tapsmofrq=None, nTaper=None, taper="hann", taper_opt=None, jackknife=False,
-                         channelcmb=None, select=None, compute_method=None, routine_classes=None, **kwargs):
+                         channelcmb=None, select=None, compute_method=None, routine_classes=None, precision="float32",
+                         **kwargs):
     """Cross-spectral connectivity of AnalogData on MI355X (arguments as spy.connectivityanalysis,
-    connectivity_analysis.py:51-67)."""
+    connectivity_analysis.py:51-67).
+    `precision` (not a reference argument; as in `freqanalysis`): "reference" runs the taper product and the FFT of the
+    single-trial spectra in float64 and rounds to complex64 where the reference does (mtmfft.py:96-127) - coherence, ppc
+    and Granger are RATIOS of spectra, and where a channel's power is 40 dB or more below its peak the float32
+    transform's absolute error (5e-7 of the rms bin) is no longer small against the bin itself; needs a power-of-two
+    transform length 256 ... 4096 (e.g. pad="nextpow2"), ~2x the time of the transform stage."""
+    if precision not in ("float32", "reference"):
+        raise SPYValueError("'float32' or 'reference'", varname="precision", actual=str(precision))
     if not isinstance(data, (AnalogData, SpectralData)) or data.data is None:
         raise SPYValueError("either AnalogData or SpectralData as input", "data", data.__class__.__name__)
     if method not in connectivityMethods:
@@ -47,6 +55,11 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     classes.update(routine_classes or {})
     with attached_selection(data, select):
         cmb = _parse_channelcmb(data, channelcmb)
+        if precision == "reference":
+            from ..specest import hip_spectral as hs
+            with hs.precision("reference"):
+                return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
+                                     nTaper, taper, taper_opt, compute_method, jackknife, cmb)
         return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
                              nTaper, taper, taper_opt, compute_method, jackknife, cmb)
 

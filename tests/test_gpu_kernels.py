@@ -530,3 +530,29 @@ def test_reference_precision_through_freqanalysis():
         spy.freqanalysis(spy.AnalogData(x[:2000], samplerate=1000.0), method="mtmfft", precision="reference")
     with pytest.raises(SPYValueError):
         spy.freqanalysis(data, method="wavelet", precision="reference")
+
+
+def test_reference_precision_through_connectivityanalysis():
+    """Coherence is a ratio of spectra: with a line 60 dB above the noise floor in every channel the float32
+    transform's absolute error (5e-7 of the rms bin, i.e. of the line) is ~1e-3 of the noise bins the coherence away
+    from the line is made of - outside the criterion; precision="reference" (float64 transform, complex64 rounding
+    where mtmfft.py:104-127 rounds) is inside it."""
+    import syncopy_amd as spy
+    from oracle_routines import ORACLE_CONN
+    from parity import excess
+    rng = np.random.default_rng(3)
+    nsamp, ntr, nchan = 2048, 12, 6
+    t = np.arange(nsamp * ntr) / 1000.0
+    x = rng.normal(size=(nsamp * ntr, nchan)) + 1000.0 * np.sin(2 * np.pi * 50.0 * t)[:, None] * rng.uniform(0.5, 1.5, size=nchan)
+    trl = np.stack([np.arange(ntr) * nsamp, np.arange(1, ntr + 1) * nsamp, np.zeros(ntr)], axis=1)
+    data = spy.AnalogData(x.astype(np.float32), samplerate=1000.0, trialdefinition=trl)
+    kw = dict(method="coh", taper="hann", output="abs", foilim=[100, 450])
+    ref = spy.connectivityanalysis(data, compute_method="sequential", routine_classes=ORACLE_CONN, **kw)
+    fast = spy.connectivityanalysis(data, **kw)
+    exact = spy.connectivityanalysis(data, precision="reference", **kw)
+    e_fast, e_exact = excess(fast.data, ref.data), excess(exact.data, ref.data)
+    print(f"coherence away from a 60 dB line: float32 err/tol {e_fast:.3g}, precision='reference' {e_exact:.3g}")
+    assert e_exact <= 1.0, e_exact
+    assert e_fast > e_exact
+    with pytest.raises(Exception):
+        spy.connectivityanalysis(data, precision="reference", pad=3.0, **kw)        # 3000 samples: not a power of two
