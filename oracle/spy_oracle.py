@@ -249,7 +249,11 @@ def stft(x, fs, window, nperseg, noverlap, boundary="zeros", padded=True, detren
         nadd = (-(d.shape[-1] - nperseg) % step) % nperseg
         d = np.concatenate((d, np.zeros(d.shape[:-1] + (nadd,))), axis=-1)  # float64 zeros (:117)
     nseg = (d.shape[-1] - noverlap) // step
-    frames = np.stack([d[..., s * step:s * step + nperseg] for s in range(nseg)], axis=-2)
+    # strided view of the segments exactly as stft.py:121-127 builds it: for float32 data that were neither extended
+    # nor padded `d` is a transposed view of the (N, C) trial, the last axis of the frames is then NOT contiguous, and
+    # np.mean (inside scipy.signal.detrend) sums a frame's samples in order, one accumulator per channel
+    frames = np.lib.stride_tricks.as_strided(d, shape=d.shape[:-1] + (nseg, nperseg),
+                                             strides=d.strides[:-1] + (step * d.strides[-1], d.strides[-1]))
     if detrend_kind:
         frames = sps.detrend(frames, type=detrend_kind)
     if window is not None:

@@ -52,21 +52,25 @@ class precision:
 
 
 def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_taper, freq_idx, output, keeptapers,
-             device, blocked=False, whole_trials=True):
+             device, blocked=False, whole_trials=True, float32_frames=False):
     """Cached FFTPlan; `blocked` asks for the channel-blocked hand-over layout of the CSD path (the plan's
     `.blocked` tells whether the kernel serving this length supports it).  `whole_trials`: the segments are trials
     that the reference detrends as float32 arrays (compRoutines.py:169-170, ST_compRoutines.py:405-409), so the
     mean is taken in its float32 row order; sliding-window frames are detrended in float64 there (stft.py:112-132)
-    and keep the kernels' float64 block sums."""
+    and keep the kernels' float64 block sums - unless the frames stay float32 (`float32_frames`: stft.py:101-132 with
+    boundary=None, padded=False, the `toi` array case): they are strided views of the (time x channel) trial, and
+    np.mean over their last axis walks the samples of a frame in order with one float32 accumulator per channel
+    (pairwise for a single channel) - the same rounding sequence as the mean of a whole trial."""
     fkey = None if freq_idx is None else np.asarray(freq_idx, dtype=np.int32).tobytes()
     key = (int(nsig), int(nfft), int(nchan), taper, tuple(sorted((taper_opt or {}).items())), int(nnorm),
            float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device), bool(blocked),
-           bool(whole_trials), _precision[-1])
+           bool(whole_trials), bool(float32_frames), _precision[-1])
     plan = _cache_hit(_plan_cache, key)
     if plan is None:
         tp = taper_table(taper, nsig, nnorm, taper_opt)
         plan = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
-                               keeptapers, device=device, reference_mean=whole_trials and detrend == 0)
+                               keeptapers, device=device,
+                               reference_mean=(whole_trials or float32_frames) and detrend == 0)
         if _precision[-1] == "reference":
             if not plan.set_precision(True):
                 raise SPYValueError("a power-of-two transform length 256 ... 4096 (e.g. pad='nextpow2') for "
@@ -122,7 +126,8 @@ def run_stft(dev_data, row0, soi_start, soi_stop, frames, nperseg, step, boundar
     if taper == "dpss":
         opt["sym"] = False          # mtmconvol.py:110-111
     plan = get_plan(nperseg, nperseg, nchan, taper, opt, nperseg, np.sqrt(2) / nperseg, polyremoval, False,
-                    full_freq_idx(freq_idx, nperseg), output, keeptapers, device, whole_trials=False)
+                    full_freq_idx(freq_idx, nperseg), output, keeptapers, device, whole_trials=False,
+                    float32_frames=not boundary)
     frames = np.asarray(frames, dtype=np.int64)
     lead = nperseg // 2 if boundary else 0
     starts = torch.from_numpy(row0 + soi_start + frames * step - lead).to(device)

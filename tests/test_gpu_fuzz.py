@@ -351,3 +351,83 @@ def test_granger_random_networks(seed):
     assert got.info["converged"]
     np.testing.assert_allclose(got.data, ref.data, atol=5e-2, err_msg=f"seed {seed} {kw}")
     np.testing.assert_allclose(got.data[:, 2:], ref.data[:, 2:], rtol=2e-3, atol=1e-2, err_msg=f"seed {seed} {kw}")
+
+
+@pytest.mark.parametrize("seed", range(16 * SCALE))
+def test_timefrequency_toi_foi_offsets(seed):
+    """mtmconvol / wavelet with time-of-interest arrays (regular and irregular, relative to a trial offset), foi lists,
+    multitaper windows with keeptapers, trial averages of equal-length trials, trials that start before time zero."""
+    rng = np.random.default_rng(8000 + seed)
+    polyremoval = [None, 0, 1][int(rng.integers(0, 3))]
+    nchan = int(rng.choice([1, 2, 5, 8, 17]))
+    ntr = int(rng.integers(2, 5))
+    n = int(rng.choice([300, 512, 1000, 1500, 2048]))
+    x = rng.normal(size=(ntr * n, nchan)).astype(np.float32)
+    if polyremoval is not None:
+        x += (rng.normal(size=nchan) * 20).astype(np.float32)[None, :]
+    pre = int(rng.choice([0, n // 4, n // 2]))                        # samples before time zero
+    trl = np.stack([np.arange(ntr) * n, np.arange(1, ntr + 1) * n, np.full(ntr, -pre)], axis=1)
+    data = spy.AnalogData(x, samplerate=1000.0, trialdefinition=trl)
+    t0, t1 = -pre / 1000.0, (n - pre - 1) / 1000.0
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        toi = "all"
+    elif kind == 1:
+        step = float(rng.choice([0.005, 0.01, 0.05]))
+        toi = np.arange(t0 + 0.02, t1 - 0.02, step)
+    else:
+        toi = np.sort(rng.uniform(t0, t1, size=int(rng.integers(1, 9))))
+    if rng.integers(0, 2):
+        win = int(rng.choice([32, 64, 100, 200, 256]))
+        kw = dict(method="mtmconvol", t_ftimwin=win / 1000.0, toi=toi if kind else float(rng.choice([0.0, 0.5, 0.8])))
+        if rng.integers(0, 2):
+            kw["taper"] = "hann"
+        else:
+            kw["tapsmofrq"] = float(rng.choice([10.0, 20.0]))
+            kw["keeptapers"] = bool(rng.integers(0, 2))
+        kw["output"] = "fourier" if kw.get("keeptapers") else str(rng.choice(["pow", "abs"]))
+        if rng.integers(0, 2):
+            kw["foi"] = np.sort(rng.uniform(5, 450, size=int(rng.integers(1, 7))))
+    else:
+        kw = dict(method="wavelet", wavelet="Morlet", width=float(rng.choice([4, 6, 8])), toi=toi,
+                  foi=np.sort(rng.uniform(8, 350, size=int(rng.integers(1, 7)))), output=str(rng.choice(["pow", "abs", "fourier"])))
+    kw["keeptrials"] = bool(rng.integers(0, 2)) or kw.get("keeptapers", False)
+    kw["polyremoval"] = polyremoval
+    got, ref, exact = _run_both(spy.freqanalysis, data, ORACLE_FREQ, kw)
+    if got is not None:
+        _check(got, ref, exact, f"seed {seed}: {kw} n {n} trials {ntr} ch {nchan} pre {pre}")
+        np.testing.assert_allclose(got.trialdefinition, ref.trialdefinition)
+        np.testing.assert_allclose(got.freq, ref.freq)
+
+
+@pytest.mark.parametrize("seed", range(8 * SCALE))
+def test_corr_and_jackknife_random_options(seed):
+    rng = np.random.default_rng(9000 + seed)
+    polyremoval = [None, 0, 1][int(rng.integers(0, 3))]
+    nchan = int(rng.choice([2, 3, 6, 11]))
+    n = int(rng.choice([100, 257, 500, 1000, 1024]))
+    ntr = int(rng.integers(6, 12))
+    x = rng.normal(size=(ntr * n, nchan)).astype(np.float32)
+    x[:, 1] += 0.5 * np.roll(x[:, 0], 3)                                   # a lagged coupling
+    if polyremoval is not None:
+        x += (rng.normal(size=nchan) * 10).astype(np.float32)[None, :]
+    trl = np.stack([np.arange(ntr) * n, np.arange(1, ntr + 1) * n, np.zeros(ntr)], axis=1)
+    data = spy.AnalogData(x, samplerate=1000.0, trialdefinition=trl)
+    if rng.integers(0, 2):
+        kw = dict(method="corr", keeptrials=bool(rng.integers(0, 2)), polyremoval=polyremoval)
+        got, ref, exact = _run_both(spy.connectivityanalysis, data, ORACLE_CONN, kw)
+        if got is not None:
+            _check(got, ref, exact, f"seed {seed}: {kw} n {n} trials {ntr} ch {nchan}", atol_rel=1e-5)
+        return
+    kw = dict(method="coh", tapsmofrq=float(rng.choice([5.0, 10.0])), jackknife=True, polyremoval=polyremoval,
+              output=str(rng.choice(["abs", "pow"])))
+    got, ref, exact = _run_both(spy.connectivityanalysis, data, ORACLE_CONN, kw)
+    if got is None:
+        return
+    from parity import jackknife_tolerances
+    _check(got, ref, exact, f"seed {seed}: {kw} n {n} trials {ntr} ch {nchan}")
+    if exact is None:                   # (a float32 least-squares fit moves every replicate: compared for 0 / None only)
+        tol_var, tol_bias = jackknife_tolerances(ref.data, ref.jack_var, T=ntr)
+        ev = np.abs(np.asarray(got.jack_var, dtype=np.float64) - ref.jack_var) / tol_var
+        eb = np.abs(np.asarray(got.jack_bias, dtype=np.float64) - ref.jack_bias) / (1e-5 * np.abs(ref.jack_bias) + tol_bias)
+        assert ev.max() <= 1.0 and eb.max() <= 1.0, (seed, kw, float(ev.max()), float(eb.max()))
