@@ -59,6 +59,8 @@ def _check(got, ref, exact, what, atol_rel=ATOL_REL):
     coherent ramp of ~1e-7 of a channel's offset in the data - the bins next to DC of such a channel (and every
     normalised quantity formed there) are made of it.  The kernels fit in float64; `exact` is the oracle with a float64
     fit, |ref - exact| is therefore the reference's rounding, not ours."""
+    if getattr(got, "per_trial_route", None) is not None:
+        _check(got.per_trial_route, ref, exact, what + " [per-trial route]", atol_rel)
     a, b = np.asarray(got.data), np.asarray(ref.data)
     tol = RTOL * np.abs(b) + atol_rel * np.abs(b).max()
     if exact is not None:
@@ -81,6 +83,11 @@ def _run_both(fn, data, classes, kw):
         assert e1 is not None and e2 is not None and type(e1) is type(e2), (kw, repr(e1), repr(e2))
         return None, None, None
     assert got.data.shape == ref.data.shape and got.data.dtype == ref.data.dtype, (kw, got.data.shape, ref.data.shape)
+    # the per-trial route of INTEGRATION.md (B): the reference's own trial loop around the GPU compute functions
+    seq, e3 = call(compute_method="sequential")
+    assert e3 is None, (kw, repr(e3))
+    assert seq.data.shape == ref.data.shape and seq.data.dtype == ref.data.dtype, (kw, seq.data.shape, ref.data.shape)
+    got.per_trial_route = seq
     exact = None
     if kw.get("polyremoval") == 1:
         keep = O.detrend
