@@ -350,6 +350,7 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         }
         if (long_side) {
             const long long tot = (long long)ns * nlong * p->nchan * p->nsig;
+            if ((tot + 255) / 256 > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
             hipLaunchKernelGGL(spyfft::cwt_long_convert_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                                p->ctx->stream, p->stage_long.p, p->lidx.p, nlong, ns, p->nscales, p->nchan, p->nsig,
                                p->output, reinterpret_cast<float*>(p->stage.p));
