@@ -94,7 +94,7 @@ class NormalizeCrossSpectra(_AverageRoutine):
         if 5e-7 * np.sqrt(ratio / nprod) > 1e-6:
             SPYWarning(f"the spectra span {10 * np.log10(ratio):.0f} dB below a channel's mean power over {nprod:.0f} "
                        "trial x taper products: coherence in the weakest bins may deviate from a float64 transform by more "
-                       "than 1e-6; pass precision='reference' (power-of-two lengths up to 4096, e.g. pad='nextpow2') "
+                       "than 1e-6; pass precision='reference' "
                        "for float64 transforms", caller="connectivityanalysis")
 
     def compute_hip(self, data, out):

@@ -29,8 +29,8 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     `precision` (not a reference argument; as in `freqanalysis`): "reference" runs the taper product and the FFT of the
     single-trial spectra in float64 and rounds to complex64 where the reference does (mtmfft.py:96-127) - coherence, ppc
     and Granger are RATIOS of spectra, and where a channel's power is 40 dB or more below its peak the float32
-    transform's absolute error (5e-7 of the rms bin) is no longer small against the bin itself; needs a power-of-two
-    transform length 256 ... 4096 (e.g. pad="nextpow2"), ~2x the time of the transform stage."""
+    transform's absolute error (5e-7 of the rms bin) is no longer small against the bin itself; needs a transform
+    length without a prime factor above 61; ~2x the time of the transform stage at power-of-two lengths 256 ... 4096, more elsewhere."""
     if precision not in ("float32", "reference"):
         raise SPYValueError("'float32' or 'reference'", varname="precision", actual=str(precision))
     if not isinstance(data, (AnalogData, SpectralData)) or data.data is None:

@@ -197,17 +197,7 @@ int plus4(spyhip_ctx* ctx, int L, const cd* g, int F, long long nent, const cd* 
     }
 }
 
-bool plus_plan(int L, spywil::PlusPlan* pl) {
-    pl->L = L;
-    int k = 0, n = L;
-    static const int cand[] = {4, 2, 3, 5, 7, 11, 13};
-    for (int c : cand)
-        while (n % c == 0 && n > 1) { if (k >= spywil::PO_MAXFAC) return false; pl->radix[k++] = c; n /= c; }
-    for (int p = 17; n > 1; p += 2)
-        while (n % p == 0) { if (k >= spywil::PO_MAXFAC) return false; pl->radix[k++] = p; n /= p; }
-    pl->nfac = k;
-    return true;
-}
+using spywil::plus_plan;          // f64_stockham.h
 
 // [g]^+ for nent entries over F rfft bins: the radix-16 LDS kernel for power-of-two lag-domain lengths 256 ... 4096,
 // the generic LDS kernel while two length-L arrays fit LDS, global scratch beyond (any length)

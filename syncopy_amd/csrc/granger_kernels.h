@@ -11,6 +11,7 @@
 // (real(ifft(full)) == irfft(half) exactly).
 #pragma once
 #include "cd_math.h"
+#include "f64_stockham.h"
 
 namespace spywil {
 
@@ -1018,71 +1019,8 @@ __global__ void __launch_bounds__(256) gamma0_kernel(const cd* A, int F, int n, 
 // one workgroup per entry (i,j): half spectrum g[0..F-1] -> conjugate-symmetric sequence of length
 // L = 2(F-1) -> inverse DFT (real) -> halve lag 0 and lag L/2, zero negative lags -> forward DFT.
 // Generic length: Stockham passes with radices 2..16 and O(R^2) butterflies for other primes.
-constexpr int PO_MAXFAC = 24;
-struct PlusPlan {
-    int L, nfac;
-    int radix[PO_MAXFAC];
-};
-
-__device__ __forceinline__ void po_pass(const cd* in, cd* out, int L, int R, int Ns, const cd* tw, int sign, int tid) {
-    // tw[m] = exp(-2 pi i m / L); sign = -1 forward, +1 inverse (conjugated twiddles)
-    const int nb = L / R, tws = L / (Ns * R), wr = L / R;
-    for (int jb = tid; jb < nb; jb += 256) {
-        const int k = jb % Ns;
-        const int base = (jb / Ns) * Ns * R + k;
-        for (int q = 0; q < R; ++q) {
-            cd s = make_double2(0.0, 0.0);
-            for (int r = 0; r < R; ++r) {
-                cd x = in[jb + r * nb];
-                // twiddle exp(-+2 pi i r k / (Ns R)) and DFT kernel exp(-+2 pi i r q / R)
-                long long idx = ((long long)r * k * tws + (long long)((r * q) % R) * wr) % L;
-                cd w = tw[idx];
-                if (sign > 0) w.y = -w.y;
-                s = cadd(s, cmul(x, w));
-            }
-            out[base + q * Ns] = s;
-        }
-    }
-}
-
-// radix-2 / radix-4 Stockham passes with real butterflies (the lag-domain length is a power of two whenever the
-// trial length is): one table twiddle per input instead of the R^2 table products of the generic pass
-template <int R>
-__device__ __forceinline__ void po_pass_r24(const cd* in, cd* out, int L, int Ns, const cd* tw, int sign, int tid) {
-    const int nb = L / R, tws = L / (Ns * R);
-    for (int jb = tid; jb < nb; jb += 256) {
-        const int k = jb % Ns;
-        const int base = (jb / Ns) * Ns * R + k;
-        cd x[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            x[r] = in[jb + r * nb];
-            if (r > 0 && Ns > 1) {
-                cd w = tw[r * k * tws];
-                if (sign > 0) w.y = -w.y;
-                x[r] = cmul(x[r], w);
-            }
-        }
-        if (R == 2) {
-            out[base] = cadd(x[0], x[1]);
-            out[base + Ns] = csub(x[0], x[1]);
-        } else {
-            const cd a0 = cadd(x[0], x[2]), a1 = csub(x[0], x[2]), a2 = cadd(x[1], x[3]), d = csub(x[1], x[3]);
-            // forward: multiply d by -i; inverse: by +i
-            const cd a3 = sign > 0 ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
-            out[base] = cadd(a0, a2);
-            out[base + Ns] = cadd(a1, a3);
-            out[base + 2 * Ns] = csub(a0, a2);
-            out[base + 3 * Ns] = csub(a1, a3);
-        }
-    }
-}
-
-__device__ __forceinline__ void po_pass_any(const cd* in, cd* out, int L, int R, int Ns, const cd* tw, int sign, int tid) {
-    if (R == 4) po_pass_r24<4>(in, out, L, Ns, tw, sign, tid);
-    else if (R == 2) po_pass_r24<2>(in, out, L, Ns, tw, sign, tid);
-    else po_pass(in, out, L, R, Ns, tw, sign, tid);
-}
+// (PlusPlan and the Stockham passes po_pass / po_pass_r24 / po_pass_any: f64_stockham.h, shared with the
+// reference-precision transform of any length)
 
 // body of the plus operator for entry e with the two length-L working arrays a, b (LDS or global scratch)
 __device__ __forceinline__ void plus_entry(const cd* g, int F, size_t fs, long long e, const PlusPlan& pl, const cd* tw, cd* gp,

@@ -15,13 +15,20 @@
 #include "mtmfft_mixed_plan.h"
 
 namespace spyfft {
+}  // namespace spyfft
+#include "f64_stockham.h"     // PlusPlan + plus_plan (the factor schedule of the any-length reference-precision kernel)
+namespace spyfft {
 struct F64Args {              // mtmfft_f64_kernel.h (kept out of this translation unit: it pulls in the Wilson kernels)
     MtmArgs m;
     const double* tapers64;
     const double2* tw64;
     double scale64;
+    spywil::PlusPlan plan;
+    double2* work;
+    long long wg0;
 };
 int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean);
+int f64_any_launch(hipStream_t stream, F64Args a, long long grid, long long chunk, int outk, bool mean);
 int dec_launch_a(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_b(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_c(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
@@ -65,6 +72,10 @@ struct spyhip_fft_plan {
     bool identity_freq = true;
     bool blocked = false;
     bool precision64 = false;   // float64 taper product + FFT, complex64 rounding where the reference rounds (mtmfft_f64_kernel.h)
+    bool f64_any = false;       // ... through the any-length kernel (work arrays in global memory)
+    spywil::PlusPlan f64_plan{};
+    spy::DevBuf<double2> f64_work;
+    long long f64_chunk = 0;
     spy::DevBuf<double> tapers64;
     spy::DevBuf<double2> tw64;
     std::string fp32_kernel_name;
@@ -495,10 +506,23 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
         p->precision64 = false;
         return 0;
     }
-    if (!(p->pow2 && p->log2n >= 8 && p->log2n <= 12) || p->blocked) {
-        spy::set_error("fft_plan_set_precision: the reference-precision kernel serves power-of-two nfft 256 ... 4096 in "
-                       "the standard layout (nfft = %d)", p->nfft);
+    if (p->blocked) {
+        spy::set_error("fft_plan_set_precision: the reference-precision kernels write the standard layout");
         return -3;
+    }
+    p->f64_any = !(p->pow2 && p->log2n >= 8 && p->log2n <= 12);
+    if (p->f64_any) {
+        // any other length: generic Stockham passes over work arrays in global memory; the O(R^2) pass of a prime
+        // factor R is only reasonable for small R
+        int big = 1;
+        if (p->nfft < 2 || p->nfft > (1 << 20) || !spywil::plus_plan(p->nfft, &p->f64_plan)) big = 1 << 30;
+        else for (int i = 0; i < p->f64_plan.nfac; ++i) big = std::max(big, p->f64_plan.radix[i]);
+        if (big > 61) {
+            spy::set_error("fft_plan_set_precision: the reference-precision kernels serve transform lengths up to 2^20 "
+                           "whose prime factors are at most 61 (nfft = %d)", p->nfft);
+            p->f64_any = false;
+            return -3;
+        }
     }
     if (!p->tw64.p) {
         std::vector<double2> t(p->nfft);
@@ -512,8 +536,13 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
     if (!p->precision64) p->fp32_kernel_name = p->kernel_name;
     p->precision64 = true;
     char buf[96];
-    std::snprintf(buf, sizeof buf, "mtmfft_f64_kernel<%d, %d, %s>", p->log2n,
-                  p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
+    if (p->f64_any)
+        std::snprintf(buf, sizeof buf, "mtmfft_f64_any_kernel<%d, %s> N=%d",
+                      p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true",
+                      p->nfft);
+    else
+        std::snprintf(buf, sizeof buf, "mtmfft_f64_kernel<%d, %d, %s>", p->log2n,
+                      p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
     p->kernel_name = buf;
     return 0;
 }
@@ -573,6 +602,21 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         fa.tw64 = p->tw64.p;
         fa.scale64 = (double)p->scale;
         const long long grid = (long long)nseg * npairs;
+        if (p->f64_any) {
+            // two length-nfft complex128 work arrays per workgroup: launches of at most 1 GiB of them
+            const size_t per = (size_t)2 * p->nfft * sizeof(double2);
+            long long chunk = std::max<long long>(p->ctx->num_cu, ((size_t)1 << 30) / per);
+            if (chunk > grid) chunk = grid;
+            if (chunk > p->f64_chunk) {
+                if (p->f64_work.p) { SPY_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); (void)hipFree(p->f64_work.p); p->f64_work.p = nullptr; }
+                if (p->f64_work.alloc((size_t)chunk * 2 * p->nfft)) return -2;
+                p->f64_chunk = chunk;
+            }
+            fa.plan = p->f64_plan;
+            fa.work = p->f64_work.p;
+            return spyfft::f64_any_launch(p->ctx->stream, fa, grid, p->f64_chunk,
+                                          p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), !p->keeptapers);
+        }
         if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
         return spyfft::f64_launch(p->ctx->stream, fa, p->log2n, (unsigned)grid,
                                   p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), !p->keeptapers);

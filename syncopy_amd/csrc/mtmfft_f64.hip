@@ -1,4 +1,6 @@
 // Launchers of the reference-precision tapered FFT (mtmfft_f64_kernel.h); its own translation unit.
+#include <algorithm>
+
 #include "spy_common.h"
 #include "mtmfft_f64_kernel.h"
 
@@ -36,6 +38,32 @@ int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, i
         case 12: return f64_launch_mode<12>(stream, a, grid, outk, mean);
         default: spy::set_error("reference-precision FFT: power-of-two lengths 256 ... 4096 only (got 2^%d)", log2n); return -3;
     }
+}
+
+template <int OUTK, bool MEAN>
+static int f64_any_launch_one(hipStream_t stream, const F64Args& a, unsigned grid) {
+    hipLaunchKernelGGL((mtmfft_f64_any_kernel<OUTK, MEAN>), dim3(grid), dim3(256), 0, stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// `work` holds 2 * nfft complex128 per workgroup for `chunk` workgroups: the grid goes in launches of that many
+int f64_any_launch(hipStream_t stream, F64Args a, long long grid, long long chunk, int outk, bool mean) {
+    for (long long w0 = 0; w0 < grid; w0 += chunk) {
+        a.wg0 = w0;
+        const unsigned g = (unsigned)std::min(chunk, grid - w0);
+        int rc;
+        switch (outk * 2 + (mean ? 1 : 0)) {
+            case 0: rc = f64_any_launch_one<0, false>(stream, a, g); break;
+            case 1: rc = f64_any_launch_one<0, true>(stream, a, g); break;
+            case 2: rc = f64_any_launch_one<1, false>(stream, a, g); break;
+            case 3: rc = f64_any_launch_one<1, true>(stream, a, g); break;
+            case 4: rc = f64_any_launch_one<2, false>(stream, a, g); break;
+            default: rc = f64_any_launch_one<2, true>(stream, a, g); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 }  // namespace spyfft

@@ -11,6 +11,7 @@
 // afterwards: X(c0)[f] = (Z[f] + conj(Z[N-f]))/2, X(c1)[f] = (Z[f] - conj(Z[N-f]))/(2i).
 #pragma once
 #include "cd_math.h"
+#include "f64_stockham.h"
 #include "wilson_plus_kernel.h"
 #include "mtmfft_kernel.h"
 
@@ -21,6 +22,11 @@ struct F64Args {
     const double* tapers64;      // (ntaper x nsig) float64: the reference's windows, not rounded to float32
     const double2* tw64;         // exp(-2 pi i m / nfft)
     double scale64;              // unused by the arithmetic (the float32 m.scale multiplies, as in the reference)
+    // any-length variant (mtmfft_f64_any_kernel): factor schedule, two length-nfft work arrays per workgroup, first
+    // work item of this launch
+    spywil::PlusPlan plan;
+    double2* work;
+    long long wg0;
 };
 
 // sum of NS doubles over the workgroup (T threads), broadcast; scratch = LDS (free at that point); two barriers
@@ -227,6 +233,135 @@ __global__ void __launch_bounds__((spywil::PCfg<LOG2N>::T)) mtmfft_f64_kernel(F6
                 if (has1) *reinterpret_cast<float*>(slab + o + 4) = macc1[e] / nt;
             }
         }
+    }
+}
+
+// The same transform for ANY length the radix-16 register kernel does not serve (2000, 5000, 16384, 3000 ...): one
+// workgroup of 256 threads per (segment, channel pair), the complex128 sequence in two length-nfft work arrays in
+// global memory (L2-resident while the workgroup owns them), generic Stockham passes (f64_stockham.h: radix 2 / 4
+// butterflies, O(R^2) passes for the other prime factors).  Identical rounding points; the taper mean accumulates in
+// the output slab in float32 in taper order and is divided once, as the register kernel's accumulators are.  Speed is
+// not the point of this kernel (10-30 x the float32 kernels): it exists so that precision="reference" is not limited to
+// power-of-two lengths up to 4096.
+template <int OUTK, bool MEAN>
+__global__ void __launch_bounds__(256) mtmfft_f64_any_kernel(F64Args fa) {
+    using spywil::cd;
+    constexpr bool CPLX = (OUTK == 2);
+    const MtmArgs& a = fa.m;
+    __shared__ double red[32];
+    const int N = fa.plan.L, tid = threadIdx.x;
+    const long long wg = fa.wg0 + blockIdx.x;
+    const int npair = (a.nchan + 1) / 2;
+    const int b = (int)(wg / npair), p = (int)(wg % npair);
+    const int c0 = 2 * p;
+    const bool has1 = c0 + 1 < a.nchan;
+    const unsigned col0 = (unsigned)(a.chan_idx ? a.chan_idx[c0] : c0);
+    const unsigned col1 = has1 ? (unsigned)(a.chan_idx ? a.chan_idx[c0 + 1] : c0 + 1) : 0u;
+    const long long start = a.seg_start[b];
+    const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
+    const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
+    const int rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
+    const float* seg = a.data + start * a.ld;
+    cd* A = reinterpret_cast<cd*>(fa.work) + (size_t)blockIdx.x * 2 * (size_t)N;
+    cd* B = A + N;
+
+    // ---- polynomial removal in float32, exactly as the register kernel above
+    float m0 = 0.f, m1 = 0.f;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const float mid = 0.5f * (float)(a.nsig - 1);
+    const bool fit = !(a.detrend == 0 && a.means) && a.detrend >= 0;
+    if (a.detrend == 0 && a.means) {
+        m0 = a.means[(size_t)b * a.nchan + c0];
+        m1 = has1 ? a.means[(size_t)b * a.nchan + c0 + 1] : 0.f;
+    } else if (fit) {
+        for (int n = tid; n < a.nsig; n += 256) {
+            const bool ok = (n >= rlo) && (n < rhi);
+            const float x0 = ok ? seg[(size_t)n * a.ld + col0] : 0.f;
+            const float x1 = (ok && has1) ? seg[(size_t)n * a.ld + col1] : 0.f;
+            s[0] += (double)x0;
+            s[1] += (double)x1;
+            if (a.detrend == 1) {
+                const double dn = (double)((float)n - mid);
+                s[2] += dn * x0;
+                s[3] += dn * x1;
+            }
+        }
+        f64_block_sum<4, 256>(s, red, tid);
+    }
+    const double inv = 1.0 / a.nsig;
+    const double den = (a.detrend == 1 && a.nsig > 1) ? 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0)) : 0.0;
+
+    const int kout = MEAN ? 1 : a.ntaper;
+    constexpr unsigned OSZ = CPLX ? 8u : 4u;
+    const int nf = N / 2 + 1;
+    for (int k = 0; k < a.ntaper; ++k) {
+        const double* w = fa.tapers64 + (size_t)k * a.nsig;
+        double ds[2] = {0.0, 0.0};
+        for (int n = tid; n < N; n += 256) {
+            cd v = make_double2(0.0, 0.0);
+            if (n < a.nsig) {
+                const bool ok = (n >= rlo) && (n < rhi);
+                float x0 = ok ? seg[(size_t)n * a.ld + col0] : 0.f;
+                float x1 = (ok && has1) ? seg[(size_t)n * a.ld + col1] : 0.f;
+                if (fit) {
+                    const double dn = (double)((float)n - mid);
+                    x0 -= (float)(s[0] * inv + s[2] * den * dn);
+                    x1 -= (float)(s[1] * inv + s[3] * den * dn);
+                } else {
+                    x0 -= m0;
+                    x1 -= m1;
+                }
+                v = make_double2(w[n] * (double)x0, w[n] * (double)x1);          // win *= data_arr (float64)
+                ds[0] += v.x;
+                ds[1] += v.y;
+            }
+            A[n] = v;
+        }
+        if (a.demean_taper) {                                                      // win -= win.mean(axis=0) (float64)
+            f64_block_sum<2, 256>(ds, red, tid);
+            const double d0 = ds[0] / a.nsig, d1 = ds[1] / a.nsig;
+            for (int n = tid; n < a.nsig; n += 256) A[n] = make_double2(A[n].x - d0, A[n].y - d1);
+        }
+        __syncthreads();
+        cd *src = A, *dst = B;
+        int Ns = 1;
+        for (int q = 0; q < fa.plan.nfac; ++q) {
+            spywil::po_pass_any(src, dst, N, fa.plan.radix[q], Ns, reinterpret_cast<const cd*>(fa.tw64), -1, tid);
+            __syncthreads();
+            Ns *= fa.plan.radix[q];
+            cd* t = src; src = dst; dst = t;
+        }
+        char* const slab = reinterpret_cast<char*>(a.out) +
+                           ((size_t)b * kout + (MEAN ? 0 : k)) * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
+        const float nt = (float)a.ntaper;
+        for (int f = tid; f < nf; f += 256) {
+            const cd z = src[f];
+            const cd zp = f == 0 ? z : src[N - f];
+            const cd X0 = make_double2(0.5 * (z.x + zp.x), 0.5 * (z.y - zp.y));
+            const cd X1 = make_double2(0.5 * (z.y + zp.y), 0.5 * (zp.x - z.x));
+            const float2 s0 = make_float2(__fmul_rn((float)X0.x, a.scale), __fmul_rn((float)X0.y, a.scale));
+            const float2 s1 = make_float2(__fmul_rn((float)X1.x, a.scale), __fmul_rn((float)X1.y, a.scale));
+            const int fi = a.fpos ? a.fpos[f] : f;
+            if (fi < 0) continue;
+            const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;
+            const bool first = !MEAN || k == 0, last = MEAN && k == a.ntaper - 1;
+            if (CPLX) {
+                float2* q0 = reinterpret_cast<float2*>(slab + o);
+                float2 v0 = s0, v1 = s1;
+                if (!first) { v0.x += q0[0].x; v0.y += q0[0].y; if (has1) { v1.x += q0[1].x; v1.y += q0[1].y; } }
+                if (last) { v0.x /= nt; v0.y /= nt; v1.x /= nt; v1.y /= nt; }
+                q0[0] = v0;
+                if (has1) q0[1] = v1;
+            } else {
+                float* q0 = reinterpret_cast<float*>(slab + o);
+                float v0 = convert_real<OUTK>(s0, a.out_kind), v1 = convert_real<OUTK>(s1, a.out_kind);
+                if (!first) { v0 += q0[0]; if (has1) v1 += q0[1]; }
+                if (last) { v0 /= nt; v1 /= nt; }
+                q0[0] = v0;
+                if (has1) q0[1] = v1;
+            }
+        }
+        __syncthreads();          // the work arrays are rewritten by the next taper
     }
 }
 

@@ -40,7 +40,7 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
     `precision` (not a reference argument): "float32" (default) transforms in float32 - ~1e-7 of a channel's largest
     bin; "reference" runs the taper product and the FFT in float64 and rounds to complex64 where the reference does
     (mtmfft.py:96-127): every bin to 1e-5 of itself, ~5x the time; methods 'mtmfft' / 'mtmconvol' / 'welch' with a
-    power-of-two transform length 256 ... 4096 (e.g. pad='nextpow2')."""
+    transform length without a prime factor above 61 (power-of-two lengths 256 ... 4096 are the fast case)."""
     if precision not in ("float32", "reference"):
         raise SPYValueError("'float32' or 'reference'", varname="precision", actual=str(precision))
     if precision == "reference" and method not in ("mtmfft", "mtmconvol", "welch"):

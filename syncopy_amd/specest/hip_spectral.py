@@ -73,8 +73,9 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
                                reference_mean=(whole_trials or float32_frames) and detrend == 0)
         if _precision[-1] == "reference":
             if not plan.set_precision(True):
-                raise SPYValueError("a power-of-two transform length 256 ... 4096 (e.g. pad='nextpow2') for "
-                                    "precision='reference'", varname="precision", actual=f"nfft = {int(nfft)}")
+                raise SPYValueError("a transform length up to 2^20 without a prime factor above 61 (e.g. "
+                                    "pad='nextpow2') for precision='reference'", varname="precision",
+                                    actual=f"nfft = {int(nfft)}")
         elif blocked:
             plan.set_blocked(True)
         _bounded_put(_plan_cache, key, plan)

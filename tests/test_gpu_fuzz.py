@@ -442,3 +442,29 @@ def test_corr_and_jackknife_random_options(seed):
         ev = np.abs(np.asarray(got.jack_var, dtype=np.float64) - ref.jack_var) / tol_var
         eb = np.abs(np.asarray(got.jack_bias, dtype=np.float64) - ref.jack_bias) / (1e-5 * np.abs(ref.jack_bias) + tol_bias)
         assert ev.max() <= 1.0 and eb.max() <= 1.0, (seed, kw, float(ev.max()), float(eb.max()))
+
+
+@pytest.mark.parametrize("seed", range(12 * SCALE))
+def test_reference_precision_random_lengths(seed):
+    """precision="reference" (float64 taper product and transform, complex64 rounding where mtmfft.py:104-127 rounds) at
+    random lengths - powers of two (radix-16 register kernel up to 4096) and anything else without a prime factor above 61
+    (generic Stockham passes) - on data with 60 dB of dynamic range: the criterion everywhere, and bin by bin PURE
+    rtol 1e-5 on at least 99 % of the bins, which the float32 kernels cannot give (~5 % there)."""
+    rng = np.random.default_rng(10000 + seed)
+    n = int(rng.choice([100, 250, 256, 360, 500, 729, 1000, 1024, 1500, 2000, 2048, 2500, 3000, 4096, 5000, 6000, 8192]))
+    nchan, ntr = int(rng.choice([1, 2, 3, 8])), int(rng.integers(1, 4))
+    t = np.arange(n * ntr) / 1000.0
+    x = rng.normal(size=(n * ntr, nchan)) + 1000.0 * np.sin(2 * np.pi * 40.0 * t)[:, None] + 50.0
+    trl = np.stack([np.arange(ntr) * n, np.arange(1, ntr + 1) * n, np.zeros(ntr)], axis=1)
+    data = spy.AnalogData(x.astype(np.float32), samplerate=1000.0, trialdefinition=trl)
+    kw = dict(method="mtmfft", output="fourier", keeptapers=True, keeptrials=True, polyremoval=0)
+    if rng.integers(0, 2):
+        kw["taper"] = "hann"
+    else:
+        kw["tapsmofrq"] = float(rng.choice([3.0, 8.0]))
+    got = spy.freqanalysis(data, precision="reference", **kw)
+    ref = spy.freqanalysis(data, compute_method="sequential", routine_classes=ORACLE_FREQ, **kw)
+    _check(got, ref, None, f"seed {seed}: n {n} ch {nchan} {kw}")
+    err = np.abs(got.data.astype(np.complex128) - ref.data)
+    frac = float((err <= 1e-5 * np.abs(ref.data)).mean())
+    assert frac >= 0.99, (seed, n, frac)

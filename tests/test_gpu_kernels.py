@@ -488,7 +488,16 @@ def test_reference_precision_resolves_60dB(be):
                                   dict(nsig=256, nfft=256, K=2, output="abs", keeptapers=True, detrend=-1, nchan=3,
                                        demean=True),
                                   dict(nsig=2048, nfft=2048, K=4, output="fourier", keeptapers=False, detrend=0, nchan=2,
-                                       freq_idx=[0, 5, 1024, 77])])
+                                       freq_idx=[0, 5, 1024, 77]),
+                                  # any other length: the generic Stockham kernel on work arrays in global memory
+                                  dict(nsig=2000, nfft=2000, K=7, output="pow", keeptapers=False, detrend=0, nchan=5),
+                                  dict(nsig=5000, nfft=5000, K=3, output="fourier", keeptapers=True, detrend=1, nchan=3),
+                                  dict(nsig=1001, nfft=1001, K=2, output="abs", keeptapers=True, detrend=-1, nchan=2,
+                                       demean=True),                                   # odd: 7 x 11 x 13
+                                  dict(nsig=3000, nfft=4500, K=3, output="fourier", keeptapers=False, detrend=0, nchan=4,
+                                       freq_idx=[0, 9, 2250, 300]),
+                                  dict(nsig=10000, nfft=16384, K=2, output="pow", keeptapers=True, detrend=0, nchan=3),
+                                  dict(nsig=100, nfft=100, K=2, output="fourier", keeptapers=True, detrend=0, nchan=1)])
 def test_reference_precision_options(be, case):
     """Every option of the plan through the float64 kernel: padding, detrending modes, demean_taper, taper mean,
     conversions, frequency selection, odd channel counts - vs the oracle, which now agrees to complex64 rounding."""
@@ -513,7 +522,8 @@ def test_reference_precision_options(be, case):
     if case["output"] == "fourier":
         # bin by bin to complex64 rounding (the float32 scale multiplies rounded values on both sides)
         err = np.abs(got.astype(np.complex128) - ref[0])
-        rt = 1e-5 if case["detrend"] == 1 else 4e-7           # (the line fit: the reference's own float32 lstsq noise)
+        # (the line fit: the reference's own float32 lstsq noise; a taper mean adds K - 1 float32 additions and a division)
+        rt = 1e-5 if case["detrend"] == 1 else (4e-7 if case["keeptapers"] else 1e-6)
         assert np.all(err <= rt * np.abs(ref[0]) + 1e-12 * np.abs(ref[0]).max()), float((err / np.abs(ref[0])).max())
 
 
@@ -526,8 +536,14 @@ def test_reference_precision_through_freqanalysis():
     ref, _ = O.mtmfft(O.detrend(x.copy(), 0), 1000.0, 4096, "hann", {})
     err = np.abs(a.data[0].astype(np.complex128) - ref)
     assert (err <= 1e-5 * np.abs(ref)).mean() >= 0.99
+    # 2000 samples: the any-length float64 kernel; 4099 is prime (a factor above 61): refused
+    b = spy.freqanalysis(spy.AnalogData(x[:2000], samplerate=1000.0), method="mtmfft", taper="hann", output="fourier",
+                         precision="reference")
+    ref, _ = O.mtmfft(O.detrend(x[:2000].copy(), 0), 1000.0, 2000, "hann", {})
+    err = np.abs(b.data[0].astype(np.complex128) - ref)
+    assert (err <= 1e-5 * np.abs(ref)).mean() >= 0.99
     with pytest.raises(SPYValueError):
-        spy.freqanalysis(spy.AnalogData(x[:2000], samplerate=1000.0), method="mtmfft", precision="reference")
+        spy.freqanalysis(spy.AnalogData(np.tile(x, (2, 1))[:4099], samplerate=1000.0), method="mtmfft", precision="reference")
     with pytest.raises(SPYValueError):
         spy.freqanalysis(data, method="wavelet", precision="reference")
 
@@ -559,4 +575,4 @@ def test_reference_precision_through_connectivityanalysis():
     assert e_exact <= 1.0, e_exact
     assert e_fast > e_exact
     with pytest.raises(Exception):
-        spy.connectivityanalysis(data, precision="reference", pad=3.0, **kw)        # 3000 samples: not a power of two
+        spy.connectivityanalysis(data, precision="reference", pad=3.001, **kw)      # 3001 samples: a prime above 61
