@@ -548,7 +548,8 @@ def test_reference_precision_through_freqanalysis():
         spy.freqanalysis(data, method="wavelet", precision="reference")
 
 
-def test_reference_precision_through_connectivityanalysis():
+@pytest.mark.parametrize("nsamp", [2048, 2000])
+def test_reference_precision_through_connectivityanalysis(nsamp):
     """Coherence is a ratio of spectra: with a line 60 dB above the noise floor in every channel the float32
     transform's absolute error (5e-7 of the rms bin, i.e. of the line) is ~1e-3 of the noise bins the coherence away
     from the line is made of - outside the criterion; precision="reference" (float64 transform, complex64 rounding
@@ -557,7 +558,7 @@ def test_reference_precision_through_connectivityanalysis():
     from oracle_routines import ORACLE_CONN
     from parity import excess
     rng = np.random.default_rng(3)
-    nsamp, ntr, nchan = 2048, 12, 6
+    ntr, nchan = 12, 6              # (2048: the radix-16 float64 kernel; 2000: the any-length one)
     t = np.arange(nsamp * ntr) / 1000.0
     x = rng.normal(size=(nsamp * ntr, nchan)) + 1000.0 * np.sin(2 * np.pi * 50.0 * t)[:, None] * rng.uniform(0.5, 1.5, size=nchan)
     trl = np.stack([np.arange(ntr) * nsamp, np.arange(1, ntr + 1) * nsamp, np.zeros(ntr)], axis=1)
