@@ -66,9 +66,66 @@ __device__ __forceinline__ void po_pass_r24(const cd* in, cd* out, int L, int Ns
     }
 }
 
+// radix-3 / 5 / 7 passes: one table twiddle per input and the R x R DFT kernel from compile-time constants (the
+// generic pass fetches R^2 table products per butterfly through a 64-bit modulo) - the decimal trial lengths of the
+// plus operator (5000 samples = 2^3 5^4) and of the reference-precision transform (2000, 5000 ...)
+template <int R> struct DftConst;
+template <> struct DftConst<3> {
+    static constexpr double c[3] = {1.0, -0.5, -0.5};
+    static constexpr double s[3] = {0.0, 0.86602540378443864676, -0.86602540378443864676};
+};
+template <> struct DftConst<5> {
+    static constexpr double c[5] = {1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410,
+                                    0.30901699437494742410};
+    static constexpr double s[5] = {0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917,
+                                    -0.95105651629515357212};
+};
+template <> struct DftConst<7> {
+    static constexpr double c[7] = {1.0, 0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624,
+                                    -0.90096886790241912624, -0.22252093395631440429, 0.62348980185873353053};
+    static constexpr double s[7] = {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048,
+                                    -0.43388373911755812048, -0.97492791218182360702, -0.78183148246802980871};
+};
+
+template <int R>
+__device__ __forceinline__ void po_pass_small(const cd* in, cd* out, int L, int Ns, const cd* tw, int sign, int tid) {
+    const int nb = L / R, tws = L / (Ns * R);
+    const double sg = sign > 0 ? 1.0 : -1.0;            // exp(sign 2 pi i m / R) = c[m] + i sign s[m]
+    for (int jb = tid; jb < nb; jb += 256) {
+        const int k = jb % Ns;
+        const int base = (jb / Ns) * Ns * R + k;
+        cd x[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            x[r] = in[jb + r * nb];
+            if (r > 0 && Ns > 1) {
+                cd w = tw[r * k * tws];
+                if (sign > 0) w.y = -w.y;
+                x[r] = cmul(x[r], w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            cd acc = x[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                constexpr int dummy = 0; (void)dummy;
+                const int m = (r * q) % R;
+                const double wr = DftConst<R>::c[m], wi = sg * DftConst<R>::s[m];
+                acc.x += x[r].x * wr - x[r].y * wi;
+                acc.y += x[r].x * wi + x[r].y * wr;
+            }
+            out[base + q * Ns] = acc;
+        }
+    }
+}
+
 __device__ __forceinline__ void po_pass_any(const cd* in, cd* out, int L, int R, int Ns, const cd* tw, int sign, int tid) {
     if (R == 4) po_pass_r24<4>(in, out, L, Ns, tw, sign, tid);
     else if (R == 2) po_pass_r24<2>(in, out, L, Ns, tw, sign, tid);
+    else if (R == 5) po_pass_small<5>(in, out, L, Ns, tw, sign, tid);
+    else if (R == 3) po_pass_small<3>(in, out, L, Ns, tw, sign, tid);
+    else if (R == 7) po_pass_small<7>(in, out, L, Ns, tw, sign, tid);
     else po_pass(in, out, L, R, Ns, tw, sign, tid);
 }
 
