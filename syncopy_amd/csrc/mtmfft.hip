@@ -583,12 +583,13 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             if (p->means.alloc(need)) return -2;
             p->means_cap = need;
         }
-        const int ncb = (p->nchan + 63) / 64;
+        const int bt = std::min(256, ((p->nchan + 63) / 64) * 64);      // threads per workgroup: whole waves, up to four
+        const int ncb = (p->nchan + bt - 1) / bt;
         for (int s0 = 0; s0 < nseg; s0 += 65535) {
             MtmArgs m = a;
             m.seg_start += s0; m.seg_lo += s0; m.seg_hi += s0;
             const int ns = std::min(65535, nseg - s0);
-            hipLaunchKernelGGL(spyfft::seq_mean_kernel, dim3(ncb, ns), dim3(64), 0, p->ctx->stream, m,
+            hipLaunchKernelGGL(spyfft::seq_mean_kernel, dim3(ncb, ns), dim3(bt), 0, p->ctx->stream, m,
                                p->means.p + (size_t)s0 * p->nchan);
         }
         SPY_HIP_CHECK(hipGetLastError());

@@ -93,8 +93,8 @@ __device__ inline float np_pairwise_rows(const float* p, long long ld, int i0, i
     return __fadd_rn(np_pairwise_rows(p, ld, i0, n2, rlo, rhi), np_pairwise_rows(p, ld, i0 + n2, n - n2, rlo, rhi));
 }
 
-static __global__ void __launch_bounds__(64) seq_mean_kernel(MtmArgs a, float* means) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+static __global__ void __launch_bounds__(256) seq_mean_kernel(MtmArgs a, float* means) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;      // (up to 256 adjacent channels per workgroup: whole 1-KiB rows)
     const int b = blockIdx.y;
     if (c >= a.nchan) return;
     const long long col = a.chan_idx ? a.chan_idx[c] : c;
