@@ -151,8 +151,8 @@ int spyhip_fft_plan_set_blocked(spyhip_fft_plan* plan, int on);
  * product and float64 FFT, the spectrum rounded to complex64 and scaled in float32 exactly where
  * specest/mtmfft.py:104-127 does it - every bin to ~1e-7 of ITSELF (pure rtol 1e-5 also 60 dB below the peak), at
  * about twice the cost for power-of-two nfft 256 ... 4096 (radix-16 register kernel); every other nfft up to 2^20
- * without a prime factor above 61 runs generic Stockham passes over work arrays in global memory (10-30 x the cost:
- * there for the precision, not the speed); standard layout; -3 otherwise. */
+ * without a prime factor above 61 runs generic Stockham passes over work arrays in LDS (nfft <= 5120: ~8 x the cost)
+ * or global memory (10-14 x: there for the precision, not the speed); standard layout; -3 otherwise. */
 int spyhip_fft_plan_set_precision(spyhip_fft_plan* plan, int reference);
 /* Constant detrending (detrend = SPYHIP_DETREND_CONSTANT) with the per-channel mean taken EXACTLY as the reference
  * takes it for whole trials: scipy.signal.detrend on the float32 (time x channel) array is data - np.mean(data, 0),

@@ -604,8 +604,16 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         fa.scale64 = (double)p->scale;
         const long long grid = (long long)nseg * npairs;
         if (p->f64_any) {
-            // two length-nfft complex128 work arrays per workgroup: launches of at most 1 GiB of them
+            // two length-nfft complex128 work arrays per workgroup: in LDS while they fit (leaving room for the static
+            // reduction scratch), else in global memory, launches of at most 1 GiB of them
             const size_t per = (size_t)2 * p->nfft * sizeof(double2);
+            fa.plan = p->f64_plan;
+            if (per + 1024 <= (size_t)p->ctx->lds_per_block) {
+                fa.work = nullptr;
+                if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
+                return spyfft::f64_any_launch(p->ctx->stream, fa, grid, grid,
+                                              p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), !p->keeptapers);
+            }
             long long chunk = std::max<long long>(p->ctx->num_cu, ((size_t)1 << 30) / per);
             if (chunk > grid) chunk = grid;
             if (chunk > p->f64_chunk) {
@@ -613,7 +621,6 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
                 if (p->f64_work.alloc((size_t)chunk * 2 * p->nfft)) return -2;
                 p->f64_chunk = chunk;
             }
-            fa.plan = p->f64_plan;
             fa.work = p->f64_work.p;
             return spyfft::f64_any_launch(p->ctx->stream, fa, grid, p->f64_chunk,
                                           p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), !p->keeptapers);

@@ -262,7 +262,10 @@ __global__ void __launch_bounds__(256) mtmfft_f64_any_kernel(F64Args fa) {
     const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
     const int rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
     const float* seg = a.data + start * a.ld;
-    cd* A = reinterpret_cast<cd*>(fa.work) + (size_t)blockIdx.x * 2 * (size_t)N;
+    // the two work arrays: LDS while they fit (nfft <= 5120: launched with 32 nfft bytes of dynamic LDS and work =
+    // nullptr), global memory beyond
+    SPY_DYN_SMEM(cd, ldsbuf);
+    cd* A = fa.work ? reinterpret_cast<cd*>(fa.work) + (size_t)blockIdx.x * 2 * (size_t)N : ldsbuf;
     cd* B = A + N;
 
     // ---- polynomial removal in float32, exactly as the register kernel above
