@@ -92,10 +92,13 @@ class NormalizeCrossSpectra(_AverageRoutine):
         ratio = float((diag.mean(dim=0) / diag.amin(dim=0).clamp_min(1e-38)).max())
         nprod = 1.0 / scale
         if 5e-7 * np.sqrt(ratio / nprod) > 1e-6:
+            if hs._advice is not None:            # precision="auto": the front end repeats the call in float64
+                hs._advice.append((ratio, nprod))
+                return
             SPYWarning(f"the spectra span {10 * np.log10(ratio):.0f} dB below a channel's mean power over {nprod:.0f} "
                        "trial x taper products: coherence in the weakest bins may deviate from a float64 transform by more "
-                       "than 1e-6; pass precision='reference' "
-                       "for float64 transforms", caller="connectivityanalysis")
+                       "than 1e-6; pass precision='reference' (or leave the default 'auto') for float64 transforms",
+                       caller="connectivityanalysis")
 
     def compute_hip(self, data, out):
         raw = getattr(data, "_acc_raw", None)

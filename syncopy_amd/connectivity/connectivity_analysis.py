@@ -22,7 +22,7 @@ from .ST_compRoutines import CrossCovariance, CrossSpectra, SpectralDyadicProduc
 @unwrap_cfg
 def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi=None, foilim=None, pad="maxperlen",
                          polyremoval=0, tapsmofrq=None, nTaper=None, taper="hann", taper_opt=None, jackknife=False,
-                         channelcmb=None, select=None, compute_method=None, routine_classes=None, precision="float32",
+                         channelcmb=None, select=None, compute_method=None, routine_classes=None, precision="auto",
                          **kwargs):
     """Cross-spectral connectivity of AnalogData on MI355X (arguments as spy.connectivityanalysis,
     connectivity_analysis.py:51-67).
@@ -30,9 +30,13 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     single-trial spectra in float64 and rounds to complex64 where the reference does (mtmfft.py:96-127) - coherence, ppc
     and Granger are RATIOS of spectra, and where a channel's power is 40 dB or more below its peak the float32
     transform's absolute error (5e-7 of the rms bin) is no longer small against the bin itself; needs a transform
-    length without a prime factor above 61; ~2x the time of the transform stage at power-of-two lengths 256 ... 4096, more elsewhere."""
-    if precision not in ("float32", "reference"):
-        raise SPYValueError("'float32' or 'reference'", varname="precision", actual=str(precision))
+    length without a prime factor above 61; ~2x the time of the transform stage at power-of-two lengths 256 ... 4096, more
+    elsewhere.  "float32": the fast kernels whatever the data.  "auto" (default): float32, and for method="coh" on the
+    device route the call is repeated in float64 when the accumulated auto-spectra show that the float32 error in the
+    coherence would pass 1e-6 (more dynamic range than ~4 x the number of trial x taper products; the benchmark's AR(2)
+    data never triggers it)."""
+    if precision not in ("float32", "reference", "auto"):
+        raise SPYValueError("'float32', 'reference' or 'auto'", varname="precision", actual=str(precision))
     if not isinstance(data, (AnalogData, SpectralData)) or data.data is None:
         raise SPYValueError("either AnalogData or SpectralData as input", "data", data.__class__.__name__)
     if method not in connectivityMethods:
@@ -55,13 +59,33 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     classes.update(routine_classes or {})
     with attached_selection(data, select):
         cmb = _parse_channelcmb(data, channelcmb)
+        from ..specest import hip_spectral as hs
+
+        def run():
+            return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
+                                 nTaper, taper, taper_opt, compute_method, jackknife, cmb)
         if precision == "reference":
-            from ..specest import hip_spectral as hs
             with hs.precision("reference"):
-                return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
-                                     nTaper, taper, taper_opt, compute_method, jackknife, cmb)
-        return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
-                             nTaper, taper, taper_opt, compute_method, jackknife, cmb)
+                return run()
+        if precision == "float32" or method != "coh":
+            return run()
+        # "auto": the float32 attempt reports through hs._advice whether the data ask for float64 transforms
+        hs._advice = []
+        try:
+            res = run()
+            asked = bool(hs._advice)
+        finally:
+            hs._advice = None
+        if not asked:
+            return res
+        try:
+            with hs.precision("reference"):
+                return run()
+        except SPYValueError:                       # (a transform length the float64 kernels do not serve)
+            SPYWarning("the dynamic range of the spectra asks for float64 transforms, which this transform length does not "
+                       "have (a prime factor above 61): float32 result returned; pad='nextpow2' would allow them",
+                       caller="connectivityanalysis")
+            return res
 
 
 def _parse_channelcmb(data, channelcmb):

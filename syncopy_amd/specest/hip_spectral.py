@@ -31,6 +31,8 @@ def _cache_hit(cache, key):
 
 
 _precision = ["float32"]        # arithmetic of the tapered FFT plans created inside `with precision(...)`
+_advice = None                  # a list while connectivityanalysis(precision="auto") runs its float32 attempt: the
+                                # coherence stage records here that the data's dynamic range asks for float64 transforms
 
 
 class precision:

@@ -566,11 +566,13 @@ def test_reference_precision_through_connectivityanalysis(nsamp):
     kw = dict(method="coh", taper="hann", output="abs")
     ref = spy.connectivityanalysis(data, compute_method="sequential", routine_classes=ORACLE_CONN, **kw)
     with pytest.warns(UserWarning, match="precision='reference'"):          # the float32 path says what it cannot do
-        fast = spy.connectivityanalysis(data, **kw)
+        fast = spy.connectivityanalysis(data, precision="float32", **kw)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         exact = spy.connectivityanalysis(data, precision="reference", **kw)
+        auto = spy.connectivityanalysis(data, **kw)          # the default: notices the dynamic range, repeats in float64
+    assert np.array_equal(auto.data, exact.data)
     e_fast, e_exact = excess(fast.data, ref.data), excess(exact.data, ref.data)
     print(f"coherence away from a 60 dB line: float32 err/tol {e_fast:.3g}, precision='reference' {e_exact:.3g}")
     assert e_exact <= 1.0, e_exact
