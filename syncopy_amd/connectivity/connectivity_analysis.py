@@ -31,9 +31,9 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     and Granger are RATIOS of spectra, and where a channel's power is 40 dB or more below its peak the float32
     transform's absolute error (5e-7 of the rms bin) is no longer small against the bin itself; needs a transform
     length without a prime factor above 61; ~2x the time of the transform stage at power-of-two lengths 256 ... 4096, more
-    elsewhere.  "float32": the fast kernels whatever the data.  "auto" (default): float32, and for method="coh" on the
-    device route the call is repeated in float64 when the accumulated auto-spectra show that the float32 error in the
-    coherence would pass 1e-6 (more dynamic range than ~4 x the number of trial x taper products; the benchmark's AR(2)
+    elsewhere.  "float32": the fast kernels whatever the data.  "auto" (default): float32, and for method="coh" / "ppc"
+    on the device route the call is repeated in float64 when the auto-spectra show that the float32 error in the
+    result would pass its floor (coherence 1e-6, ppc 5e-6; (more dynamic range than ~4 x the number of trial x taper products; the benchmark's AR(2)
     data never triggers it)."""
     if precision not in ("float32", "reference", "auto"):
         raise SPYValueError("'float32', 'reference' or 'auto'", varname="precision", actual=str(precision))
@@ -67,13 +67,16 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
         if precision == "reference":
             with hs.precision("reference"):
                 return run()
-        if precision == "float32" or method != "coh":
+        if precision == "float32" or method not in ("coh", "ppc"):
             return run()
         # "auto": the float32 attempt reports through hs._advice whether the data ask for float64 transforms
         hs._advice = []
+        res = None
         try:
             res = run()
             asked = bool(hs._advice)
+        except _RepeatInFloat64:
+            asked = True
         finally:
             hs._advice = None
         if not asked:
@@ -85,7 +88,11 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
             SPYWarning("the dynamic range of the spectra asks for float64 transforms, which this transform length does not "
                        "have (a prime factor above 61): float32 result returned; pad='nextpow2' would allow them",
                        caller="connectivityanalysis")
-            return res
+            return res if res is not None else run()
+
+
+class _RepeatInFloat64(Exception):
+    """Raised inside the float32 attempt of precision="auto" by a stage that gives up early (ppc)."""
 
 
 def _parse_channelcmb(data, channelcmb):
@@ -315,6 +322,8 @@ def _ppc(data, classes, st, compute_method, log_dict):
     if compute_method in (None, "hip") and hasattr(st, "ppc_hip"):
         st.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=False)
         res = st.ppc_hip(data)                       # (F, Ci, Cj) from raw trials, (nTime, F, Ci, Cj) from spectra
+        if res is None:                              # precision="auto": the spectra's dynamic range asks for float64
+            raise _RepeatInFloat64()
         out._dev = res if res.dim() == 4 else res.unsqueeze(0)
         out.data = backend.to_host(out._dev)
         st.process_metadata(data, out)

@@ -573,6 +573,13 @@ def test_reference_precision_through_connectivityanalysis(nsamp):
         exact = spy.connectivityanalysis(data, precision="reference", **kw)
         auto = spy.connectivityanalysis(data, **kw)          # the default: notices the dynamic range, repeats in float64
     assert np.array_equal(auto.data, exact.data)
+    # ppc: phases of single-trial cross spectra - the same data, the same switch
+    pk = dict(method="ppc", taper="hann")
+    pref = spy.connectivityanalysis(data, compute_method="sequential", routine_classes=ORACLE_CONN, **pk)
+    e32 = excess(spy.connectivityanalysis(data, precision="float32", **pk).data, pref.data, atol_rel=5e-6)
+    eauto = excess(spy.connectivityanalysis(data, **pk).data, pref.data, atol_rel=5e-6)
+    print(f"ppc away from a 60 dB line: float32 err/tol {e32:.3g}, precision='auto' {eauto:.3g}")
+    assert eauto <= 1.0 < e32
     e_fast, e_exact = excess(fast.data, ref.data), excess(exact.data, ref.data)
     print(f"coherence away from a 60 dB line: float32 err/tol {e_fast:.3g}, precision='reference' {e_exact:.3g}")
     assert e_exact <= 1.0, e_exact
