@@ -266,21 +266,24 @@ class CrossSpectra(ComputationalRoutine):
         F, C = self.targetShapes[0][1], self.targetShapes[0][2]
         T = self.numTrials
         mine = [rows[k] for k in self.my_trials()]
+        if hs._advice is not None and hs._precision[-1] != "reference" and F >= 4:
+            # precision="auto" (connectivity_analysis.py): ppc is made of PHASES of single-trial cross spectra - the
+            # float32 transform's absolute error (5e-7 of a channel's rms bin) turns into 5e-7 sqrt(R) of phase error
+            # where the power sits a factor R below the channel's mean, and a trial weighs 2/T in the pair average.
+            # Judged on the auto-spectra of (up to) 16 of this rank's trials; the largest R over the ranks decides, so
+            # that every rank takes the same branch (the sum over ranks below is a collective).
+            ratio = 0.0
+            for _, spec in hs.run_mtmfft_batches(dev, mine[:16], chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
+                                                 cfg["demean_taper"], False, pr, freq_idx, "fourier", True, reuse=True):
+                p = spec.abs().square().mean(dim=(0, 1))[2:]                          # (F - 2, C)
+                ratio = max(ratio, float((p.mean(dim=0) / p.amin(dim=0).clamp_min(1e-38)).max()))
+            ratio = parallel.allreduce_max(ratio)
+            if 5e-7 * np.sqrt(ratio) * 2 / T > 5e-6 / np.sqrt(max(T, 1)):
+                hs._advice.append((ratio, T))
+                return None                                                            # the caller repeats in float64
         U = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
-        first = True
         for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
                                              cfg["demean_taper"], False, pr, freq_idx, "fourier", True, reuse=True):
-            if first and hs._advice is not None and hs._precision[-1] != "reference" and F >= 4:
-                # precision="auto" (connectivity_analysis.py): ppc is made of PHASES of single-trial cross spectra - the
-                # float32 transform's absolute error (5e-7 of a channel's rms bin) turns into 5e-7 sqrt(R) of phase error
-                # where the power sits a factor R below the channel's mean, and a trial weighs 2/T in the pair average.
-                # Judged on the auto-spectra of (up to) the first 16 trials of the first batch.
-                p = spec[:16].abs().square().mean(dim=(0, 1))[2:]                    # (F - 2, C)
-                ratio = float((p.mean(dim=0) / p.amin(dim=0).clamp_min(1e-38)).max())
-                if 5e-7 * np.sqrt(ratio) * 2 / T > 5e-6 / np.sqrt(max(T, 1)):
-                    hs._advice.append((ratio, T))
-                    return None                                                        # the caller repeats in float64
-            first = False
             backend.ppc_accumulate(spec.reshape(-1, F, C), spec.shape[1], U)
         parallel.allreduce_sum_(U)
         self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T
