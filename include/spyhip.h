@@ -160,7 +160,9 @@ int spyhip_fft_plan_set_precision(spyhip_fft_plan* plan, int reference);
  * For channels riding on an offset that rounding sequence is what the bins next to DC consist of.  on = 1: a
  * pre-pass reproduces it literally (one thread per channel walks the rows in order); on = 0 (default): float64
  * block sums inside the transform kernel - the better match for per-segment detrending of sliding windows, which
- * the reference does in float64 (specest/stft.py:112-132). */
+ * the reference does in float64 (specest/stft.py:112-132); on = 2: the same, and the plan is told that the reference
+ * holds these segments as FLOAT64 arrays (zero-extended / padded windows): the reference-precision kernels
+ * (spyhip_fft_plan_set_precision) then subtract the trend in float64 instead of rounding the samples to float32. */
 int spyhip_fft_plan_set_reference_mean(spyhip_fft_plan* plan, int on);
 /* name of the dominant kernel a plan launches (for rocprof matching) */
 const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* plan);

@@ -219,9 +219,10 @@ class FFTPlan:
         self.kout = self.ntaper if self.keeptapers else 1
         self.out_dtype = torch.complex64 if self.kind == 2 else torch.float32
         self.blocked = False
-        self.reference_mean = bool(reference_mean)
+        self.reference_mean = int(reference_mean)      # 0 | 1 (True): float32 arrays, reference-order mean | 2: float64 segments
         if self.reference_mean:
-            check(self.ctx.lib.spyhip_fft_plan_set_reference_mean(self.handle, 1), "spyhip_fft_plan_set_reference_mean")
+            check(self.ctx.lib.spyhip_fft_plan_set_reference_mean(self.handle, self.reference_mean),
+                  "spyhip_fft_plan_set_reference_mean")
 
     def set_precision(self, reference=True):
         """`reference=True`: float64 taper product and FFT, rounded to complex64 where the reference rounds

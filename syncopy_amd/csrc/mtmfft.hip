@@ -80,6 +80,7 @@ struct spyhip_fft_plan {
     spy::DevBuf<double2> tw64;
     std::string fp32_kernel_name;
     bool ref_mean = false;      // constant detrending with the reference's float32 row-order means (seq_mean_kernel)
+    bool seg_f64 = false;       // the reference holds the segments as float64 arrays (padded sliding windows)
     spy::DevBuf<float> means;
     size_t means_cap = 0;
     std::string kernel_name;
@@ -549,7 +550,8 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
 
 extern "C" int spyhip_fft_plan_set_reference_mean(spyhip_fft_plan* p, int on) {
     if (!p) { spy::set_error("fft_plan_set_reference_mean: null plan"); return -1; }
-    p->ref_mean = on != 0;
+    p->ref_mean = on == 1;
+    p->seg_f64 = on == 2;
     return 0;
 }
 
@@ -575,6 +577,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     a.nfsel = p->nfsel; a.out_kind = p->output; a.out = out_d;
     a.blocked = p->blocked ? 1 : 0;
     a.means = nullptr;
+    a.seg_f64 = p->seg_f64 ? 1 : 0;
     if (p->ref_mean && p->detrend == 0) {
         // the per-channel means of every segment in the reference's summation order, ahead of the transform
         const size_t need = (size_t)nseg * p->nchan;

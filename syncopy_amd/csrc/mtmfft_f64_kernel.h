@@ -88,6 +88,9 @@ __global__ void __launch_bounds__((spywil::PCfg<LOG2N>::T)) mtmfft_f64_kernel(F6
         x1[e] = (ok && has1) ? seg[(size_t)n * a.ld + col1] : 0.f;
     }
     // ---- polynomial removal in float32 (scipy.signal.detrend on the float32 trial, compRoutines.py:169-172)
+    bool f64t = false;
+    double t0c = 0.0, t1c = 0.0, t0s = 0.0, t1s = 0.0;       // float64 trend (constant, slope about the centre)
+    const float midc = 0.5f * (float)(a.nsig - 1);
     if (a.detrend == 0 && a.means) {
         const float m0 = a.means[(size_t)b * a.nchan + c0], m1 = has1 ? a.means[(size_t)b * a.nchan + c0 + 1] : 0.f;
 #pragma unroll
@@ -115,13 +118,19 @@ __global__ void __launch_bounds__((spywil::PCfg<LOG2N>::T)) mtmfft_f64_kernel(F6
         f64_block_sum<4, T>(s, reinterpret_cast<double*>(lds), j);
         const double inv = 1.0 / a.nsig;
         const double den = (a.detrend == 1 && a.nsig > 1) ? 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0)) : 0.0;
+        if (a.seg_f64) {
+            // float64 segments in the reference: the trend is subtracted in float64 (kept apart, applied with the taper)
+            f64t = true;
+            t0c = s[0] * inv; t1c = s[1] * inv; t0s = s[2] * den; t1s = s[3] * den;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int n = j + T * e;
-            if (n < a.nsig) {
-                const double dn = (double)((float)n - mid);
-                x0[e] -= (float)(s[0] * inv + s[2] * den * dn);
-                x1[e] -= (float)(s[1] * inv + s[3] * den * dn);
+            for (int e = 0; e < 16; ++e) {
+                const int n = j + T * e;
+                if (n < a.nsig) {
+                    const double dn = (double)((float)n - mid);
+                    x0[e] -= (float)(s[0] * inv + s[2] * den * dn);
+                    x1[e] -= (float)(s[1] * inv + s[3] * den * dn);
+                }
             }
         }
     }
@@ -144,7 +153,13 @@ __global__ void __launch_bounds__((spywil::PCfg<LOG2N>::T)) mtmfft_f64_kernel(F6
         for (int e = 0; e < 16; ++e) {
             const int n = j + T * e;
             const double wn = n < a.nsig ? w[n] : 0.0;
-            v[e] = make_double2(wn * (double)x0[e], wn * (double)x1[e]);       // win *= data_arr (float64)
+            double d0 = (double)x0[e], d1 = (double)x1[e];
+            if (f64t) {
+                const double dn = (double)((float)n - midc);
+                d0 -= t0c + t0s * dn;
+                d1 -= t1c + t1s * dn;
+            }
+            v[e] = make_double2(wn * d0, wn * d1);                               // win *= data_arr (float64)
         }
         if (a.demean_taper) {                                                  // win -= win.mean(axis=0) (float64)
             double s[2] = {0.0, 0.0};
@@ -306,15 +321,20 @@ __global__ void __launch_bounds__(256) mtmfft_f64_any_kernel(F64Args fa) {
                 const bool ok = (n >= rlo) && (n < rhi);
                 float x0 = ok ? seg[(size_t)n * a.ld + col0] : 0.f;
                 float x1 = (ok && has1) ? seg[(size_t)n * a.ld + col1] : 0.f;
-                if (fit) {
+                double d0, d1;
+                if (fit && a.seg_f64) {                                            // float64 segments: float64 trend
                     const double dn = (double)((float)n - mid);
-                    x0 -= (float)(s[0] * inv + s[2] * den * dn);
-                    x1 -= (float)(s[1] * inv + s[3] * den * dn);
+                    d0 = (double)x0 - (s[0] * inv + s[2] * den * dn);
+                    d1 = (double)x1 - (s[1] * inv + s[3] * den * dn);
+                } else if (fit) {
+                    const double dn = (double)((float)n - mid);
+                    d0 = (double)(x0 - (float)(s[0] * inv + s[2] * den * dn));
+                    d1 = (double)(x1 - (float)(s[1] * inv + s[3] * den * dn));
                 } else {
-                    x0 -= m0;
-                    x1 -= m1;
+                    d0 = (double)(x0 - m0);
+                    d1 = (double)(x1 - m1);
                 }
-                v = make_double2(w[n] * (double)x0, w[n] * (double)x1);          // win *= data_arr (float64)
+                v = make_double2(w[n] * d0, w[n] * d1);                           // win *= data_arr (float64)
                 ds[0] += v.x;
                 ds[1] += v.y;
             }

@@ -53,6 +53,8 @@ struct MtmArgs {
                                 // (nseg*ntaper, ceil(nchan/4), nfsel, 4) instead of (nseg, ntaper, nfsel, nchan)
     const float* means;         // (nseg x nchan) per-channel means in the reference's summation order
                                 // (seq_mean_kernel) used for detrend == 0, or nullptr: float64 block sums
+    int seg_f64;                // the segments are FLOAT64 arrays in the reference (zero-extended / padded sliding windows,
+                                // stft.py:101-117): the float64 kernels then subtract the trend in float64 as well
 };
 
 // Per-channel mean of a segment exactly as the reference takes it.  scipy.signal.detrend(type="constant") on the

@@ -72,7 +72,7 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
         tp = taper_table(taper, nsig, nnorm, taper_opt)
         plan = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
                                keeptapers, device=device,
-                               reference_mean=(whole_trials or float32_frames) and detrend == 0)
+                               reference_mean=(1 if detrend == 0 else 0) if (whole_trials or float32_frames) else 2)
         if _precision[-1] == "reference":
             if not plan.set_precision(True):
                 raise SPYValueError("a transform length up to 2^20 without a prime factor above 61 (e.g. "
