@@ -237,6 +237,12 @@ def mtmfft_cF(trl, foi=None, timeAxis=0, keeptapers=True, polyremoval=None, outp
 # --------------------------------------------------------------------------
 # S3/S4: STFT and sliding-window multi-taper FFT
 # --------------------------------------------------------------------------
+def detrend_frames(frames, kind):
+    """stft.py:130-132: scipy.signal.detrend of every segment along the last axis, in the segments' own dtype (a
+    function of its own so that tests can measure what the float32 least-squares fit of float32 frames costs)."""
+    return sps.detrend(frames, type=kind)
+
+
 def stft(x, fs, window, nperseg, noverlap, boundary="zeros", padded=True, detrend_kind=False):
     """specest/stft.py:16-159 for ``axis=0`` input (N, C).
     Returns (F_w, C, nSeg) complex128."""
@@ -255,7 +261,7 @@ def stft(x, fs, window, nperseg, noverlap, boundary="zeros", padded=True, detren
     frames = np.lib.stride_tricks.as_strided(d, shape=d.shape[:-1] + (nseg, nperseg),
                                              strides=d.strides[:-1] + (step * d.strides[-1], d.strides[-1]))
     if detrend_kind:
-        frames = sps.detrend(frames, type=detrend_kind)
+        frames = detrend_frames(frames, detrend_kind)
     if window is not None:
         frames = frames * window
     ftr = np.fft.rfft(frames, axis=-1)

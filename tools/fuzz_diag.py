@@ -10,7 +10,8 @@ import parity
 kind = sys.argv[1]
 fn = {"mtmfft": T.test_mtmfft_random_options, "conn": T.test_connectivity_random_options,
       "tf": T.test_timefrequency_random_options, "sel": T.test_mtmfft_selections_and_window_options,
-      "welch": T.test_welch_and_superlet_random_options}[kind]
+      "welch": T.test_welch_and_superlet_random_options, "toi": T.test_timefrequency_toi_foi_offsets,
+      "consel": T.test_connectivity_selections_and_spectral_input, "corr": T.test_corr_and_jackknife_random_options}[kind]
 def report(got, ref, exact, what="", atol_rel=parity.ATOL_REL, rtol=parity.RTOL):
     a = np.asarray(got.data); b = np.asarray(ref.data)
     tol = rtol * np.abs(b) + atol_rel * np.abs(b).max()
