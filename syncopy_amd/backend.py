@@ -410,17 +410,31 @@ def csd_kernel_name(nchan, blocked=False):
     return "spycsd::csd_accum_kernel<3, 2, 0>" if ntiles >= 6 else "spycsd::csd_accum_kernel<1, 1, 0>"
 
 
-_lib_comm = {}          # device index -> True once the library's own RCCL communicator is up
+_lib_comm = {}          # device index -> identity of the process group the library's RCCL communicator was built under
+
+
+def _group_identity():
+    """What makes the communicator stale: another WORLD group object, world size or rank (destroy_process_group +
+    init_process_group between two analyses)."""
+    import torch.distributed as dist
+    return (id(dist.group.WORLD), dist.get_world_size(), dist.get_rank())
 
 
 def _library_comm(ctx):
-    """The library's RCCL communicator on this context (include/spyhip.h: spyhip_comm_*), created once per process:
-    rank 0 draws the unique id, the existing process group carries its 128 bytes to the others (the only use of
-    torch.distributed on this path), every rank joins.  Collective: all ranks arrive here together - at the first
-    sum over ranks of an analysis."""
+    """The library's RCCL communicator on this context (include/spyhip.h: spyhip_comm_*), created once per process
+    group: rank 0 draws the unique id, the existing process group carries its 128 bytes to the others (the only use
+    of torch.distributed on this path), every rank joins.  Collective: all ranks arrive here together - at the first
+    sum over ranks of an analysis.  A communicator built under an earlier process group (other size / rank / group
+    object) is destroyed and rebuilt - reusing it would hang or sum over the wrong ranks.  The communicator spans the
+    WORLD group."""
     import torch.distributed as dist
-    if _lib_comm.get(ctx.device):
+    ident = _group_identity()
+    have = _lib_comm.get(ctx.device)
+    if have == ident:
         return
+    if have is not None:
+        check(ctx.lib.spyhip_comm_destroy(ctx.handle), "spyhip_comm_destroy")
+        _lib_comm.pop(ctx.device, None)
     rank, size = dist.get_rank(), dist.get_world_size()
     uid = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
@@ -431,16 +445,24 @@ def _library_comm(ctx):
     dist.broadcast(uid, src=0)
     raw = (C.c_ubyte * 128).from_buffer_copy(uid.cpu().numpy().tobytes())
     check(ctx.lib.spyhip_comm_init(ctx.handle, raw, rank, size), "spyhip_comm_init")
-    _lib_comm[ctx.device] = True
+    _lib_comm[ctx.device] = ident
 
 
 def shutdown_library_comm():
-    """Destroy the library's RCCL communicators (before the process group that bootstrapped them goes away)."""
+    """Destroy the library's RCCL communicators (before the process group that bootstrapped them goes away).  Also
+    registered with atexit (below)."""
     for dev in list(_lib_comm):
         ctx = _contexts.get(dev)
         if ctx is not None:
-            check(ctx.lib.spyhip_comm_destroy(ctx.handle), "spyhip_comm_destroy")
+            try:
+                check(ctx.lib.spyhip_comm_destroy(ctx.handle), "spyhip_comm_destroy")
+            except Exception:                       # noqa: BLE001 - teardown: the device may be gone already
+                pass
         _lib_comm.pop(dev, None)
+
+
+import atexit as _atexit
+_atexit.register(shutdown_library_comm)
 
 
 def csd_allreduce_(acc):

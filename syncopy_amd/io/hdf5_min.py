@@ -193,6 +193,8 @@ class _Reader:
                 e = a + 8 + 40 * k
                 noff, hdr = self.u(e, 8), self.u(e + 8, 8)
                 end = self.buf.find(b"\0", seg + noff)
+                if end < 0:
+                    raise HDF5FormatError(f"{self.path}: unterminated link name in the local heap (truncated file?)")
                 out[self.buf[seg + noff:end].decode("utf-8")] = hdr
             return
         if self.buf[a:a + 4] != b"TREE" or self.buf[a + 4] != 0:
@@ -222,6 +224,8 @@ class _Reader:
             names, offs, types = [], [], []
             for _ in range(nmemb):
                 end = self.buf.find(b"\0", q)
+                if end < 0:
+                    raise HDF5FormatError(f"{self.path}: unterminated member name in a compound datatype (truncated file?)")
                 name = self.buf[q:end].decode("ascii")
                 if ver < 3:
                     q += (end - q + 8) // 8 * 8

@@ -99,6 +99,14 @@ def _plain(value, seen=None):
     return str(value)
 
 
+def _tail_bytes(text, nbytes):
+    """The longest tail of `text` whose UTF-8 encoding has at most `nbytes` bytes (never cuts inside a character)."""
+    raw = text.encode("utf-8")
+    if len(raw) <= nbytes:
+        return text
+    return raw[-nbytes:].decode("utf-8", errors="ignore")
+
+
 def _log_entry(text):
     stamp = time.strftime("%a %b %d %H:%M:%S %Y")
     try:
@@ -173,18 +181,24 @@ def save(out, container=None, tag=None, filename=None, overwrite=False):
             attrs[key] = np.asarray(v)
         else:
             attrs[key] = v
+    shortened = set()
     while True:
         try:
             offsets = hdf5_min.write_file(data_file, {"data": np.asarray(data), "trialdefinition": trl}, attrs)
             break
         except hdf5_min.AttributeTooLarge as exc:
             # an HDF5 attribute holds < 64 KiB: shorten it as the reference does when h5py refuses it
-            # (save_spy_container.py:263-272); the full value stays in the .info side-car
+            # (save_spy_container.py:263-272); the full value stays in the .info side-car.  The limit is in BYTES of
+            # the encoded value, and every attribute is shortened at most once: a second refusal is an error, not a loop
+            if exc.name in shortened:
+                raise
+            shortened.add(exc.name)
             v = attrs[exc.name]
             if isinstance(v, str):
-                short = "... " + v[-(32 << 10):]
-            elif isinstance(v, (list, tuple, np.ndarray)) and len(v) > 2:
-                short = [str(v[0]), "...", str(v[-1])]
+                short = "... " + _tail_bytes(v, 32 << 10)
+            elif isinstance(v, (list, tuple, np.ndarray)) and len(v) > 0:
+                # (a list of strings is stored with the width of its longest element: 3 elements of <= 8 KiB each)
+                short = [_tail_bytes(str(v[0]), 8 << 10), "...", _tail_bytes(str(v[-1]), 8 << 10)]
             else:
                 raise
             SPYWarning(f"attribute '{exc.name}' is too large for the HDF5 container ({exc.size} bytes): stored "

@@ -56,8 +56,11 @@ def _new_like(data, arr, trialdefinition, dim=None, trials_sel=None):
         val = np.asarray(getattr(data, prop))
         if prop == "channel" and data.selection is not None:
             val = val[list(data.selection.channel)]
-        if prop == dim:
-            continue                     # the averaged dimension keeps no labels (compRoutines.py:131-141)
+        if dim is not None and dim in prop:
+            # the averaged dimension: one entry labelled with the operation; a numerical freq axis is gone
+            # (compRoutines.py:131-141 - `dim in prop`, so dim="channel" also relabels channel_i / channel_j)
+            setattr(out, prop, None if dim == "freq" else np.array(["mean"]))
+            continue
         setattr(out, prop, val)
     out.cfg = dict(getattr(data, "cfg", {}) or {})
     return out

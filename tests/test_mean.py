@@ -45,6 +45,23 @@ def test_oracle_mean_matches_reference(src, key, opts):
         assert np.array_equal(np.asarray(out.trialdefinition, dtype=float), Z[key + "_trldef"].astype(float))
 
 
+def test_mean_output_labels_follow_the_reference():
+    """statistics/compRoutines.py:131-141: the averaged dimension carries ONE label, the operation's name; a numerical
+    frequency axis is gone (None); other dimensions keep their (selected) labels; unsupported selection keys raise."""
+    from syncopy_amd.shared.errors import SPYValueError
+    how = dict(compute_method="sequential", routine_classes=O.STAT_OPS)
+    out = spy.mean(_analog(), dim="channel", **how)
+    assert list(out.channel) == ["mean"]
+    spec = _spectral("spec")
+    spec.freq = np.arange(spec.data.shape[2], dtype=float)
+    out = spy.mean(spec, dim="freq", **how)
+    assert out.freq is None and list(out.channel) == list(spec.channel)
+    out = spy.mean(spec, dim="channel", keeptrials=False, **how)
+    assert list(out.channel) == ["mean"] and np.array_equal(out.freq, spec.freq)
+    with pytest.raises(SPYValueError):
+        spy.mean(spec, dim="trials", select={"frequency": [1, 10]}, **how)
+
+
 def test_mean_argument_checks():
     from syncopy_amd.shared.errors import SPYTypeError, SPYValueError
     with pytest.raises(SPYValueError):

@@ -7,6 +7,7 @@ import shutil
 import subprocess
 
 import numpy as np
+from struct import error as struct_error
 import pytest
 
 import syncopy_amd as spy
@@ -199,6 +200,48 @@ def test_large_attributes_are_truncated_not_fatal(tmp_path):
     assert any("too large" in str(x.message) for x in w)
     back = spy.load(str(tmp_path / "biglog.analog"))
     assert np.array_equal(np.asarray(back.data), x) and back.log.count("line of history") == 6000
+
+
+def test_multibyte_log_and_huge_label_terminate(tmp_path):
+    """The attribute limit is in BYTES: a log of multi-byte characters and a single label beyond 64 KiB are shortened
+    once (on their encoded size) and saved - never an endless retry."""
+    import signal
+    import warnings
+
+    def _alarm(*_):
+        raise TimeoutError("save() did not return")
+    x = np.zeros((16, 2), dtype=np.float32)
+    obj = spy.AnalogData(x, samplerate=100.0, trialdefinition=np.array([[0, 16, 0]]), channel=["a" * 70000, "b"])
+    obj.log = "\u65e5" * 70000                                  # 210 kB of UTF-8
+    old = signal.signal(signal.SIGALRM, _alarm)
+    signal.alarm(30)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            spy.save(obj, filename=str(tmp_path / "mb"))
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+    assert sum("too large" in str(m.message) for m in w) >= 2
+    back = spy.load(str(tmp_path / "mb.analog"))
+    assert back.log.count("\u65e5") == 70000 and len(back.channel[0]) == 70000
+
+
+def test_truncated_file_is_a_format_error(tmp_path):
+    """A file cut inside its metadata raises HDF5FormatError instead of yielding garbage names."""
+    from syncopy_amd.io import hdf5_min
+    x = np.zeros((4, 2), dtype=np.float32)
+    path = str(tmp_path / "t.h5")
+    hdf5_min.write_file(path, {"data": x, "trialdefinition": np.zeros((1, 3))}, {"k": "v"})
+    raw = bytearray(open(path, "rb").read())
+    i = raw.find(b"trialdefinition\0")
+    assert i > 0
+    cut = bytes(raw[:i + 5]).replace(b"\0", b"\1")              # no terminator anywhere behind the heap offset
+    with open(path, "wb") as fh:
+        fh.write(cut)
+    with pytest.raises(Exception) as ei:
+        hdf5_min.read_datasets(path)
+    assert isinstance(ei.value, (hdf5_min.HDF5FormatError, IndexError, ValueError, struct_error))
 
 
 def test_reader_maps_instead_of_reading(tmp_path):
