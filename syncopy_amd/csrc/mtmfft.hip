@@ -26,7 +26,17 @@ struct F64Args {              // mtmfft_f64_kernel.h (kept out of this translati
     spywil::PlusPlan plan;
     double2* work;
     long long wg0;
+    int blue_n;
+    const double2* chirp64;
+    const double2* bhat64;
 };
+int dec64_launch_a(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_b(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_c(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_d(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_e(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_f(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_g(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean);
 int f64_any_launch(hipStream_t stream, F64Args a, long long grid, long long chunk, int outk, bool mean);
 int dec_launch_a(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
@@ -73,6 +83,9 @@ struct spyhip_fft_plan {
     bool blocked = false;
     bool precision64 = false;   // float64 taper product + FFT, complex64 rounding where the reference rounds (mtmfft_f64_kernel.h)
     bool f64_any = false;       // ... through the any-length kernel (work arrays in global memory)
+    bool f64_dec = false;       // ... through the compile-time-schedule kernel (mtmfft_dec64_kernel.h)
+    int f64_blue = 0;           // any-length kernel in its Bluestein form: the length M = 2^m >= 2 nfft - 1
+    spy::DevBuf<double2> chirp64, bhat64;
     spywil::PlusPlan f64_plan{};
     spy::DevBuf<double2> f64_work;
     long long f64_chunk = 0;
@@ -511,33 +524,71 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
         spy::set_error("fft_plan_set_precision: the reference-precision kernels write the standard layout");
         return -3;
     }
-    p->f64_any = !(p->pow2 && p->log2n >= 8 && p->log2n <= 12);
+    SPY_HIP_CHECK(hipSetDevice(p->ctx->device));
+    // compile-time radix schedules (mtmfft_dec64_launch.h): the powers of two 256 ... 16384 and the decimal lengths
+    static const int dec64_lengths[] = {256, 512, 1024, 2048, 4096, 8192, 16384, 200, 500, 1000, 2000, 2500, 4000, 5000, 10000};
+    p->f64_dec = false;
+    for (int n : dec64_lengths) p->f64_dec = p->f64_dec || (n == p->nfft);
+    if (std::getenv("SPYHIP_F64_OLD")) p->f64_dec = false;           // A/B runs against the generic kernels
+    p->f64_any = !p->f64_dec && !(p->pow2 && p->log2n >= 8 && p->log2n <= 12);
+    p->f64_blue = 0;
+    int twlen = p->nfft;
     if (p->f64_any) {
-        // any other length: generic Stockham passes over work arrays in global memory; the O(R^2) pass of a prime
-        // factor R is only reasonable for small R
-        int big = 1;
-        if (p->nfft < 2 || p->nfft > (1 << 20) || !spywil::plus_plan(p->nfft, &p->f64_plan)) big = 1 << 30;
-        else for (int i = 0; i < p->f64_plan.nfac; ++i) big = std::max(big, p->f64_plan.radix[i]);
-        if (big > 61) {
-            spy::set_error("fft_plan_set_precision: the reference-precision kernels serve transform lengths up to 2^20 "
-                           "whose prime factors are at most 61 (nfft = %d)", p->nfft);
+        // any other length: generic Stockham passes over work arrays in LDS / global memory; the O(R^2) pass of a prime
+        // factor R is only reasonable for small R - beyond 61 the transform takes Bluestein's form on M = 2^m >= 2 nfft - 1
+        if (p->nfft < 2 || p->nfft > (1 << 20)) {
+            spy::set_error("fft_plan_set_precision: the reference-precision kernels serve transform lengths 2 ... 2^20 (nfft = %d)",
+                           p->nfft);
             p->f64_any = false;
             return -3;
         }
+        int big = 1;
+        if (!spywil::plus_plan(p->nfft, &p->f64_plan)) big = 1 << 30;
+        else for (int i = 0; i < p->f64_plan.nfac; ++i) big = std::max(big, p->f64_plan.radix[i]);
+        if (big > 61 || std::getenv("SPYHIP_F64_BLUESTEIN")) {
+            int M = 16;
+            while (M < 2 * p->nfft - 1) M <<= 1;
+            spywil::plus_plan(M, &p->f64_plan);
+            p->f64_blue = M;
+            twlen = M;
+            if (!p->chirp64.p) {
+                const int nfft = p->nfft;
+                std::vector<double2> chirp(nfft);
+                std::vector<double> br(M, 0.0), bi(M, 0.0);
+                for (long long n = 0; n < nfft; ++n) {
+                    const long long q = (n * n) % (2LL * nfft);              // exact phase reduction
+                    const double ang = PI * (double)q / (double)nfft;
+                    chirp[n] = make_double2(std::cos(ang), -std::sin(ang));
+                    br[n] = std::cos(ang);
+                    bi[n] = std::sin(ang);
+                    if (n > 0) { br[M - n] = br[n]; bi[M - n] = bi[n]; }
+                }
+                spy::fft_host(br, bi);
+                std::vector<double2> bhat(M);
+                for (int i = 0; i < M; ++i) bhat[i] = make_double2(br[i] / M, bi[i] / M);
+                if (p->chirp64.upload(chirp, p->ctx->stream) || p->bhat64.upload(bhat, p->ctx->stream)) return -2;
+            }
+        }
     }
     if (!p->tw64.p) {
-        std::vector<double2> t(p->nfft);
-        for (int m = 0; m < p->nfft; ++m) {
-            const double ang = -2.0 * PI * (double)m / (double)p->nfft;
+        std::vector<double2> t(twlen);
+        for (int m = 0; m < twlen; ++m) {
+            const double ang = -2.0 * PI * (double)m / (double)twlen;
             t[m] = make_double2(std::cos(ang), std::sin(ang));
         }
-        SPY_HIP_CHECK(hipSetDevice(p->ctx->device));
         if (p->tw64.upload(t, p->ctx->stream)) return -2;
     }
     if (!p->precision64) p->fp32_kernel_name = p->kernel_name;
     p->precision64 = true;
-    char buf[96];
-    if (p->f64_any)
+    char buf[128];
+    if (p->f64_dec)
+        std::snprintf(buf, sizeof buf, "mtmfft_dec64_kernel<N = %d, %d, %s>", p->nfft,
+                      p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
+    else if (p->f64_blue)
+        std::snprintf(buf, sizeof buf, "mtmfft_f64_any_kernel<%d, %s> N=%d (Bluestein, M = %d)",
+                      p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true",
+                      p->nfft, p->f64_blue);
+    else if (p->f64_any)
         std::snprintf(buf, sizeof buf, "mtmfft_f64_any_kernel<%d, %s> N=%d",
                       p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true",
                       p->nfft);
@@ -606,11 +657,28 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         fa.tw64 = p->tw64.p;
         fa.scale64 = (double)p->scale;
         const long long grid = (long long)nseg * npairs;
+        const int outk64 = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+        if (p->f64_dec) {
+            int rc;
+            if ((rc = spyfft::dec64_launch_a(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_b(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_c(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_d(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_e(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_f(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_g(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            spy::set_error("fft_exec: no reference-precision schedule for nfft = %d", p->nfft);
+            return -1;
+        }
         if (p->f64_any) {
-            // two length-nfft complex128 work arrays per workgroup: in LDS while they fit (leaving room for the static
-            // reduction scratch), else in global memory, launches of at most 1 GiB of them
-            const size_t per = (size_t)2 * p->nfft * sizeof(double2);
+            // two complex128 work arrays (length nfft, or the Bluestein length M) per workgroup: in LDS while they fit
+            // (leaving room for the static reduction scratch), else in global memory, launches of at most 1 GiB of them
+            const size_t wlen = p->f64_blue ? (size_t)p->f64_blue : (size_t)p->nfft;
+            const size_t per = (size_t)2 * wlen * sizeof(double2);
             fa.plan = p->f64_plan;
+            fa.blue_n = p->f64_blue ? p->nfft : 0;
+            fa.chirp64 = p->chirp64.p;
+            fa.bhat64 = p->bhat64.p;
             if (per + 1024 <= (size_t)p->ctx->lds_per_block) {
                 fa.work = nullptr;
                 if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
@@ -621,7 +689,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             if (chunk > grid) chunk = grid;
             if (chunk > p->f64_chunk) {
                 if (p->f64_work.p) { SPY_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); (void)hipFree(p->f64_work.p); p->f64_work.p = nullptr; }
-                if (p->f64_work.alloc((size_t)chunk * 2 * p->nfft)) return -2;
+                if (p->f64_work.alloc((size_t)chunk * 2 * wlen)) return -2;
                 p->f64_chunk = chunk;
             }
             fa.work = p->f64_work.p;

@@ -1,0 +1,25 @@
+// The compile-time schedules of the reference-precision tapered FFT (mtmfft_dec64_kernel.h) - one place: the launchers
+// (mtmfft_dec64_launch.h), the plan's length table (mtmfft.hip) and the kernel emulator of the tests read it.
+#pragma once
+#include "mtmfft_dec64_kernel.h"
+
+namespace spyfft {
+
+//                       V   R1  R2  R3  G   SPLIT  XRES
+using D64_256   = CfgD64<16, 16, 1,  1,  16>;
+using D64_512   = CfgD64<16, 16, 2,  1,  8>;
+using D64_1024  = CfgD64<16, 16, 4,  1,  4>;
+using D64_2048  = CfgD64<16, 16, 8,  1,  2>;
+using D64_4096  = CfgD64<16, 16, 16, 1,  1>;
+using D64_8192  = CfgD64<16, 16, 16, 2,  1>;
+using D64_16384 = CfgD64<16, 16, 16, 4,  1, true, false>;
+using D64_200   = CfgD64<10, 10, 2,  1,  8>;
+using D64_500   = CfgD64<10, 10, 5,  1,  4>;
+using D64_1000  = CfgD64<10, 10, 10, 1,  2>;
+using D64_2000  = CfgD64<10, 10, 10, 2,  1>;
+using D64_2500  = CfgD64<10, 10, 5,  5,  1>;
+using D64_5000  = CfgD64<10, 10, 10, 5,  1>;
+using D64_4000  = CfgD64<20, 20, 10, 1,  1>;
+using D64_10000 = CfgD64<20, 20, 5,  5,  1, true>;
+
+}  // namespace spyfft

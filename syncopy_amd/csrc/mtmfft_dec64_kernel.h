@@ -1,0 +1,460 @@
+// K1r, second generation: the reference-precision tapered FFT (float64 taper product and transform, complex64 rounding
+// exactly where specest/mtmfft.py:96-127 rounds; spyhip_fft_plan_set_precision) with COMPILE-TIME radix schedules - the
+// structure of mtmfft_dec_kernel.h carried over to complex128:
+//
+//   * a work item is a channel PAIR of one segment: (c0, c1) are the real and the imaginary part of ONE complex128
+//     transform of length N = V R1 R2 R3, separated afterwards (X(c0)[f] = (Z[f] + conj(Z[N-f]))/2,
+//     X(c1)[f] = (Z[f] - conj(Z[N-f]))/(2i));
+//   * T = N / V threads per pair, G pairs per workgroup (thread id = j G + h); thread j keeps the float32 samples
+//     n = j + T e (e < V) of its two channels in registers across all tapers (the segment is read from HBM once) -
+//     except where the register file cannot hold them (XRES = false: N = 16384 with 1024 threads re-reads them per taper);
+//   * Stockham passes with immediates: the first (radix V) takes the tapered samples straight from the registers, the
+//     last leaves bin j + T e in register e: P - 1 exchanges through LDS for P passes.  An exchange moves complex128
+//     values (16 bytes, the float4 layout of the float32 kernel) or, with SPLIT, the real parts and then the imaginary
+//     parts through ONE 8-byte plane (half the LDS: N = 16384 needs it to fit at all);
+//   * XCD-aware block -> (segment, pair group) map: the 16 / G workgroups whose 8-byte pieces share a 128-byte line
+//     of a trial row run on one XCD back to back, as in the float32 kernels.
+//
+// The generic kernels this replaces on the common lengths (mtmfft_f64_kernel.h): the radix-16 register kernel without
+// the XCD map and with 4-byte loads (powers of two 256 ... 4096) and the run-time-radix Stockham passes over work arrays
+// in LDS / global memory (everything else: 7.6x the float32 time at N = 2000, 8.8x at 5000, 9x at 16384).
+#pragma once
+#include "cd_math.h"
+#include "f64_dft.h"
+#include "fft2_device.h"          // block_sum
+#include "mtmfft_kernel.h"        // MtmArgs, convert_real, ldg / stg
+#include "mtmfft_f64_kernel.h"    // F64Args
+
+namespace spyfft {
+
+template <int V_, int R1_, int R2_, int R3_, int G_, bool SPLIT_ = false, bool XRES_ = true>
+struct CfgD64 {
+    static constexpr int V = V_, R1 = R1_, R2 = R2_, R3 = R3_, G = G_;
+    static constexpr bool SPLIT = SPLIT_, XRES = XRES_;
+    static constexpr int N = V * R1 * R2 * R3;
+    static constexpr int T = N / V;                          // threads per channel pair
+    static constexpr int NPASS = 2 + (R2 > 1 ? 1 : 0) + (R3 > 1 ? 1 : 0);
+    static constexpr int NTHREADS = ((T * G + 63) / 64) * 64;
+    static constexpr int PLANE = N + N / V + 1;              // elements per pair: one pad per V values
+    static constexpr int ESTRIDE = (T + T / V) * G;          // LDS distance of e -> e + 1
+    static constexpr size_t LDS_BYTES = (size_t)PLANE * G * (SPLIT ? 8 : 16);
+    // waves per SIMD the register allocation is held to: what LDS lets co-reside, capped by what the schedule needs
+    // (2 V sample + 4 V value + 4 R butterfly registers and ~50 others: V = 10 -> 168 registers, V = 16 / 20 -> 256);
+    // a 1024-thread workgroup has no choice (128)
+    static constexpr int WG_PER_CU = (int)((160 * 1024) / LDS_BYTES) < 1 ? 1 : (int)((160 * 1024) / LDS_BYTES);
+    static constexpr int WPE_RAW = (NTHREADS / 64) * WG_PER_CU / 4;
+    static constexpr int WPE_CAP = NTHREADS == 1024 ? 4 : (V <= 10 ? 3 : 2);
+    static constexpr int WPE = WPE_RAW < 1 ? 1 : (WPE_RAW > WPE_CAP ? WPE_CAP : WPE_RAW);
+    static_assert(R1 > 1 && V % R1 == 0 && V % R2 == 0 && V % R3 == 0, "every radix divides the values per thread");
+    static_assert(T % V == 0, "T multiple of V: idx(j + T e) stays affine in e");
+    static_assert(NTHREADS <= 1024 && (64 % G) == 0 && (V % 2) == 0, "workgroup shape");
+    __device__ static __forceinline__ int idx(int i, int h) { return (i + i / V) * G + h; }
+};
+
+// exchange through LDS: thread-private slots wbase[m] + r WS out, rb + e ESTRIDE back
+template <class C, int R, int MB, int WS>
+__device__ __forceinline__ void d64_exchange(spywil::cd (&v)[C::V], void* ldsv, const int (&wbase)[MB], int rb, bool active) {
+    using spywil::cd;
+    constexpr int V = C::V;
+    if constexpr (!C::SPLIT) {
+        cd* lds = reinterpret_cast<cd*>(ldsv);
+        __syncthreads();              // (write-after-read: earlier reads of the buffer by any thread are done)
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < R; ++r) lds[wbase[m] + r * WS] = v[m + MB * r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = lds[rb + e * C::ESTRIDE];
+    } else {
+        double* lds = reinterpret_cast<double*>(ldsv);
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < R; ++r) lds[wbase[m] + r * WS] = v[m + MB * r].x;
+        }
+        __syncthreads();
+        double re[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) re[e] = lds[rb + e * C::ESTRIDE];
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < R; ++r) lds[wbase[m] + r * WS] = v[m + MB * r].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = make_double2(re[e], lds[rb + e * C::ESTRIDE]);
+    }
+}
+
+// One pass.  In: v[e] = in[j + T e] (pass 0: the tapered samples).  Out: LAST - v[e] = X[j + T e] in registers;
+// otherwise the outputs go through LDS and v[e] = out[j + T e] comes back.  tw[m] = exp(-2 pi i m / N).
+template <class C, int R, int Ns, bool FIRST, bool LAST>
+__device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j, int h, bool active,
+                                         const spywil::cd* __restrict__ tw) {
+    using spywil::cd;
+    using spywil::cmul;
+    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, MB = V / R;
+    int wbase[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int b = j + T * m;
+        const int q = b / Ns, k = b - q * Ns;
+        cd u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = v[m + MB * r];
+        if (!FIRST) {
+            // w^r, r < R, from w^1 .. w^3 and w^4, w^8, ...: (R + 3) / 4 + 2 table reads instead of R - 1
+            const int st = k * (N / (Ns * R));
+            constexpr int NA = (R + 3) / 4;
+            cd wb[4], wa[NA];
+#pragma unroll
+            for (int l = 1; l < 4; ++l) wb[l] = (l < R) ? tw[l * st] : make_double2(1.0, 0.0);
+#pragma unroll
+            for (int a = 1; a < NA; ++a) wa[a] = tw[4 * a * st];
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                const int hi = r >> 2, lo = r & 3;
+                const cd w = (hi == 0) ? wb[lo] : (lo == 0 ? wa[hi] : cmul(wa[hi], wb[lo]));
+                u[r] = cmul(u[r], w);
+            }
+        }
+        spywil::d_dft<R>(u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[m + MB * r] = u[r];
+        // LDS slot of output r: idx(q Ns R + k + r Ns); Ns is 1 (first pass, R = V) or a multiple of V
+        wbase[m] = FIRST ? (b * (V + 1)) * G + h : (q * (Ns * R + Ns * R / V) + k + k / V) * G + h;
+    }
+    if (LAST) return;
+    constexpr int WS = FIRST ? G : (Ns + Ns / V) * G;
+    d64_exchange<C, R, MB, WS>(v, lds, wbase, C::idx(j, h), active);
+}
+
+// sample n of the two channels of a pair (float32, as the reference holds the trial); zero outside [rlo, rhi)
+struct D64Src {
+    const float* seg;
+    long long ld;
+    unsigned col0, col1;
+    int rlo, rhi;
+    bool some, vec2, has0, has1;
+    // the V samples n = j + T e of a thread, branches outside the unrolled loops (straight-line loads: the register
+    // allocator copes badly with sixteen diamonds)
+    template <int V, int T>
+    __device__ __forceinline__ void get_all(int j, float (&u0)[V], float (&u1)[V]) const {
+        if (some) {
+            if (vec2) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const int n = j + T * e;
+                    const int nc = min(max(n, rlo), rhi - 1);
+                    const float2 t = *reinterpret_cast<const float2*>(seg + (size_t)nc * ld + col0);
+                    u0[e] = (n == nc) ? t.x : 0.f;
+                    u1[e] = (n == nc) ? t.y : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const int n = j + T * e;
+                    const int nc = min(max(n, rlo), rhi - 1);
+                    const float t0 = seg[(size_t)nc * ld + col0], t1 = seg[(size_t)nc * ld + col1];
+                    u0[e] = (n == nc && has0) ? t0 : 0.f;
+                    u1[e] = (n == nc && has1) ? t1 : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) u0[e] = u1[e] = 0.f;
+        }
+    }
+};
+
+// OUTK: 0 = power, 1 = any other real conversion, 2 = complex; MEAN: average over tapers
+template <class C, int OUTK, bool MEAN>
+__global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F64Args fa) {
+    using spywil::cd;
+    constexpr bool CPLX = (OUTK == 2);
+    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, HV = V / 2;
+    const MtmArgs& a = fa.m;
+    SPY_DYN_SMEM(char, ldsraw);
+    void* const lds = ldsraw;
+
+    const int tid = threadIdx.x;
+    const int h = tid % G, jt = tid / G;
+    const bool active = jt < T;                   // the workgroup is padded to whole waves
+    const int j0 = active ? jt : 0;
+
+    // XCD-aware block -> (segment, pair group), as mtmfft_dec_kernel
+    const long long id = blockIdx.x;
+    const int xcd = (int)(id & 7);
+    const long long y = id >> 3;
+    const long long nclt = (long long)a.nseg * a.ncl, chunk = (nclt + 7) >> 3;
+    const long long cidx = (long long)xcd * chunk + y / a.S;
+    const int qs = (int)(y % a.S);
+    if (cidx >= nclt) return;
+    const int b = (int)(cidx / a.ncl);
+    const int pg = (int)(cidx % a.ncl) * a.S + qs;
+    if (pg >= a.npg) return;
+
+    const int c0 = 2 * (pg * G + h);
+    const bool has0 = active && c0 < a.nchan, has1 = active && c0 + 1 < a.nchan;
+    D64Src src;
+    src.col0 = has0 ? (unsigned)(a.chan_idx ? a.chan_idx[c0] : c0) : 0u;
+    src.col1 = has1 ? (unsigned)(a.chan_idx ? a.chan_idx[c0 + 1] : c0 + 1) : 0u;
+    src.has0 = has0; src.has1 = has1;
+    const long long start = a.seg_start[b];
+    const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
+    src.rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
+    src.rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
+    src.seg = a.data + start * a.ld;              // only rows in [rlo, rhi) are dereferenced
+    src.ld = a.ld;
+    src.vec2 = (a.chan_idx == nullptr) && has1 && ((a.ld & 1) == 0) && ((reinterpret_cast<size_t>(a.data) & 7) == 0);
+    src.some = src.rhi > src.rlo;
+
+    float x0[V], x1[V];           // XRES: resident across the tapers; otherwise refilled per taper
+    src.template get_all<V, T>(j0, x0, x1);
+
+    // ---- polynomial removal in float32 (scipy.signal.detrend on the float32 trial, compRoutines.py:169-172): the
+    // reference-order means (detrend 0) or a float64 fit whose trend is rounded to float32 before it is subtracted;
+    // float64 segments (seg_f64: padded sliding windows, stft.py:101-117) subtract the float64 trend
+    const float mid = 0.5f * (float)(a.nsig - 1);
+    float m0 = 0.f, m1 = 0.f;                          // constant detrending with the reference-order means
+    double t0c = 0.0, t1c = 0.0, t0s = 0.0, t1s = 0.0; // fitted trend: constant and slope about the centre
+    const bool fit = !(a.detrend == 0 && a.means) && a.detrend >= 0;
+    if (a.detrend == 0 && a.means) {
+        m0 = has0 ? a.means[(size_t)b * a.nchan + c0] : 0.f;
+        m1 = has1 ? a.means[(size_t)b * a.nchan + c0 + 1] : 0.f;
+    } else if (fit) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        const float lin = a.detrend == 1 ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int n = j0 + T * e;
+            const float m = (active && n < a.nsig) ? 1.f : 0.f;           // branch-free masks (exact: 0 or 1)
+            const float u0 = m * x0[e], u1 = m * x1[e];
+            const double dn = (double)(lin * ((float)n - mid));           // exact: half-integers < 2^23
+            s[0] += (double)u0;
+            s[1] += (double)u1;
+            s[2] += dn * u0;
+            s[3] += dn * u1;
+        }
+        block_sum<C::NTHREADS, G, 4>(s, reinterpret_cast<double*>(lds), tid, h);
+        const double inv = 1.0 / a.nsig;
+        const double den = (a.detrend == 1 && a.nsig > 1) ? 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0)) : 0.0;
+        t0c = s[0] * inv; t1c = s[1] * inv; t0s = s[2] * den; t1s = s[3] * den;
+    }
+    const bool f64t = fit && a.seg_f64;
+    // float32 trend of sample n (what the reference subtracts from the float32 trial); float64 segments: see the taper loop
+    if constexpr (C::XRES) {
+        if (fit && !f64t) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int n = j0 + T * e;
+                const double dn = (double)((float)n - mid);
+                const float r0 = (float)(t0c + t0s * dn), r1 = (float)(t1c + t1s * dn);
+                x0[e] -= n < a.nsig ? r0 : 0.f;
+                x1[e] -= n < a.nsig ? r1 : 0.f;
+            }
+        } else if (!fit) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const bool in = j0 + T * e < a.nsig;
+                x0[e] -= in ? m0 : 0.f;
+                x1[e] -= in ? m1 : 0.f;
+            }
+        }
+    }
+
+    float macc0[MEAN ? HV + 1 : 1], macc1[MEAN ? HV + 1 : 1], mim0[(MEAN && CPLX) ? HV + 1 : 1], mim1[(MEAN && CPLX) ? HV + 1 : 1];
+    if (MEAN) {
+#pragma unroll
+        for (int e = 0; e <= HV; ++e) {
+            macc0[e] = macc1[e] = 0.f;
+            if (CPLX) mim0[e] = mim1[e] = 0.f;
+        }
+    }
+    const int kout = MEAN ? 1 : a.ntaper;
+    constexpr unsigned OSZ = CPLX ? 8u : 4u;
+    const bool fast = has1 && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) && ((a.nchan & 1) == 0);
+    const cd* const tw = reinterpret_cast<const cd*>(fa.tw64);
+
+    for (int k = 0; k < a.ntaper; ++k) {
+        const int j = opaque(j0);     // (keeps the twiddle loads and the index arithmetic of the passes inside the loop)
+        const double* w = fa.tapers64 + (size_t)k * a.nsig;
+        cd v[V];
+        if constexpr (!C::XRES) {
+            // not resident: the samples come back from L2 for every taper, detrended in float32 as above
+            src.template get_all<V, T>(j, x0, x1);
+            if (!f64t) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const int n = j + T * e;
+                    const double dn = (double)((float)n - mid);
+                    const float r0 = fit ? (float)(t0c + t0s * dn) : m0, r1 = fit ? (float)(t1c + t1s * dn) : m1;
+                    x0[e] -= n < a.nsig ? r0 : 0.f;
+                    x1[e] -= n < a.nsig ? r1 : 0.f;
+                }
+            }
+        }
+        if (f64t) {
+            // float64 segments in the reference: the trend is subtracted in float64
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int n = j + T * e;
+                const double wn = n < a.nsig ? w[n] : 0.0;
+                const double dn = (double)((float)n - mid);
+                v[e] = make_double2(wn * ((double)x0[e] - (t0c + t0s * dn)), wn * ((double)x1[e] - (t1c + t1s * dn)));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int n = j + T * e;
+                const double wn = n < a.nsig ? w[n] : 0.0;
+                v[e] = make_double2(wn * (double)x0[e], wn * (double)x1[e]);     // win *= data_arr (float64)
+            }
+        }
+        if (a.demean_taper) {                                                  // win -= win.mean(axis=0) (float64)
+            double ds[2] = {0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                ds[0] += v[e].x;
+                ds[1] += v[e].y;
+            }
+            if (!active) ds[0] = ds[1] = 0.0;
+            __syncthreads();          // block_sum writes its scratch into the buffer other waves may still be reading
+            block_sum<C::NTHREADS, G, 2>(ds, reinterpret_cast<double*>(lds), tid, h);
+            const double dm0 = ds[0] / a.nsig, dm1 = ds[1] / a.nsig;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if (j + T * e < a.nsig) {
+                    v[e].x -= dm0;
+                    v[e].y -= dm1;
+                }
+            }
+        }
+
+        // ---- the passes: radix V from the registers, then R1 (R2, R3); the last one leaves v[e] = Z[j + T e]
+        d64_pass<C, V, 1, true, false>(v, lds, j, h, active, tw);
+        d64_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, tw);
+        if constexpr (C::NPASS >= 3) d64_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, tw);
+        if constexpr (C::NPASS >= 4) d64_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, tw);
+
+        // ---- separation: partner bin N - f lives in the upper slots
+        double zpx[C::SPLIT ? HV : 1];
+        {
+            const int wb = C::idx(j, h);
+            if constexpr (!C::SPLIT) {
+                cd* L = reinterpret_cast<cd*>(lds);
+                __syncthreads();              // the FFT's last reads of the buffer are done everywhere
+                if (active) {
+#pragma unroll
+                    for (int e = HV; e < V; ++e) L[wb + e * C::ESTRIDE] = v[e];
+                }
+                __syncthreads();
+            } else {
+                double* L = reinterpret_cast<double*>(lds);
+                __syncthreads();
+                if (active) {
+#pragma unroll
+                    for (int e = HV; e < V; ++e) L[wb + e * C::ESTRIDE] = v[e].x;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < HV; ++e) {
+                    const int f = j + T * e;
+                    zpx[e] = f == 0 ? v[0].x : L[C::idx(N - f, h)];
+                }
+                __syncthreads();
+                if (active) {
+#pragma unroll
+                    for (int e = HV; e < V; ++e) L[wb + e * C::ESTRIDE] = v[e].y;
+                }
+                __syncthreads();
+            }
+        }
+        char* const slab = reinterpret_cast<char*>(a.out) +
+                           ((size_t)b * kout + (MEAN ? 0 : k)) * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
+#pragma unroll
+        for (int e = 0; e <= HV; ++e) {
+            int f;
+            cd X0, X1;
+            if (e < HV) {
+                if (!active) break;
+                f = j + T * e;
+                const cd z = v[e];
+                cd p;
+                if constexpr (!C::SPLIT) {
+                    p = f == 0 ? z : reinterpret_cast<const cd*>(lds)[C::idx(N - f, h)];
+                } else {
+                    p = make_double2(zpx[C::SPLIT ? e : 0], f == 0 ? z.y : reinterpret_cast<const double*>(lds)[C::idx(N - f, h)]);
+                }
+                X0 = make_double2(0.5 * (z.x + p.x), 0.5 * (z.y - p.y));
+                X1 = make_double2(0.5 * (z.y + p.y), 0.5 * (p.x - z.x));
+            } else {
+                if (j != 0 || !active) break;
+                f = N / 2;
+                X0 = make_double2(v[HV].x, 0.0);
+                X1 = make_double2(v[HV].y, 0.0);
+            }
+            // complex64 storage, then the float32 normalisation factor (mtmfft.py:104,117-127)
+            const float2 s0 = make_float2(__fmul_rn((float)X0.x, a.scale), __fmul_rn((float)X0.y, a.scale));
+            const float2 s1 = make_float2(__fmul_rn((float)X1.x, a.scale), __fmul_rn((float)X1.y, a.scale));
+            if (MEAN) {
+                if (CPLX) {
+                    macc0[e] += s0.x; mim0[e] += s0.y;
+                    macc1[e] += s1.x; mim1[e] += s1.y;
+                } else {
+                    macc0[e] += convert_real<OUTK>(s0, a.out_kind);
+                    macc1[e] += convert_real<OUTK>(s1, a.out_kind);
+                }
+                continue;
+            }
+            if (fast) {
+                const size_t o = ((size_t)f * a.nchan + c0) * OSZ;
+                if (CPLX) *reinterpret_cast<float4*>(slab + o) = make_float4(s0.x, s0.y, s1.x, s1.y);
+                else *reinterpret_cast<float2*>(slab + o) = make_float2(convert_real<OUTK>(s0, a.out_kind),
+                                                                        convert_real<OUTK>(s1, a.out_kind));
+                continue;
+            }
+            const int fi = a.fpos ? a.fpos[f] : f;
+            if (fi < 0) continue;
+            const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;
+            if (CPLX) {
+                if (has0) *reinterpret_cast<float2*>(slab + o) = s0;
+                if (has1) *reinterpret_cast<float2*>(slab + o + 8) = s1;
+            } else {
+                if (has0) *reinterpret_cast<float*>(slab + o) = convert_real<OUTK>(s0, a.out_kind);
+                if (has1) *reinterpret_cast<float*>(slab + o + 4) = convert_real<OUTK>(s1, a.out_kind);
+            }
+        }
+        // no barrier here: the next taper's first LDS write sits behind one (d64_exchange / block_sum)
+    }
+
+    if (MEAN) {
+        char* const slab = reinterpret_cast<char*>(a.out) + (size_t)b * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
+        const float nt = (float)a.ntaper;
+#pragma unroll
+        for (int e = 0; e <= HV; ++e) {
+            if (!active || (e == HV && j0 != 0)) break;
+            const int f = e < HV ? j0 + T * e : N / 2;
+            const int fi = a.fpos ? a.fpos[f] : f;
+            if (fi < 0) continue;
+            const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;
+            if (CPLX) {
+                if (has0) *reinterpret_cast<float2*>(slab + o) = make_float2(macc0[e] / nt, mim0[e] / nt);
+                if (has1) *reinterpret_cast<float2*>(slab + o + 8) = make_float2(macc1[e] / nt, mim1[e] / nt);
+            } else {
+                if (has0) *reinterpret_cast<float*>(slab + o) = macc0[e] / nt;
+                if (has1) *reinterpret_cast<float*>(slab + o + 4) = macc1[e] / nt;
+            }
+        }
+    }
+}
+
+}  // namespace spyfft

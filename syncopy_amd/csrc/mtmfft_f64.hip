@@ -43,7 +43,7 @@ int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, i
 template <int OUTK, bool MEAN>
 static int f64_any_launch_one(hipStream_t stream, const F64Args& a, unsigned grid) {
     auto kern = mtmfft_f64_any_kernel<OUTK, MEAN>;
-    const size_t lds = a.work ? 0 : (size_t)2 * a.plan.L * sizeof(double2);
+    const size_t lds = a.work ? 0 : (size_t)2 * a.plan.L * sizeof(double2);      // (plan.L: nfft or the Bluestein length)
     if (lds) SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
     SPY_HIP_CHECK(hipGetLastError());

@@ -27,6 +27,11 @@ struct F64Args {
     spywil::PlusPlan plan;
     double2* work;
     long long wg0;
+    // Bluestein form of the any-length kernel (a prime factor above 61): plan.L = M = 2^m >= 2 nfft - 1 and tw64 belongs
+    // to M; chirp64[n] = exp(-i pi n^2 / nfft) (nfft entries), bhat64 = FFT_M of the wrapped conjugate chirp, / M
+    int blue_n;                  // nfft of the Bluestein form, 0 otherwise
+    const double2* chirp64;
+    const double2* bhat64;
 };
 
 // sum of NS doubles over the workgroup (T threads), broadcast; scratch = LDS (free at that point); two barriers
@@ -264,7 +269,8 @@ __global__ void __launch_bounds__(256) mtmfft_f64_any_kernel(F64Args fa) {
     constexpr bool CPLX = (OUTK == 2);
     const MtmArgs& a = fa.m;
     __shared__ double red[32];
-    const int N = fa.plan.L, tid = threadIdx.x;
+    const int L = fa.plan.L, tid = threadIdx.x;         // work-array length: nfft, or the Bluestein length M
+    const int N = fa.blue_n ? fa.blue_n : L;            // transform length
     const long long wg = fa.wg0 + blockIdx.x;
     const int npair = (a.nchan + 1) / 2;
     const int b = (int)(wg / npair), p = (int)(wg % npair);
@@ -280,8 +286,8 @@ __global__ void __launch_bounds__(256) mtmfft_f64_any_kernel(F64Args fa) {
     // the two work arrays: LDS while they fit (nfft <= 5120: launched with 32 nfft bytes of dynamic LDS and work =
     // nullptr), global memory beyond
     SPY_DYN_SMEM(cd, ldsbuf);
-    cd* A = fa.work ? reinterpret_cast<cd*>(fa.work) + (size_t)blockIdx.x * 2 * (size_t)N : ldsbuf;
-    cd* B = A + N;
+    cd* A = fa.work ? reinterpret_cast<cd*>(fa.work) + (size_t)blockIdx.x * 2 * (size_t)L : ldsbuf;
+    cd* B = A + L;
 
     // ---- polynomial removal in float32, exactly as the register kernel above
     float m0 = 0.f, m1 = 0.f;
@@ -315,7 +321,7 @@ __global__ void __launch_bounds__(256) mtmfft_f64_any_kernel(F64Args fa) {
     for (int k = 0; k < a.ntaper; ++k) {
         const double* w = fa.tapers64 + (size_t)k * a.nsig;
         double ds[2] = {0.0, 0.0};
-        for (int n = tid; n < N; n += 256) {
+        for (int n = tid; n < L; n += 256) {
             cd v = make_double2(0.0, 0.0);
             if (n < a.nsig) {
                 const bool ok = (n >= rlo) && (n < rhi);
@@ -347,12 +353,35 @@ __global__ void __launch_bounds__(256) mtmfft_f64_any_kernel(F64Args fa) {
         }
         __syncthreads();
         cd *src = A, *dst = B;
-        int Ns = 1;
-        for (int q = 0; q < fa.plan.nfac; ++q) {
-            spywil::po_pass_any(src, dst, N, fa.plan.radix[q], Ns, reinterpret_cast<const cd*>(fa.tw64), -1, tid);
+        if (fa.blue_n) {
+            // chirp-z: Z[k] = c[k] IFFT_M(FFT_M(z c) Bhat)[k], c[n] = exp(-i pi n^2 / nfft) (phases reduced exactly on the host)
+            const cd* ch = reinterpret_cast<const cd*>(fa.chirp64);
+            const cd* bh = reinterpret_cast<const cd*>(fa.bhat64);
+            for (int n = tid; n < a.nsig; n += 256) src[n] = spywil::cmul(src[n], ch[n]);
             __syncthreads();
-            Ns *= fa.plan.radix[q];
-            cd* t = src; src = dst; dst = t;
+            for (int dir = 0; dir < 2; ++dir) {
+                int Ns = 1;
+                for (int q = 0; q < fa.plan.nfac; ++q) {
+                    spywil::po_pass_any(src, dst, L, fa.plan.radix[q], Ns, reinterpret_cast<const cd*>(fa.tw64), dir ? +1 : -1, tid);
+                    __syncthreads();
+                    Ns *= fa.plan.radix[q];
+                    cd* t = src; src = dst; dst = t;
+                }
+                if (dir == 0) {
+                    for (int n = tid; n < L; n += 256) src[n] = spywil::cmul(src[n], bh[n]);
+                } else {
+                    for (int n = tid; n < N; n += 256) src[n] = spywil::cmul(src[n], ch[n]);
+                }
+                __syncthreads();
+            }
+        } else {
+            int Ns = 1;
+            for (int q = 0; q < fa.plan.nfac; ++q) {
+                spywil::po_pass_any(src, dst, L, fa.plan.radix[q], Ns, reinterpret_cast<const cd*>(fa.tw64), -1, tid);
+                __syncthreads();
+                Ns *= fa.plan.radix[q];
+                cd* t = src; src = dst; dst = t;
+            }
         }
         char* const slab = reinterpret_cast<char*>(a.out) +
                            ((size_t)b * kout + (MEAN ? 0 : k)) * (size_t)a.nfsel * (size_t)a.nchan * OSZ;

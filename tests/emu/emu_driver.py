@@ -82,6 +82,67 @@ def seq_mean(data, seg_start, seg_lo, seg_hi, nsig, chan_idx=None):
     return means
 
 
+def twiddles64(n):
+    ang = -2.0 * np.pi * np.arange(n, dtype=np.float64) / n
+    return np.ascontiguousarray(np.stack([np.cos(ang), np.sin(ang)], axis=1))
+
+
+def fft_exec_f64(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
+                 freq_idx=None, output="pow", keeptapers=True, chan_idx=None, reference_mean=False, seg_f64=False,
+                 dec=True, bluestein=False):
+    """Emulated spyhip_fft_exec of a plan with spyhip_fft_plan_set_precision(plan, 1): `dec` - the compile-time
+    schedule of mtmfft_dec64_kernel for this nfft; otherwise the any-length kernel, `bluestein` in its chirp-z form
+    (tables as spyhip_fft_plan_set_precision builds them)."""
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    ld = data.shape[1]
+    nchan = ld if chan_idx is None else len(chan_idx)
+    ci = None if chan_idx is None else np.ascontiguousarray(chan_idx, dtype=np.int32)
+    ss = np.ascontiguousarray(seg_start, dtype=np.int64)
+    sl = np.ascontiguousarray(seg_lo, dtype=np.int64)
+    sh = np.ascontiguousarray(seg_hi, dtype=np.int64)
+    nseg, K = len(ss), tapers.shape[0]
+    tp = np.ascontiguousarray(tapers, dtype=np.float64)
+    nf = nfft // 2 + 1
+    if freq_idx is None:
+        fpos, nfsel = None, nf
+    else:
+        fi = np.asarray(freq_idx, dtype=np.int64)
+        nfsel = len(fi)
+        fpos = np.full(nf, -1, dtype=np.int32)
+        fpos[fi] = np.arange(nfsel, dtype=np.int32)
+    kind = OUT_KINDS[output]
+    out = np.full((nseg, K if keeptapers else 1, nfsel, nchan), np.nan, dtype=np.complex64 if kind == 2 else np.float32)
+    M, chirp, bhat = 0, None, None
+    if bluestein:
+        M = 16
+        while M < 2 * nfft - 1:
+            M *= 2
+        n = np.arange(nfft, dtype=np.int64)
+        ang = np.pi * ((n * n) % (2 * nfft)).astype(np.float64) / nfft
+        chirp = np.ascontiguousarray(np.stack([np.cos(ang), -np.sin(ang)], axis=1))
+        b = np.zeros(M, dtype=np.complex128)
+        b[:nfft] = np.cos(ang) + 1j * np.sin(ang)
+        b[M - n[1:]] = b[n[1:]]
+        B = np.fft.fft(b) / M
+        bhat = np.ascontiguousarray(np.stack([B.real, B.imag], axis=1))
+    means = None
+    if reference_mean and detrend == 0:
+        means = seq_mean(data, ss, sl, sh, nsig, chan_idx)
+        lib().emu_set_means(_p(means, C.c_float))
+    try:
+        rc = lib().emu_mtmfft_f64(
+            C.c_int(nfft), C.c_int(M), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int), _p(ss, C.c_longlong),
+            _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg), C.c_int(nsig), C.c_int(nchan), C.c_int(K),
+            _p(tp, C.c_double), _p(twiddles64(M if bluestein else nfft), C.c_double), _p(chirp, C.c_double),
+            _p(bhat, C.c_double), C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), C.c_int(int(seg_f64)),
+            _p(fpos, C.c_int), C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), C.c_int(int(dec and not bluestein)),
+            out.ctypes.data_as(C.c_void_p))
+    finally:
+        lib().emu_set_means(None)
+    assert rc == 0, f"no emulated reference-precision kernel for nfft={nfft} (rc={rc})"
+    return out
+
+
 LAST_MIXED = {}
 
 

@@ -29,6 +29,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/cwt_kernel.h"
 #include "../../syncopy_amd/csrc/granger_kernels.h"
 #include "../../syncopy_amd/csrc/wilson_plus_kernel.h"
+#include "../../syncopy_amd/csrc/mtmfft_dec64_cfg.h"
 
 namespace spy {
 void set_error(const char*, ...) {}
@@ -848,3 +849,86 @@ void emu_w_granger(const double* CSD, const double* H, const double* Sigma, int 
 }
 
 }  // extern "C"
+
+// ---- reference-precision tapered FFT: compile-time schedules (mtmfft_dec64_kernel.h) and the any-length kernel
+// (mtmfft_f64_kernel.h, incl. its Bluestein form)
+template <class Cf>
+static void run_dec64_mode(spyfft::F64Args fa, int nseg, int nchan, int outk, int mean) {
+    MtmArgs& a = fa.m;
+    const int G = Cf::G;
+    const int npairs = (nchan + 1) / 2;
+    a.npg = (npairs + G - 1) / G;
+    int S = 16 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+    a.S = S;
+    a.ncl = (a.npg + S - 1) / S;
+    const long long nclusters = (long long)nseg * a.ncl;
+    const unsigned grid = (unsigned)(((nclusters + 7) / 8) * S * 8);
+    auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(Cf::NTHREADS), Cf::LDS_BYTES, fn); };
+    switch (outk * 2 + mean) {
+        case 0: go([&] { spyfft::mtmfft_dec64_kernel<Cf, 0, false>(fa); }); break;
+        case 1: go([&] { spyfft::mtmfft_dec64_kernel<Cf, 0, true>(fa); }); break;
+        case 2: go([&] { spyfft::mtmfft_dec64_kernel<Cf, 1, false>(fa); }); break;
+        case 3: go([&] { spyfft::mtmfft_dec64_kernel<Cf, 1, true>(fa); }); break;
+        case 4: go([&] { spyfft::mtmfft_dec64_kernel<Cf, 2, false>(fa); }); break;
+        default: go([&] { spyfft::mtmfft_dec64_kernel<Cf, 2, true>(fa); }); break;
+    }
+}
+
+extern "C" int emu_mtmfft_f64(int nfft, int blue_m, const float* data, long long ld, const int* chan_idx,
+                              const long long* seg_start, const long long* seg_lo, const long long* seg_hi, int nseg,
+                              int nsig, int nchan, int ntaper, const double* tapers64, const double* tw64,
+                              const double* chirp64, const double* bhat64, float scale, int detrend, int demean_taper,
+                              int seg_f64, const int* fpos, int nfsel, int out_kind, int keeptapers, int use_dec, void* out) {
+    spyfft::F64Args fa{};
+    MtmArgs& a = fa.m;
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
+    a.scale = scale; a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
+    a.out_kind = out_kind; a.out = out; a.means = g_means; a.seg_f64 = seg_f64;
+    fa.tapers64 = tapers64;
+    fa.tw64 = reinterpret_cast<const double2*>(tw64);
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    const int mean = keeptapers ? 0 : 1;
+    if (use_dec) {
+        switch (nfft) {
+            case 256: run_dec64_mode<spyfft::D64_256>(fa, nseg, nchan, outk, mean); break;
+            case 512: run_dec64_mode<spyfft::D64_512>(fa, nseg, nchan, outk, mean); break;
+            case 1024: run_dec64_mode<spyfft::D64_1024>(fa, nseg, nchan, outk, mean); break;
+            case 2048: run_dec64_mode<spyfft::D64_2048>(fa, nseg, nchan, outk, mean); break;
+            case 4096: run_dec64_mode<spyfft::D64_4096>(fa, nseg, nchan, outk, mean); break;
+            case 8192: run_dec64_mode<spyfft::D64_8192>(fa, nseg, nchan, outk, mean); break;
+            case 16384: run_dec64_mode<spyfft::D64_16384>(fa, nseg, nchan, outk, mean); break;
+            case 200: run_dec64_mode<spyfft::D64_200>(fa, nseg, nchan, outk, mean); break;
+            case 500: run_dec64_mode<spyfft::D64_500>(fa, nseg, nchan, outk, mean); break;
+            case 1000: run_dec64_mode<spyfft::D64_1000>(fa, nseg, nchan, outk, mean); break;
+            case 2000: run_dec64_mode<spyfft::D64_2000>(fa, nseg, nchan, outk, mean); break;
+            case 2500: run_dec64_mode<spyfft::D64_2500>(fa, nseg, nchan, outk, mean); break;
+            case 4000: run_dec64_mode<spyfft::D64_4000>(fa, nseg, nchan, outk, mean); break;
+            case 5000: run_dec64_mode<spyfft::D64_5000>(fa, nseg, nchan, outk, mean); break;
+            case 10000: run_dec64_mode<spyfft::D64_10000>(fa, nseg, nchan, outk, mean); break;
+            default: return -1;
+        }
+        return 0;
+    }
+    // any-length kernel; work arrays in "LDS" (the emulator's dynamic buffer has no size limit)
+    const int L = blue_m ? blue_m : nfft;
+    if (!spywil::plus_plan(L, &fa.plan)) return -2;
+    fa.work = nullptr;
+    fa.wg0 = 0;
+    fa.blue_n = blue_m ? nfft : 0;
+    fa.chirp64 = reinterpret_cast<const double2*>(chirp64);
+    fa.bhat64 = reinterpret_cast<const double2*>(bhat64);
+    const unsigned grid = (unsigned)((long long)nseg * ((nchan + 1) / 2));
+    const size_t lds = (size_t)2 * L * sizeof(double2);
+    auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(256), lds, fn); };
+    switch (outk * 2 + mean) {
+        case 0: go([&] { spyfft::mtmfft_f64_any_kernel<0, false>(fa); }); break;
+        case 1: go([&] { spyfft::mtmfft_f64_any_kernel<0, true>(fa); }); break;
+        case 2: go([&] { spyfft::mtmfft_f64_any_kernel<1, false>(fa); }); break;
+        case 3: go([&] { spyfft::mtmfft_f64_any_kernel<1, true>(fa); }); break;
+        case 4: go([&] { spyfft::mtmfft_f64_any_kernel<2, false>(fa); }); break;
+        default: go([&] { spyfft::mtmfft_f64_any_kernel<2, true>(fa); }); break;
+    }
+    return 0;
+}

@@ -38,6 +38,7 @@ static inline double2 make_double2(double a, double b) { return double2{a, b}; }
 // IEEE round-to-nearest float32 add / divide (the host compiler does not contract or re-associate them)
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline void __threadfence() {}
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }

@@ -630,3 +630,61 @@ def test_csd_3m_more_than_512_channels():
     E.csd_accumulate(coherent.astype(np.complex64), acc4, force_4m=True)
     scale = np.abs(acc4[0, 0, 0])
     assert np.abs(acc4[:, ii, jj].imag).max() <= 1e-6 * scale       # real multiples of one signal: Im = 0 up to rounding
+
+
+# K1r second generation: reference-precision transforms (mtmfft_dec64_kernel.h, mtmfft_f64_kernel.h incl. Bluestein)
+def _f64_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=False, freq_idx=None, chan_idx=None, nseg=1,
+              seed=3, dec=True, bluestein=False, pure_frac=0.99):
+    """Data with 60 dB of dynamic range (a 40 Hz line 1000 x the noise, an offset): the criterion everywhere, and for
+    complex output PURE rtol 1e-5 bin by bin on >= 99 % of the bins - which only a float64 transform delivers."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(nsig * nseg + 9) / 1000.0
+    data = (rng.normal(size=(nsig * nseg + 9, nchan)) + 1000.0 * np.sin(2 * np.pi * 40.0 * t)[:, None] + 50.0).astype("f4")
+    ss = np.array([4 + i * nsig for i in range(nseg)])
+    taper, topt = ("dpss", {"NW": (K + 1) / 2, "Kmax": K}) if K > 1 else ("hann", {})
+    tapers = O.taper_table(taper, nsig, nfft, topt)
+    out = E.fft_exec_f64(data, ss, ss, ss + nsig, nsig, nfft, tapers, O.spec_scale(nsig, nfft), detrend, demean_taper,
+                         freq_idx, output, keeptapers, chan_idx=chan_idx, reference_mean=True, dec=dec, bluestein=bluestein)
+    freqs = np.fft.rfftfreq(nfft, 1e-3)
+    foi = freqs if freq_idx is None else freqs[freq_idx]
+    for b in range(nseg):
+        x = data[ss[b]:ss[b] + nsig]
+        if chan_idx is not None:
+            x = x[:, chan_idx]
+        ref, _ = O.mtmfft_cF(np.array(x, order="C"), foi=foi, keeptapers=keeptapers, polyremoval=None if detrend < 0 else detrend,
+                             output=output, method_kwargs=dict(samplerate=1000.0, taper=taper, taper_opt=topt,
+                                                               nSamples=nfft, demean_taper=demean_taper))
+        assert_parity(out[b], ref[0], what=f"segment {b}")
+        if output == "fourier" and detrend != 1:
+            err = np.abs(out[b].astype(np.complex128) - ref[0])
+            frac = float((err <= 1e-5 * np.abs(ref[0])).mean())
+            assert frac >= pure_frac, (nfft, frac)
+
+
+@pytest.mark.parametrize("nfft,nchan,K", [(256, 33, 2), (512, 17, 1), (1024, 9, 2), (2048, 5, 2), (4096, 3, 2),
+                                          (200, 17, 2), (500, 9, 1), (1000, 5, 2), (2000, 3, 2), (2500, 2, 1)])
+def test_dec64_kernel_vs_oracle(nfft, nchan, K):
+    _f64_case(nfft, nfft, nchan, K, "fourier", True, 0)
+
+
+@pytest.mark.parametrize("nfft", [8192, 16384, 4000, 5000, 10000])
+def test_dec64_kernel_long_schedules(nfft):
+    # 8192: four passes; 16384: 1024 threads, split exchange, samples re-read per taper; 10000: split exchange, V = 20
+    _f64_case(nfft, nfft, 2, 1, "fourier", True, 0)
+
+
+def test_dec64_kernel_options():
+    _f64_case(900, 1000, 4, 2, "pow", False, 1)                                   # padding, linear trend, taper mean
+    _f64_case(1700, 2000, 6, 2, "abs", True, 0, freq_idx=np.array([0, 1, 999, 1000, 37]), chan_idx=[5, 0, 3])
+    _f64_case(256, 256, 7, 3, "fourier", False, -1, demean_taper=True, nseg=2)    # complex taper mean, demean_taper
+    _f64_case(500, 512, 2, 1, "imag", True, 0, nseg=2)
+    _f64_case(2048, 2048, 1, 2, "pow", True, 0)                                   # a single channel: half a pair
+
+
+@pytest.mark.parametrize("nfft,nchan,K,bluestein", [(360, 3, 2, False), (1009, 2, 1, True), (134, 3, 2, True),
+                                                     (3001, 1, 1, True), (268, 2, 1, False)])
+def test_f64_any_kernel_and_bluestein_vs_oracle(nfft, nchan, K, bluestein):
+    # 1009 and 3001 are primes, 134 = 2 x 67, 268 = 4 x 67 through the O(R^2) pass AND through the chirp-z form
+    _f64_case(nfft, nfft, nchan, K, "fourier", True, 0, dec=False, bluestein=bluestein)
+    if nfft == 268:
+        _f64_case(nfft, nfft, nchan, K, "fourier", True, 0, dec=False, bluestein=True)
