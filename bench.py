@@ -31,6 +31,10 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F64_TFLOPS = 78.6          # MI355X_MICROARCH.md: FP64 vector / matrix
 PEAK_HBM_GBS = 8000.0
+# SURVEY 8(d) bound of the headline on one GPU: K4's 3.775e9 algorithmic flops per trial at 157.3 TFLOP/s = 24.0 us
+# -> 41.7 k trials/s (the transform stage in front of it is not in this bound: headline_frac prices the WHOLE step,
+# K0 + K1 + K4 + K5 back to back, against K4's matrix bound alone)
+HEADLINE_BOUND_TRIALS_PER_S = 41.7e3
 
 
 def parse():
@@ -195,7 +199,7 @@ def pmc_traffic(nrows, nfreq, nchan):
     (bytes or None, provenance): the counters are only reported for the launch shape AND the kernel sources they were
     taken on (first line of the file: shape and `k4_sources_sha`)."""
     sha = k4_sources_sha()
-    for name in ("r3_pmc_counters_final.txt", "r2_pmc_counters_final.txt", "r1_pmc_counters_final.txt"):
+    for name in ("r4_pmc_headline.txt", "r3_pmc_counters_final.txt", "r2_pmc_counters_final.txt", "r1_pmc_counters_final.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -223,6 +227,43 @@ def pmc_traffic(nrows, nfreq, nchan):
         elif name == "WRITE_SIZE":
             total += 1024.0 * float(rest)
     return (total or None), prov
+
+
+PMC_SECONDARY = "r4_pmc_secondary.txt"
+
+
+def pmc_secondary(mode):
+    """HBM bytes per trial of one `secondary` workload from the committed counter file (profiles/r4_pmc_secondary.txt,
+    written by tools/final_bench.sh through the torch-free tools/pmc_harness2.cpp - same plans, shapes and launch
+    arguments): sum over the workload's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x 1024 x dispatches, divided by the
+    repetitions and trials of the harness run (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    Returns (bytes per trial or None, provenance)."""
+    path = os.path.join(ROOT, "profiles", PMC_SECONDARY)
+    prov = {"from_profile": "profiles/" + PMC_SECONDARY, "section": mode}
+    if not os.path.exists(path):
+        return None, {"from_profile": None}
+    import re
+    total, inside, T, reps, kernels = 0.0, False, None, None, []
+    for ln in open(path):
+        if ln.startswith("## "):
+            inside = ln.split()[1] == mode
+            if inside:
+                mt, mr = re.search(r"T=(\d+)", ln), re.search(r"reps=(\d+)", ln)
+                T, reps = (int(mt.group(1)) if mt else None), (int(mr.group(1)) if mr else None)
+            continue
+        if not inside:
+            continue
+        if not ln.startswith(" "):
+            kernels.append(ln.split("[")[0].strip())
+            continue
+        name = ln.split()[0]
+        mn, mm = re.search(r"n=\s*(\d+)", ln), re.search(r"mean=([0-9.eE+-]+)", ln)
+        if name in ("FETCH_SIZE", "WRITE_SIZE") and mn and mm:
+            total += (2.0 if name == "FETCH_SIZE" else 1.0) * 1024.0 * float(mm.group(1)) * int(mn.group(1))
+    if not total or not T or not reps:
+        return None, prov
+    prov.update({"trials": T, "reps": reps, "kernels": [k for k in kernels if k.startswith("spy")]})
+    return total / (T * reps), prov
 
 
 class _QuietStdout:
@@ -255,6 +296,14 @@ def _event_ms(torch, fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
+def _traffic(mode, algorithmic_bytes):
+    """`traffic` fields of a secondary entry: counter bytes per trial, their ratio to the algorithmic bytes, the files a
+    reader needs to recompute the entry (kernel durations: profiles/r4_secondary_kernel_stats.txt, section `mode`)."""
+    t, prov = pmc_secondary(mode)
+    return {"traffic_bytes_per_trial": t, "traffic_over_algorithmic": (t / algorithmic_bytes) if t else None,
+            "traffic_source": prov, "kernel_stats": "profiles/r4_secondary_kernel_stats.txt#" + mode}
+
+
 def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
     """The other SURVEY 8(d) numbers, inputs resident in HBM, each priced against the bound SURVEY 8(d) names:
     frac = max(bytes / 8 TB/s, flops / peak) / measured time."""
@@ -275,7 +324,15 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
                 "channel_samples_per_s": T / (ms * 1e-3) * N * C, "kernel": plan.kernel_name,
                 "bound": "fft-flop (fp32 vector peak) vs hbm, whichever is larger", "bound_us_per_trial": bound_us,
                 "bytes_per_trial": byt, "flop_per_trial": flop, "frac": bound_us / (1e3 * ms / T),
-                "hbm_GBps": byt * T / (ms * 1e-3) / 1e9})
+                "hbm_GBps": byt * T / (ms * 1e-3) / 1e9, **_traffic("c2", byt)})
+    # ---- the same under precision="reference" (float64 taper product and transform, mtmfft_dec64_kernel.h)
+    if plan.set_precision(True):
+        ms64 = _event_ms(torch, lambda: plan.execute(data, starts, out=buf))
+        out.append({"name": "c2 under precision='reference' (float64 transform, complex64 rounding where mtmfft.py:104-127 rounds)",
+                    "value": T / (ms64 * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms64 / T, "kernel": plan.kernel_name,
+                    "ratio_to_float32": ms64 / ms, "bound": "fp64 vector %.1f TFLOP/s on the same flop count" % PEAK_F64_TFLOPS,
+                    "bound_us_per_trial": flop / (PEAK_F64_TFLOPS * 1e12) * 1e6,
+                    "frac": flop / (PEAK_F64_TFLOPS * 1e12) / (1e-3 * ms64 / T), **_traffic("c2f64", byt)})
     del buf, plan
     # ---- c2 at trial lengths that are not powers of two (1 kHz x 2 s / 5 s; BASELINE configs[0] is N = 2000):
     # the packed mixed-radix engine K1m
@@ -294,7 +351,12 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
                     "value": T2 / (ms * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms / T2,
                     "channel_samples_per_s": T2 / (ms * 1e-3) * N2 * C, "kernel": plan.kernel_name,
                     "bound": "fft-flop (fp32 vector peak) vs hbm, whichever is larger", "bound_us_per_trial": bound_us,
-                    "bytes_per_trial": byt, "flop_per_trial": flop, "frac": bound_us / (1e3 * ms / T2)})
+                    "bytes_per_trial": byt, "flop_per_trial": flop, "frac": bound_us / (1e3 * ms / T2),
+                    **_traffic("n%d" % N2, byt)})
+        if plan.set_precision(True):
+            ms64 = _event_ms(torch, lambda: plan.execute(d2, st2, out=buf))
+            out[-1]["reference_precision"] = {"us_per_trial": 1e3 * ms64 / T2, "ratio_to_float32": ms64 / ms,
+                                              "kernel": plan.kernel_name, **_traffic("n%df64" % N2, byt)}
         del buf, plan, d2
     # ---- c4: 128 ch x 16384 samples (configs[3]); (i) 512-sample Hann windows, 50 % overlap
     C4, N4, T4 = 128, 16384, 200
@@ -315,7 +377,8 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
     out.append({"name": "c4 mtmconvol (BASELINE configs[3] i): %d ch x %d samp x %d trials, hann nperseg 512, 50 %% overlap, pow" % (C4, N4, T4),
                 "value": T4 / (ms * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms / T4, "kernel": plan.kernel_name,
                 "bound": "hbm", "bytes_per_trial": byt, "bound_us_per_trial": byt / (PEAK_HBM_GBS * 1e9) * 1e6,
-                "frac": byt / (PEAK_HBM_GBS * 1e9) / (1e-3 * ms / T4), "hbm_GBps": byt * T4 / (ms * 1e-3) / 1e9})
+                "frac": byt / (PEAK_HBM_GBS * 1e9) / (1e-3 * ms / T4), "hbm_GBps": byt * T4 / (ms * 1e-3) / 1e9,
+                **_traffic("conv", byt)})
     del buf, plan
     # ---- c4 (ii): Morlet wavelets, 25 scales 4 .. 100 Hz, every sample, trial average accumulated on the device
     foi = np.arange(4, 104, 4, dtype=float)
@@ -330,7 +393,8 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
                 "value": T4 / (ms * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms / T4,
                 "kernel": "spycwt::cwt2_kernel (4 block groups) + cwt_scatter_kernel",
                 "bound": "max(hbm at keeptrials accounting, fft-flop lower estimate)", "bytes_per_trial": byt,
-                "flop_per_trial": flop_lo, "bound_us_per_trial": bound_us, "frac": bound_us / (1e3 * ms / T4)})
+                "flop_per_trial": flop_lo, "bound_us_per_trial": bound_us, "frac": bound_us / (1e3 * ms / T4),
+                **_traffic("wav", byt)})
     del res, plan, d4
     # ---- headline through the front end: spy.connectivityanalysis(method="coh") on host-resident AnalogData.  First
     # call = PCIe-inclusive (trial queue uploaded host -> HBM, plans and tapers built); warm call = front-end inclusive
@@ -359,12 +423,15 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
     # ---- c5: Wilson / Granger AV stage on the CSD of the resident trials (demean_taper as method='granger' sets it)
     plan = be.FFTPlan(N, N, C, tapers, np.sqrt(2) / N, 0, True, None, "fourier", True, reference_mean=refmean)
     acc = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
-    Tg = min(T, 400)
-    for b0 in range(0, Tg, 100):
-        be.csd_accumulate(plan.execute(data, starts[b0:b0 + 100]), acc)
+    Tg = T
+    torch.cuda.synchronize()
+    t_st = time.perf_counter()
+    for b0 in range(0, Tg, 500):
+        be.csd_accumulate(plan.execute(data, starts[b0:b0 + 500]), acc)
     be.csd_finalize(acc, 1.0 / (K * Tg))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    dt_st = t0 - t_st
     G, meta = be.granger(acc, niter=100)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -372,11 +439,13 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
     iters = stats.get("iterations")
     flop_it = 2 * (F - 1) * 8.0 * C ** 3 * 6            # inverse + 4 GEMMs on the 2(F-1) lag-domain bins
     flop_it_exec = F * 8.0 * C ** 3 * 5                 # what K6 executes: inverse + 4 products on the F rfft bins
-    entry = {"name": "c5 Granger AV stage (BASELINE configs[4], one GPU): regularize_csd + wilson_sf + granger on %d x %d x %d" % (F, C, C),
+    entry = {"name": "c5 (BASELINE configs[4]) on one GPU: AV stage regularize_csd + wilson_sf + granger on %d x %d x %d (value), after the ST stage of %d trials with demean_taper (st_stage_s)" % (F, C, C, T),
              "value": dt, "unit": "s", "higher_is_better": False, "converged": meta["converged"],
              "max_rel_err": meta["max rel. err"], "cond0": meta["initial cond. num"], "iterations": iters,
              "kernel": "spywil::zinv_mfma_kernel / zgemm_mfma_kernel<0..3> / plus4_kernel", "bound": "fp64 %.1f TFLOP/s" % PEAK_F64_TFLOPS,
              "flop_per_iteration": flop_it, "executed_flop_per_iteration": flop_it_exec,
+             "st_stage_s": dt_st, "st_trials": Tg, "st_plus_av_s": dt_st + dt,
+             "kernel_stats": "profiles/r4_wilson_kernel_stats.csv", "counters": "profiles/r4_wilson_pmc.txt",
              "note": "frac prices the flops the kernels execute (conjugate symmetry: F of the reference's 2(F-1) bins) "
                      "against the fp64 matrix peak; algorithmic_frac uses SURVEY 8(d)'s count for the full spectrum"}
     if iters:
@@ -437,7 +506,8 @@ def main():
     ev_csd, ev_fft, ev_coll = [], [], []
     nstep = [0]
 
-    def step(timed):
+    def step(timed, fft_plan=None):
+        fft_plan = fft_plan or plan
         slot = nstep[0] % len(accs)
         nstep[0] += 1
         acc = accs[slot]
@@ -451,7 +521,7 @@ def main():
             if timed:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
-            plan.execute(data, starts_all[b0:b0 + nb], out=sp)
+            fft_plan.execute(data, starts_all[b0:b0 + nb], out=sp)
             if timed:
                 e1.record()
             be.csd_accumulate(sp, acc, blocked=blocked)
@@ -544,6 +614,31 @@ def main():
             x = spec.reshape(-1, F, C)[:, f, :].to(torch.complex128)
             dist.all_reduce(torch.view_as_real(x.T @ x.conj()))
 
+    # the same analysis with float64 transforms (precision="reference": what `connectivityanalysis` switches to by itself
+    # when the spectra's dynamic range asks for it) - K1 through mtmfft_dec64_kernel, K4 / K5 unchanged; not `value`
+    ref_prec = None
+    if not blocked and not dist_on:
+        plan64 = be.FFTPlan(N, N, C, tapers, scale, detrend=0, demean_taper=False, freq_idx=None, output="fourier",
+                            keeptapers=True, reference_mean=refmean)
+        if plan64.set_precision(True):
+            step(False, plan64)
+            fence()
+            n64 = max(2, min(args.steps, 5))
+            ev64 = len(ev_fft)
+            t64 = time.perf_counter()
+            for _ in range(n64):
+                coh64 = step(True, plan64)
+            fence()
+            el64 = time.perf_counter() - t64
+            fft64 = [a.elapsed_time(b) for a, b, _ in ev_fft[ev64:]]
+            del ev_fft[ev64:], ev_csd[ev64:]
+            ref_prec = {"name": "headline under precision='reference': the same %d trials per step with float64 taper product and "
+                                "transform (complex64 rounding where mtmfft.py:104-127 rounds), K4 / K5 unchanged" % T,
+                        "value": T * n64 / el64, "unit": "trials/s", "ms_per_step": 1e3 * el64 / n64, "steps": n64,
+                        "fft_kernel": plan64.kernel_name, "fft_ms_per_trial": sum(fft64) / (T * n64),
+                        "max_abs_diff_to_float32_coherence": float((coh64 - coh).abs().max())}
+        del plan64
+
     if rank == 0:
         assert bool(torch.isfinite(coh).all()), "non-finite coherence"
         diag = coh[:, torch.arange(C), torch.arange(C)]
@@ -571,6 +666,8 @@ def main():
             "metric": "trials/sec for mtmfft+coherence (256 ch x 4096 samples, 7 DPSS tapers, full CSD)",
             "value": value,
             "unit": "trials/s",
+            # whole step against SURVEY 8(d)'s bound of 41.7 k trials/s per GPU (K4's matrix bound)
+            "headline_frac": value / (world * HEADLINE_BOUND_TRIALS_PER_S),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -600,14 +697,18 @@ def main():
                 "achieved": achieved,
                 "peak": PEAK_MFMA_F32_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_MFMA_F32_TFLOPS,
+                # frac = what the matrix pipe really does: flops the kernel EXECUTES per launch / duration / peak (<= 1);
+                # algorithmic_frac = SURVEY 8(d)'s credited flops (8 per complex multiply-accumulate on the Hermitian-
+                # minimal triangle) / duration / peak - above frac because the 3-multiplication product executes 3/4 of them
+                "frac": ((executed / flops[0]) if executed else 1.0) * achieved / PEAK_MFMA_F32_TFLOPS,
+                "algorithmic_frac": achieved / PEAK_MFMA_F32_TFLOPS,
                 "flop_per_launch": flops[0],
                 "executed_mfma_flop_per_launch": executed,
-                "executed_frac_of_peak": (executed / flops[0]) * achieved / PEAK_MFMA_F32_TFLOPS if executed else None,
-                "note": "achieved counts 8 flop per complex multiply-accumulate on the Hermitian-minimal triangle "
-                        "(SURVEY 8d); the kernel for multiples of 16 channels uses the 3-multiplication complex product, so it "
-                        "executes fewer flops than it is credited with and frac may exceed 1 - "
-                        "executed_frac_of_peak is the matrix pipe's own utilisation",
+                "executed_TFLOPs": ((executed / flops[0]) if executed else 1.0) * achieved,
+                "note": "achieved = algorithmic flops (8 per complex multiply-accumulate on the Hermitian-minimal triangle, "
+                        "SURVEY 8d) / avg_launch_ms; executed_mfma_flop_per_launch = ceil(rows / 4) x F x sub-tiles x 3 MFMAs x "
+                        "2048 flop (= SQ_INSTS_MFMA x 2048 of profiles/r4_pmc_headline.txt); frac = executed / avg_launch_ms / peak",
+                "kernel_stats": "profiles/r4_bench_final_kernel_stats.csv (Name = the kernel above; AverageNs must agree with avg_launch_ms)",
                 "avg_launch_ms": float(np.mean(csd_ms)),
                 # spectra once + read-modify-write of the accumulator's lower triangle (16 x 16 sub-tiles for the
                 # 3-multiplication kernel, 32 x 32 tiles otherwise)
@@ -618,7 +719,7 @@ def main():
         }
         if world == 1 and not args.no_secondary:
             del spec
-            line["secondary"] = secondary(torch, be, synthdata, data, N, C, T, refmean)
+            line["secondary"] = ([ref_prec] if ref_prec else []) + secondary(torch, be, synthdata, data, N, C, T, refmean)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(C, N)
         print(json.dumps(line), flush=True)

@@ -149,10 +149,11 @@ int spyhip_fft_plan_set_blocked(spyhip_fft_plan* plan, int on);
 /* Precision of the transform.  reference = 0 (default): taper product and FFT in float32 - error ~1e-7 of a
  * channel's largest bin, inside the parity criterion |a-b| <= 1e-5 |b| + 1e-6 max|b|.  reference = 1: float64 taper
  * product and float64 FFT, the spectrum rounded to complex64 and scaled in float32 exactly where
- * specest/mtmfft.py:104-127 does it - every bin to ~1e-7 of ITSELF (pure rtol 1e-5 also 60 dB below the peak), at
- * about twice the cost for power-of-two nfft 256 ... 4096 (radix-16 register kernel); every other nfft up to 2^20
- * without a prime factor above 61 runs generic Stockham passes over work arrays in LDS (nfft <= 5120: ~8 x the cost)
- * or global memory (10-14 x: there for the precision, not the speed); standard layout; -3 otherwise. */
+ * specest/mtmfft.py:104-127 does it - every bin to ~1e-7 of ITSELF (pure rtol 1e-5 also 60 dB below the peak).  Cost:
+ * ~2x float32 where a compile-time radix schedule exists (mtmfft_dec64_kernel.h: nfft = 256 ... 16384 powers of two, 200,
+ * 500, 1000, 2000, 2500, 4000, 5000, 10000); every other nfft up to 2^20 runs generic Stockham passes over work arrays in
+ * LDS (nfft <= 5120) or global memory (4-10x), in Bluestein's chirp-z form when nfft has a prime factor above 61;
+ * standard layout only; -3 beyond 2^20 points. */
 int spyhip_fft_plan_set_precision(spyhip_fft_plan* plan, int reference);
 /* Constant detrending (detrend = SPYHIP_DETREND_CONSTANT) with the per-channel mean taken EXACTLY as the reference
  * takes it for whole trials: scipy.signal.detrend on the float32 (time x channel) array is data - np.mean(data, 0),

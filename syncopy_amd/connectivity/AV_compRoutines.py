@@ -6,7 +6,7 @@ import torch
 from .. import backend, parallel
 from ..shared.computational_routine import ComputationalRoutine
 from ..shared.const_def import spectralDTypes
-from ..shared.errors import SPYValueError, SPYWarning
+from ..shared.errors import SPYValueError
 
 
 def normalize_csd_cF(csd_av_dat, output="abs", chunkShape=None, noCompute=False):
@@ -77,33 +77,9 @@ class NormalizeCrossSpectra(_AverageRoutine):
         backend.jack_coh_accumulate(spec, ntaper, csd.contiguous(), direct.contiguous(), self.cfg["output"],
                                     ntrials_total, sum_d, sum_d2)
 
-    @staticmethod
-    def _dynamic_range_advice(raw, scale):
-        """Coherence divides spectra by spectra.  The float32 transform leaves an ABSOLUTE error of ~5e-7 of a channel's
-        rms bin in every single-trial spectrum (the reference transforms in float64), which averages down with the
-        number of (trial, taper) products N: a bin whose power sits a factor R below the channel's mean power carries
-        ~5e-7 sqrt(R / N) of error in its coherence.  Past 1e-6 - the floor of the parity criterion - say so once and
-        name the remedy ('Float32 transforms and ratios').  Judged on the frequencies the call
-        keeps: a `foilim` that cuts the loud part of the spectrum out hides it from this check."""
-        from ..specest import hip_spectral as hs
-        if hs._precision[-1] == "reference" or raw.shape[0] < 4:
-            return
-        diag = torch.diagonal(raw, dim1=1, dim2=2).real[2:]                 # (F - 2, C): the bins next to DC are detrended
-        ratio = float((diag.mean(dim=0) / diag.amin(dim=0).clamp_min(1e-38)).max())
-        nprod = 1.0 / scale
-        if 5e-7 * np.sqrt(ratio / nprod) > 1e-6:
-            if hs._advice is not None:            # precision="auto": the front end repeats the call in float64
-                hs._advice.append((ratio, nprod))
-                return
-            SPYWarning(f"the spectra span {10 * np.log10(ratio):.0f} dB below a channel's mean power over {nprod:.0f} "
-                       "trial x taper products: coherence in the weakest bins may deviate from a float64 transform by more "
-                       "than 1e-6; pass precision='reference' (or leave the default 'auto') for float64 transforms",
-                       caller="connectivityanalysis")
-
     def compute_hip(self, data, out):
         raw = getattr(data, "_acc_raw", None)
         if raw is not None:
-            self._dynamic_range_advice(raw, data._acc_scale)
             # straight from the ST stage's raw accumulator: scale + normalise + convert + mirror in one pass
             res = backend.coh_from_accumulator(raw, data._acc_scale, self.cfg["output"]).unsqueeze(0)
             out._dev = res

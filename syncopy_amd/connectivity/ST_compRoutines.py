@@ -68,8 +68,9 @@ def cross_spectra_cF(trl_dat, samplerate=1, nSamples=None, foi=None, taper="hann
     dev = torch.from_numpy(np.ascontiguousarray(dat, dtype=np.float32)).cuda()
     acc = torch.zeros(outShape[1:], dtype=torch.complex64, device=dev.device)
     pr = polyremoval if polyremoval in (0, 1) and polyremoval is not False else None
-    K = _csd_of_rows(dev, [(0, dev.shape[0])], None, nSamples, taper, taper_opt, demean_taper, pr, freq_idx,
-                     lambda i: acc, single_acc=True)
+    with hs.per_trial_route():
+        K = _csd_of_rows(dev, [(0, dev.shape[0])], None, nSamples, taper, taper_opt, demean_taper, pr, freq_idx,
+                         lambda i: acc, single_acc=True)
     backend.csd_finalize(acc, 1.0 / K)
     return backend.to_host(acc)[np.newaxis], {"freqs_hash": _freqs_hash(freqs)}
 
@@ -251,6 +252,38 @@ class CrossSpectra(ComputationalRoutine):
             out._dev_thunk = device_csd
             out.set_pending(lambda: backend.to_host(device_csd()), shape, np.complex64)
 
+    def needs_float64(self, data, method, sample=16):
+        """precision="auto" on the batched route: do the data ask for float64 transforms?  Coherence, Granger causality
+        and ppc are RATIOS (or phases) of spectra.  The float32 transform leaves an ABSOLUTE error of ~5e-7 of a channel's
+        rms bin in every single-trial spectrum - the reference transforms in float64 and has none - which averages down
+        with the number N of (trial, taper) products: a bin whose power sits a factor R below the channel's mean carries
+        ~5e-7 sqrt(R / N) of error in its coherence (floor of the parity criterion: 1e-6), and 5e-7 sqrt(R) of phase error
+        per trial in ppc, where a trial weighs 2 / T in the pair average (floor 5e-6 / sqrt(T)).  R = hs.dynamic_range of
+        the float32 spectra of (up to) `sample` of this rank's trials, the largest over the ranks so that every rank
+        takes the same branch.  Costs `sample` trials' transforms and one host synchronisation; AR(2)-type data never
+        asks, line noise 50 dB above the floor or 1/f spectra over four decades do."""
+        cfg = self.cfg
+        dev = data.device_data()
+        rows, chans = trial_rows(data), selected_channels(data)
+        nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
+        _, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
+        if freq_idx.size < 4:
+            return False
+        pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
+        T = len(rows)
+        lo, hi = parallel.my_shard(T)
+        mine = rows[lo:hi][:sample]
+        ratio, K = 0.0, 1
+        with hs.precision("float32"):
+            for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
+                                                 cfg["demean_taper"], False, pr, None, "fourier", True, reuse=True):
+                ratio = max(ratio, hs.dynamic_range(spec, kept=freq_idx))        # whole axis: see hs.dynamic_range
+                K = spec.shape[1]
+        ratio = parallel.allreduce_max(ratio)
+        if method == "ppc":
+            return bool(5e-7 * np.sqrt(ratio) * 2 / T > 5e-6 / np.sqrt(max(T, 1)))
+        return bool(5e-7 * np.sqrt(ratio / (T * K)) > 1e-6)
+
     def ppc_hip(self, data):
         """Pairwise phase consistency with the kernels (connectivity_analysis.py:624-663, ST_compRoutines.py:159-233):
         the tapered spectra of each batch of trials go straight into K7, which forms every trial's taper-averaged
@@ -266,21 +299,6 @@ class CrossSpectra(ComputationalRoutine):
         F, C = self.targetShapes[0][1], self.targetShapes[0][2]
         T = self.numTrials
         mine = [rows[k] for k in self.my_trials()]
-        if hs._advice is not None and hs._precision[-1] != "reference" and F >= 4:
-            # precision="auto" (connectivity_analysis.py): ppc is made of PHASES of single-trial cross spectra - the
-            # float32 transform's absolute error (5e-7 of a channel's rms bin) turns into 5e-7 sqrt(R) of phase error
-            # where the power sits a factor R below the channel's mean, and a trial weighs 2/T in the pair average.
-            # Judged on the auto-spectra of (up to) 16 of this rank's trials; the largest R over the ranks decides, so
-            # that every rank takes the same branch (the sum over ranks below is a collective).
-            ratio = 0.0
-            for _, spec in hs.run_mtmfft_batches(dev, mine[:16], chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
-                                                 cfg["demean_taper"], False, pr, freq_idx, "fourier", True, reuse=True):
-                p = spec.abs().square().mean(dim=(0, 1))[2:]                          # (F - 2, C)
-                ratio = max(ratio, float((p.mean(dim=0) / p.amin(dim=0).clamp_min(1e-38)).max()))
-            ratio = parallel.allreduce_max(ratio)
-            if 5e-7 * np.sqrt(ratio) * 2 / T > 5e-6 / np.sqrt(max(T, 1)):
-                hs._advice.append((ratio, T))
-                return None                                                            # the caller repeats in float64
         U = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
         for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
                                              cfg["demean_taper"], False, pr, freq_idx, "fourier", True, reuse=True):
@@ -363,7 +381,10 @@ def _padded_spectra(dev, rows, chans, n, polyremoval, max_bytes=8 << 30):
     L = backend.ccov_nfft(n)
     nchan = dev.shape[1] if chans is None else len(chans)
     ci = None if chans is None else torch.tensor(np.asarray(chans), dtype=torch.int32, device=dev.device)
-    plan = hs.get_plan(n, L, nchan, "boxcar", None, n, 1.0, polyremoval, False, None, "fourier", True, dev.device)
+    # float32 on every route: the reference's own cross-covariances are float32 FFT convolutions
+    # (scipy.signal.fftconvolve of float32 trials, ST_compRoutines.py:540-573)
+    with hs.precision("float32"):
+        plan = hs.get_plan(n, L, nchan, "boxcar", None, n, 1.0, polyremoval, False, None, "fourier", True, dev.device)
     per_trial = (L // 2 + 1) * nchan * 8
     bmax = max(1, int(max_bytes // per_trial))
     for i in range(0, len(rows), bmax):

@@ -29,12 +29,14 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
     `precision` (not a reference argument; as in `freqanalysis`): "reference" runs the taper product and the FFT of the
     single-trial spectra in float64 and rounds to complex64 where the reference does (mtmfft.py:96-127) - coherence, ppc
     and Granger are RATIOS of spectra, and where a channel's power is 40 dB or more below its peak the float32
-    transform's absolute error (5e-7 of the rms bin) is no longer small against the bin itself; needs a transform
-    length without a prime factor above 61; ~2x the time of the transform stage at power-of-two lengths 256 ... 4096, more
-    elsewhere.  "float32": the fast kernels whatever the data.  "auto" (default): float32, and for method="coh" / "ppc"
-    on the device route the call is repeated in float64 when the auto-spectra show that the float32 error in the
-    result would pass its floor (coherence 1e-6, ppc 5e-6; (more dynamic range than ~4 x the number of trial x taper products; the benchmark's AR(2)
-    data never triggers it)."""
+    transform's absolute error (5e-7 of the rms bin) is no longer small against the bin itself; any transform length up
+    to 2^20; ~2x the time of the transform stage at the lengths with a compile-time schedule (powers of two 256 ...
+    16384, 200 ... 10000 decimal), 4-10x elsewhere.  "float32": the fast kernels whatever the data.  "auto" (default):
+    the per-trial route (compute_method="sequential") transforms in float64 (its cost is invisible next to the copies);
+    the batched route transforms the first 16 trials in float32, looks at the dynamic range of their spectra
+    (CrossSpectra.needs_float64: coh / granger / ppc) and runs the analysis with float64 transforms when the float32
+    error in the result would pass its floor (the benchmark's AR(2) data never does; cost of the look: 16 trials'
+    transforms and one host synchronisation per call)."""
     if precision not in ("float32", "reference", "auto"):
         raise SPYValueError("'float32', 'reference' or 'auto'", varname="precision", actual=str(precision))
     if not isinstance(data, (AnalogData, SpectralData)) or data.data is None:
@@ -64,35 +66,8 @@ def connectivityanalysis(data, method="coh", keeptrials=False, output="abs", foi
         def run():
             return _connectivity(data, classes, method, keeptrials, output, foi, foilim, pad, polyremoval, tapsmofrq,
                                  nTaper, taper, taper_opt, compute_method, jackknife, cmb)
-        if precision == "reference":
-            with hs.precision("reference"):
-                return run()
-        if precision == "float32" or method not in ("coh", "ppc"):
+        with hs.precision(precision):
             return run()
-        # "auto": the float32 attempt reports through hs._advice whether the data ask for float64 transforms
-        hs._advice = []
-        res = None
-        try:
-            res = run()
-            asked = bool(hs._advice)
-        except _RepeatInFloat64:
-            asked = True
-        finally:
-            hs._advice = None
-        if not asked:
-            return res
-        try:
-            with hs.precision("reference"):
-                return run()
-        except SPYValueError:                       # (a transform length the float64 kernels do not serve)
-            SPYWarning("the dynamic range of the spectra asks for float64 transforms, which this transform length does not "
-                       "have (a prime factor above 61): float32 result returned; pad='nextpow2' would allow them",
-                       caller="connectivityanalysis")
-            return res if res is not None else run()
-
-
-class _RepeatInFloat64(Exception):
-    """Raised inside the float32 attempt of precision="auto" by a stage that gives up early (ppc)."""
 
 
 def _parse_channelcmb(data, channelcmb):
@@ -322,8 +297,6 @@ def _ppc(data, classes, st, compute_method, log_dict):
     if compute_method in (None, "hip") and hasattr(st, "ppc_hip"):
         st.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=False)
         res = st.ppc_hip(data)                       # (F, Ci, Cj) from raw trials, (nTime, F, Ci, Cj) from spectra
-        if res is None:                              # precision="auto": the spectra's dynamic range asks for float64
-            raise _RepeatInFloat64()
         out._dev = res if res.dim() == 4 else res.unsqueeze(0)
         out.data = backend.to_host(out._dev)
         st.process_metadata(data, out)
@@ -351,12 +324,17 @@ def _run_stages(data, classes, st, method, keeptrials, output, compute_method, j
     """ST stage (single-trial cross spectra, trial-averaged unless kept) -> AV stage, plus the jackknife.
     Coherence outputs that are the imaginary part or the phase run K4 with directly summed imaginary parts
     (backend.csd_phase_exact): the default 3-multiplication kernels subtract three rounded row sums there."""
-    exact = method == "coh" and output in ("imag", "angle") and compute_method in (None, "hip")
-    if exact:
-        from .. import backend
-        with backend.csd_phase_exact(True):
-            return _run_stages_impl(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
-    return _run_stages_impl(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
+    from contextlib import ExitStack
+    from ..specest import hip_spectral as hs
+    batched = compute_method in (None, "hip")
+    with ExitStack() as stack:
+        if (batched and hs.requested_precision() is None and method in ("coh", "granger", "ppc")
+                and isinstance(data, AnalogData) and hasattr(st, "needs_float64") and st.needs_float64(data, method)):
+            stack.enter_context(hs.soft_reference())          # precision="auto": the data ask for float64 transforms
+        if method == "coh" and output in ("imag", "angle") and batched:
+            from .. import backend
+            stack.enter_context(backend.csd_phase_exact(True))
+        return _run_stages_impl(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict)
 
 
 def _run_stages_impl(data, classes, st, method, keeptrials, output, compute_method, jackknife, log_dict):

@@ -357,10 +357,12 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         std::snprintf(buf, sizeof buf, "mtmfft_dec_kernel<N = %d, %s>", nfft, mode);
         p->kernel_name = buf;
     } else if (!std::getenv("SPYHIP_NO_MIXED") && !std::getenv("SPYHIP_FORCE_GENERIC") && !std::getenv("SPYHIP_FORCE_LONG") &&
-               // (one taper and a Bluestein length M <= 4096 - sliding Hann windows of 500 samples, say: the chirp-z
-               // kernel keeps the segment in registers and wins by 10-20 %; from two tapers on, and for M = 8192,
-               // the mixed-radix engine is ahead)
-               !(ntaper == 1 && 2 * nfft - 1 <= 4096 && !std::getenv("SPYHIP_FORCE_MIXED")) &&
+               // (round 3 sent ONE taper with a Bluestein length M <= 4096 to the chirp-z kernel - 10-20 % faster on
+               // sliding windows - but its two length-M transforms and three pointwise products leave ~4x the float32
+               // error of a direct transform: short Hann windows left the criterion in the seeded sweep, and a 64-point
+               // window went through M = 256.  5-smooth lengths take the mixed-radix engine whatever the taper count;
+               // SPYHIP_PREFER_BLUESTEIN=1 restores the old choice for A/B runs)
+               !(ntaper == 1 && 2 * nfft - 1 <= 4096 && std::getenv("SPYHIP_PREFER_BLUESTEIN") && !std::getenv("SPYHIP_FORCE_MIXED")) &&
                spyfft::mix_schedule(nfft, (nchan + 3) / 4, &p->mix, &p->mix_threads, &p->lds_bytes) &&
                p->lds_bytes <= ctx->lds_per_block) {
         // 5-smooth lengths (2000, 3000, 5000, 500 ...): the packed mixed-radix engine

@@ -218,7 +218,8 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
     src.some = src.rhi > src.rlo;
 
     float x0[V], x1[V];           // XRES: resident across the tapers; otherwise refilled per taper
-    src.template get_all<V, T>(j0, x0, x1);
+    const bool fit = !(a.detrend == 0 && a.means) && a.detrend >= 0;
+    if (C::XRES || fit) src.template get_all<V, T>(j0, x0, x1);
 
     // ---- polynomial removal in float32 (scipy.signal.detrend on the float32 trial, compRoutines.py:169-172): the
     // reference-order means (detrend 0) or a float64 fit whose trend is rounded to float32 before it is subtracted;
@@ -226,7 +227,6 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
     const float mid = 0.5f * (float)(a.nsig - 1);
     float m0 = 0.f, m1 = 0.f;                          // constant detrending with the reference-order means
     double t0c = 0.0, t1c = 0.0, t0s = 0.0, t1s = 0.0; // fitted trend: constant and slope about the centre
-    const bool fit = !(a.detrend == 0 && a.means) && a.detrend >= 0;
     if (a.detrend == 0 && a.means) {
         m0 = has0 ? a.means[(size_t)b * a.nchan + c0] : 0.f;
         m1 = has1 ? a.means[(size_t)b * a.nchan + c0 + 1] : 0.f;
@@ -271,12 +271,15 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         }
     }
 
-    float macc0[MEAN ? HV + 1 : 1], macc1[MEAN ? HV + 1 : 1], mim0[(MEAN && CPLX) ? HV + 1 : 1], mim1[(MEAN && CPLX) ? HV + 1 : 1];
-    if (MEAN) {
+    // taper mean: float32 accumulators in registers - or, where a 1024-thread workgroup leaves no room for them, in
+    // the output slab itself (every thread owns its bins; same float32 additions in taper order, one division at the end)
+    constexpr bool MREG = MEAN && C::NTHREADS < 1024;
+    float macc0[MREG ? HV + 1 : 1], macc1[MREG ? HV + 1 : 1], mim0[(MREG && CPLX) ? HV + 1 : 1], mim1[(MREG && CPLX) ? HV + 1 : 1];
+    if constexpr (MREG) {
 #pragma unroll
         for (int e = 0; e <= HV; ++e) {
             macc0[e] = macc1[e] = 0.f;
-            if (CPLX) mim0[e] = mim1[e] = 0.f;
+            if constexpr (CPLX) mim0[e] = mim1[e] = 0.f;
         }
     }
     const int kout = MEAN ? 1 : a.ntaper;
@@ -288,21 +291,40 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         const int j = opaque(j0);     // (keeps the twiddle loads and the index arithmetic of the passes inside the loop)
         const double* w = fa.tapers64 + (size_t)k * a.nsig;
         cd v[V];
+        bool filled = false;
         if constexpr (!C::XRES) {
             // not resident: the samples come back from L2 for every taper, detrended in float32 as above
-            src.template get_all<V, T>(j, x0, x1);
-            if (!f64t) {
+            if (src.some && src.vec2 && !f64t) {
+                // the common case in one straight pass: nothing but v[] stays live (a 1024-thread workgroup has 128 registers)
+                filled = true;
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     const int n = j + T * e;
+                    const int nc = min(max(n, src.rlo), src.rhi - 1);
+                    const float2 t = *reinterpret_cast<const float2*>(src.seg + (size_t)nc * src.ld + src.col0);
                     const double dn = (double)((float)n - mid);
                     const float r0 = fit ? (float)(t0c + t0s * dn) : m0, r1 = fit ? (float)(t1c + t1s * dn) : m1;
-                    x0[e] -= n < a.nsig ? r0 : 0.f;
-                    x1[e] -= n < a.nsig ? r1 : 0.f;
+                    const float u0 = ((n == nc) ? t.x : 0.f) - (n < a.nsig ? r0 : 0.f);
+                    const float u1 = ((n == nc) ? t.y : 0.f) - (n < a.nsig ? r1 : 0.f);
+                    const double wn = n < a.nsig ? w[n] : 0.0;
+                    v[e] = make_double2(wn * (double)u0, wn * (double)u1);
+                }
+            } else {
+                src.template get_all<V, T>(j, x0, x1);
+                if (!f64t) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const int n = j + T * e;
+                        const double dn = (double)((float)n - mid);
+                        const float r0 = fit ? (float)(t0c + t0s * dn) : m0, r1 = fit ? (float)(t1c + t1s * dn) : m1;
+                        x0[e] -= n < a.nsig ? r0 : 0.f;
+                        x1[e] -= n < a.nsig ? r1 : 0.f;
+                    }
                 }
             }
         }
-        if (f64t) {
+        if (filled) {
+        } else if (f64t) {
             // float64 segments in the reference: the trend is subtracted in float64
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -405,13 +427,42 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
             // complex64 storage, then the float32 normalisation factor (mtmfft.py:104,117-127)
             const float2 s0 = make_float2(__fmul_rn((float)X0.x, a.scale), __fmul_rn((float)X0.y, a.scale));
             const float2 s1 = make_float2(__fmul_rn((float)X1.x, a.scale), __fmul_rn((float)X1.y, a.scale));
-            if (MEAN) {
-                if (CPLX) {
+            if constexpr (MREG) {
+                if constexpr (CPLX) {
                     macc0[e] += s0.x; mim0[e] += s0.y;
                     macc1[e] += s1.x; mim1[e] += s1.y;
                 } else {
                     macc0[e] += convert_real<OUTK>(s0, a.out_kind);
                     macc1[e] += convert_real<OUTK>(s1, a.out_kind);
+                }
+                continue;
+            }
+            if (MEAN) {
+                const int fi = a.fpos ? a.fpos[f] : f;
+                if (fi < 0) continue;
+                const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;
+                const bool first = k == 0, last = k == a.ntaper - 1;
+                const float nt = (float)a.ntaper;
+                if (CPLX) {
+                    float2* q = reinterpret_cast<float2*>(slab + o);
+                    float2 v0 = s0, v1 = s1;
+                    if (!first) {
+                        if (has0) { v0.x += q[0].x; v0.y += q[0].y; }
+                        if (has1) { v1.x += q[1].x; v1.y += q[1].y; }
+                    }
+                    if (last) { v0.x /= nt; v0.y /= nt; v1.x /= nt; v1.y /= nt; }
+                    if (has0) q[0] = v0;
+                    if (has1) q[1] = v1;
+                } else {
+                    float* q = reinterpret_cast<float*>(slab + o);
+                    float v0 = convert_real<OUTK>(s0, a.out_kind), v1 = convert_real<OUTK>(s1, a.out_kind);
+                    if (!first) {
+                        if (has0) v0 += q[0];
+                        if (has1) v1 += q[1];
+                    }
+                    if (last) { v0 /= nt; v1 /= nt; }
+                    if (has0) q[0] = v0;
+                    if (has1) q[1] = v1;
                 }
                 continue;
             }
@@ -436,7 +487,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         // no barrier here: the next taper's first LDS write sits behind one (d64_exchange / block_sum)
     }
 
-    if (MEAN) {
+    if constexpr (MREG) {
         char* const slab = reinterpret_cast<char*>(a.out) + (size_t)b * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
         const float nt = (float)a.ntaper;
 #pragma unroll
@@ -446,7 +497,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
             const int fi = a.fpos ? a.fpos[f] : f;
             if (fi < 0) continue;
             const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;
-            if (CPLX) {
+            if constexpr (CPLX) {
                 if (has0) *reinterpret_cast<float2*>(slab + o) = make_float2(macc0[e] / nt, mim0[e] / nt);
                 if (has1) *reinterpret_cast<float2*>(slab + o + 8) = make_float2(macc1[e] / nt, mim1[e] / nt);
             } else {

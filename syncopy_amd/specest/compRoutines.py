@@ -46,9 +46,10 @@ def mtmfft_cF(trl_dat, foi=None, timeAxis=0, keeptapers=True, polyremoval=None, 
         return outShape, spectralDTypes[output]
 
     dev = _as_device_trial(trl_dat, timeAxis)
-    res = hs.run_mtmfft(dev, [(0, dev.shape[0])], None, nSamples, method_kwargs["taper"], method_kwargs["taper_opt"],
-                        method_kwargs.get("demean_taper", False), method_kwargs.get("ft_compat", False), polyremoval,
-                        freq_idx, output, keeptapers)[0]
+    with hs.per_trial_route():
+        res = hs.run_mtmfft(dev, [(0, dev.shape[0])], None, nSamples, method_kwargs["taper"], method_kwargs["taper_opt"],
+                            method_kwargs.get("demean_taper", False), method_kwargs.get("ft_compat", False), polyremoval,
+                            freq_idx, output, keeptapers)[0]
     spec = hs.backend.to_host(res)[np.newaxis]
     return spec, {"freqs_hash": _freqs_hash(freqs)}
 
@@ -155,8 +156,9 @@ def mtmconvol_cF(trl_dat, soi, postselect, equidistant=True, toi=None, foi=None,
     if noCompute:
         return outShape, spectralDTypes[output]
     dev = _as_device_trial(trl_dat, timeAxis)
-    res = _mtmconvol_device(dev, 0, dev.shape[0], soi, postselect, equidistant, toi, foi, keeptapers, polyremoval,
-                            output, method_kwargs, None)
+    with hs.per_trial_route():
+        res = _mtmconvol_device(dev, 0, dev.shape[0], soi, postselect, equidistant, toi, foi, keeptapers, polyremoval,
+                                output, method_kwargs, None)
     return hs.backend.to_host(res)
 
 

@@ -32,17 +32,21 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
                  polyremoval=0, taper="hann", demean_taper=False, taper_opt=None, tapsmofrq=None, nTaper=None,
                  keeptapers=False, toi="all", t_ftimwin=None, wavelet="Morlet", width=6, order=None, order_max=None,
                  order_min=1, c_1=3, adaptive=False, ft_compat=False, select=None, compute_method=None,
-                 routine_classes=None, precision="float32", **kwargs):
+                 routine_classes=None, precision="auto", **kwargs):
     """Spectral estimation of AnalogData on MI355X.  Arguments as spy.freqanalysis
     (freqanalysis.py:62-90).  `compute_method`: None/'hip' (batched from the in-HBM trial
     queue) or 'sequential' (the reference's per-trial loop over the same kernels).
     `routine_classes` lets tests substitute compute classes (e.g. bound to the CPU oracle).
-    `precision` (not a reference argument): "float32" (default) transforms in float32 - ~1e-7 of a channel's largest
-    bin; "reference" runs the taper product and the FFT in float64 and rounds to complex64 where the reference does
-    (mtmfft.py:96-127): every bin to 1e-5 of itself, ~5x the time; methods 'mtmfft' / 'mtmconvol' / 'welch' with a
-    transform length without a prime factor above 61 (power-of-two lengths 256 ... 4096 are the fast case)."""
-    if precision not in ("float32", "reference"):
-        raise SPYValueError("'float32' or 'reference'", varname="precision", actual=str(precision))
+    `precision` (not a reference argument): "float32" transforms in float32 - ~1e-7 of a channel's largest bin;
+    "reference" runs the taper product and the FFT in float64 and rounds to complex64 where the reference does
+    (mtmfft.py:96-127): every bin to 1e-5 of itself, ~2x the time at the lengths with a compile-time schedule (powers of
+    two 256 ... 16384, 200 ... 10000 decimal), 4-10x elsewhere; methods 'mtmfft' / 'mtmconvol' / 'welch', any transform
+    length up to 2^20.  "auto" (default): float64 on the per-trial route (compute_method="sequential": the copies
+    dominate there) and, on the batched route, for the outputs that isolate a PART of the complex spectrum - 'fourier',
+    'real', 'imag', 'angle', 'absreal', 'absimag' - where a small part next to a large one inherits the large one's
+    float32 error; 'pow' and 'abs' stay float32 (inside the criterion by its floor)."""
+    if precision not in ("float32", "reference", "auto"):
+        raise SPYValueError("'float32', 'reference' or 'auto'", varname="precision", actual=str(precision))
     if precision == "reference" and method not in ("mtmfft", "mtmconvol", "welch"):
         raise SPYValueError("method 'mtmfft', 'mtmconvol' or 'welch' for precision='reference'", varname="method", actual=method)
     if not isinstance(data, AnalogData) or data.data is None:
@@ -69,16 +73,14 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
             raise SPYValueError("0, 1 or None", varname="polyremoval", actual=polyremoval)
         polyremoval = int(polyremoval)
 
+    from . import hip_spectral as hs
     with attached_selection(data, select):
-        if precision == "reference":
-            from . import hip_spectral as hs
-            with hs.precision("reference"):
-                return _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval,
-                                     taper, demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin,
-                                     wavelet, width, ft_compat, compute_method, (order_max, order_min, c_1, adaptive))
-        return _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
-                             demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin, wavelet, width,
-                             ft_compat, compute_method, (order_max, order_min, c_1, adaptive))
+        soft = (precision == "auto" and compute_method in (None, "hip") and method in ("mtmfft", "mtmconvol", "welch")
+                and output not in ("pow", "abs"))
+        with (hs.soft_reference() if soft else hs.precision(precision)):
+            return _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
+                                 demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin, wavelet, width,
+                                 ft_compat, compute_method, (order_max, order_min, c_1, adaptive))
 
 
 def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
@@ -238,10 +240,42 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
 
     out = SpectralData(dimord=SpectralData._defaultDimord)
     cr.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=keeptrials)
-    cr.compute(data, out, parallel=False, log_dict=log_dct, method=compute_method)
+    from contextlib import ExitStack
+    from . import hip_spectral as hs
+    with ExitStack() as stack:
+        if (hs.requested_precision() is None and compute_method in (None, "hip") and hasattr(cr, "compute_hip")
+                and method in ("mtmfft", "mtmconvol", "welch") and _selection_hides_peak(data, cr, method, foi, freqs)):
+            stack.enter_context(hs.soft_reference())      # precision="auto": kept bins far below the spectrum's peak
+        cr.compute(data, out, parallel=False, log_dict=log_dct, method=compute_method)
     if method == "welch":
         out = _time_mean(out)
     return out
+
+
+def _selection_hides_peak(data, cr, method, foi, freqs):
+    """See hip_spectral.selection_hides_peak: a handful of this rank's trials (mtmfft) or of the first trial's windows
+    (mtmconvol / welch) through the float32 kernels, whole axis, against the bins the call keeps."""
+    from .. import parallel
+    from ..datatype import selected_channels, trial_rows
+    from . import hip_spectral as hs
+    if foi is None or freqs is None or len(foi) >= len(freqs):
+        return False
+    _, fidx = best_match(freqs, foi, squash_duplicates=True)
+    rows, chans = trial_rows(data), selected_channels(data)
+    lo, hi = parallel.my_shard(len(rows))
+    mine = rows[lo:hi]
+    mk = cr.cfg["method_kwargs"]
+    if method == "mtmfft":
+        seg, nfft, pr, opt = mine, mk["nSamples"], cr.cfg["polyremoval"], mk["taper_opt"]
+    else:
+        n = mk["nperseg"]
+        seg = [(a, a + n) for r0, r1 in mine[:1] for a in range(r0, r1 - n + 1, max(n, (r1 - r0) // 16))]
+        # windows picked by a `toi` array are never detrended (compRoutines.py:392-408), sliding ones per frame
+        pr = None if not cr.cfg.get("equidistant", True) else cr.cfg["polyremoval"]
+        nfft, opt = n, dict(mk["taper_opt"] or {})
+        if mk["taper"] == "dpss":
+            opt["sym"] = False
+    return hs.selection_hides_peak(data.device_data(), seg, chans, nfft, mk["taper"], opt, pr, fidx, len(freqs))
 
 
 def _windows_at(toi, even, nperseg, fs, tStart):

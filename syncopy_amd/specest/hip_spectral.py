@@ -30,18 +30,58 @@ def _cache_hit(cache, key):
     return value
 
 
-_precision = ["float32"]        # arithmetic of the tapered FFT plans created inside `with precision(...)`
-_advice = None                  # a list while connectivityanalysis(precision="auto") runs its float32 attempt: the
-                                # coherence stage records here that the data's dynamic range asks for float64 transforms
+# Arithmetic of the tapered-FFT plans requested from here on - a stack of "float32" | "reference" | None.
+#   None (the default, precision="auto" of the front ends): the ROUTE decides -
+#     * compute functions called one trial at a time (the reference's own trial loop, INTEGRATION.md route B) transform in
+#       float64: every call moves a trial over PCIe both ways, the transform's cost is invisible next to that, and the
+#       result then carries the reference's own rounding (mtmfft.py:96-127) whatever the data;
+#     * the batched routes transform in float32 unless the front end decided otherwise for this call (`freqanalysis`:
+#       outputs that isolate a part of the complex spectrum; `connectivityanalysis`: `needs_float64` below).
+_precision = [None]
+
+
+class PrecisionUnavailable(SPYValueError):
+    """No float64 kernel serves this transform length (beyond 2^20 points)."""
 
 
 class precision:
     """`with hs.precision("reference"):` - tapered-FFT plans requested inside the block transform in float64 and round
-    to complex64 where the reference does (mtmfft.py:96-127; spyhip_fft_plan_set_precision).  Default "float32"."""
+    to complex64 where the reference does (mtmfft.py:96-127; spyhip_fft_plan_set_precision); "float32": the fast
+    kernels; "auto" / None: the route's default (above)."""
 
     def __init__(self, kind):
-        if kind not in ("float32", "reference"):
-            raise SPYValueError("'float32' or 'reference'", varname="precision", actual=str(kind))
+        if kind not in ("float32", "reference", "auto", None):
+            raise SPYValueError("'float32', 'reference' or 'auto'", varname="precision", actual=str(kind))
+        self.kind = None if kind == "auto" else kind
+
+    def __enter__(self):
+        _precision.append(self.kind)
+        return self
+
+    def __exit__(self, *exc):
+        _precision.pop()
+        return False
+
+
+def requested_precision():
+    """What the innermost `with precision(...)` asked for: "float32", "reference" or None (the route decides)."""
+    return _precision[-1]
+
+
+def per_trial_route():
+    """Context of a compute function that serves ONE trial per call: float64 transforms unless the caller fixed the
+    precision."""
+    return _Pushed("reference?" if _precision[-1] is None else _precision[-1])
+
+
+def soft_reference():
+    """Context of a batched call whose front end chose float64 transforms on its own (precision="auto"): as
+    "reference", but a length no float64 kernel serves falls back to float32 instead of raising."""
+    return _Pushed("reference?")
+
+
+class _Pushed:
+    def __init__(self, kind):
         self.kind = kind
 
     def __enter__(self):
@@ -51,6 +91,52 @@ class precision:
     def __exit__(self, *exc):
         _precision.pop()
         return False
+
+
+def plan_precision():
+    return "reference" if _precision[-1] in ("reference", "reference?") else "float32"
+
+
+def dynamic_range(spec, kept=None):
+    """How far the weakest part of a channel's KEPT spectrum sits below its mean power, judged on tapered spectra
+    (B, K, F, C) complex64 of a few trials over the WHOLE frequency axis: max over channels of mean_f P / q_2%(P[kept])
+    with P = the trial- and taper-averaged power.  The mean runs over every bin - an offset nobody removed or a line
+    outside the kept band raises the float32 transform's error in the kept bins just the same; the two kept bins next
+    to DC are left out of the quantile (they belong to the detrending).  A low percentile, not the minimum: one empty
+    bin (a notch, the Nyquist bin of an even filter) is not what the spectrum is like."""
+    p = spec.abs().square().mean(dim=(0, 1))
+    num = p.mean(dim=0)
+    if kept is not None:
+        kept = np.asarray(kept)
+        kept = kept[kept >= 2] if (kept >= 2).sum() >= 4 else kept
+        p = p.index_select(0, torch.as_tensor(kept, device=p.device))
+    elif p.shape[0] >= 6:
+        p = p[2:]
+    q = torch.quantile(p.float(), 0.02, dim=0).clamp_min(1e-38)
+    return float((num / q).max())
+
+
+def selection_hides_peak(dev_data, rows, chan_idx, nfft, taper, taper_opt, polyremoval, freq_idx, nfull):
+    """precision="auto" for 'pow' / 'abs' spectra on the batched route.  The float32 transform's error is ~1.5e-7 of the
+    LARGEST bin of a spectrum; the parity criterion's floor is 1e-6 of the largest bin that is KEPT.  With the whole
+    frequency axis kept the first is always inside the second.  A `foi` / `foilim` selection that leaves the dominant
+    bins out - an offset nobody removed (polyremoval=None; the un-detrended windows of a `toi` array), line noise below
+    a high-pass band - turns that error into 1.5e-7 x (largest bin / largest kept bin) of the output's scale: float64
+    transforms from a factor 3 on.  Judged on the float32 power spectra of the segments `rows` (equal length, a
+    handful), the largest ratio over the ranks decides."""
+    from .. import parallel
+    if freq_idx is None or len(freq_idx) >= nfull or len(rows) == 0:
+        return False
+    n = rows[0][1] - rows[0][0]
+    rows = [r for r in rows if r[1] - r[0] == n][:16]
+    N = n if nfft is None else int(nfft)
+    with precision("float32"):
+        spec = run_mtmfft(dev_data, rows, chan_idx, N, taper, taper_opt, False, False, polyremoval, None, "pow", False)
+    p = torch.stack(spec, dim=0)[:, 0]                                    # (B, F, C)
+    kept = p.index_select(1, torch.as_tensor(np.asarray(freq_idx), device=p.device))
+    ratio = float((p.amax(dim=(0, 1)) / kept.amax(dim=(0, 1)).clamp_min(1e-38)).max()) if kept.numel() else 0.0
+    ratio = parallel.allreduce_max(ratio)
+    return bool(np.sqrt(ratio) > 3.0)
 
 
 def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_taper, freq_idx, output, keeptapers,
@@ -66,18 +152,17 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
     fkey = None if freq_idx is None else np.asarray(freq_idx, dtype=np.int32).tobytes()
     key = (int(nsig), int(nfft), int(nchan), taper, tuple(sorted((taper_opt or {}).items())), int(nnorm),
            float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device), bool(blocked),
-           bool(whole_trials), bool(float32_frames), _precision[-1])
+           bool(whole_trials), bool(float32_frames), plan_precision())
     plan = _cache_hit(_plan_cache, key)
     if plan is None:
         tp = taper_table(taper, nsig, nnorm, taper_opt)
         plan = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
                                keeptapers, device=device,
                                reference_mean=(1 if detrend == 0 else 0) if (whole_trials or float32_frames) else 2)
-        if _precision[-1] == "reference":
-            if not plan.set_precision(True):
-                raise SPYValueError("a transform length up to 2^20 without a prime factor above 61 (e.g. "
-                                    "pad='nextpow2') for precision='reference'", varname="precision",
-                                    actual=f"nfft = {int(nfft)}")
+        if plan_precision() == "reference":
+            if not plan.set_precision(True) and _precision[-1] == "reference":
+                raise PrecisionUnavailable("a transform length up to 2^20 for float64 transforms", varname="precision",
+                                           actual=f"nfft = {int(nfft)}")
         elif blocked:
             plan.set_blocked(True)
         _bounded_put(_plan_cache, key, plan)

@@ -59,6 +59,20 @@ def main(out_path):
         res["library_allreduce_bit_exact"] = np.array(torch.equal(
             torch.view_as_real(acc2[:, ii, jj].contiguous()), torch.view_as_real(acc[:, ii, jj].contiguous())))
         res["library_comm_up"] = np.array(bool(be._lib_comm))
+        if os.environ.get("SPY_NCCL_C5"):
+            # BASELINE configs[4] through the front end, trial-sharded over the ranks of this group: every rank holds
+            # the recording, transforms its contiguous shard of the trials, ONE all-reduce of the packed CSD triangle,
+            # then the frequency-sharded Wilson factorisation (tests/test_gpu_production.py holds the group-less twin)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from test_gpu_production import c5_dataset
+            T5 = int(os.environ["SPY_NCCL_C5"])
+            big = c5_dataset(T5)
+            g5 = spy.connectivityanalysis(big, method="granger", tapsmofrq=1)
+            res["c5_info"] = np.array([g5.info["converged"], g5.info["max rel. err"], g5.info["reg. factor"],
+                                       g5.info["initial cond. num"]], dtype=np.float64)
+            res["c5_sample"] = np.ascontiguousarray(g5.data[0, ::64, :16, :16])
+            del big, g5
+            spy.release_device_buffers()
         res["world"] = np.array(world)
         torch.cuda.synchronize()
         if dist.get_rank() == 0:

@@ -473,7 +473,7 @@ def test_reference_precision_resolves_60dB(be):
     for prec in ("float32", "reference"):
         plan = be.FFTPlan(N, N, C, tap, sc, 0, False, None, "fourier", True, reference_mean=True)
         if prec == "reference":
-            assert plan.set_precision(True) and "f64" in plan.kernel_name
+            assert plan.set_precision(True) and "64_kernel" in plan.kernel_name
         got = plan.execute(dev, starts).cpu().numpy()[0].astype(np.complex128)
         err = np.abs(got - ref)
         frac[prec] = float((err <= 1e-5 * np.abs(ref)).mean())
@@ -536,14 +536,21 @@ def test_reference_precision_through_freqanalysis():
     ref, _ = O.mtmfft(O.detrend(x.copy(), 0), 1000.0, 4096, "hann", {})
     err = np.abs(a.data[0].astype(np.complex128) - ref)
     assert (err <= 1e-5 * np.abs(ref)).mean() >= 0.99
-    # 2000 samples: the any-length float64 kernel; 4099 is prime (a factor above 61): refused
+    # 2000 samples: a decimal schedule; 4099 is prime: the float64 kernel in its Bluestein form (round 4: any length)
     b = spy.freqanalysis(spy.AnalogData(x[:2000], samplerate=1000.0), method="mtmfft", taper="hann", output="fourier",
                          precision="reference")
     ref, _ = O.mtmfft(O.detrend(x[:2000].copy(), 0), 1000.0, 2000, "hann", {})
     err = np.abs(b.data[0].astype(np.complex128) - ref)
     assert (err <= 1e-5 * np.abs(ref)).mean() >= 0.99
-    with pytest.raises(SPYValueError):
-        spy.freqanalysis(spy.AnalogData(np.tile(x, (2, 1))[:4099], samplerate=1000.0), method="mtmfft", precision="reference")
+    xp = np.tile(x, (2, 1))[:4099]
+    c = spy.freqanalysis(spy.AnalogData(xp, samplerate=1000.0), method="mtmfft", taper="hann", output="fourier",
+                         precision="reference")
+    ref, _ = O.mtmfft(O.detrend(xp.copy(), 0), 1000.0, 4099, "hann", {})
+    err = np.abs(c.data[0].astype(np.complex128) - ref)
+    assert (err <= 1e-5 * np.abs(ref)).mean() >= 0.99
+    # the default ("auto") transforms complex outputs in float64 on the batched route, power spectra in float32
+    d = spy.freqanalysis(data, method="mtmfft", taper="hann", output="fourier")
+    assert np.array_equal(d.data, a.data)
     with pytest.raises(SPYValueError):
         spy.freqanalysis(data, method="wavelet", precision="reference")
 
@@ -565,14 +572,15 @@ def test_reference_precision_through_connectivityanalysis(nsamp):
     data = spy.AnalogData(x.astype(np.float32), samplerate=1000.0, trialdefinition=trl)
     kw = dict(method="coh", taper="hann", output="abs")
     ref = spy.connectivityanalysis(data, compute_method="sequential", routine_classes=ORACLE_CONN, **kw)
-    with pytest.warns(UserWarning, match="precision='reference'"):          # the float32 path says what it cannot do
-        fast = spy.connectivityanalysis(data, precision="float32", **kw)
+    fast = spy.connectivityanalysis(data, precision="float32", **kw)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         exact = spy.connectivityanalysis(data, precision="reference", **kw)
-        auto = spy.connectivityanalysis(data, **kw)          # the default: notices the dynamic range, repeats in float64
+        auto = spy.connectivityanalysis(data, **kw)          # the default: looks at 16 trials' spectra, picks float64
+        seq = spy.connectivityanalysis(data, compute_method="sequential", **kw)   # per-trial route: float64 by default
     assert np.array_equal(auto.data, exact.data)
+    assert excess(seq.data, ref.data) <= 1.0
     # ppc: phases of single-trial cross spectra - the same data, the same switch
     pk = dict(method="ppc", taper="hann")
     pref = spy.connectivityanalysis(data, compute_method="sequential", routine_classes=ORACLE_CONN, **pk)
@@ -584,8 +592,35 @@ def test_reference_precision_through_connectivityanalysis(nsamp):
     print(f"coherence away from a 60 dB line: float32 err/tol {e_fast:.3g}, precision='reference' {e_exact:.3g}")
     assert e_exact <= 1.0, e_exact
     assert e_fast > e_exact
-    with pytest.raises(Exception):
-        spy.connectivityanalysis(data, precision="reference", pad=3.001, **kw)      # 3001 samples: a prime above 61
+    # 3001 samples: a prime - served by the Bluestein form of the float64 kernel since round 4
+    refp = spy.connectivityanalysis(data, compute_method="sequential", routine_classes=ORACLE_CONN, pad=3.001, **kw)
+    gotp = spy.connectivityanalysis(data, precision="reference", pad=3.001, **kw)
+    assert excess(gotp.data, refp.data) <= 1.0
+
+
+def test_auto_precision_for_granger():
+    """precision="auto" for Granger causality: random-walk channels (1/f^2 spectra: the upper half of the axis sits
+    60 dB and more below a channel's mean power) with a lagged coupling ask for float64 transforms - the default equals
+    precision="reference", differs from "float32", and agrees with the oracle at the fuzz test's Granger tolerance."""
+    import syncopy_amd as spy
+    from oracle_routines import ORACLE_CONN
+    rng = np.random.default_rng(11)
+    nsamp, ntr, nchan = 1024, 40, 3
+    e = rng.normal(size=(ntr, nsamp, nchan))
+    w = np.cumsum(e, axis=1) + 0.05 * rng.normal(size=e.shape)
+    w[:, 2:, 1] += 0.4 * w[:, :-2, 0]                                   # channel 0 drives channel 1
+    x = w.reshape(ntr * nsamp, nchan).astype(np.float32)
+    trl = np.stack([np.arange(ntr) * nsamp, np.arange(1, ntr + 1) * nsamp, np.zeros(ntr)], axis=1)
+    data = spy.AnalogData(x, samplerate=1000.0, trialdefinition=trl)
+    gk = dict(method="granger", taper="hann")           # 40 products: float64 from a dynamic range of 160 on
+    gref = spy.connectivityanalysis(data, compute_method="sequential", routine_classes=ORACLE_CONN, **gk)
+    gauto = spy.connectivityanalysis(data, **gk)
+    gexact = spy.connectivityanalysis(data, precision="reference", **gk)
+    g32 = spy.connectivityanalysis(data, precision="float32", **gk)
+    assert np.array_equal(gauto.data, gexact.data) and not np.array_equal(gauto.data, g32.data)
+    assert gauto.info["reg. factor"] == gref.info["reg. factor"]
+    if gref.info["reg. factor"] != -1:
+        np.testing.assert_allclose(gauto.data[:, 2:], gref.data[:, 2:], rtol=2e-3, atol=1e-2)
 
 
 @pytest.mark.parametrize("method,kw", [("mtmconvol", dict(t_ftimwin=0.5, toi=0.5, taper="hann")),

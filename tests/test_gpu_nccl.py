@@ -72,6 +72,25 @@ def test_front_ends_under_nccl_group(tmp_path):
     np.testing.assert_allclose(z["granger"], gr.data, rtol=1e-4, atol=1e-6)
 
 
+def test_c5_granger_sharded_under_nccl_group(tmp_path):
+    """BASELINE configs[4] as one front-end call under the process group (trial shards + RCCL all-reduce of the CSD +
+    frequency-sharded Wilson): two ranks whenever two GPUs are visible, else a group of one with the collectives forced
+    on; compared with the group-less call on the same data."""
+    from test_gpu_production import c5_dataset
+    n = min(_ngpu(), 2)
+    T = 2560
+    out = tmp_path / "c5.npz"
+    r = _launch([os.path.join(ROOT, "tests", "nccl_worker.py"), str(out)], n, {"SPY_FORCE_COLLECTIVE": "1", "SPY_NCCL_C5": str(T)})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = np.load(out)
+    assert int(z["world"]) == n and bool(z["c5_info"][0]) and z["c5_info"][1] < 5e-6 and z["c5_info"][2] == 0
+    ref = spy.connectivityanalysis(c5_dataset(T), method="granger", tapsmofrq=1)
+    assert ref.info["converged"]
+    np.testing.assert_allclose(z["c5_info"][3], ref.info["initial cond. num"], rtol=1e-5)
+    np.testing.assert_allclose(z["c5_sample"], ref.data[0, ::64, :16, :16], rtol=1e-4, atol=1e-6)
+    spy.release_device_buffers()
+
+
 def test_bench_distributed_branch():
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, nccl), on the GPUs present."""
     n = min(_ngpu(), 2)

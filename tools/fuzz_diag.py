@@ -13,9 +13,18 @@ fn = {"mtmfft": T.test_mtmfft_random_options, "conn": T.test_connectivity_random
       "welch": T.test_welch_and_superlet_random_options, "toi": T.test_timefrequency_toi_foi_offsets,
       "consel": T.test_connectivity_selections_and_spectral_input, "corr": T.test_corr_and_jackknife_random_options}[kind]
 def report(got, ref, exact, what="", atol_rel=parity.ATOL_REL, rtol=parity.RTOL):
+    if getattr(got, "per_trial_route", None) is not None:
+        report(got.per_trial_route, ref, exact, what + " [per-trial route]", atol_rel, rtol)
     a = np.asarray(got.data); b = np.asarray(ref.data)
     tol = rtol * np.abs(b) + atol_rel * np.abs(b).max()
     if exact is not None:
+        base = tol.copy()
+        e0 = np.abs(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64) - b)
+        x = np.asarray(exact.data)
+        ex = np.abs(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64) - x)
+        k = np.unravel_index(np.argmax(e0 / base), base.shape)
+        print(f"    WITHOUT the detrend widening: max err/tol {float((e0 / base).max()):.3g} at {tuple(int(v) for v in k)}; "
+              f"there |ref - exact|/tol {float(np.abs(b - x)[k] / base[k]):.3g}; |got - exact|/tol max {float((ex / base).max()):.3g}")
         tol = tol + 2 * np.abs(b - np.asarray(exact.data))
     err = np.abs(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64) - b)
     r = err / np.where(tol == 0, 1e-38, tol)
