@@ -303,6 +303,13 @@ int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int nscales, co
                            double dt, double w0, int detrend, int output, const int32_t* tpos,
                            int ntime_out, spyhip_cwt_plan** plan);
 int spyhip_cwt_plan_destroy(spyhip_cwt_plan* plan);
+/* reference = 1: the transform as scipy.signal.fftconvolve computes it for cwt_time / cwtSL (specest/wavelets/
+ * transform.py:88-108, specest/superlet.py:311-375): float64 FFT convolution of the detrended float32 trial with the
+ * complex128 taps, rounded to complex64 where the reference stores it - one length-2^m >= nsig + taps - 1 convolution per
+ * (segment, channel), generic Stockham passes over work arrays in global memory (~50x the float32 kernels: for
+ * precision="reference" and the per-trial route, where the copies cost as much).  0 (default): the float32 overlap-save
+ * kernels (~5e-7 of a trial's largest coefficient). */
+int spyhip_cwt_plan_set_precision(spyhip_cwt_plan* plan, int reference);
 /* seg_start_d: row of sample 0 of each pre-selected signal; trial_lo_d/trial_hi_d: rows of the
  * whole trial (detrending range); accumulate: 0 = store, 1 = out_d[b] += result of segment b,
  * 2 = out_d[0] += sum over the nseg segments (trial averaging: one read-modify-write of the output per chunk

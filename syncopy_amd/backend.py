@@ -312,6 +312,11 @@ class CWTPlan:
         self.handle = h
         self.out_dtype = torch.complex64 if self.kind == 2 else torch.float32
 
+    def set_precision(self, reference=True):
+        """`reference=True`: float64 FFT convolutions rounded to complex64 where the reference rounds
+        (spyhip_cwt_plan_set_precision).  Returns False if this plan cannot."""
+        return self.ctx.lib.spyhip_cwt_plan_set_precision(self.handle, int(bool(reference))) == 0
+
     def out_shape(self, nseg):
         return (nseg, self.ntime_out, self.nscales, self.nchan)
 

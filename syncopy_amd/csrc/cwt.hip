@@ -7,6 +7,7 @@
 #include "spy_common.h"
 #include "host_fft.h"
 #include "cwt_kernel.h"
+#include "cwt64_kernel.h"
 
 using spyfft::CwtArgs;
 
@@ -33,6 +34,16 @@ struct spyhip_cwt_plan {
     spy::DevBuf<int> lidx;        // their scale indices on the device
     spy::DevBuf<float2> stage_long;   // (chunk, long scale, channel, time) complex sums of the pieces (real outputs)
     int chunk_long = 0;
+    // reference precision (spyhip_cwt_plan_set_precision, cwt64_kernel.h): the sampled kernels are kept on the host
+    // so that their float64 spectra can be built when asked for
+    std::vector<std::vector<double>> ker_re, ker_im;
+    std::vector<int> ker_c;
+    bool precision64 = false;
+    int L64 = 0;
+    spywil::PlusPlan plan64{};
+    spy::DevBuf<double2> tw64, hspec64, work64;
+    spy::DevBuf<int> centre64;
+    long long chunk64 = 0;
     ~spyhip_cwt_plan() { for (auto* g : groups) delete g; }
 };
 
@@ -144,6 +155,11 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
     auto* p = new spyhip_cwt_plan();
     p->ctx = ctx; p->nsig = nsig; p->nchan = nchan; p->nscales = nscales;
     p->detrend = detrend; p->output = output;
+    for (int s = 0; s < nscales; ++s) {
+        p->ker_re.push_back(kers[s].re);
+        p->ker_im.push_back(kers[s].im);
+        p->ker_c.push_back(kers[s].c);
+    }
     // block length per scale, within what the LDS FFTs support
     std::vector<int> need(nscales);
     for (int s = 0; s < nscales; ++s) {
@@ -250,6 +266,43 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
     return 0;
 }
 
+extern "C" int spyhip_cwt_plan_set_precision(spyhip_cwt_plan* p, int reference) {
+    if (!p) { spy::set_error("cwt_plan_set_precision: null plan"); return -1; }
+    if (!reference) { p->precision64 = false; return 0; }
+    if (!p->hspec64.p) {
+        SPY_HIP_CHECK(hipSetDevice(p->ctx->device));
+        size_t lmax = 1;
+        for (const auto& k : p->ker_re) lmax = std::max(lmax, k.size());
+        long long L = 16;
+        while (L < (long long)p->nsig + (long long)lmax - 1) L <<= 1;
+        if (L > (1 << 22)) { spy::set_error("cwt_plan_set_precision: convolution length %lld beyond 2^22", L); return -3; }
+        p->L64 = (int)L;
+        if (!spywil::plus_plan(p->L64, &p->plan64)) { spy::set_error("cwt_plan_set_precision: no radix schedule"); return -3; }
+        std::vector<double2> tw(L), hs((size_t)p->nscales * L);
+        for (long long m = 0; m < L; ++m) {
+            const double ang = -2.0 * PI * (double)m / (double)L;
+            tw[m] = make_double2(std::cos(ang), std::sin(ang));
+        }
+        for (int sc = 0; sc < p->nscales; ++sc) {
+            std::vector<double> re(L, 0.0), im(L, 0.0);
+            for (size_t m = 0; m < p->ker_re[sc].size(); ++m) { re[m] = p->ker_re[sc][m]; im[m] = p->ker_im[sc][m]; }
+            spy::fft_host(re, im);
+            for (long long k = 0; k < L; ++k) hs[(size_t)sc * L + k] = make_double2(re[k] / (double)L, im[k] / (double)L);
+        }
+        if (p->tw64.upload(tw, p->ctx->stream) || p->hspec64.upload(hs, p->ctx->stream) ||
+            p->centre64.upload(p->ker_c, p->ctx->stream)) return -2;
+    }
+    p->precision64 = true;
+    return 0;
+}
+
+template <int OUTK>
+static int launch_cwt64(spyhip_cwt_plan* p, const spyfft::Cwt64Args& a, unsigned grid) {
+    hipLaunchKernelGGL(spyfft::cwt64_kernel<OUTK>, dim3(grid), dim3(256), 0, p->ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int spyhip_cwt_plan_destroy(spyhip_cwt_plan* p) {
     delete p;
     return 0;
@@ -322,7 +375,32 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         if (a.trend) c.trend = a.trend + (size_t)s0 * p->nchan * 2;
         c.nseg = ns;
         if (p->nscales > 65535 || ns > 65535) { spy::set_error("cwt_exec: grid too large"); return -1; }
+        if (p->precision64) {
+            // float64 convolutions, one workgroup per (segment, channel), three length-L work arrays each: launches of
+            // at most ~2 GiB of them
+            spyfft::Cwt64Args fa{};
+            fa.c = c;
+            fa.L = p->L64; fa.plan = p->plan64; fa.tw64 = p->tw64.p; fa.hspec64 = p->hspec64.p; fa.centre = p->centre64.p;
+            const long long items = (long long)ns * p->nchan;
+            const size_t per = (size_t)3 * p->L64 * sizeof(double2);
+            long long cw = std::max<long long>(2LL * p->ctx->num_cu, (long long)(((size_t)2 << 30) / per));
+            if (cw > items) cw = items;
+            if (cw > p->chunk64) {
+                if (p->work64.p) { SPY_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); (void)hipFree(p->work64.p); p->work64.p = nullptr; }
+                if (p->work64.alloc((size_t)cw * 3 * p->L64)) return -2;
+                p->chunk64 = cw;
+            }
+            fa.work = p->work64.p;
+            for (long long w0 = 0; w0 < items; w0 += p->chunk64) {
+                fa.wg0 = w0;
+                const unsigned g = (unsigned)std::min<long long>(p->chunk64, items - w0);
+                int rc = p->output == SPYHIP_OUT_FOURIER ? launch_cwt64<2>(p, fa, g)
+                         : (p->output == SPYHIP_OUT_POW ? launch_cwt64<0>(p, fa, g) : launch_cwt64<1>(p, fa, g));
+                if (rc) return rc;
+            }
+        }
         for (const CwtGroup* gr : p->groups) {           // one launch per block length
+            if (p->precision64) break;
             CwtArgs k = c;
             k.nscales = gr->nscales;
             k.sidx = gr->sidx.p;
@@ -348,7 +426,7 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
             }
             if (rc) return rc;
         }
-        if (long_side) {
+        if (long_side && !p->precision64) {
             const long long tot = (long long)ns * nlong * p->nchan * p->nsig;
             if ((tot + 255) / 256 > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
             hipLaunchKernelGGL(spyfft::cwt_long_convert_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,

@@ -211,6 +211,20 @@ def _postselect_map(nsig, postselect):
 _cwt_plans = {}
 
 
+def _cwt_reference():
+    """Wavelet transforms run in float64 only when the call says precision="reference".  The reference's own transform is
+    scipy.signal.fftconvolve of the float32 trial - whose forward FFT scipy computes in SINGLE precision (error 1.5e-7 of
+    the largest coefficient): float64 convolutions are closer to the exact result, not to the reference, and cost ~50x -
+    no route takes them by default."""
+    return hs.requested_precision() == "reference"
+
+
+def _cwt_precision(plan):
+    if _cwt_reference() and not plan.set_precision(True):
+        raise hs.PrecisionUnavailable("a convolution length up to 2^22 for float64 wavelet transforms", varname="precision",
+                                      actual=f"nsig = {plan.nsig}")
+
+
 def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwargs, sum_trials=False):
     """Wavelet spectra of trials `rows` (absolute [start, stop)) with per-trial pre/post-selections.
     Returns a list of (nTime, 1, nScales, C) device tensors - or, with `sum_trials`, their sum as ONE such
@@ -233,10 +247,11 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
         return None
     for nsig, tpos, nuniq, gather, members in groups.values():
         pkey = (nsig, nchan, scales.tobytes(), dt, w0, polyremoval, output, None if tpos is None else tpos.tobytes(),
-                str(device))
+                str(device), _cwt_reference())
         plan = hs._cache_hit(_cwt_plans, pkey)
         if plan is None:
             plan = hs.backend.CWTPlan(nsig, nchan, scales, dt, w0, polyremoval, output, tpos, nuniq, device=device)
+            _cwt_precision(plan)
             hs._bounded_put(_cwt_plans, pkey, plan)
         starts = torch.tensor([m[1] for m in members], dtype=torch.int64, device=device)
         lo = torch.tensor([m[2] for m in members], dtype=torch.int64, device=device)
@@ -341,12 +356,13 @@ def _superlet_device(dev, rows, pre, post, chans, polyremoval, output, method_kw
             acc = torch.empty((len(part), ntime, scales.size, nchan), dtype=wdt, device=device)
             for n, (cycles, sc0, expo) in enumerate(steps):
                 pkey = ("sl", nsig, nchan, scales[sc0:].tobytes(), dt, cycles, polyremoval, real,
-                        None if tpos is None else tpos.tobytes(), str(device))
+                        None if tpos is None else tpos.tobytes(), str(device), _cwt_reference())
                 plan = hs._cache_hit(_cwt_plans, pkey)
                 if plan is None:
                     plan = hs.backend.CWTPlan(nsig, nchan, scales[sc0:], dt, detrend=polyremoval,
                                               output="abs" if real else "fourier", tpos=tpos,
                                               ntime_out=nuniq, device=device, sl_cycles=cycles)
+                    _cwt_precision(plan)
                     hs._bounded_put(_cwt_plans, pkey, plan)
                 buf = hs.backend.handover_buffer(plan.out_shape(len(part)), device, dtype=wdt)
                 spec = plan.execute(dev, starts, lo, hi, chan_idx=ci, out=buf)

@@ -40,15 +40,14 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
     `precision` (not a reference argument): "float32" transforms in float32 - ~1e-7 of a channel's largest bin;
     "reference" runs the taper product and the FFT in float64 and rounds to complex64 where the reference does
     (mtmfft.py:96-127): every bin to 1e-5 of itself, ~2x the time at the lengths with a compile-time schedule (powers of
-    two 256 ... 16384, 200 ... 10000 decimal), 4-10x elsewhere; methods 'mtmfft' / 'mtmconvol' / 'welch', any transform
-    length up to 2^20.  "auto" (default): float64 on the per-trial route (compute_method="sequential": the copies
+    two 256 ... 16384, 200 ... 10000 decimal), 4-10x elsewhere, any transform length up to 2^20; for 'wavelet' / 'superlet'
+    float64 FFT convolutions (~50x the float32 kernels; closer to the exact result than the reference itself, whose
+    scipy.signal.fftconvolve transforms the float32 trial in single precision - never chosen by "auto").  "auto" (default): float64 on the per-trial route (compute_method="sequential": the copies
     dominate there) and, on the batched route, for the outputs that isolate a PART of the complex spectrum - 'fourier',
     'real', 'imag', 'angle', 'absreal', 'absimag' - where a small part next to a large one inherits the large one's
     float32 error; 'pow' and 'abs' stay float32 (inside the criterion by its floor)."""
     if precision not in ("float32", "reference", "auto"):
         raise SPYValueError("'float32', 'reference' or 'auto'", varname="precision", actual=str(precision))
-    if precision == "reference" and method not in ("mtmfft", "mtmconvol", "welch"):
-        raise SPYValueError("method 'mtmfft', 'mtmconvol' or 'welch' for precision='reference'", varname="method", actual=method)
     if not isinstance(data, AnalogData) or data.data is None:
         raise SPYTypeError(data, varname="data", expected="non-empty AnalogData")
     classes = {"mtmfft": MultiTaperFFT, "mtmconvol": MultiTaperFFTConvol}

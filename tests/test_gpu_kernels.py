@@ -645,3 +645,48 @@ def test_reference_precision_of_sliding_windows(method, kw):
     assert_parity(got.data, ref.data, what=method)
     err = np.abs(got.data.astype(np.float64) - ref.data)
     assert (err <= 1e-5 * np.abs(ref.data)).mean() >= 0.99
+
+
+def test_reference_precision_of_wavelets_and_superlets():
+    """precision="reference" for the wavelet methods (cwt64_kernel.h: float64 FFT convolutions, complex64 rounding where
+    cwt_time / cwtSL store their result).  The reference's own scipy.signal.fftconvolve transforms the float32 trial in
+    SINGLE precision (error 1.5e-7 of the largest coefficient), so the yardstick is the oracle fed float64 trials: with a
+    5 Hz line 60 dB above the noise the high-frequency scales - made of the noise alone - are exact to float32 rounding
+    under precision="reference" and carry the line's transform error in the default kernels (and in the reference)."""
+    import scipy.signal as sps
+    import syncopy_amd as spy
+    from oracle_routines import ORACLE_FREQ
+    from parity import excess
+    rng = np.random.default_rng(21)
+    nsamp, ntr, nchan = 3000, 2, 3
+    t = np.arange(nsamp * ntr) / 1000.0
+    x = rng.normal(size=(nsamp * ntr, nchan)) + 1000.0 * np.sin(2 * np.pi * 5.0 * t)[:, None]
+    trl = np.stack([np.arange(ntr) * nsamp, np.arange(1, ntr + 1) * nsamp, np.zeros(ntr)], axis=1)
+    data = spy.AnalogData(x.astype(np.float32), samplerate=1000.0, trialdefinition=trl)
+    keep = sps.fftconvolve
+
+    def conv64(in1, in2, mode="full", axes=None):
+        return keep(np.asarray(in1, dtype=np.float64), in2, mode=mode, axes=axes)
+    for kw in (dict(method="wavelet", foi=np.array([40.0, 90.0, 200.0]), output="fourier"),
+               dict(method="wavelet", foi=np.array([60.0, 150.0]), output="pow", toi=np.arange(0.5, 2.5, 0.01)),
+               dict(method="superlet", foi=np.array([50.0, 120.0, 250.0]), order_max=4, c_1=2, adaptive=True, output="abs")):
+        ref = spy.freqanalysis(data, compute_method="sequential", routine_classes=ORACLE_FREQ, polyremoval=0, **kw)
+        sps.fftconvolve = conv64
+        try:
+            ref64 = spy.freqanalysis(data, compute_method="sequential", routine_classes=ORACLE_FREQ, polyremoval=0, **kw)
+        finally:
+            sps.fftconvolve = keep
+        exact = spy.freqanalysis(data, precision="reference", polyremoval=0, **kw)
+        fast = spy.freqanalysis(data, polyremoval=0, **kw)
+        b = np.asarray(ref64.data)
+
+        def pure(a):
+            err = np.abs(np.asarray(a).astype(np.complex128 if np.iscomplexobj(b) else np.float64) - b)
+            return float((err <= 2e-5 * np.abs(b)).mean())
+        fr64, fr32, frref = pure(exact.data), pure(fast.data), pure(ref.data)
+        print(f"{kw['method']} {kw['output']}: elements within pure rtol 2e-5 of the float64 oracle - precision='reference' "
+              f"{100 * fr64:.2f} %, default kernels {100 * fr32:.1f} %, the reference's own single-precision transform {100 * frref:.1f} %")
+        assert fr64 >= 0.99 and fr64 > fr32, (kw["method"], fr64, fr32)
+        # (against the REFERENCE this data set shows the reference's own single-precision transform error - up to 5e-6 of
+        # a coefficient here; the float64 result is held to the float64 oracle by the criterion as well)
+        assert excess(exact.data, ref64.data) <= 1.0
