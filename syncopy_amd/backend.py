@@ -68,20 +68,28 @@ _pin = {}
 _copy_pool = None
 
 
+_COPY_THREADS = 8
+
+
+def _pool():
+    global _copy_pool
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _copy_pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="spyhip-copy")
+    return _copy_pool
+
+
 def _host_copy(dst, src):
-    """dst[:] = src for large byte arrays, split over four threads (NumPy releases the GIL in its copy loops): one
+    """dst[:] = src for large byte arrays, split over the copy threads (NumPy releases the GIL in its copy loops): one
     thread moves ~10 GB/s into freshly allocated pageable memory (page faults included), which made the drain of the
     pinned staging buffer - not the bus - the slow half of a large result's way to the host."""
-    global _copy_pool
     n = dst.shape[0]
     if n < (8 << 20):
         dst[:] = src
         return
-    if _copy_pool is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="spyhip-copy")
-    step = (n + 3) // 4
-    futs = [_copy_pool.submit(np.copyto, dst[o:o + step], src[o:o + step]) for o in range(0, n, step)]
+    pool = _pool()
+    step = (n + _COPY_THREADS - 1) // _COPY_THREADS
+    futs = [pool.submit(np.copyto, dst[o:o + step], src[o:o + step]) for o in range(0, n, step)]
     for f in futs:
         f.result()
 
@@ -116,20 +124,118 @@ def to_host(t):
     return out
 
 
-def _staging():
-    stage = _pin.get("buf")
+def _staging(name="buf", nbytes=_PIN_BYTES):
+    stage = _pin.get(name)
     if stage is None:
-        stage = _pin["buf"] = (torch.empty(_PIN_BYTES, dtype=torch.uint8, pin_memory=True),
-                               torch.empty(_PIN_BYTES, dtype=torch.uint8, pin_memory=True))
+        stage = _pin[name] = (torch.empty(nbytes, dtype=torch.uint8, pin_memory=True),
+                              torch.empty(nbytes, dtype=torch.uint8, pin_memory=True))
     return stage
 
 
-def to_device(host, device, time_axis=0):
+_H2D_CHUNK = 128 << 20          # bytes per staging buffer of the ingress (two of them alternate; its own pair: a result
+                                # may be on its way to the host through to_host's buffers at the same time)
+
+
+def _staged_fill(view, src):
+    """view[...] = src (2-D, float32 view of a pinned buffer; src any dtype / orientation), rows split over the copy
+    threads: one thread converts / copies ~10 GB/s, the bus takes 57."""
+    n = view.shape[0]
+    if view.nbytes < (8 << 20):
+        np.copyto(view, src, casting="unsafe")
+        return
+    pool = _pool()
+    step = (n + _COPY_THREADS - 1) // _COPY_THREADS
+    futs = [pool.submit(np.copyto, view[o:o + step], src[o:o + step], "unsafe") for o in range(0, n, step)]
+    for f in futs:
+        f.result()
+
+
+class Upload:
+    """A recording on its way into the in-HBM trial queue (the reference streams trial by
+    trial, computational_routine.py:1001-1032).  A background thread fills two alternating pinned staging buffers
+    (rows split over a thread pool, converted to float32 / transposed while staging) and enqueues the copies on a
+    stream of its own; after every chunk it leaves a mark (last row, event).  Consumers that walk the trials in order
+    call `wait_rows(row_end)` before they launch work on rows < row_end: the calling thread waits until that chunk has
+    been ENQUEUED, then torch's current stream waits for its event - kernels on the first trials run while the later
+    ones are still on the bus.  `finish()` waits for everything (what `AnalogData.device_data()` does for callers that
+    do not know about uploads in flight)."""
+
+    def __init__(self, host, dev, time_axis):
+        import threading
+        self.dev, self.host, self.time_axis = dev, host, time_axis
+        self.nrows = dev.shape[0]
+        self.marks = []                      # [(row_end, event)] in row order
+        self.cond = threading.Condition()
+        self.error = None
+        self.complete = False
+        self.thread = threading.Thread(target=self._run, name="spyhip-upload", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            dev, host = self.dev, self.host
+            torch.cuda.set_device(dev.device)
+            ntime, nchan = dev.shape
+            stage = _staging("h2d", _H2D_CHUNK)
+            rows_per = self.chunk_rows()
+            stream = torch.cuda.Stream(device=dev.device)
+            busy = [None, None]
+            for k, r0 in enumerate(range(0, ntime, rows_per)):
+                r1 = min(ntime, r0 + rows_per)
+                buf = stage[k & 1]
+                if busy[k & 1] is not None:
+                    busy[k & 1].synchronize()              # the copy that last used this buffer has left it
+                pinned = buf[:(r1 - r0) * nchan * 4].view(torch.float32).view(r1 - r0, nchan)
+                _staged_fill(pinned.numpy(), host[r0:r1] if self.time_axis == 0 else host[:, r0:r1].T)
+                with torch.cuda.stream(stream):
+                    dev[r0:r1].copy_(pinned, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                busy[k & 1] = ev
+                with self.cond:
+                    self.marks.append((r1, ev))
+                    self.cond.notify_all()
+            for ev in busy:
+                if ev is not None:
+                    ev.synchronize()
+        except BaseException as exc:                       # noqa: BLE001 - handed to the waiting thread
+            self.error = exc
+        finally:
+            with self.cond:
+                self.complete = True
+                self.cond.notify_all()
+
+    def chunk_rows(self):
+        return max(1, _H2D_CHUNK // (4 * max(self.dev.shape[1], 1)))
+
+    def wait_rows(self, row_end, stream=None):
+        """Rows [0, row_end) are in HBM as far as `stream` (default: torch's current stream) is concerned."""
+        row_end = min(int(row_end), self.nrows)
+        with self.cond:
+            while not self.complete and not (self.marks and self.marks[-1][0] >= row_end):
+                self.cond.wait()
+            if self.error is not None:
+                raise self.error
+            ev = next((e for r, e in self.marks if r >= row_end), self.marks[-1][1] if self.marks else None)
+        if ev is not None:
+            (stream or torch.cuda.current_stream(self.dev.device)).wait_event(ev)
+
+    def finish(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        self.wait_rows(self.nrows)
+        self.host = None
+
+
+def to_device(host, device, time_axis=0, background=False):
     """Host recording -> (time x channel) float32 matrix in HBM: the ingress of the in-HBM trial queue.
     `host` may be an np.memmap onto a `.spy` data file (io/spy_container.py) of any size: blocks of rows are read
     (and, if needed, converted to float32 / transposed - dimord ["channel", "time"], compRoutines.py:143-146) straight
     into two alternating pinned staging buffers and copied to the device asynchronously, so the file is never held in
-    host memory as a whole and the disk read of block k+1 overlaps the PCIe copy of block k."""
+    host memory as a whole and the disk read of block k+1 overlaps the PCIe copy of block k.
+    `background=True` returns (tensor, Upload or None) at once: the copy proceeds on a thread and a stream of its own
+    (class Upload) - None when the recording is small enough for one plain copy."""
     ntime, nchan = (host.shape if time_axis == 0 else host.shape[::-1])
     dev = torch.empty((ntime, nchan), dtype=torch.float32, device=device)
     nbytes = ntime * nchan * 4
@@ -137,24 +243,11 @@ def to_device(host, device, time_axis=0):
               and not isinstance(host, np.memmap))
     if direct and nbytes < (64 << 20):
         dev.copy_(torch.from_numpy(host))
-        return dev
-    stage = _staging()
-    rows_per = max(1, _PIN_BYTES // (4 * max(nchan, 1)))
-    stream = torch.cuda.current_stream(dev.device)
-    events = [None, None]
-    for k, r0 in enumerate(range(0, ntime, rows_per)):
-        r1 = min(ntime, r0 + rows_per)
-        buf = stage[k & 1]
-        if events[k & 1] is not None:
-            events[k & 1].synchronize()                # the copy that last used this buffer has left it
-        view = buf[:(r1 - r0) * nchan * 4].view(torch.float32).view(r1 - r0, nchan).numpy()
-        np.copyto(view, host[r0:r1] if time_axis == 0 else host[:, r0:r1].T, casting="unsafe")
-        dev[r0:r1].copy_(buf[:(r1 - r0) * nchan * 4].view(torch.float32).view(r1 - r0, nchan), non_blocking=True)
-        events[k & 1] = torch.cuda.Event()
-        events[k & 1].record(stream)
-    for ev in events:
-        if ev is not None:
-            ev.synchronize()
+        return (dev, None) if background else dev
+    up = Upload(host, dev, time_axis)
+    if background:
+        return dev, up
+    up.finish()
     return dev
 
 

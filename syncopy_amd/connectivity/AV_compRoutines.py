@@ -83,7 +83,10 @@ class NormalizeCrossSpectra(_AverageRoutine):
             # straight from the ST stage's raw accumulator: scale + normalise + convert + mirror in one pass
             res = backend.coh_from_accumulator(raw, data._acc_scale, self.cfg["output"]).unsqueeze(0)
             out._dev = res
-            out.data = backend.to_host(res)
+            # the 0.5 GB result stays in HBM until somebody reads `.data` (then one pinned, chunked copy): a chained
+            # analysis or a plot of a few channel pairs never pays for the whole array
+            out.set_pending(lambda: backend.to_host(res), tuple(res.shape),
+                            np.complex64 if res.is_complex() else np.float32)
             return
         dev = self._device_input(data)
         res = torch.stack([backend.coh_normalize(dev[t].contiguous(), self.cfg["output"])

@@ -29,14 +29,14 @@ def _freq_selection(nSamples, samplerate, foi):
 
 
 def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, polyremoval, freq_idx, acc_of_trial,
-                 single_acc=False):
+                 single_acc=False, upload=None):
     """Accumulate sum_k X_k X_k^H of every trial in `rows` into `acc_of_trial(i)` (device (F,C,C) c64).
     `single_acc`: every trial lands in the same accumulator, so the spectra may take the channel-blocked
     hand-over layout between the FFT and the CSD kernel (coalesced stores, identical results)."""
     ntaper = 1
     for sel, spec in hs.run_mtmfft_batches(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, False,
                                            polyremoval, freq_idx, "fourier", True,
-                                           blocked=single_acc and backend.USE_BLOCKED_HANDOVER, reuse=True):
+                                           blocked=single_acc and backend.USE_BLOCKED_HANDOVER, reuse=True, upload=upload):
         ntaper = spec.spyhip_ntaper
         if spec.spyhip_blocked:
             backend.csd_accumulate(spec, acc_of_trial(sel[0]), blocked=True)
@@ -207,9 +207,11 @@ class CrossSpectra(ComputationalRoutine):
                  "tapsmofrq", "nTaper", "pad", "output"]
 
     def compute_hip(self, data, out):
-        """Trial-accumulated CSD straight from the in-HBM trial queue (MFMA rank-K updates)."""
+        """Trial-accumulated CSD straight from the in-HBM trial queue (MFMA rank-K updates).  A recording that is still
+        being uploaded (first call on host data) is consumed chunk by chunk behind the copy (backend.Upload)."""
         cfg = self.cfg
-        dev = data.device_data()
+        dev = data.device_data(partial=True)
+        upload = data.upload_in_flight()
         rows, chans = trial_rows(data), selected_channels(data)
         nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
         freqs, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
@@ -225,7 +227,8 @@ class CrossSpectra(ComputationalRoutine):
             acc = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
             getter = lambda i: acc                         # noqa: E731
         K = _csd_of_rows(dev, rows, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"], cfg["demean_taper"], pr,
-                         freq_idx, getter, single_acc=not self.keeptrials) if rows else 1
+                         freq_idx, getter, single_acc=not self.keeptrials, upload=upload) if rows else 1
+        data.device_data()                                  # (an upload in flight ends here at the latest)
         K = int(cfg["taper_opt"].get("Kmax", K)) if cfg["taper_opt"] else K
         self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T
         if self.keeptrials:
@@ -263,7 +266,8 @@ class CrossSpectra(ComputationalRoutine):
         takes the same branch.  Costs `sample` trials' transforms and one host synchronisation; AR(2)-type data never
         asks, line noise 50 dB above the floor or 1/f spectra over four decades do."""
         cfg = self.cfg
-        dev = data.device_data()
+        dev = data.device_data(partial=True)
+        upload = data.upload_in_flight()
         rows, chans = trial_rows(data), selected_channels(data)
         nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
         _, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
@@ -276,7 +280,8 @@ class CrossSpectra(ComputationalRoutine):
         ratio, K = 0.0, 1
         with hs.precision("float32"):
             for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
-                                                 cfg["demean_taper"], False, pr, None, "fourier", True, reuse=True):
+                                                 cfg["demean_taper"], False, pr, None, "fourier", True, reuse=True,
+                                                 upload=upload):
                 ratio = max(ratio, hs.dynamic_range(spec, kept=freq_idx))        # whole axis: see hs.dynamic_range
                 K = spec.shape[1]
         ratio = parallel.allreduce_max(ratio)

@@ -56,6 +56,10 @@ class _Base:
     def invalidate(self):
         """Forget device copies of `.data`.  Assigning `.data` does this by itself; after editing the host array IN
         PLACE (`obj.data[...] = ...`) call it explicitly - in-place edits cannot be seen from here."""
+        up = getattr(self, "_upload", None)
+        if up is not None:
+            up.finish()                   # (never drop a tensor a copy thread still writes into)
+        self._upload = None
         self._device = None
         self._device_key = None
 
@@ -139,8 +143,11 @@ class AnalogData(_Base):
             channel = ["channel" + str(i + 1).zfill(len(str(nchan))) for i in range(nchan)]
         self.channel = np.array(channel)
 
-    def device_data(self, device=None):
-        """The (time x channel) float32 matrix in HBM (uploaded once, C-order, channel fastest)."""
+    def device_data(self, device=None, partial=False):
+        """The (time x channel) float32 matrix in HBM (uploaded once, C-order, channel fastest).
+        `partial=True`: do not wait for an upload in flight - the caller walks the trials in order and asks
+        `upload_in_flight().wait_rows(row_end)` before it touches rows (backend.Upload): kernels on the first trials
+        overlap the PCIe copy of the later ones."""
         import torch
         from ..backend import require_gpu
         require_gpu()                      # loud failure: there is no CPU path
@@ -151,9 +158,20 @@ class AnalogData(_Base):
         key = (id(self._data), self._data.shape, tuple(self.dimord), str(dev))
         if self._device is None or self._device_key != key:
             from ..backend import to_device
-            self._device = to_device(self.data, dev, time_axis=self.dimord.index("time"))
+            self._device, self._upload = to_device(self.data, dev, time_axis=self.dimord.index("time"), background=True)
             self._device_key = key
+        if not partial and getattr(self, "_upload", None) is not None:
+            self._upload.finish()
+            self._upload = None
         return self._device
+
+    def upload_in_flight(self):
+        """backend.Upload of a device copy that is still being filled, or None."""
+        up = getattr(self, "_upload", None)
+        if up is not None and up.complete:
+            up.finish()
+            self._upload = up = None
+        return up
 
     def selectdata(self, select=None):
         self.selection = None if select is None else Selection(self, select)

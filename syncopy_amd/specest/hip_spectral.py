@@ -225,7 +225,7 @@ def run_stft(dev_data, row0, soi_start, soi_stop, frames, nperseg, step, boundar
 
 
 def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_taper, ft_compat, polyremoval,
-                       freq_idx, output, keeptapers, max_bytes=32 << 30, blocked=False, reuse=False):
+                       freq_idx, output, keeptapers, max_bytes=32 << 30, blocked=False, reuse=False, upload=None):
     """Generator over (trial indices, (B, Kout, F, C) device tensor) batches: trials of equal length share a
     plan; a batch is bounded by `max_bytes` of spectra so the intermediate stays a small part of HBM.
     With `blocked` the tensor is in the plan's hand-over layout whenever `tensor.dim() == 4 and
@@ -242,8 +242,14 @@ def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_
                         full_freq_idx(freq_idx, N), output, keeptapers, device, blocked=blocked)
         per_trial = int(np.prod(plan.out_shape(1))) * (8 if plan.kind == 2 else 4)
         bmax = max(1, int(max_bytes // per_trial))
+        if upload is not None and not upload.complete:
+            # the recording is still on its way into HBM (backend.Upload): batches of about one upload chunk, each
+            # launched as soon as its rows have arrived - the transforms of chunk k run under the copy of chunk k + 1
+            bmax = max(1, min(bmax, 2 * upload.chunk_rows() // max(n, 1)))
         for i in range(0, which.size, bmax):
             sel = which[i:i + bmax]
+            if upload is not None:
+                upload.wait_rows(max(rows[j][1] for j in sel))
             starts = torch.tensor([rows[j][0] for j in sel], dtype=torch.int64, device=device)
             # reuse=True: the consumer is done with a batch before it asks for the next one (stream order), so all
             # batches - and all later calls of the same shape - share one device buffer

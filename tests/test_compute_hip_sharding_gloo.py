@@ -38,11 +38,11 @@ def _patch():
     from syncopy_amd.specest import hip_spectral as hs
     calls = {"rows": []}
 
-    def device_data(self, device=None):
+    def device_data(self, device=None, partial=False):
         return torch.from_numpy(np.ascontiguousarray(self.data, dtype=np.float32))
 
     def run_mtmfft_batches(dev, rows, chans, nfft, taper, taper_opt, demean_taper, ft_compat, polyremoval, freq_idx, output,
-                           keeptapers, max_bytes=0, blocked=False, reuse=False):
+                           keeptapers, max_bytes=0, blocked=False, reuse=False, upload=None):
         calls["rows"].extend(rows)
         x = dev.numpy()
         specs = []
@@ -70,6 +70,7 @@ def _patch():
         return parallel.allreduce_sum_(acc)
 
     AnalogData.device_data = device_data
+    AnalogData.upload_in_flight = lambda self: None
     hs.run_mtmfft_batches = run_mtmfft_batches
     backend.csd_accumulate, backend.csd_finalize, backend.csd_allreduce_ = csd_accumulate, csd_finalize, csd_allreduce_
     backend.require_gpu = lambda: None

@@ -552,7 +552,7 @@ def test_reference_precision_through_freqanalysis():
     d = spy.freqanalysis(data, method="mtmfft", taper="hann", output="fourier")
     assert np.array_equal(d.data, a.data)
     with pytest.raises(SPYValueError):
-        spy.freqanalysis(data, method="wavelet", precision="reference")
+        spy.freqanalysis(data, method="mtmfft", precision="double")
 
 
 @pytest.mark.parametrize("nsamp", [2048, 2000])
