@@ -63,6 +63,8 @@ const char* spyhip_last_error(void);
 int spyhip_ctx_create(int device, spyhip_ctx** ctx);
 int spyhip_ctx_destroy(spyhip_ctx* ctx);
 /* `stream` is a hipStream_t (NULL = the null stream) */
+/* Give back the device memory a context keeps between calls (split-launch scratch, the work arrays of spyhip_granger). */
+int spyhip_ctx_trim(spyhip_ctx* ctx);
 int spyhip_ctx_set_stream(spyhip_ctx* ctx, void* stream);
 int spyhip_ctx_synchronize(spyhip_ctx* ctx);
 

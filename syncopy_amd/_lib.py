@@ -24,6 +24,7 @@ SIGNATURES = {
     "spyhip_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "spyhip_ctx_destroy": (C.c_int, [vp]),
     "spyhip_ctx_set_stream": (C.c_int, [vp, vp]),
+    "spyhip_ctx_trim": (C.c_int, [vp]),
     "spyhip_ctx_synchronize": (C.c_int, [vp]),
     "spyhip_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "spyhip_free": (C.c_int, [vp, vp]),

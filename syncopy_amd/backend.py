@@ -262,6 +262,8 @@ def release_buffers():
     Exposed as `syncopy_amd.release_device_buffers()`."""
     _handover.clear()
     _pin.clear()
+    for ctx in _contexts.values():
+        ctx.lib.spyhip_ctx_trim(ctx.handle)
     if torch.cuda.is_available():
         torch.cuda.empty_cache()
 

@@ -46,8 +46,18 @@ extern "C" int spyhip_ctx_destroy(spyhip_ctx* ctx) {
         if (ctx->comm) (void)spyhip_comm_destroy(ctx);
         if (ctx->scratch) (void)hipFree(ctx->scratch);
         if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
+        if (ctx->arena) (void)hipFree(ctx->arena);
     }
     delete ctx;
+    return 0;
+}
+
+extern "C" int spyhip_ctx_trim(spyhip_ctx* ctx) {
+    if (!ctx) { spy::set_error("ctx_trim: null ctx"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    if (ctx->arena) { (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_bytes = 0; }
     return 0;
 }
 

@@ -27,6 +27,8 @@ struct spyhip_ctx {
     int comm_rank = -1, comm_nranks = 0;
     void* comm_buf = nullptr;       // packed lower triangle travelling through spyhip_allreduce_csd
     size_t comm_buf_bytes = 0;
+    void* arena = nullptr;          // work arrays of spyhip_granger (5 x F n^2 complex128 ...): kept between calls - a
+    size_t arena_bytes = 0;         // hipMalloc + hipFree of 11 GB per call cost 0.05 ... 1 s; spyhip_ctx_trim frees it
 #endif
     int csd_phase_exact = 0;        // spyhip_csd_set_phase_exact: 4-multiplication K4 kernels only (csd.hip)
     int granger_iters = 0;          // Wilson iterations of the last spyhip_granger call on this context
