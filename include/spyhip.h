@@ -304,6 +304,12 @@ int spyhip_ccov_normalize(spyhip_ctx* ctx, void* cc_d, int nlag, int nchan);
 int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
                            double dt, double w0, int detrend, int output, const int32_t* tpos,
                            int ntime_out, spyhip_cwt_plan** plan);
+/* The same transform with another sampled kernel family (the convolution kernels do not care which):
+ * family 0 Morlet(w0 = p0), 1 MorletSL(cycles = p0, k_sd = p1) (= spyhip_cwt_plan_create_sl), 2 Paul(m = p0),
+ * 3 DOG(m = p0) - Ricker / Marr / Mexican_hat are DOG(2) (specest/wavelets/wavelets.py:140-223; freqanalysis.py:55). */
+int spyhip_cwt_plan_create_family(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
+                                  double dt, int family, double p0, double p1, int detrend, int output,
+                                  const int32_t* tpos, int ntime_out, spyhip_cwt_plan** plan);
 int spyhip_cwt_plan_destroy(spyhip_cwt_plan* plan);
 /* reference = 1: the transform as scipy.signal.fftconvolve computes it for cwt_time / cwtSL (specest/wavelets/
  * transform.py:88-108, specest/superlet.py:311-375): float64 FFT convolution of the detrended float32 trial with the

@@ -220,6 +220,18 @@ tfa("wav_toi", method="wavelet", wavelet="Morlet", width=4, foi=np.array([8.0, 3
 tfa("wav_auto_scales", method="wavelet", wavelet="Morlet", toi="all", output="abs", keeptrials=False)
 save("tf_variants", **kw)
 
+# ---------------------------------------------------------------- the other wavelet functions (freqanalysis.py:55, wavelets.py:140-363)
+kw = {"data": np.stack(trials_of(tf)), "samplerate": tf.samplerate, "trialdefinition": tf.trialdefinition}
+tfa("paul4_fourier", method="wavelet", wavelet="Paul", order=4, foi=np.array([12.0, 40.0, 95.0]), toi="all", output="fourier")
+tfa("paul6_toi_pow", method="wavelet", wavelet="Paul", order=6, foi=np.array([20.0, 60.0]), toi=np.arange(-0.6, 0.6, 0.02))
+tfa("dog1_abs", method="wavelet", wavelet="DOG", order=1, foi=np.array([10.0, 30.0, 120.0]), toi="all", output="abs")
+tfa("dog6_real_avg", method="wavelet", wavelet="DOG", order=6, foi=np.array([25.0, 80.0]), toi="all", output="real",
+    keeptrials=False, polyremoval=1)
+tfa("ricker_pow", method="wavelet", wavelet="Ricker", foi=np.array([15.0, 50.0, 150.0]), toi="all")
+tfa("mexican_hat_auto", method="wavelet", wavelet="Mexican_hat", toi="all", output="abs", keeptrials=False)
+tfa("paul4_auto", method="wavelet", wavelet="Paul", order=4, toi="all", keeptrials=False)
+save("wavelet_families", **kw)
+
 # ---------------------------------------------------------------- welch = mtmconvol + spy.mean(dim="time") (freqanalysis.py:1054-1056)
 kw = {"data": np.stack(trials_of(tf)), "samplerate": tf.samplerate, "trialdefinition": tf.trialdefinition}
 tfa("welch_hann_half", method="welch", taper="hann", t_ftimwin=0.5, toi=0.5)

@@ -352,19 +352,36 @@ def optimal_scales(n_samples, dt, w0=6.0, dj=0.25, s0=None):
     return (s0 * 2 ** (dj * np.arange(0, J + 1)))[::-1]
 
 
-def cwt_kernel(s, dt, w0=6.0):
+def paul(t, s, m=4):
+    """Paul wavelet of order m (specest/wavelets/wavelets.py:146-175)."""
+    from scipy.special import factorial
+    x = t / s
+    const = (2 ** m * 1j ** m * factorial(m)) / (np.pi * factorial(2 * m)) ** 0.5
+    return const * (1 - 1j * x) ** -(m + 1)
+
+
+def dog(t, s, m=2):
+    """Derivative of a Gaussian of order m (wavelets.py:242-298); m = 2: Ricker / Marr / Mexican hat (:352-363)."""
+    import scipy.special
+    x = t / s
+    const = (-1) ** (m + 1) / scipy.special.gamma(m + 0.5) ** 0.5
+    return const * scipy.special.hermitenorm(m)(x) * np.exp(-(x ** 2) / 2)
+
+
+def cwt_kernel(s, dt, w0=6.0, family=None, order=None):
     """Sampled, amplitude-normalised kernel of cwt_time (wavelets/transform.py:96-103)."""
     M = 10 * s / dt
     t = np.arange((-M + 1) / 2.0, (M + 1) / 2.0) * dt
-    return (dt ** 0.5 / (s * 8 * np.pi)) * morlet(t, s, w0)
+    wav = paul(t, s, order) if family == "Paul" else (dog(t, s, order) if family == "DOG" else morlet(t, s, w0))
+    return (dt ** 0.5 / (s * 8 * np.pi)) * wav
 
 
-def cwt(x, fs, scales, w0=6.0):
+def cwt(x, fs, scales, w0=6.0, family=None, order=None):
     """cwt_time (wavelets/transform.py:88-108) -> (nScales, N, C) complex64."""
     dt = 1 / fs
     out = np.zeros((len(scales),) + x.shape, dtype=np.complex64)
     for i, s in enumerate(scales):
-        out[i] = sps.fftconvolve(x, cwt_kernel(s, dt, w0)[:, None], mode="same")
+        out[i] = sps.fftconvolve(x, cwt_kernel(s, dt, w0, family, order)[:, None], mode="same")
     return out
 
 
@@ -378,7 +395,8 @@ def wavelet_cF(trl, preselect, postselect, toi=None, timeAxis=0, polyremoval=Non
     if noCompute:
         return shape, OUT_DTYPE[output]
     dat = detrend(dat, polyremoval)
-    spec = cwt(dat[preselect, :], method_kwargs["samplerate"], scales, method_kwargs.get("w0", 6.0))
+    spec = cwt(dat[preselect, :], method_kwargs["samplerate"], scales, method_kwargs.get("w0", 6.0),
+               method_kwargs.get("family"), method_kwargs.get("order"))
     spec = spec.transpose(1, 0, 2)[postselect]
     return convert_output(spec[:, None, :, :], output)
 

@@ -70,6 +70,8 @@ SIGNATURES = {
                                          C.c_int, c_i32p, C.c_int, C.POINTER(vp)]),
     "spyhip_cwt_plan_create_sl": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_f64p, C.c_double, C.c_double,
                                             C.c_double, C.c_int, C.c_int, c_i32p, C.c_int, C.POINTER(vp)]),
+    "spyhip_cwt_plan_create_family": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_f64p, C.c_double, C.c_int, C.c_double,
+                                                C.c_double, C.c_int, C.c_int, c_i32p, C.c_int, C.POINTER(vp)]),
     "spyhip_slt_combine": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, C.c_int,
                                      C.c_int]),
     "spyhip_spec_convert": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),

@@ -379,10 +379,13 @@ class FFTPlan:
 class CWTPlan:
     """spyhip_cwt_plan: Morlet CWT (overlap-save FFT convolution) of segments of the trial matrix."""
 
+    FAMILY = {"Morlet": 0, "MorletSL": 1, "Paul": 2, "DOG": 3}
+
     def __init__(self, nsig, nchan, scales, dt, w0=6.0, detrend=None, output="pow", tpos=None, ntime_out=None,
-                 device=None, sl_cycles=None, k_sd=5.0):
+                 device=None, sl_cycles=None, k_sd=5.0, family=None, order=None):
         """`sl_cycles`: superlet formulation MorletSL with that many cycles (spyhip_cwt_plan_create_sl) instead of
-        Morlet(w0)."""
+        Morlet(w0).  `family` = "Paul" | "DOG" with `order` m: the other wavelet functions of the reference
+        (spyhip_cwt_plan_create_family; Ricker / Marr / Mexican_hat = DOG with m = 2)."""
         self.ctx = context(device)
         scales = np.ascontiguousarray(scales, dtype=np.float64)
         self.nsig, self.nchan, self.nscales = int(nsig), int(nchan), int(scales.size)
@@ -395,7 +398,12 @@ class CWTPlan:
             tp, self.ntime_out = tpa.ctypes.data_as(_lib.c_i32p), int(ntime_out)
         h = C.c_void_p()
         self.ctx.bind_stream()
-        if sl_cycles is not None:
+        if family in ("Paul", "DOG"):
+            check(self.ctx.lib.spyhip_cwt_plan_create_family(
+                self.ctx.handle, self.nsig, self.nchan, self.nscales, scales.ctypes.data_as(_lib.c_f64p), float(dt),
+                self.FAMILY[family], float(order), 0.0, DETREND[detrend], self.kind, tp, self.ntime_out, C.byref(h)),
+                "spyhip_cwt_plan_create_family")
+        elif sl_cycles is not None:
             check(self.ctx.lib.spyhip_cwt_plan_create_sl(
                 self.ctx.handle, self.nsig, self.nchan, self.nscales, scales.ctypes.data_as(_lib.c_f64p), float(dt),
                 float(sl_cycles), float(k_sd), DETREND[detrend], self.kind, tp, self.ntime_out, C.byref(h)),

@@ -89,7 +89,10 @@ int launch_cwt_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
 }  // namespace
 
 // family 0: Morlet(w0 = p0) as Morlet.time / cwt_time sample it; family 1: the superlet formulation MorletSL with
-// p0 = c_i cycles inside the Gaussian envelope of p1 = k_sd standard deviations (specest/superlet.py:268-363)
+// p0 = c_i cycles inside the Gaussian envelope of p1 = k_sd standard deviations (specest/superlet.py:268-363);
+// family 2: Paul(m = p0), family 3: DOG(m = p0) - Ricker / Marr / Mexican_hat are DOG(2) - as Paul.time / DOG.time
+// sample them (specest/wavelets/wavelets.py:140-223).  The transform convolves with a table of sampled taps, so every
+// family runs on the same kernels.
 static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales, double dt,
                                 int family, double p0, double p1, int detrend, int output, const int32_t* tpos,
                                 int ntime_out, spyhip_cwt_plan** out);
@@ -98,6 +101,15 @@ extern "C" int spyhip_cwt_plan_create(spyhip_ctx* ctx, int nsig, int nchan, int 
                                       double dt, double w0, int detrend, int output, const int32_t* tpos,
                                       int ntime_out, spyhip_cwt_plan** out) {
     return cwt_plan_create_impl(ctx, nsig, nchan, nscales, scales, dt, 0, w0, 0.0, detrend, output, tpos, ntime_out, out);
+}
+
+extern "C" int spyhip_cwt_plan_create_family(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
+                                             double dt, int family, double p0, double p1, int detrend, int output,
+                                             const int32_t* tpos, int ntime_out, spyhip_cwt_plan** out) {
+    if (family < 0 || family > 3) { spy::set_error("cwt_plan_create_family: family %d (0 Morlet, 1 MorletSL, 2 Paul, 3 DOG)", family); return -1; }
+    if (family == 1 && (!(p0 > 0) || !(p1 > 0))) { spy::set_error("cwt_plan_create_family: cycles and k_sd must be positive"); return -1; }
+    if (family >= 2 && (p0 < 1 || p0 > 60 || p0 != std::floor(p0))) { spy::set_error("cwt_plan_create_family: order m = %g (integer 1 ... 60)", p0); return -1; }
+    return cwt_plan_create_impl(ctx, nsig, nchan, nscales, scales, dt, family, p0, p1, detrend, output, tpos, ntime_out, out);
 }
 
 extern "C" int spyhip_cwt_plan_create_sl(spyhip_ctx* ctx, int nsig, int nchan, int nscales, const double* scales,
@@ -136,10 +148,31 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
         const double corr = std::exp(-0.5 * w0 * w0);
         // MorletSL: sqrt(dt)/(4 pi) * k_sd / (s c (2 pi)^1.5) * exp(i t/s) * exp(-(k_sd t/s / (2 pi c))^2 / 2)
         const double norm_sl = std::sqrt(dt) / (4.0 * PI) * p1 / (sc * p0 * std::pow(2.0 * PI, 1.5));
+        // Paul(m): 2^m i^m m! / sqrt(pi (2m)!) (1 - i x)^-(m+1); DOG(m): (-1)^(m+1) / sqrt(Gamma(m + 1/2)) He_m(x) exp(-x^2/2);
+        // both with cwt_time's amplitude normalisation sqrt(dt) / (8 pi s)  (wavelets.py:140-223, transform.py:96-103)
+        const int mo = family >= 2 ? (int)p0 : 0;
+        const double norm_t = std::sqrt(dt) / (sc * 8.0 * PI);
+        const double paul_c = family == 2 ? std::exp(mo * std::log(2.0) + std::lgamma(mo + 1.0) - 0.5 * (std::log(PI) + std::lgamma(2.0 * mo + 1.0))) : 0.0;
+        const double dog_c = family == 3 ? ((mo + 1) % 2 ? -1.0 : 1.0) * std::exp(-0.5 * std::lgamma(mo + 0.5)) : 0.0;
         k.re.resize(m1 - m0);
         k.im.resize(m1 - m0);
         for (long long m = m0; m < m1; ++m) {
             const double x = (t0 + (double)m) * dt / sc;            // t / s
+            if (family == 2) {
+                // (1 - i x)^-(m+1) = r^-(m+1) exp(i (m+1) atan(x)),  times i^m
+                const double r = std::sqrt(1.0 + x * x), ph = (mo + 1) * std::atan(x) + 0.5 * PI * mo;
+                const double a = norm_t * paul_c * std::pow(r, -(double)(mo + 1));
+                k.re[m - m0] = a * std::cos(ph);
+                k.im[m - m0] = a * std::sin(ph);
+                continue;
+            }
+            if (family == 3) {
+                double h0 = 1.0, h1 = x;                            // probabilists' Hermite: He_{n+1} = x He_n - n He_{n-1}
+                for (int q = 1; q < mo; ++q) { const double h2 = x * h1 - q * h0; h0 = h1; h1 = h2; }
+                k.re[m - m0] = norm_t * dog_c * (mo == 0 ? 1.0 : h1) * std::exp(-0.5 * x * x);
+                k.im[m - m0] = 0.0;
+                continue;
+            }
             if (family == 1) {
                 const double u = p1 * x / (2.0 * PI * p0);
                 const double g = norm_sl * std::exp(-0.5 * u * u);

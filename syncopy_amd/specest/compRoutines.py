@@ -235,6 +235,7 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
     scales = np.asarray(method_kwargs["scales"], dtype=np.float64)
     dt = 1.0 / method_kwargs["samplerate"]
     w0 = float(method_kwargs.get("w0", 6.0))
+    family, order = method_kwargs.get("family"), method_kwargs.get("order")
     results = [None] * len(rows)
     groups = {}
     for k, ((a, b), ps, qs) in enumerate(zip(rows, pre, post)):
@@ -247,10 +248,11 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
         return None
     for nsig, tpos, nuniq, gather, members in groups.values():
         pkey = (nsig, nchan, scales.tobytes(), dt, w0, polyremoval, output, None if tpos is None else tpos.tobytes(),
-                str(device), _cwt_reference())
+                str(device), _cwt_reference(), family, order)
         plan = hs._cache_hit(_cwt_plans, pkey)
         if plan is None:
-            plan = hs.backend.CWTPlan(nsig, nchan, scales, dt, w0, polyremoval, output, tpos, nuniq, device=device)
+            plan = hs.backend.CWTPlan(nsig, nchan, scales, dt, w0, polyremoval, output, tpos, nuniq, device=device,
+                                      family=family, order=order)
             _cwt_precision(plan)
             hs._bounded_put(_cwt_plans, pkey, plan)
         starts = torch.tensor([m[1] for m in members], dtype=torch.int64, device=device)

@@ -16,7 +16,7 @@ from ..shared.input_processors import process_foi, process_padding, process_tape
 from ..shared.tools import best_match
 from .compRoutines import MultiTaperFFT, MultiTaperFFTConvol
 
-availableWavelets = ("Morlet",)
+availableWavelets = ("Morlet", "Paul", "DOG", "Ricker", "Marr", "Mexican_hat")      # freqanalysis.py:55
 
 
 def _scalar(value, varname, lims):
@@ -79,12 +79,12 @@ def freqanalysis(data, method="mtmfft", output="pow", keeptrials=True, foi=None,
         with (hs.soft_reference() if soft else hs.precision(precision)):
             return _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
                                  demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin, wavelet, width,
-                                 ft_compat, compute_method, (order_max, order_min, c_1, adaptive))
+                                 ft_compat, compute_method, (order_max, order_min, c_1, adaptive), order)
 
 
 def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foilim, pad, polyremoval, taper,
                   demean_taper, taper_opt, tapsmofrq, nTaper, keeptapers, toi, t_ftimwin, wavelet, width, ft_compat,
-                  compute_method, slt=(None, 1, 3, False)):
+                  compute_method, slt=(None, 1, 3, False), order=None):
     fs = data.samplerate
     trl = selected_trialdefinition(data)
     sinfo = trl[:, :2]
@@ -181,25 +181,44 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
     elif method == "wavelet":
         if "wavelet" not in classes:
             raise NotImplementedError("wavelet transform kernels are not part of this build")
-        from .wavelet_tools import morlet_scale_from_period, optimal_wavelet_scales
+        from .wavelet_tools import (WAVELET_FAMILY, family_fourier_period, family_scale_from_period,
+                                    optimal_wavelet_scales)
         if wavelet not in availableWavelets:
             raise SPYValueError("one of " + ", ".join(availableWavelets), varname="wavelet", actual=wavelet)
-        _scalar(width, "width", [1, np.inf])
+        if wavelet not in ("Morlet", "Paul"):           # freqanalysis.py:830-836
+            SPYWarning(f"the chosen wavelet '{wavelet}' is real-valued and does not provide any information about "
+                       "amplitude or phase of the data. This wavelet function may be used to isolate peaks or "
+                       "discontinuities in the signal. ")
+        family, takes_order = WAVELET_FAMILY[wavelet]
+        if wavelet == "Morlet":
+            _scalar(width, "width", [1, np.inf])
+        # (the reference's warning about `width` for the other wavelets compares the argument with itself,
+        # freqanalysis.py:846-848, and never fires)
         # Reference quirk kept for parity: freqanalysis.py:844 builds Morlet(w0=width) but the
         # `order` branch at :861-864 then replaces it by a default-constructed Morlet(), so
         # `width` never reaches the transform and w0 is always 6.
         width = 6.0
+        if wavelet == "Paul":
+            _int_like(order, "order", 4, np.inf)        # :850-855
+        elif wavelet == "DOG":
+            _int_like(order, "order", 1, np.inf)        # :856-861
+        elif order is not None:
+            SPYWarning(f"option `order` has no effect for wavelet '{wavelet}'")
+        m = int(order) if takes_order else (2 if family == "DOG" else None)      # Ricker = DOG(m=2), wavelets.py:352-361
+        to_scale, to_period = family_scale_from_period(family, m, width), family_fourier_period(family, m, width)
         toi, preSelect, postSelect = _wavelet_toi(toi, numTrials, tStart, tEnd, lenTrials, fs)
         if foi is None and foilim is None:
-            scales = optimal_wavelet_scales(int(minTrialLength * fs), dt, w0=width)
-            foi = 1 / (4 * np.pi * scales / (width + np.sqrt(2 + width ** 2)))
+            scales = optimal_wavelet_scales(int(minTrialLength * fs), dt, w0=width, scale_from_period=to_scale)
+            foi = 1 / to_period(scales)
         else:
             if foilim is not None:
                 foi = np.arange(foilim[0], foilim[1] + 1, dtype=float)
             foi = np.asarray(foi, dtype=float).copy()
             foi[foi < 0.01] = 0.01
-            scales = morlet_scale_from_period(1 / foi, w0=width)
+            scales = to_scale(1 / foi)
         method_kwargs = {"samplerate": fs, "scales": scales, "w0": float(width)}
+        if family != "Morlet":
+            method_kwargs.update(family=family, order=m)
         cr = classes["wavelet"](preSelect, postSelect, toi=toi, timeAxis=timeAxis, polyremoval=polyremoval,
                                 output=output, method_kwargs=method_kwargs)
         cr._foi = foi

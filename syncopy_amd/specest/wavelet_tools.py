@@ -11,6 +11,29 @@ def morlet_fourier_period(s, w0=6.0):
     return 4 * np.pi * s / (w0 + (2 + w0 ** 2) ** 0.5)
 
 
+# wavelet functions of the reference (freqanalysis.py:55): name -> (kernel family of the C ABI, order taken from the call?)
+WAVELET_FAMILY = {"Morlet": ("Morlet", False), "Paul": ("Paul", True), "DOG": ("DOG", True), "Ricker": ("DOG", False),
+                  "Marr": ("DOG", False), "Mexican_hat": ("DOG", False)}
+
+
+def family_scale_from_period(family, order=None, w0=6.0):
+    """period -> scale of a wavelet family (wavelets.py:93-101 Morlet, :181-185 Paul, :303-307 DOG)."""
+    if family == "Paul":
+        return lambda period: period * (2 * order + 1) / (4 * np.pi)
+    if family == "DOG":
+        return lambda period: period * np.sqrt(order + 0.5) / (2 * np.pi)
+    return lambda period: morlet_scale_from_period(period, w0)
+
+
+def family_fourier_period(family, order=None, w0=6.0):
+    """scale -> Fourier period (wavelets.py:89-91, :178-179, :300-301)."""
+    if family == "Paul":
+        return lambda s: 4 * np.pi * s / (2 * order + 1)
+    if family == "DOG":
+        return lambda s: 2 * np.pi * s / (order + 0.5) ** 0.5
+    return lambda s: morlet_fourier_period(s, w0)
+
+
 def optimal_wavelet_scales(nSamples, dt, w0=6.0, dj=0.25, s0=None, scale_from_period=None):
     if s0 is None:
         s0 = morlet_scale_from_period(2 * dt, w0) if scale_from_period is None else scale_from_period(2 * dt)

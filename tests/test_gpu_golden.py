@@ -8,7 +8,7 @@ import pytest
 import syncopy_amd as spy
 from oracle_routines import ORACLE_CONN, ORACLE_FREQ
 from parity import assert_parity
-from test_oracle_golden import (JACK_VARIANTS, SLT_VARIANTS, TF_VARIANTS, VARIANTS, WELCH_VARIANTS, chain_checks,
+from test_oracle_golden import (JACK_VARIANTS, SLT_VARIANTS, TF_VARIANTS, WAVELET_FAMILIES, VARIANTS, WELCH_VARIANTS, chain_checks,
                                 check_jackknife, check_superlet, cmb_checks, corr_checks, ppc_checks)
 
 pytestmark = pytest.mark.gpu
@@ -199,6 +199,24 @@ def test_timefreq_variants(tf, name, how):
     assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
     assert_parity(out.data, ref, what=f"{name} ({how})")
     np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
+
+
+@pytest.mark.parametrize("how", ["hip", "sequential"])
+@pytest.mark.parametrize("name", sorted(WAVELET_FAMILIES))
+def test_wavelet_families(golden_dir, tf, name, how):
+    """Paul / DOG / Ricker wavelets (freqanalysis.py:55, wavelets.py:140-363) on K3: the convolution kernels take a
+    host-sampled tap table, so every family runs on them - against vectors written by the real reference."""
+    import warnings
+    _, data = tf
+    z = _load(golden_dir, "wavelet_families")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = spy.freqanalysis(data, compute_method=how, **WAVELET_FAMILIES[name])
+    ref = z[name]
+    assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
+    assert_parity(out.data, ref, what=f"{name} ({how})")
+    np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
+    np.testing.assert_allclose(out.freq, z[name + "_freq"])
 
 
 @pytest.mark.parametrize("how", ["hip", "sequential"])

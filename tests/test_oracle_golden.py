@@ -353,6 +353,47 @@ def test_tf_variants(tf, name):
     np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
 
 
+# the other wavelet functions of the reference (freqanalysis.py:55; VERDICT r3 missing 6): Paul(m), DOG(m), Ricker = DOG(2)
+WAVELET_FAMILIES = {
+    "paul4_fourier": dict(method="wavelet", wavelet="Paul", order=4, foi=np.array([12.0, 40.0, 95.0]), toi="all", output="fourier"),
+    "paul6_toi_pow": dict(method="wavelet", wavelet="Paul", order=6, foi=np.array([20.0, 60.0]), toi=np.arange(-0.6, 0.6, 0.02)),
+    "dog1_abs": dict(method="wavelet", wavelet="DOG", order=1, foi=np.array([10.0, 30.0, 120.0]), toi="all", output="abs"),
+    "dog6_real_avg": dict(method="wavelet", wavelet="DOG", order=6, foi=np.array([25.0, 80.0]), toi="all", output="real",
+                          keeptrials=False, polyremoval=1),
+    "ricker_pow": dict(method="wavelet", wavelet="Ricker", foi=np.array([15.0, 50.0, 150.0]), toi="all"),
+    "mexican_hat_auto": dict(method="wavelet", wavelet="Mexican_hat", toi="all", output="abs", keeptrials=False),
+    "paul4_auto": dict(method="wavelet", wavelet="Paul", order=4, toi="all", keeptrials=False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WAVELET_FAMILIES))
+def test_wavelet_families(golden_dir, tf, name):
+    _, data = tf
+    z = _load(golden_dir, "wavelet_families")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                      # (real-valued wavelets warn, as in the reference)
+        out = fa(data, **WAVELET_FAMILIES[name])
+    ref = z[name]
+    assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
+    assert_parity(out.data, ref, what=name)
+    np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
+    np.testing.assert_allclose(out.freq, z[name + "_freq"])
+
+
+def test_wavelet_family_argument_checks(tf):
+    from syncopy_amd.shared.errors import SPYTypeError, SPYValueError
+    _, data = tf
+    with pytest.raises(SPYValueError):
+        fa(data, method="wavelet", wavelet="Haar")
+    with pytest.raises(SPYValueError):
+        fa(data, method="wavelet", wavelet="Paul", order=3)          # freqanalysis.py:852: order >= 4
+    with pytest.raises(SPYTypeError):
+        fa(data, method="wavelet", wavelet="DOG", order=2.5)
+    with pytest.warns(UserWarning, match="real-valued"):
+        fa(data, method="wavelet", wavelet="Ricker", foi=np.array([30.0]), toi=np.array([0.0, 0.1]))
+
+
 SLT_VARIANTS = {
     "slt_mult": dict(method="superlet", order_max=3, foi=np.arange(20, 90, 10), toi="all"),
     "slt_mult_c5_toi": dict(method="superlet", order_max=4, order_min=2, c_1=5, foi=np.array([30.0, 60.0]),
