@@ -5,13 +5,13 @@
 
 namespace spyfft {
 
-//                       V   R1  R2  R3  G   SPLIT  XRES
+//                       V   R1  R2  R3  G   SPLIT  XRES  HOIST
 using D64_256   = CfgD64<16, 16, 1,  1,  16>;
 using D64_512   = CfgD64<16, 16, 2,  1,  8>;
 using D64_1024  = CfgD64<16, 16, 4,  1,  4>;
 using D64_2048  = CfgD64<16, 16, 8,  1,  2>;
 using D64_4096  = CfgD64<16, 16, 16, 1,  1>;
-using D64_8192  = CfgD64<16, 16, 16, 2,  1>;
+using D64_8192  = CfgD64<16, 16, 16, 2,  1, false, true, false>;
 // 16384: 512 threads x 32 values, two split exchanges (a 16-value schedule needs 1024 threads = 128 registers per thread:
 // measured 242 vs 204 us/trial for the complex spectra and 1040 vs 184 with the taper mean, profiles/r4_precision_probe.txt)
 using D64_16384 = CfgD64<32, 32, 16, 1,  1, true, false>;

@@ -27,10 +27,14 @@
 
 namespace spyfft {
 
-template <int V_, int R1_, int R2_, int R3_, int G_, bool SPLIT_ = false, bool XRES_ = true>
+template <int V_, int R1_, int R2_, int R3_, int G_, bool SPLIT_ = false, bool XRES_ = true, bool HOIST_ = true>
 struct CfgD64 {
     static constexpr int V = V_, R1 = R1_, R2 = R2_, R3 = R3_, G = G_;
     static constexpr bool SPLIT = SPLIT_, XRES = XRES_;
+    // HOIST: the base twiddles of the later passes stay in registers across the tapers and their powers are formed by
+    // multiplication (d64_pass); false: every power comes from the table inside the taper loop (N = 8192: the four
+    // passes' base twiddles do not fit next to 16 resident values per thread - measured 61.9 vs 53.8 us/trial)
+    static constexpr bool HOIST = HOIST_;
     static constexpr int N = V * R1 * R2 * R3;
     static constexpr int T = N / V;                          // threads per channel pair
     static constexpr int NPASS = 2 + (R2 > 1 ? 1 : 0) + (R3 > 1 ? 1 : 0);
@@ -95,13 +99,17 @@ __device__ __forceinline__ void d64_exchange(spywil::cd (&v)[C::V], void* ldsv, 
 }
 
 // One pass.  In: v[e] = in[j + T e] (pass 0: the tapered samples).  Out: LAST - v[e] = X[j + T e] in registers;
-// otherwise the outputs go through LDS and v[e] = out[j + T e] comes back.  tw[m] = exp(-2 pi i m / N).
+// otherwise the outputs go through LDS and v[e] = out[j + T e] comes back.  w1[m] = exp(-2 pi i k_m / (Ns R)), the base
+// twiddle of butterfly m = j + T m of this pass: it does not depend on the taper, so the kernel fetches it ONCE per
+// workgroup (d64_twiddles) and every power w^r, r < R, is formed from it in registers (w^2 = w w, w^3, w^4 = (w^2)^2,
+// w^8 ..., then w^(4a + l) = w^(4a) w^l: ~R complex products instead of (R + 3) / 4 + 2 table reads per butterfly and
+// taper - with two waves per SIMD the kernel waits on L2 latency, not on the vector pipe).
 template <class C, int R, int Ns, bool FIRST, bool LAST>
 __device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j, int h, bool active,
-                                         const spywil::cd* __restrict__ tw) {
+                                         const spywil::cd* w1) {
     using spywil::cd;
     using spywil::cmul;
-    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, MB = V / R;
+    constexpr int V = C::V, T = C::T, G = C::G, MB = V / R;
     int wbase[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -111,14 +119,30 @@ __device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = v[m + MB * r];
         if (!FIRST) {
-            // w^r, r < R, from w^1 .. w^3 and w^4, w^8, ...: (R + 3) / 4 + 2 table reads instead of R - 1
-            const int st = k * (N / (Ns * R));
             constexpr int NA = (R + 3) / 4;
-            cd wb[4], wa[NA];
+            cd wb[4], wa[NA > 1 ? NA : 2];
+            if constexpr (C::HOIST) {
+                wb[1] = w1[m];
+#ifndef SPY_HOST_EMU
+                // (the powers are taper-invariant too: without this the compiler hoists all of them out of the taper loop
+                // and spills ~100 registers; only the base twiddle is meant to stay live)
+                asm volatile("" : "+v"(wb[1].x), "+v"(wb[1].y));
+#endif
+            }
+            if constexpr (C::HOIST) {
+                wb[2] = cmul(wb[1], wb[1]);
+                wb[3] = cmul(wb[2], wb[1]);
+                wa[1] = cmul(wb[2], wb[2]);
 #pragma unroll
-            for (int l = 1; l < 4; ++l) wb[l] = (l < R) ? tw[l * st] : make_double2(1.0, 0.0);
+                for (int a = 2; a < NA; ++a) wa[a] = (a % 2 == 0) ? cmul(wa[a / 2], wa[a / 2]) : cmul(wa[a - 1], wa[1]);
+            } else {
+                // w1 = the table itself (d64_twiddles_none): powers by table reads, as the first generation did
+                const int st = k * (C::N / (Ns * R));
 #pragma unroll
-            for (int a = 1; a < NA; ++a) wa[a] = tw[4 * a * st];
+                for (int l = 1; l < 4; ++l) wb[l] = (l < R) ? w1[l * st] : make_double2(1.0, 0.0);
+#pragma unroll
+                for (int a = 1; a < NA; ++a) wa[a] = w1[4 * a * st];
+            }
 #pragma unroll
             for (int r = 1; r < R; ++r) {
                 const int hi = r >> 2, lo = r & 3;
@@ -135,6 +159,24 @@ __device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j
     if (LAST) return;
     constexpr int WS = FIRST ? G : (Ns + Ns / V) * G;
     d64_exchange<C, R, MB, WS>(v, lds, wbase, C::idx(j, h), active);
+}
+
+// the base twiddles of one pass for thread j: w1[m] = tw[k_m N / (Ns R)], k_m = (j + T m) mod Ns
+template <class C, int R, int Ns>
+__device__ __forceinline__ void d64_twiddles(spywil::cd (&w1)[C::V / R], int j, const spywil::cd* __restrict__ tw) {
+    constexpr int MB = C::V / R;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int b = j + C::T * m;
+        w1[m] = tw[(b % Ns) * (C::N / (Ns * R))];
+    }
+}
+
+// taper weight of sample n (0 beyond the window): branch-free - a clamped 32-bit offset from the wave-uniform row pointer
+// and a select, instead of one exec-masked branch per value
+__device__ __forceinline__ double tapw(const double* w, unsigned n, unsigned nsig_m1) {
+    const double wl = ldg<double>(w, min(n, nsig_m1) * 8u);
+    return n <= nsig_m1 ? wl : 0.0;
 }
 
 // sample n of the two channels of a pair (float32, as the reference holds the trial); zero outside [rlo, rhi)
@@ -286,7 +328,15 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
     constexpr unsigned OSZ = CPLX ? 8u : 4u;
     const bool fast = has1 && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) && ((a.nchan & 1) == 0);
     const cd* const tw = reinterpret_cast<const cd*>(fa.tw64);
+    // base twiddles of the later passes: taper-invariant, fetched once (4 registers per butterfly and pass)
+    cd w1a[V / C::R1], w1b[C::R2 > 1 ? V / C::R2 : 1], w1c[C::R3 > 1 ? V / C::R3 : 1];
+    if constexpr (C::HOIST) {
+        d64_twiddles<C, C::R1, V>(w1a, j0, tw);
+        if constexpr (C::NPASS >= 3) d64_twiddles<C, C::R2, V * C::R1>(w1b, j0, tw);
+        if constexpr (C::NPASS >= 4) d64_twiddles<C, C::R3, V * C::R1 * C::R2>(w1c, j0, tw);
+    }
 
+    const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
     for (int k = 0; k < a.ntaper; ++k) {
         const int j = opaque(j0);     // (keeps the twiddle loads and the index arithmetic of the passes inside the loop)
         const double* w = fa.tapers64 + (size_t)k * a.nsig;
@@ -306,7 +356,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
                     const float r0 = fit ? (float)(t0c + t0s * dn) : m0, r1 = fit ? (float)(t1c + t1s * dn) : m1;
                     const float u0 = ((n == nc) ? t.x : 0.f) - (n < a.nsig ? r0 : 0.f);
                     const float u1 = ((n == nc) ? t.y : 0.f) - (n < a.nsig ? r1 : 0.f);
-                    const double wn = n < a.nsig ? w[n] : 0.0;
+                    const double wn = tapw(w, (unsigned)n, nsig_m1);
                     v[e] = make_double2(wn * (double)u0, wn * (double)u1);
                 }
             } else {
@@ -329,7 +379,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const int n = j + T * e;
-                const double wn = n < a.nsig ? w[n] : 0.0;
+                const double wn = tapw(w, (unsigned)n, nsig_m1);
                 const double dn = (double)((float)n - mid);
                 v[e] = make_double2(wn * ((double)x0[e] - (t0c + t0s * dn)), wn * ((double)x1[e] - (t1c + t1s * dn)));
             }
@@ -337,7 +387,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const int n = j + T * e;
-                const double wn = n < a.nsig ? w[n] : 0.0;
+                const double wn = tapw(w, (unsigned)n, nsig_m1);
                 v[e] = make_double2(wn * (double)x0[e], wn * (double)x1[e]);     // win *= data_arr (float64)
             }
         }
@@ -362,10 +412,10 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         }
 
         // ---- the passes: radix V from the registers, then R1 (R2, R3); the last one leaves v[e] = Z[j + T e]
-        d64_pass<C, V, 1, true, false>(v, lds, j, h, active, tw);
-        d64_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, tw);
-        if constexpr (C::NPASS >= 3) d64_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, tw);
-        if constexpr (C::NPASS >= 4) d64_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, tw);
+        d64_pass<C, V, 1, true, false>(v, lds, j, h, active, nullptr);
+        d64_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, C::HOIST ? w1a : tw);
+        if constexpr (C::NPASS >= 3) d64_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, C::HOIST ? w1b : tw);
+        if constexpr (C::NPASS >= 4) d64_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, C::HOIST ? w1c : tw);
 
         // ---- separation: partner bin N - f lives in the upper slots
         double zpx[C::SPLIT ? HV : 1];
