@@ -14,7 +14,7 @@ using D64_4096  = CfgD64<16, 16, 16, 1,  1>;
 using D64_8192  = CfgD64<16, 16, 16, 2,  1, false, true, false>;
 // 16384: 512 threads x 32 values, two split exchanges (a 16-value schedule needs 1024 threads = 128 registers per thread:
 // measured 242 vs 204 us/trial for the complex spectra and 1040 vs 184 with the taper mean, profiles/r4_precision_probe.txt)
-using D64_16384 = CfgD64<32, 32, 16, 1,  1, true, false>;
+using D64_16384 = CfgD64<32, 32, 16, 1,  1, true, false, false>;   // (HOIST off: 532 vs 184 us/trial with the taper mean)
 using D64_200   = CfgD64<10, 10, 2,  1,  8>;
 using D64_500   = CfgD64<10, 10, 5,  1,  4>;
 using D64_1000  = CfgD64<10, 10, 10, 1,  2>;

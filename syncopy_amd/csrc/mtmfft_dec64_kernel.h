@@ -315,7 +315,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
 
     // taper mean: float32 accumulators in registers - or, where a 1024-thread workgroup leaves no room for them, in
     // the output slab itself (every thread owns its bins; same float32 additions in taper order, one division at the end)
-    constexpr bool MREG = MEAN && C::NTHREADS < 1024;
+    constexpr bool MREG = MEAN && C::NTHREADS < 1024 && V <= 20;          // (V = 32: 128 value registers leave no room either)
     float macc0[MREG ? HV + 1 : 1], macc1[MREG ? HV + 1 : 1], mim0[(MREG && CPLX) ? HV + 1 : 1], mim1[(MREG && CPLX) ? HV + 1 : 1];
     if constexpr (MREG) {
 #pragma unroll
