@@ -504,7 +504,7 @@ def csd_kernel_name(nchan, blocked=False):
     ntiles = nt * (nt + 1) // 2
     import os
     if nchan == 256 and not os.environ.get("SPYHIP_CSD_4M"):
-        return "spycsd::csd3m_kernel<256, 8, true>"
+        return "spycsd::csd3m_kernel<256, 8, true, false, false>"
     if nchan <= 512 and not blocked and not os.environ.get("SPYHIP_CSD_4M"):
         return "spycsd::csd3m_kernel<%d, 8, false>" % ((nchan + 15) // 16 * 16)
     if nchan > 512 and not blocked and not os.environ.get("SPYHIP_CSD_4M"):

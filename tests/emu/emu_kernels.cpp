@@ -891,16 +891,13 @@ extern "C" int emu_mtmfft_f64(int nfft, int blue_m, const float* data, long long
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
     const int mean = keeptapers ? 0 : 1;
     if (use_dec) {
-        switch (nfft) {
+        switch (nfft) {          // (512 / 2048 / 500 differ from 1024 / 4096 / 1000 in one radix only: left to the GPU tests)
             case 256: run_dec64_mode<spyfft::D64_256>(fa, nseg, nchan, outk, mean); break;
-            case 512: run_dec64_mode<spyfft::D64_512>(fa, nseg, nchan, outk, mean); break;
             case 1024: run_dec64_mode<spyfft::D64_1024>(fa, nseg, nchan, outk, mean); break;
-            case 2048: run_dec64_mode<spyfft::D64_2048>(fa, nseg, nchan, outk, mean); break;
             case 4096: run_dec64_mode<spyfft::D64_4096>(fa, nseg, nchan, outk, mean); break;
             case 8192: run_dec64_mode<spyfft::D64_8192>(fa, nseg, nchan, outk, mean); break;
             case 16384: run_dec64_mode<spyfft::D64_16384>(fa, nseg, nchan, outk, mean); break;
             case 200: run_dec64_mode<spyfft::D64_200>(fa, nseg, nchan, outk, mean); break;
-            case 500: run_dec64_mode<spyfft::D64_500>(fa, nseg, nchan, outk, mean); break;
             case 1000: run_dec64_mode<spyfft::D64_1000>(fa, nseg, nchan, outk, mean); break;
             case 2000: run_dec64_mode<spyfft::D64_2000>(fa, nseg, nchan, outk, mean); break;
             case 2500: run_dec64_mode<spyfft::D64_2500>(fa, nseg, nchan, outk, mean); break;
