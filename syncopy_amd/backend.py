@@ -150,6 +150,10 @@ def _staged_fill(view, src):
         f.result()
 
 
+import threading as _threading
+_upload_lock = _threading.Lock()        # the pinned staging pair of the ingress serves one upload at a time
+
+
 class Upload:
     """A recording on its way into the in-HBM trial queue (the reference streams trial by
     trial, computational_routine.py:1001-1032).  A background thread fills two alternating pinned staging buffers
@@ -173,37 +177,41 @@ class Upload:
 
     def _run(self):
         try:
-            dev, host = self.dev, self.host
-            torch.cuda.set_device(dev.device)
-            ntime, nchan = dev.shape
-            stage = _staging("h2d", _H2D_CHUNK)
-            rows_per = self.chunk_rows()
-            stream = torch.cuda.Stream(device=dev.device)
-            busy = [None, None]
-            for k, r0 in enumerate(range(0, ntime, rows_per)):
-                r1 = min(ntime, r0 + rows_per)
-                buf = stage[k & 1]
-                if busy[k & 1] is not None:
-                    busy[k & 1].synchronize()              # the copy that last used this buffer has left it
-                pinned = buf[:(r1 - r0) * nchan * 4].view(torch.float32).view(r1 - r0, nchan)
-                _staged_fill(pinned.numpy(), host[r0:r1] if self.time_axis == 0 else host[:, r0:r1].T)
-                with torch.cuda.stream(stream):
-                    dev[r0:r1].copy_(pinned, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(stream)
-                busy[k & 1] = ev
-                with self.cond:
-                    self.marks.append((r1, ev))
-                    self.cond.notify_all()
-            for ev in busy:
-                if ev is not None:
-                    ev.synchronize()
+            with _upload_lock:
+                self._copy()
         except BaseException as exc:                       # noqa: BLE001 - handed to the waiting thread
             self.error = exc
         finally:
             with self.cond:
                 self.complete = True
                 self.cond.notify_all()
+
+    def _copy(self):
+        dev, host = self.dev, self.host
+        torch.cuda.set_device(dev.device)
+        ntime, nchan = dev.shape
+        stage = _staging("h2d", _H2D_CHUNK)
+        rows_per = self.chunk_rows()
+        stream = torch.cuda.Stream(device=dev.device)
+        busy = [None, None]
+        for k, r0 in enumerate(range(0, ntime, rows_per)):
+            r1 = min(ntime, r0 + rows_per)
+            buf = stage[k & 1]
+            if busy[k & 1] is not None:
+                busy[k & 1].synchronize()              # the copy that last used this buffer has left it
+            pinned = buf[:(r1 - r0) * nchan * 4].view(torch.float32).view(r1 - r0, nchan)
+            _staged_fill(pinned.numpy(), host[r0:r1] if self.time_axis == 0 else host[:, r0:r1].T)
+            with torch.cuda.stream(stream):
+                dev[r0:r1].copy_(pinned, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            busy[k & 1] = ev
+            with self.cond:
+                self.marks.append((r1, ev))
+                self.cond.notify_all()
+        for ev in busy:
+            if ev is not None:
+                ev.synchronize()
 
     def chunk_rows(self):
         return max(1, _H2D_CHUNK // (4 * max(self.dev.shape[1], 1)))
