@@ -2,7 +2,6 @@
 // overlap-save CWT kernel (spyhip_cwt_plan_create / spyhip_cwt_exec).
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 #include <string>
 
 #include "spy_common.h"
@@ -380,28 +379,17 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         }
         SPY_HIP_CHECK(hipGetLastError());
     }
-    // Trial sums (accumulate = 2) on the packed kernels: the workgroups walk the segments themselves and sum into
-    // NPARTS staging copies (CwtArgs::seg_per_part) - the staging is written and re-read NPARTS times per call instead
-    // of once per segment, and every group is ONE launch over all segments.  (Kernels cut into pieces and the
-    // 16384-point engine keep the per-segment staging.)
-    bool sum_in_staging = accumulate == 2 && !p->precision64 && p->long_scales.empty() && nseg > 1 &&
-                          !std::getenv("SPYHIP_CWT_NO_STAGE_SUM");
-    for (const CwtGroup* gr : p->groups) sum_in_staging = sum_in_staging && gr->log2n <= 13;
-    const int nparts_env = std::getenv("SPYHIP_CWT_PARTS") ? std::atoi(std::getenv("SPYHIP_CWT_PARTS")) : 16;
-    const int nparts = sum_in_staging ? std::min(nseg, std::max(1, nparts_env)) : 0;
-    const int seg_per_part = sum_in_staging ? (nseg + nparts - 1) / nparts : 0;
     // staging buffer: as many segments per chunk as fit ~4 GiB (at least one): enough workgroups per launch that
     // the last partial round of the grid over 256 CUs stays a small fraction
     const size_t esz = (p->output == SPYHIP_OUT_FOURIER) ? 8 : 4;
     const size_t per_seg = (size_t)p->nscales * p->nchan * p->nsig * esz;
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nseg, ((size_t)4 << 30) / std::max<size_t>(per_seg, 1)));
-    if (sum_in_staging) chunk = nparts;           // (the staging holds the parts; all segments go in one round)
     if (chunk > p->chunk) {
         if (p->stage.p) { (void)hipFree(p->stage.p); p->stage.p = nullptr; }
         if (p->stage.alloc(per_seg * chunk)) return -2;
         p->chunk = chunk;
     }
-    chunk = sum_in_staging ? nseg : p->chunk;
+    chunk = p->chunk;
     a.stage = p->stage.p;
     const int nlong = (int)p->long_scales.size();
     const bool long_side = nlong > 0 && esz == 4;      // real outputs: the pieces are summed as complex numbers first
@@ -419,7 +407,6 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         c.trial_hi = a.trial_hi + s0;
         if (a.trend) c.trend = a.trend + (size_t)s0 * p->nchan * 2;
         c.nseg = ns;
-        c.seg_per_part = seg_per_part;
         if (p->nscales > 65535 || ns > 65535) { spy::set_error("cwt_exec: grid too large"); return -1; }
         if (p->precision64) {
             // float64 convolutions, one workgroup per (segment, channel), three length-L work arrays each: launches of
@@ -458,7 +445,7 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
             }
             const long long nunit = gr->log2n <= 13 ? (p->nchan + 1) / 2 : p->nchan;   // channel pairs / channels
             const long long ngrp = (nunit + gr->G - 1) / gr->G;
-            const long long grid = (long long)(sum_in_staging ? (ns + seg_per_part - 1) / seg_per_part : ns) * ngrp * gr->nblocks;
+            const long long grid = (long long)ns * ngrp * gr->nblocks;
             if (grid > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
             const unsigned g = (unsigned)grid;
             int rc;
@@ -479,7 +466,6 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
                                p->ctx->stream, p->stage_long.p, p->lidx.p, nlong, ns, p->nscales, p->nchan, p->nsig,
                                p->output, reinterpret_cast<float*>(p->stage.p));
         }
-        if (sum_in_staging) c.nseg = (ns + seg_per_part - 1) / seg_per_part;      // the scatter adds the parts
         const dim3 sg((p->nsig + 63) / 64, p->nscales, accumulate == 2 ? 1 : ns);
         if (esz == 8) hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float2>, sg, dim3(256), 0, p->ctx->stream, c);
         else hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float>, sg, dim3(256), 0, p->ctx->stream, c);

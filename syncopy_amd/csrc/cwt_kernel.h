@@ -45,10 +45,6 @@ struct CwtArgs {
     const int* sidx;              // scale s of this launch -> scale index of the plan (nullptr = identity): scales
     int nscales_total;            // are grouped by the block length their kernel support needs (0 = nscales)
     int stage_add;                // 1: add to the staging values (later pieces of a kernel longer than one block)
-    int seg_per_part;             // > 0 (trial sums, accumulate = 2, packed kernels): a workgroup walks seg_per_part
-                                  // segments and SUMS their converted values into staging row `part` - the staging then
-                                  // holds nparts partial sums instead of one copy per segment (nparts x instead of nseg x
-                                  // 210 MB written and re-read at c4's shape), cwt_scatter_kernel adds the parts
 };
 
 // per (segment, channel): mean and least-squares slope over the trial rows [lo, hi), in two
@@ -252,92 +248,69 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArg
     const int blk = (int)(id % a.nblocks);
     id /= a.nblocks;
     const int cg = (int)(id % ngrp);
-    const int part = (int)(id / ngrp);          // segment of the chunk - or, with seg_per_part, the part of the trial sum
+    const int b = (int)(id / ngrp);
     const int c0 = 2 * (cg * G + h);
     const bool has[2] = {c0 < a.nchan, c0 + 1 < a.nchan};
     long long col[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) col[i] = has[i] ? (a.chan_idx ? a.chan_idx[c0 + i] : c0 + i) : 0;
+    const long long start = a.seg_start[b], tlo = a.trial_lo[b];
     const int o0 = blk * a.V;
-    const int nend = min(o0 + a.V, a.nsig);
-    const int b_lo = a.seg_per_part > 0 ? part * a.seg_per_part : part;
-    const int b_hi = a.seg_per_part > 0 ? min(a.nseg, b_lo + a.seg_per_part) : part + 1;
 
-    for (int b = b_lo; b < b_hi; ++b) {
-        const bool add = b > b_lo;              // (workgroup-uniform) later segments of a part add to its staging row
-        const long long start = a.seg_start[b], tlo = a.trial_lo[b];
-        double mean[2] = {0.0, 0.0}, slope[2] = {0.0, 0.0}, mid = 0.0;
-        if (a.detrend >= 0) {
-            mid = 0.5 * (double)(a.trial_hi[b] - tlo - 1);
+    double mean[2] = {0.0, 0.0}, slope[2] = {0.0, 0.0}, mid = 0.0;
+    if (a.detrend >= 0) {
+        mid = 0.5 * (double)(a.trial_hi[b] - tlo - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (has[i]) {
+                const double* t = a.trend + ((size_t)b * a.nchan + c0 + i) * 2;
+                mean[i] = t[0];
+                slope[i] = t[1];
+            }
+    }
+
+    // ---- block samples u = o0 - halo + i, zero outside the signal (fftconvolve's zero padding)
+    C2 v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int u = o0 - a.halo + j + T * e;
+        float x[2] = {0.f, 0.f};
+        if (u >= 0 && u < a.nsig) {
+            const long long row = start + u;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 if (has[i]) {
-                    const double* t = a.trend + ((size_t)b * a.nchan + c0 + i) * 2;
-                    mean[i] = t[0];
-                    slope[i] = t[1];
+                    x[i] = a.data[row * a.ld + col[i]];
+                    if (a.detrend >= 0) x[i] -= (float)(mean[i] + slope[i] * ((double)(row - tlo) - mid));
                 }
         }
+        v[e].r = v2f{x[0], x[1]};
+        v[e].i = splat(0.f);
+    }
+    fft2_forward<LOG2N, G>(v, lds, j, h, a.tw);
+    C2 Z[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Z[e] = v[e];
 
-        // ---- block samples u = o0 - halo + i, zero outside the signal (fftconvolve's zero padding)
-        C2 v[16];
+    const int nend = min(o0 + a.V, a.nsig);
+    for (int s = 0; s < a.nscales; ++s) {
+        const float2* H = a.hspec + (size_t)s * N;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = cmul_s(Z[e], ldg<float2>(H, (unsigned)(j + T * e) * 8u));
+        fft2_inverse<LOG2N, G>(v, lds, j, h, a.tw);
+        const int sh = a.cshift[s];
+        const size_t rowo = (((size_t)b * (a.nscales_total ? a.nscales_total : a.nscales) + (a.sidx ? a.sidx[s] : s)) * a.nchan + c0) *
+                            (size_t)a.nsig;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int u = o0 - a.halo + j + T * e;
-            float x[2] = {0.f, 0.f};
-            if (u >= 0 && u < a.nsig) {
-                const long long row = start + u;
+            const int n = j + T * e - sh + o0;
+            if (n < o0 || n >= nend) continue;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    if (has[i]) {
-                        x[i] = a.data[row * a.ld + col[i]];
-                        if (a.detrend >= 0) x[i] -= (float)(mean[i] + slope[i] * ((double)(row - tlo) - mid));
-                    }
-            }
-            v[e].r = v2f{x[0], x[1]};
-            v[e].i = splat(0.f);
-        }
-        fft2_forward<LOG2N, G>(v, lds, j, h, a.tw);
-        C2 Z[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Z[e] = v[e];
-
-        for (int s = 0; s < a.nscales; ++s) {
-            const float2* H = a.hspec + (size_t)s * N;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = cmul_s(Z[e], ldg<float2>(H, (unsigned)(j + T * e) * 8u));
-            const int sh = a.cshift[s];
-            const size_t rowo = (((size_t)part * (a.nscales_total ? a.nscales_total : a.nscales) + (a.sidx ? a.sidx[s] : s)) * a.nchan + c0) *
-                                (size_t)a.nsig;
-            // the partial sums this segment adds to: requested BEFORE the inverse transform, consumed after it
-            float oldv[CPLX ? 1 : 16][2];
-            if (!CPLX && add) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int n = j + T * e - sh + o0;
-                    const bool in = n >= o0 && n < nend;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        oldv[CPLX ? 0 : e][i] = (in && has[i]) ? reinterpret_cast<const float*>(a.stage)[rowo + (size_t)i * a.nsig + n] : 0.f;
-                }
-            }
-            fft2_inverse<LOG2N, G>(v, lds, j, h, a.tw);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = j + T * e - sh + o0;
-                if (n < o0 || n >= nend) continue;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (!has[i]) continue;
-                    const float2 y = make_float2(v[e].r[i], v[e].i[i]);
-                    if (CPLX) {
-                        float2* const d = reinterpret_cast<float2*>(a.stage) + rowo + (size_t)i * a.nsig + n;
-                        *d = add ? cadd(*d, y) : y;
-                    } else {
-                        float* const d = reinterpret_cast<float*>(a.stage) + rowo + (size_t)i * a.nsig + n;
-                        const float val = convert_real<OUTK>(y, a.out_kind);
-                        *d = add ? oldv[CPLX ? 0 : e][i] + val : val;
-                    }
-                }
+            for (int i = 0; i < 2; ++i) {
+                if (!has[i]) continue;
+                const float2 y = make_float2(v[e].r[i], v[e].i[i]);
+                if (CPLX) reinterpret_cast<float2*>(a.stage)[rowo + (size_t)i * a.nsig + n] = y;
+                else reinterpret_cast<float*>(a.stage)[rowo + (size_t)i * a.nsig + n] = convert_real<OUTK>(y, a.out_kind);
             }
         }
     }

@@ -37,6 +37,9 @@ int dec64_launch_d(hipStream_t stream, const F64Args& a, int nfft, int npairs, i
 int dec64_launch_e(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_f(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_g(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_h(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_i(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_j(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean);
 int f64_any_launch(hipStream_t stream, F64Args a, long long grid, long long chunk, int outk, bool mean);
 int dec_launch_a(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
@@ -529,7 +532,8 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
     }
     SPY_HIP_CHECK(hipSetDevice(p->ctx->device));
     // compile-time radix schedules (mtmfft_dec64_launch.h): the powers of two 256 ... 16384 and the decimal lengths
-    static const int dec64_lengths[] = {256, 512, 1024, 2048, 4096, 8192, 16384, 200, 500, 1000, 2000, 2500, 4000, 5000, 10000};
+    static const int dec64_lengths[] = {256, 512, 1024, 2048, 4096, 8192, 16384, 200, 500, 1000, 2000, 2500, 4000, 5000, 10000,
+                                        600, 1500, 3000, 6000, 7500, 768, 1536, 3072, 6144};
     p->f64_dec = false;
     for (int n : dec64_lengths) p->f64_dec = p->f64_dec || (n == p->nfft);
     if (std::getenv("SPYHIP_F64_OLD")) p->f64_dec = false;           // A/B runs against the generic kernels
@@ -670,6 +674,9 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             if ((rc = spyfft::dec64_launch_e(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
             if ((rc = spyfft::dec64_launch_f(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
             if ((rc = spyfft::dec64_launch_g(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_h(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_i(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_j(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
             spy::set_error("fft_exec: no reference-precision schedule for nfft = %d", p->nfft);
             return -1;
         }

@@ -23,5 +23,16 @@ using D64_2500  = CfgD64<10, 10, 5,  5,  1>;
 using D64_5000  = CfgD64<10, 10, 10, 5,  1>;
 using D64_4000  = CfgD64<20, 20, 10, 1,  1>;
 using D64_10000 = CfgD64<20, 20, 5,  5,  1, true>;
+// 3 x (a schedule above): three sub-transforms side by side + one radix-3 combine (CfgD64::P)
+//                       V   R1  R2  R3  G   SPLIT  XRES  HOIST P
+using D64_600   = CfgD64<10, 10, 2,  1,  4, false, true, true, 3>;
+using D64_1500  = CfgD64<10, 10, 5,  1,  2, false, true, true, 3>;
+using D64_3000  = CfgD64<10, 10, 10, 1,  1, false, true, true, 3>;
+using D64_6000  = CfgD64<10, 10, 10, 2,  1, false, true, true, 3>;
+using D64_7500  = CfgD64<10, 10, 5,  5,  1, false, true, true, 3>;
+using D64_768   = CfgD64<16, 16, 1,  1,  4, false, true, true, 3>;
+using D64_1536  = CfgD64<16, 16, 2,  1,  2, false, true, true, 3>;
+using D64_3072  = CfgD64<16, 16, 4,  1,  1, false, true, true, 3>;
+using D64_6144  = CfgD64<16, 16, 8,  1,  1, false, true, true, 3>;
 
 }  // namespace spyfft

@@ -27,19 +27,26 @@
 
 namespace spyfft {
 
-template <int V_, int R1_, int R2_, int R3_, int G_, bool SPLIT_ = false, bool XRES_ = true, bool HOIST_ = true>
+template <int V_, int R1_, int R2_, int R3_, int G_, bool SPLIT_ = false, bool XRES_ = true, bool HOIST_ = true, int P_ = 1>
 struct CfgD64 {
     static constexpr int V = V_, R1 = R1_, R2 = R2_, R3 = R3_, G = G_;
+    // P > 1: decimation in time in front of the schedule - N = P M: P groups of T threads transform the sub-sequences
+    // x[P n + r] (length M = V R1 R2 R3, one LDS region each) side by side, then ONE radix-P combine through LDS:
+    // X[k + M q] = sum_r w_P^(r q) W_N^(r k) F_r[k].  Trial lengths 3 x (a length with a schedule): 3000, 6000, 1500, 3072 ...
+    static constexpr int P = P_;
     static constexpr bool SPLIT = SPLIT_, XRES = XRES_;
     // HOIST: the base twiddles of the later passes stay in registers across the tapers and their powers are formed by
     // multiplication (d64_pass); false: every power comes from the table inside the taper loop (N = 8192: the four
     // passes' base twiddles do not fit next to 16 resident values per thread - measured 61.9 vs 53.8 us/trial)
     static constexpr bool HOIST = HOIST_;
-    static constexpr int N = V * R1 * R2 * R3;
-    static constexpr int T = N / V;                          // threads per channel pair
+    static constexpr int M = V * R1 * R2 * R3;               // length of one sub-transform (= N without decimation)
+    static constexpr int N = P * M;
+    static constexpr int T = M / V;                          // threads per sub-transform
+    static constexpr int TT = P * T;                         // threads per channel pair
     static constexpr int NPASS = 2 + (R2 > 1 ? 1 : 0) + (R3 > 1 ? 1 : 0);
-    static constexpr int NTHREADS = ((T * G + 63) / 64) * 64;
-    static constexpr int PLANE = N + N / V + 1;              // elements per pair: one pad per V values
+    static constexpr int NTHREADS = ((TT * G + 63) / 64) * 64;
+    static constexpr int PL1 = M + M / V + 1;                // LDS elements of one sub-transform: one pad per V values
+    static constexpr int PLANE = P * PL1;                    // elements per pair
     static constexpr int ESTRIDE = (T + T / V) * G;          // LDS distance of e -> e + 1
     static constexpr size_t LDS_BYTES = (size_t)PLANE * G * (SPLIT ? 8 : 16);
     // waves per SIMD the register allocation is held to: what LDS lets co-reside, capped by what the schedule needs
@@ -52,6 +59,7 @@ struct CfgD64 {
     static_assert(R1 > 1 && V % R1 == 0 && V % R2 == 0 && V % R3 == 0, "every radix divides the values per thread");
     static_assert(T % V == 0, "T multiple of V: idx(j + T e) stays affine in e");
     static_assert(NTHREADS <= 1024 && (64 % G) == 0 && (V % 2) == 0, "workgroup shape");
+    static_assert(P == 1 || (P == 3 && !SPLIT && XRES), "decimation: radix 3, plain exchanges, resident samples");
     __device__ static __forceinline__ int idx(int i, int h) { return (i + i / V) * G + h; }
 };
 
@@ -106,7 +114,7 @@ __device__ __forceinline__ void d64_exchange(spywil::cd (&v)[C::V], void* ldsv, 
 // taper - with two waves per SIMD the kernel waits on L2 latency, not on the vector pipe).
 template <class C, int R, int Ns, bool FIRST, bool LAST>
 __device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j, int h, bool active,
-                                         const spywil::cd* w1) {
+                                         const spywil::cd* w1, int region = 0) {
     using spywil::cd;
     using spywil::cmul;
     constexpr int V = C::V, T = C::T, G = C::G, MB = V / R;
@@ -137,7 +145,7 @@ __device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j
                 for (int a = 2; a < NA; ++a) wa[a] = (a % 2 == 0) ? cmul(wa[a / 2], wa[a / 2]) : cmul(wa[a - 1], wa[1]);
             } else {
                 // w1 = the table itself (d64_twiddles_none): powers by table reads, as the first generation did
-                const int st = k * (C::N / (Ns * R));
+                const int st = k * (C::M / (Ns * R)) * C::P;
 #pragma unroll
                 for (int l = 1; l < 4; ++l) wb[l] = (l < R) ? w1[l * st] : make_double2(1.0, 0.0);
 #pragma unroll
@@ -154,11 +162,11 @@ __device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j
 #pragma unroll
         for (int r = 0; r < R; ++r) v[m + MB * r] = u[r];
         // LDS slot of output r: idx(q Ns R + k + r Ns); Ns is 1 (first pass, R = V) or a multiple of V
-        wbase[m] = FIRST ? (b * (V + 1)) * G + h : (q * (Ns * R + Ns * R / V) + k + k / V) * G + h;
+        wbase[m] = region + (FIRST ? (b * (V + 1)) * G + h : (q * (Ns * R + Ns * R / V) + k + k / V) * G + h);
     }
     if (LAST) return;
     constexpr int WS = FIRST ? G : (Ns + Ns / V) * G;
-    d64_exchange<C, R, MB, WS>(v, lds, wbase, C::idx(j, h), active);
+    d64_exchange<C, R, MB, WS>(v, lds, wbase, region + C::idx(j, h), active);
 }
 
 // the base twiddles of one pass for thread j: w1[m] = tw[k_m N / (Ns R)], k_m = (j + T m) mod Ns
@@ -168,7 +176,7 @@ __device__ __forceinline__ void d64_twiddles(spywil::cd (&w1)[C::V / R], int j, 
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         const int b = j + C::T * m;
-        w1[m] = tw[(b % Ns) * (C::N / (Ns * R))];
+        w1[m] = tw[(b % Ns) * (C::M / (Ns * R)) * C::P];
     }
 }
 
@@ -189,7 +197,7 @@ struct D64Src {
     // the V samples n = j + T e of a thread, branches outside the unrolled loops (straight-line loads: the register
     // allocator copes badly with sixteen diamonds)
     template <int V, int T>
-    __device__ __forceinline__ void get_all(int j, float (&u0)[V], float (&u1)[V]) const {
+    __device__ __forceinline__ void get_all(int j, float (&u0)[V], float (&u1)[V]) const {      // samples j + T e
         if (some) {
             if (vec2) {
 #pragma unroll
@@ -222,15 +230,18 @@ template <class C, int OUTK, bool MEAN>
 __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F64Args fa) {
     using spywil::cd;
     constexpr bool CPLX = (OUTK == 2);
-    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, HV = V / 2;
+    constexpr int V = C::V, N = C::N, T = C::T, TT = C::TT, P = C::P, G = C::G, HV = V / 2;
     const MtmArgs& a = fa.m;
     SPY_DYN_SMEM(char, ldsraw);
     void* const lds = ldsraw;
 
     const int tid = threadIdx.x;
     const int h = tid % G, jt = tid / G;
-    const bool active = jt < T;                   // the workgroup is padded to whole waves
-    const int j0 = active ? jt : 0;
+    const bool active = jt < TT;                  // the workgroup is padded to whole waves
+    const int j0 = active ? jt : 0;               // thread of the pair: bins j0 + TT e in the epilogue
+    // decimation (P > 1): group r0 = j0 / T transforms the samples P n + r0; js0 = its thread index inside the group.
+    // Thread j0 then holds the SAMPLES jn0 + TT e with jn0 = P js0 + r0 (P = 1: jn0 = js0 = j0, TT = T)
+    const int r0 = j0 / T, js0 = j0 - r0 * T, jn0 = P * js0 + r0;
 
     // XCD-aware block -> (segment, pair group), as mtmfft_dec_kernel
     const long long id = blockIdx.x;
@@ -261,7 +272,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
 
     float x0[V], x1[V];           // XRES: resident across the tapers; otherwise refilled per taper
     const bool fit = !(a.detrend == 0 && a.means) && a.detrend >= 0;
-    if (C::XRES || fit) src.template get_all<V, T>(j0, x0, x1);
+    if (C::XRES || fit) src.template get_all<V, TT>(jn0, x0, x1);
 
     // ---- polynomial removal in float32 (scipy.signal.detrend on the float32 trial, compRoutines.py:169-172): the
     // reference-order means (detrend 0) or a float64 fit whose trend is rounded to float32 before it is subtracted;
@@ -277,7 +288,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         const float lin = a.detrend == 1 ? 1.f : 0.f;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const int n = j0 + T * e;
+            const int n = jn0 + TT * e;
             const float m = (active && n < a.nsig) ? 1.f : 0.f;           // branch-free masks (exact: 0 or 1)
             const float u0 = m * x0[e], u1 = m * x1[e];
             const double dn = (double)(lin * ((float)n - mid));           // exact: half-integers < 2^23
@@ -297,16 +308,16 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         if (fit && !f64t) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = j0 + T * e;
+                const int n = jn0 + TT * e;
                 const double dn = (double)((float)n - mid);
-                const float r0 = (float)(t0c + t0s * dn), r1 = (float)(t1c + t1s * dn);
-                x0[e] -= n < a.nsig ? r0 : 0.f;
-                x1[e] -= n < a.nsig ? r1 : 0.f;
+                const float q0 = (float)(t0c + t0s * dn), q1 = (float)(t1c + t1s * dn);
+                x0[e] -= n < a.nsig ? q0 : 0.f;
+                x1[e] -= n < a.nsig ? q1 : 0.f;
             }
         } else if (!fit) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const bool in = j0 + T * e < a.nsig;
+                const bool in = jn0 + TT * e < a.nsig;
                 x0[e] -= in ? m0 : 0.f;
                 x1[e] -= in ? m1 : 0.f;
             }
@@ -328,17 +339,20 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
     constexpr unsigned OSZ = CPLX ? 8u : 4u;
     const bool fast = has1 && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) && ((a.nchan & 1) == 0);
     const cd* const tw = reinterpret_cast<const cd*>(fa.tw64);
+    const cd wdit = P > 1 ? tw[r0 * js0] : make_double2(1.0, 0.0), wdit_step = P > 1 ? tw[r0 * T] : make_double2(1.0, 0.0);
     // base twiddles of the later passes: taper-invariant, fetched once (4 registers per butterfly and pass)
     cd w1a[V / C::R1], w1b[C::R2 > 1 ? V / C::R2 : 1], w1c[C::R3 > 1 ? V / C::R3 : 1];
     if constexpr (C::HOIST) {
-        d64_twiddles<C, C::R1, V>(w1a, j0, tw);
-        if constexpr (C::NPASS >= 3) d64_twiddles<C, C::R2, V * C::R1>(w1b, j0, tw);
-        if constexpr (C::NPASS >= 4) d64_twiddles<C, C::R3, V * C::R1 * C::R2>(w1c, j0, tw);
+        d64_twiddles<C, C::R1, V>(w1a, js0, tw);
+        if constexpr (C::NPASS >= 3) d64_twiddles<C, C::R2, V * C::R1>(w1b, js0, tw);
+        if constexpr (C::NPASS >= 4) d64_twiddles<C, C::R3, V * C::R1 * C::R2>(w1c, js0, tw);
     }
 
     const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
     for (int k = 0; k < a.ntaper; ++k) {
-        const int j = opaque(j0);     // (keeps the twiddle loads and the index arithmetic of the passes inside the loop)
+        const int je = opaque(j0);    // (keeps the index arithmetic of the passes inside the loop)
+        const int r = je / T, j = je - r * T, jn = P * j + r;        // group, thread inside it, first sample (P = 1: r = 0, jn = j = je)
+        const int region = r * C::PL1 * G;
         const double* w = fa.tapers64 + (size_t)k * a.nsig;
         cd v[V];
         bool filled = false;
@@ -349,7 +363,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
                 filled = true;
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    const int n = j + T * e;
+                    const int n = jn + TT * e;
                     const int nc = min(max(n, src.rlo), src.rhi - 1);
                     const float2 t = *reinterpret_cast<const float2*>(src.seg + (size_t)nc * src.ld + src.col0);
                     const double dn = (double)((float)n - mid);
@@ -360,11 +374,11 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
                     v[e] = make_double2(wn * (double)u0, wn * (double)u1);
                 }
             } else {
-                src.template get_all<V, T>(j, x0, x1);
+                src.template get_all<V, TT>(jn, x0, x1);
                 if (!f64t) {
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
-                        const int n = j + T * e;
+                        const int n = jn + TT * e;
                         const double dn = (double)((float)n - mid);
                         const float r0 = fit ? (float)(t0c + t0s * dn) : m0, r1 = fit ? (float)(t1c + t1s * dn) : m1;
                         x0[e] -= n < a.nsig ? r0 : 0.f;
@@ -378,7 +392,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
             // float64 segments in the reference: the trend is subtracted in float64
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = j + T * e;
+                const int n = jn + TT * e;
                 const double wn = tapw(w, (unsigned)n, nsig_m1);
                 const double dn = (double)((float)n - mid);
                 v[e] = make_double2(wn * ((double)x0[e] - (t0c + t0s * dn)), wn * ((double)x1[e] - (t1c + t1s * dn)));
@@ -386,7 +400,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         } else {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = j + T * e;
+                const int n = jn + TT * e;
                 const double wn = tapw(w, (unsigned)n, nsig_m1);
                 v[e] = make_double2(wn * (double)x0[e], wn * (double)x1[e]);     // win *= data_arr (float64)
             }
@@ -404,7 +418,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
             const double dm0 = ds[0] / a.nsig, dm1 = ds[1] / a.nsig;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                if (j + T * e < a.nsig) {
+                if (jn + TT * e < a.nsig) {
                     v[e].x -= dm0;
                     v[e].y -= dm1;
                 }
@@ -412,16 +426,63 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         }
 
         // ---- the passes: radix V from the registers, then R1 (R2, R3); the last one leaves v[e] = Z[j + T e]
-        d64_pass<C, V, 1, true, false>(v, lds, j, h, active, nullptr);
-        d64_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, C::HOIST ? w1a : tw);
-        if constexpr (C::NPASS >= 3) d64_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, C::HOIST ? w1b : tw);
-        if constexpr (C::NPASS >= 4) d64_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, C::HOIST ? w1c : tw);
+        d64_pass<C, V, 1, true, false>(v, lds, j, h, active, nullptr, region);
+        d64_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, C::HOIST ? w1a : tw, region);
+        if constexpr (C::NPASS >= 3) d64_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, C::HOIST ? w1b : tw, region);
+        if constexpr (C::NPASS >= 4) d64_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, C::HOIST ? w1c : tw, region);
+
+        if constexpr (P == 3) {
+            // ---- radix-3 combine of the three sub-transforms: v[e] = F_r[k], k = j + T e  ->  X[k + M r]
+            cd* const L = reinterpret_cast<cd*>(lds);
+            if (r > 0) {
+                // W_N^(r k) = W_N^(r j) (W_N^(r T))^e: two table values per thread, fetched ONCE per workgroup (an L2
+                // round trip between two barriers of every taper otherwise), the rest by multiplication
+                cd w = wdit, step = wdit_step;
+#ifndef SPY_HOST_EMU
+                asm volatile("" : "+v"(w.x), "+v"(w.y));        // (keeps the powers inside the taper loop, see d64_pass)
+#endif
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    v[e] = spywil::cmul(v[e], w);
+                    if (e + 1 < V) w = spywil::cmul(w, step);
+                }
+            }
+            __syncthreads();              // (the last exchange's reads are done everywhere)
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) L[region + C::idx(j + T * e, h)] = v[e];
+            }
+            __syncthreads();
+            // X[k + M q] = g0 + w3^q g1 + w3^(2q) g2 = g0 + a (g1 + g2) + c (-i)(g1 - g2) for this thread's q = r:
+            // a = 1, c = 0 (q = 0); a = -1/2, c = +-sqrt(3)/2 (q = 1, 2)
+            const double ca = r == 0 ? 1.0 : -0.5;
+            const double cc = r == 0 ? 0.0 : (r == 1 ? 0.86602540378443864676 : -0.86602540378443864676);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int ki = C::idx(j + T * e, h);
+                const cd g0 = r == 0 ? v[e] : L[ki];
+                const cd g1 = r == 1 ? v[e] : L[C::PL1 * G + ki];
+                const cd g2 = r == 2 ? v[e] : L[2 * C::PL1 * G + ki];
+                const double sx = g1.x + g2.x, sy = g1.y + g2.y, dx = g1.x - g2.x, dy = g1.y - g2.y;
+                v[e] = make_double2(fma(cc, dy, fma(ca, sx, g0.x)), fma(-cc, dx, fma(ca, sy, g0.y)));
+            }
+            __syncthreads();
+            if (active) {                 // natural order over all N bins: idx(k + M r)
+#pragma unroll
+                for (int e = 0; e < V; ++e) L[C::idx(j + T * e + C::M * r, h)] = v[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e <= HV; ++e) v[e] = L[C::idx(je + TT * e, h)];     // the epilogue's mapping: bins je + TT e
+        }
 
         // ---- separation: partner bin N - f lives in the upper slots
         double zpx[C::SPLIT ? HV : 1];
         {
             const int wb = C::idx(j, h);
-            if constexpr (!C::SPLIT) {
+            if constexpr (P > 1) {
+                // (all N bins sit in LDS in natural order already)
+            } else if constexpr (!C::SPLIT) {
                 cd* L = reinterpret_cast<cd*>(lds);
                 __syncthreads();              // the FFT's last reads of the buffer are done everywhere
                 if (active) {
@@ -458,7 +519,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
             cd X0, X1;
             if (e < HV) {
                 if (!active) break;
-                f = j + T * e;
+                f = je + TT * e;
                 const cd z = v[e];
                 cd p;
                 if constexpr (!C::SPLIT) {
@@ -469,7 +530,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
                 X0 = make_double2(0.5 * (z.x + p.x), 0.5 * (z.y - p.y));
                 X1 = make_double2(0.5 * (z.y + p.y), 0.5 * (p.x - z.x));
             } else {
-                if (j != 0 || !active) break;
+                if (je != 0 || !active) break;
                 f = N / 2;
                 X0 = make_double2(v[HV].x, 0.0);
                 X1 = make_double2(v[HV].y, 0.0);
@@ -543,7 +604,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
 #pragma unroll
         for (int e = 0; e <= HV; ++e) {
             if (!active || (e == HV && j0 != 0)) break;
-            const int f = e < HV ? j0 + T * e : N / 2;
+            const int f = e < HV ? j0 + TT * e : N / 2;
             const int fi = a.fpos ? a.fpos[f] : f;
             if (fi < 0) continue;
             const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;

@@ -904,6 +904,13 @@ extern "C" int emu_mtmfft_f64(int nfft, int blue_m, const float* data, long long
             case 4000: run_dec64_mode<spyfft::D64_4000>(fa, nseg, nchan, outk, mean); break;
             case 5000: run_dec64_mode<spyfft::D64_5000>(fa, nseg, nchan, outk, mean); break;
             case 10000: run_dec64_mode<spyfft::D64_10000>(fa, nseg, nchan, outk, mean); break;
+            case 600: run_dec64_mode<spyfft::D64_600>(fa, nseg, nchan, outk, mean); break;
+            case 768: run_dec64_mode<spyfft::D64_768>(fa, nseg, nchan, outk, mean); break;
+            case 1500: run_dec64_mode<spyfft::D64_1500>(fa, nseg, nchan, outk, mean); break;
+            case 3000: run_dec64_mode<spyfft::D64_3000>(fa, nseg, nchan, outk, mean); break;
+            case 3072: run_dec64_mode<spyfft::D64_3072>(fa, nseg, nchan, outk, mean); break;
+            case 6000: run_dec64_mode<spyfft::D64_6000>(fa, nseg, nchan, outk, mean); break;
+            case 7500: run_dec64_mode<spyfft::D64_7500>(fa, nseg, nchan, outk, mean); break;
             default: return -1;
         }
         return 0;

@@ -673,6 +673,20 @@ def test_dec64_kernel_long_schedules(nfft):
     _f64_case(nfft, nfft, 2, 1, "fourier", True, 0)
 
 
+@pytest.mark.parametrize("nfft,nchan,K", [(600, 9, 2), (768, 5, 2), (1500, 5, 2), (3000, 3, 2), (3072, 2, 1), (6000, 2, 1),
+                                          (7500, 2, 1)])
+def test_dec64_kernel_radix3_decimation(nfft, nchan, K):
+    # N = 3 M: three scheduled sub-transforms side by side and one radix-3 combine through LDS (CfgD64::P)
+    _f64_case(nfft, nfft, nchan, K, "fourier", True, 0)
+
+
+def test_dec64_kernel_radix3_options():
+    _f64_case(2800, 3000, 3, 2, "pow", False, 1)                                  # padding, linear trend, taper mean
+    _f64_case(1400, 1500, 5, 2, "abs", True, 0, freq_idx=np.array([0, 1, 749, 750, 37, 500, 501]), chan_idx=[4, 0, 3])
+    _f64_case(600, 600, 7, 3, "fourier", False, -1, demean_taper=True, nseg=2)    # complex taper mean, demean_taper
+    _f64_case(3000, 3000, 1, 2, "pow", True, 0)                                   # a single channel: half a pair
+
+
 def test_dec64_kernel_options():
     _f64_case(900, 1000, 4, 2, "pow", False, 1)                                   # padding, linear trend, taper mean
     _f64_case(1700, 2000, 6, 2, "abs", True, 0, freq_idx=np.array([0, 1, 999, 1000, 37]), chan_idx=[5, 0, 3])

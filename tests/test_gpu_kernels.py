@@ -497,7 +497,19 @@ def test_reference_precision_resolves_60dB(be):
                                   dict(nsig=3000, nfft=4500, K=3, output="fourier", keeptapers=False, detrend=0, nchan=4,
                                        freq_idx=[0, 9, 2250, 300]),
                                   dict(nsig=10000, nfft=16384, K=2, output="pow", keeptapers=True, detrend=0, nchan=3),
-                                  dict(nsig=100, nfft=100, K=2, output="fourier", keeptapers=True, detrend=0, nchan=1)])
+                                  dict(nsig=100, nfft=100, K=2, output="fourier", keeptapers=True, detrend=0, nchan=1),
+                                  # 3 x a scheduled length: radix-3 decimation in front of the schedule (CfgD64::P)
+                                  dict(nsig=3000, nfft=3000, K=7, output="pow", keeptapers=False, detrend=0, nchan=5),
+                                  dict(nsig=5500, nfft=6000, K=3, output="abs", keeptapers=True, detrend=1, nchan=3),
+                                  dict(nsig=6144, nfft=6144, K=2, output="fourier", keeptapers=False, detrend=0, nchan=4,
+                                       freq_idx=[0, 9, 3072, 300, 2048, 2049]),
+                                  dict(nsig=1500, nfft=1500, K=2, output="abs", keeptapers=True, detrend=-1, nchan=7,
+                                       demean=True),
+                                  dict(nsig=7500, nfft=7500, K=2, output="fourier", keeptapers=True, detrend=0, nchan=2),
+                                  dict(nsig=700, nfft=768, K=3, output="fourier", keeptapers=True, detrend=0, nchan=9),
+                                  dict(nsig=600, nfft=600, K=2, output="pow", keeptapers=True, detrend=0, nchan=17),
+                                  dict(nsig=1536, nfft=1536, K=2, output="fourier", keeptapers=True, detrend=0, nchan=5),
+                                  dict(nsig=3072, nfft=3072, K=4, output="real", keeptapers=False, detrend=0, nchan=3)])
 def test_reference_precision_options(be, case):
     """Every option of the plan through the float64 kernel: padding, detrending modes, demean_taper, taper mean,
     conversions, frequency selection, odd channel counts - vs the oracle, which now agrees to complex64 rounding."""
