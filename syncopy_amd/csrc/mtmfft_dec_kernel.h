@@ -33,19 +33,32 @@ __device__ __forceinline__ void dec_dft(C2 (&t)[R]) {
     else static_assert(R == 2, "radix of the compile-time schedules: 2, 4, 5, 8, 10, 16, 20");
 }
 
-template <int V_, int R1_, int R2_, int R3_, int G_>
+template <int V_, int R1_, int R2_, int R3_, int G_, int P_ = 1, bool SPLIT_ = false>
 struct CfgD {
     static constexpr int V = V_, R1 = R1_, R2 = R2_, R3 = R3_, G = G_;
-    static constexpr int N = V * R1 * R2 * R3;
-    static constexpr int T = N / V;                          // threads per channel quad
+    // P = 3: radix-3 decimation in time in FRONT of the schedule - N = 3 M: three groups of T threads transform the
+    // sub-sequences x[3 n + r] (length M = V R1 R2 R3, one LDS region each) side by side, then one combine through LDS:
+    // X[k + M q] = sum_r w_3^(r q) W_N^(r k) F_r[k]  (3000 = 3 x 1000, 6000 = 3 x 2000, 1500, 7500, 600: lengths no
+    // radix dividing 10 or 20 ends; mtmfft_dec64_kernel.h carries the same wrapper)
+    static constexpr int P = P_;
+    // SPLIT: an exchange moves the real parts and then the imaginary parts of the packed values through ONE 8-byte plane
+    // (half the LDS, twice the barriers): N = 10000 needs it to fit at all, N = 5000 to hold two workgroups per CU
+    static constexpr bool SPLIT = SPLIT_;
+    static constexpr int M = V * R1 * R2 * R3;               // length of one sub-transform (= N without decimation)
+    static constexpr int N = P * M;
+    static constexpr int T = M / V;                          // threads per sub-transform
+    static constexpr int TT = P * T;                         // threads per channel quad
     static constexpr int NPASS = 2 + (R2 > 1 ? 1 : 0) + (R3 > 1 ? 1 : 0);
-    static constexpr int NTHREADS = ((T * G + 63) / 64) * 64;
-    static constexpr int PLANE = N + N / V + 1;              // float4 units per quad: one pad per V values
+    static constexpr int NTHREADS = ((TT * G + 63) / 64) * 64;
+    static constexpr int PL1 = M + M / V + 1;                // float4 units of one sub-transform: one pad per V values
+    static constexpr int PLANE = P * PL1;                    // ... per quad
     static constexpr int ESTRIDE = (T + T / V) * G;          // LDS distance of e -> e + 1
-    static constexpr size_t LDS_BYTES = (size_t)PLANE * G * 16;
+    static constexpr size_t LDS_BYTES = (size_t)PLANE * G * (SPLIT ? 8 : 16);
     static_assert(R1 > 1 && V % R1 == 0 && V % R2 == 0 && V % R3 == 0, "every radix divides the values per thread");
     static_assert(T % V == 0, "T multiple of V: idx(j + T e) stays affine in e");
     static_assert(NTHREADS <= 1024 && (64 % G) == 0, "workgroup shape");
+    static_assert(P == 1 || (P == 3 && !SPLIT), "decimation: radix 3, plain exchanges");
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's LDS");
     __device__ static __forceinline__ int idx(int i, int h) { return (i + i / V) * G + h; }
 };
 
@@ -53,8 +66,8 @@ struct CfgD {
 // otherwise the outputs go through LDS and v[e] = out[j + T e] comes back.
 template <class C, int R, int Ns, bool FIRST, bool LAST>
 __device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int h, bool active,
-                                         const float2* __restrict__ tw) {
-    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, MB = V / R;
+                                         const float2* __restrict__ tw, int region = 0) {
+    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, MB = V / R;      // (tw has N entries: W_M^k = tw[P k])
     int wbase[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -72,27 +85,59 @@ __device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int 
 #pragma unroll
         for (int r = 0; r < R; ++r) v[m + MB * r] = u[r];
         // LDS slot of output r: idx(q Ns R + k + r Ns); Ns is 1 (first pass, R = V) or a multiple of V
-        wbase[m] = FIRST ? (b * (V + 1)) * G + h : (q * (Ns * R + Ns * R / V) + k + k / V) * G + h;
+        wbase[m] = region + (FIRST ? (b * (V + 1)) * G + h : (q * (Ns * R + Ns * R / V) + k + k / V) * G + h);
     }
     if (LAST) return;
     constexpr int WS = FIRST ? G : (Ns + Ns / V) * G;
-    __syncthreads();              // (write-after-read: earlier reads of the buffer by any thread are done)
-    if (active) {
+    const int rb = region + C::idx(j, h);
+    if constexpr (!C::SPLIT) {
+        __syncthreads();              // (write-after-read: earlier reads of the buffer by any thread are done)
+        if (active) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const C2 t = v[m + MB * r];
-                lds[wbase[m] + r * WS] = make_float4(t.r[0], t.r[1], t.i[0], t.i[1]);
-            }
-    }
-    __syncthreads();
-    const int rb = C::idx(j, h);
+                for (int r = 0; r < R; ++r) {
+                    const C2 t = v[m + MB * r];
+                    lds[wbase[m] + r * WS] = make_float4(t.r[0], t.r[1], t.i[0], t.i[1]);
+                }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-        const float4 t = lds[rb + e * C::ESTRIDE];
-        v[e].r = v2f{t.x, t.y};
-        v[e].i = v2f{t.z, t.w};
+        for (int e = 0; e < V; ++e) {
+            const float4 t = lds[rb + e * C::ESTRIDE];
+            v[e].r = v2f{t.x, t.y};
+            v[e].i = v2f{t.z, t.w};
+        }
+    } else {
+        float2* const L = reinterpret_cast<float2*>(lds);
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < R; ++r) L[wbase[m] + r * WS] = make_float2(v[m + MB * r].r[0], v[m + MB * r].r[1]);
+        }
+        __syncthreads();
+        v2f re[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float2 t = L[rb + e * C::ESTRIDE];
+            re[e] = v2f{t.x, t.y};
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < R; ++r) L[wbase[m] + r * WS] = make_float2(v[m + MB * r].i[0], v[m + MB * r].i[1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float2 t = L[rb + e * C::ESTRIDE];
+            v[e].r = re[e];
+            v[e].i = v2f{t.x, t.y};
+        }
     }
 }
 
@@ -100,13 +145,16 @@ __device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int 
 template <class C, int OUTK, bool MEAN>
 __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(MtmArgs a) {
     constexpr bool CPLX = (OUTK == 2);
-    constexpr int V = C::V, N = C::N, T = C::T, G = C::G, HV = V / 2;
+    constexpr int V = C::V, N = C::N, T = C::T, TT = C::TT, P = C::P, G = C::G, HV = V / 2;
     SPY_DYN_SMEM(float4, lds);
 
     const int tid = threadIdx.x;
     const int h = tid % G, jt = tid / G;
-    const bool active = jt < T;                   // the workgroup is padded to whole waves
-    const int j0 = active ? jt : 0;
+    const bool active = jt < TT;                  // the workgroup is padded to whole waves
+    const int j0 = active ? jt : 0;               // thread of the quad: bins j0 + TT e in the epilogue
+    // decimation (P = 3): group r0 = j0 / T transforms the samples 3 n + r0, js0 = its thread index inside the group;
+    // thread j0 holds the SAMPLES jn0 + TT e with jn0 = P js0 + r0 (P = 1: jn0 = js0 = j0, TT = T)
+    const int r0 = j0 / T, js0 = j0 - r0 * T, jn0 = P * js0 + r0;
 
     // XCD-aware block -> (segment, quad group), as mtmfft_quad_kernel
     const long long id = blockIdx.x;
@@ -136,7 +184,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
     const unsigned rowb = (unsigned)a.ld * 4u;        // bytes per row
     const float* seg = a.data + start * a.ld;         // wave-uniform; only rows in [rlo, rhi) are dereferenced
 
-    // ---- load the segment once: x[e] = sample n = j + T*e; r = (c0, c1), i = (c2, c3)
+    // ---- load the segment once: x[e] = sample n = jn0 + TT*e; r = (c0, c1), i = (c2, c3)
     C2 x[V];
     if (rhi > rlo) {
         const bool vec4 = (a.chan_idx == nullptr) && full && ((a.ld & 3) == 0) &&
@@ -144,7 +192,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
         if (vec4) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = j0 + T * e;
+                const int n = jn0 + TT * e;
                 const int nc = min(max(n, rlo), rhi - 1);
                 const float4 t = ldg<float4>(seg, (unsigned)nc * rowb + col[0] * 4u);
                 const bool ok = (n == nc);
@@ -154,7 +202,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
         } else {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = j0 + T * e;
+                const int n = jn0 + TT * e;
                 const int nc = min(max(n, rlo), rhi - 1);
                 float u[4];
 #pragma unroll
@@ -180,7 +228,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
         const v2f mr = v2f{f[0], f[1]}, mi = v2f{f[2], f[3]};
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const bool in = j0 + T * e < a.nsig;
+            const bool in = jn0 + TT * e < a.nsig;
             x[e].r -= in ? mr : splat(0.f);
             x[e].i -= in ? mi : splat(0.f);
         }
@@ -189,7 +237,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
         double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const int n = j0 + T * e;
+            const int n = jn0 + TT * e;
             const float m = (active && n < a.nsig) ? 1.f : 0.f;
             const float u[4] = {m * x[e].r[0], m * x[e].r[1], m * x[e].i[0], m * x[e].i[1]};
 #pragma unroll
@@ -208,7 +256,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
             const double den = 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0));
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = j0 + T * e;
+                const int n = jn0 + TT * e;
                 const double dn = (double)((float)n - mid);
                 const bool in = n < a.nsig;
                 float t[4];
@@ -222,7 +270,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
             const v2f mi = v2f{(float)(s[2] * inv), (float)(s[3] * inv)};
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const bool in = j0 + T * e < a.nsig;
+                const bool in = jn0 + TT * e < a.nsig;
                 x[e].r -= in ? mr : splat(0.f);
                 x[e].i -= in ? mi : splat(0.f);
             }
@@ -246,12 +294,14 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
                       ((a.nchan & (CPLX ? 1 : 3)) == 0);
 
     for (int k = 0; k < a.ntaper; ++k) {
-        const int j = opaque(j0);
+        const int je = opaque(j0);
+        const int r = je / T, j = je - r * T, jn = P * j + r;        // group, thread inside it, first sample (P = 1: jn = j = je)
+        const int region = r * C::PL1 * G;
         const float* w = a.tapers + (size_t)k * a.nsig;   // wave-uniform
         C2 v[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const unsigned n = (unsigned)(j + T * e);
+            const unsigned n = (unsigned)(jn + TT * e);
             const float wl = ldg<float>(w, min(n, nsig_m1) * 4u);
             const float wn = (n <= nsig_m1) ? wl : 0.f;
             v[e].r = x[e].r * wn;
@@ -273,26 +323,101 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
             const v2f mi = v2f{(float)(s[2] / a.nsig), (float)(s[3] / a.nsig)};
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const bool in = j + T * e < a.nsig;
+                const bool in = jn + TT * e < a.nsig;
                 v[e].r -= in ? mr : splat(0.f);
                 v[e].i -= in ? mi : splat(0.f);
             }
         }
 
+        C2 zpart[C::SPLIT ? HV : 1];      // (SPLIT) the partner bins Z[N - f] of this thread's bins
         // ---- the passes: radix V from the registers, then R1 (R2, R3); the last one leaves v[e] = Z[j + T e]
-        dec_pass<C, V, 1, true, false>(v, lds, j, h, active, a.tw);
-        dec_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, a.tw);
-        if constexpr (C::NPASS >= 3) dec_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, a.tw);
-        if constexpr (C::NPASS >= 4) dec_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, a.tw);
+        dec_pass<C, V, 1, true, false>(v, lds, j, h, active, a.tw, region);
+        dec_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, a.tw, region);
+        if constexpr (C::NPASS >= 3) dec_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, a.tw, region);
+        if constexpr (C::NPASS >= 4) dec_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, a.tw, region);
 
-        // ---- separate the real channels: partner bin N - f lives in the upper half
-        __syncthreads();              // the FFT's last reads of the buffer are done everywhere
-        if (active) {
-            const int wb = C::idx(j, h);
+        if constexpr (P == 3) {
+            // ---- radix-3 combine of the three sub-transforms: v[e] = F_r[k], k = j + T e  ->  X[k + M r]
+            if (r > 0) {
 #pragma unroll
-            for (int e = HV; e < V; ++e) lds[wb + e * C::ESTRIDE] = make_float4(v[e].r[0], v[e].r[1], v[e].i[0], v[e].i[1]);
+                for (int e = 0; e < V; ++e) v[e] = cmul_s(v[e], ldg<float2>(a.tw, (unsigned)(r * (j + T * e)) * 8u));   // W_N^(r k)
+            }
+            __syncthreads();              // (the last exchange's reads are done everywhere)
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    lds[region + C::idx(j + T * e, h)] = make_float4(v[e].r[0], v[e].r[1], v[e].i[0], v[e].i[1]);
+            }
+            __syncthreads();
+            // X[k + M q] = g0 + w3^q g1 + w3^(2q) g2 = g0 + ca (g1 + g2) + cc (-i)(g1 - g2) for this thread's q = r:
+            // ca = 1, cc = 0 (q = 0); ca = -1/2, cc = +-sqrt(3)/2 (q = 1, 2)
+            const float ca = r == 0 ? 1.f : -0.5f;
+            const float cc = r == 0 ? 0.f : (r == 1 ? 0.8660254037844386f : -0.8660254037844386f);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int ki = C::idx(j + T * e, h);
+                C2 g[3];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const float4 t = lds[rr * C::PL1 * G + ki];
+                    g[rr].r = v2f{t.x, t.y};
+                    g[rr].i = v2f{t.z, t.w};
+                }
+                const v2f sr = g[1].r + g[2].r, si = g[1].i + g[2].i, dr = g[1].r - g[2].r, di = g[1].i - g[2].i;
+                v[e].r = g[0].r + sr * ca + di * cc;
+                v[e].i = g[0].i + si * ca - dr * cc;
+            }
+            __syncthreads();
+            if (active) {                 // natural order over all N bins: idx(k + M r)
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    lds[C::idx(j + T * e + C::M * r, h)] = make_float4(v[e].r[0], v[e].r[1], v[e].i[0], v[e].i[1]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e <= HV; ++e) {       // the epilogue's mapping: bins je + TT e
+                const float4 t = lds[C::idx(je + TT * e, h)];
+                v[e].r = v2f{t.x, t.y};
+                v[e].i = v2f{t.z, t.w};
+            }
+        } else if constexpr (!C::SPLIT) {
+            // ---- separate the real channels: partner bin N - f lives in the upper half
+            __syncthreads();              // the FFT's last reads of the buffer are done everywhere
+            if (active) {
+                const int wb = C::idx(j, h);
+#pragma unroll
+                for (int e = HV; e < V; ++e) lds[wb + e * C::ESTRIDE] = make_float4(v[e].r[0], v[e].r[1], v[e].i[0], v[e].i[1]);
+            }
+            __syncthreads();
+        } else {
+            // ... through the 8-byte plane: the partners' real parts, then their imaginary parts
+            float2* const L = reinterpret_cast<float2*>(lds);
+            const int wb = C::idx(j, h);
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int e = HV; e < V; ++e) L[wb + e * C::ESTRIDE] = make_float2(v[e].r[0], v[e].r[1]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < HV; ++e) {
+                const int f = j + T * e;
+                const float2 t = L[C::idx(f == 0 ? N / 2 : N - f, h)];
+                zpart[e].r = v2f{t.x, t.y};
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int e = HV; e < V; ++e) L[wb + e * C::ESTRIDE] = make_float2(v[e].i[0], v[e].i[1]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < HV; ++e) {
+                const int f = j + T * e;
+                const float2 t = L[C::idx(f == 0 ? N / 2 : N - f, h)];
+                zpart[e].i = v2f{t.x, t.y};
+            }
         }
-        __syncthreads();
         char* const slab = reinterpret_cast<char*>(a.out) +
                            ((size_t)b * kout + (MEAN ? 0 : k)) * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
 #pragma unroll
@@ -301,20 +426,24 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
             int f;
             if (e < HV) {
                 if (!active) break;
-                f = j + T * e;
+                f = je + TT * e;
                 const C2 z = v[e];
                 C2 zp = z;
                 if (f != 0) {
-                    const float4 t = lds[C::idx(N - f, h)];
-                    zp.r = v2f{t.x, t.y};
-                    zp.i = v2f{t.z, t.w};
+                    if constexpr (C::SPLIT) {
+                        zp = zpart[e];
+                    } else {
+                        const float4 t = lds[C::idx(N - f, h)];
+                        zp.r = v2f{t.x, t.y};
+                        zp.i = v2f{t.z, t.w};
+                    }
                 }
                 xa.r = (z.r + zp.r) * hs;
                 xa.i = (z.i - zp.i) * hs;
                 xb.r = (z.i + zp.i) * hs;
                 xb.i = (zp.r - z.r) * hs;
             } else {
-                if (j != 0 || !active) break;
+                if (je != 0 || !active) break;
                 f = N / 2;
                 xa.r = v[HV].r * a.scale;
                 xb.r = v[HV].i * a.scale;
@@ -373,7 +502,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
 #pragma unroll
         for (int e = 0; e <= HV; ++e) {
             if (!active || (e == HV && j0 != 0)) break;
-            const int f = (e < HV) ? j0 + T * e : N / 2;
+            const int f = (e < HV) ? j0 + TT * e : N / 2;
             const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
             if (fi < 0) continue;
             const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;

@@ -266,6 +266,12 @@ int emu_mtmfft_dec(int id, const float* data, long long ld, const int* chan_idx,
         case 2000: run_dec_mode<spyfft::CfgD<10, 10, 10, 2, 1>>(a, nseg, nchan, outk, mean); break;
         case 2001: run_dec_mode<spyfft::CfgD<20, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;
         case 5000: run_dec_mode<spyfft::CfgD<10, 10, 10, 5, 1>>(a, nseg, nchan, outk, mean); break;
+        case 600: run_dec_mode<spyfft::CfgD<10, 10, 2, 1, 4, 3>>(a, nseg, nchan, outk, mean); break;
+        case 10000: run_dec_mode<spyfft::CfgD<20, 20, 5, 5, 1, 1, true>>(a, nseg, nchan, outk, mean); break;
+        case 1001: run_dec_mode<spyfft::CfgD<10, 10, 10, 1, 2, 1, true>>(a, nseg, nchan, outk, mean); break;
+        case 1500: run_dec_mode<spyfft::CfgD<10, 10, 5, 1, 2, 3>>(a, nseg, nchan, outk, mean); break;
+        case 3000: run_dec_mode<spyfft::CfgD<10, 10, 10, 1, 1, 3>>(a, nseg, nchan, outk, mean); break;
+        case 6000: run_dec_mode<spyfft::CfgD<10, 10, 10, 2, 1, 3>>(a, nseg, nchan, outk, mean); break;
         case 512: run_dec_mode<spyfft::CfgD<8, 8, 8, 1, 4>>(a, nseg, nchan, outk, mean); break;
         case 4096: run_dec_mode<spyfft::CfgD<8, 8, 8, 8, 1>>(a, nseg, nchan, outk, mean); break;
         default: return -1;

@@ -599,6 +599,34 @@ def test_dec_kernel_vs_oracle(dec, nfft, nchan, K, output, keeptapers, detrend, 
     _fft_case(nfft, nfft, nchan, K, output, keeptapers, detrend, demean_taper=demean, nseg=2 if nfft <= 1000 else 1, dec=dec)
 
 
+@pytest.mark.parametrize("nfft,nchan,K,output,keeptapers,detrend,demean", [
+    (600, 16, 2, "fourier", True, 0, False),           # 3 x 200, four quads per workgroup, fast stores
+    (1500, 5, 3, "pow", False, 1, True),               # 3 x 500: ragged channels, taper mean, linear detrend, demean_taper
+    (3000, 4, 2, "fourier", True, 0, False),           # 3 x 1000
+    (3000, 3, 2, "abs", False, -1, False),
+    (6000, 4, 1, "pow", True, 0, False),               # 3 x 2000
+])
+def test_dec_kernel_radix3_decimation(nfft, nchan, K, output, keeptapers, detrend, demean):
+    # N = 3 M: three scheduled sub-transforms side by side and one radix-3 combine through LDS (CfgD::P)
+    _fft_case(nfft, nfft, nchan, K, output, keeptapers, detrend, demean_taper=demean, nseg=2 if nfft <= 1500 else 1, dec=nfft)
+
+
+@pytest.mark.parametrize("dec,nfft,nchan,K,output,keeptapers,detrend,demean", [
+    (1001, 1000, 8, 2, "fourier", True, 0, False),     # the 1000-point schedule with split exchanges
+    (1001, 1000, 5, 3, "pow", False, 1, True),
+    (10000, 10000, 4, 1, "fourier", True, 0, False),   # 20 x 20 x 5 x 5, 500 threads
+    (10000, 10000, 3, 2, "pow", False, 0, False),
+])
+def test_dec_kernel_split_exchanges(dec, nfft, nchan, K, output, keeptapers, detrend, demean):
+    _fft_case(nfft, nfft, nchan, K, output, keeptapers, detrend, demean_taper=demean, nseg=2 if nfft <= 1000 else 1, dec=dec)
+
+
+def test_dec_kernel_radix3_padding_and_selection():
+    _fft_case(2700, 3000, 6, 2, "pow", True, 0, dec=3000, nseg=1, freq_idx=np.array([0, 1, 1499, 1500, 37, 1000, 1001]),
+              chan_idx=np.array([5, 0, 2, 2]))
+    _fft_case(1400, 1500, 4, 2, "fourier", True, 1, dec=1500, nseg=2)
+
+
 def test_dec_kernel_padding_and_selection():
     _fft_case(1700, 2000, 6, 2, "pow", True, 0, dec=2000, nseg=1, freq_idx=np.array([0, 1, 999, 1000, 37]),
               chan_idx=np.array([5, 0, 2, 2]))

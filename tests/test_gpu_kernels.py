@@ -69,6 +69,15 @@ CASES = [
     (360, 360, 3, None, {}, "angle", True, None, False),
     (1009, 1009, 2, "hann", {}, "pow", True, 0, False),                                # prime: Bluestein
     (300, 2 * 331, 3, "hann", {}, "fourier", True, 0, False),                          # Bluestein, padded
+    # 3 x a scheduled length: radix-3 decimation in front of the compile-time schedule (CfgD::P)
+    (3000, 3000, 16, "dpss", {"NW": 4, "Kmax": 7}, "pow", False, 0, False),
+    (2700, 3000, 7, "dpss", {"NW": 3, "Kmax": 5}, "fourier", True, 1, True),
+    (6000, 6000, 8, "dpss", {"NW": 3, "Kmax": 3}, "fourier", False, 0, False),
+    (7500, 7500, 5, "hann", {}, "abs", True, None, False),
+    (1500, 1500, 9, "dpss", {"NW": 2, "Kmax": 3}, "pow", True, 0, True),
+    (600, 600, 33, "hann", {}, "fourier", True, 0, False),
+    (10000, 10000, 8, "dpss", {"NW": 3, "Kmax": 4}, "pow", False, 0, False),           # split exchanges, 20 values per thread
+    (9000, 10000, 5, "dpss", {"NW": 2, "Kmax": 2}, "fourier", True, 1, True),
 ]
 
 
