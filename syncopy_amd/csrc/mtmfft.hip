@@ -50,6 +50,7 @@ int dec_launch_e(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int
 int dec_launch_f(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_g(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_h(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
+int dec_launch_i(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_c2(hipStream_t stream, const MtmArgs& a, int nquads);
 int pipe_launch(hipStream_t stream, const MtmArgs& a, int log2n, unsigned grid, int outk, bool mean);
 int pipe_max_tapers_demean();
@@ -356,7 +357,8 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
                            p->log2n, p->G, mode);
         p->kernel_name = buf;
     } else if ((nfft == 200 || nfft == 500 || nfft == 1000 || nfft == 2000 || nfft == 2500 || nfft == 4000 || nfft == 5000 || nfft == 10000 ||
-                ((nfft == 600 || nfft == 1500 || nfft == 3000 || nfft == 6000 || nfft == 7500) && !std::getenv("SPYHIP_NO_DEC3"))) &&
+                ((nfft == 600 || nfft == 1500 || nfft == 3000 || nfft == 6000 || nfft == 7500 || nfft == 768 || nfft == 1536 || nfft == 3072 ||
+                  nfft == 6144) && !std::getenv("SPYHIP_NO_DEC3"))) &&
                !std::getenv("SPYHIP_NO_DEC") && !std::getenv("SPYHIP_FORCE_GENERIC") &&
                !std::getenv("SPYHIP_FORCE_LONG") && !std::getenv("SPYHIP_FORCE_MIXED")) {
         // decimal trial lengths (1 kHz x 0.2 ... 5 s): radix schedules fixed at compile time, 10 values per thread
@@ -756,6 +758,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         if ((rc = spyfft::dec_launch_e(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
         if ((rc = spyfft::dec_launch_f(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
         if ((rc = spyfft::dec_launch_g(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_i(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
         spy::set_error("fft_exec: no decimal-length kernel for nfft = %d", p->nfft);
         return -1;
     }

@@ -169,6 +169,20 @@ __device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j
     d64_exchange<C, R, MB, WS>(v, lds, wbase, region + C::idx(j, h), active);
 }
 
+// (P = 3) bin k + M q of the length-3M transform from the twiddled sub-transforms in the three LDS regions:
+// X[k + M q] = g0 + w3^q g1 + w3^(2q) g2 = g0 + a (g1 + g2) + c (-i)(g1 - g2); a = 1, c = 0 (q = 0); a = -1/2, c = +-sqrt(3)/2
+template <class C>
+__device__ __forceinline__ spywil::cd d64_dit3_bin(const void* lds, int k, int q, int h) {
+    using spywil::cd;
+    const cd* const L = reinterpret_cast<const cd*>(lds);
+    const int ki = C::idx(k, h);
+    const cd g0 = L[ki], g1 = L[C::PL1 * C::G + ki], g2 = L[2 * C::PL1 * C::G + ki];
+    const double ca = q == 0 ? 1.0 : -0.5;
+    const double cc = q == 0 ? 0.0 : (q == 1 ? 0.86602540378443864676 : -0.86602540378443864676);
+    const double sx = g1.x + g2.x, sy = g1.y + g2.y, dx = g1.x - g2.x, dy = g1.y - g2.y;
+    return make_double2(fma(cc, dy, fma(ca, sx, g0.x)), fma(-cc, dx, fma(ca, sy, g0.y)));
+}
+
 // the base twiddles of one pass for thread j: w1[m] = tw[k_m N / (Ns R)], k_m = (j + T m) mod Ns
 template <class C, int R, int Ns>
 __device__ __forceinline__ void d64_twiddles(spywil::cd (&w1)[C::V / R], int j, const spywil::cd* __restrict__ tw) {
@@ -453,27 +467,9 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
                 for (int e = 0; e < V; ++e) L[region + C::idx(j + T * e, h)] = v[e];
             }
             __syncthreads();
-            // X[k + M q] = g0 + w3^q g1 + w3^(2q) g2 = g0 + a (g1 + g2) + c (-i)(g1 - g2) for this thread's q = r:
-            // a = 1, c = 0 (q = 0); a = -1/2, c = +-sqrt(3)/2 (q = 1, 2)
-            const double ca = r == 0 ? 1.0 : -0.5;
-            const double cc = r == 0 ? 0.0 : (r == 1 ? 0.86602540378443864676 : -0.86602540378443864676);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const int ki = C::idx(j + T * e, h);
-                const cd g0 = r == 0 ? v[e] : L[ki];
-                const cd g1 = r == 1 ? v[e] : L[C::PL1 * G + ki];
-                const cd g2 = r == 2 ? v[e] : L[2 * C::PL1 * G + ki];
-                const double sx = g1.x + g2.x, sy = g1.y + g2.y, dx = g1.x - g2.x, dy = g1.y - g2.y;
-                v[e] = make_double2(fma(cc, dy, fma(ca, sx, g0.x)), fma(-cc, dx, fma(ca, sy, g0.y)));
-            }
-            __syncthreads();
-            if (active) {                 // natural order over all N bins: idx(k + M r)
-#pragma unroll
-                for (int e = 0; e < V; ++e) L[C::idx(j + T * e + C::M * r, h)] = v[e];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e <= HV; ++e) v[e] = L[C::idx(je + TT * e, h)];     // the epilogue's mapping: bins je + TT e
+            // No second exchange: the epilogue forms the bins of its mapping, f = je + TT e, AND their partners N - f straight
+            // from the three regions (d64_dit3_bin).  Against a per-thread combine (q = r) + natural-order write + read-back:
+            // 3000 35.2 -> 24.5, 6000 79 -> 49, 3072 58 -> 16.6, 768 11.5 -> 3.3 us/trial (the 16-value schedules spilled)
         }
 
         // ---- separation: partner bin N - f lives in the upper slots
@@ -520,9 +516,14 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
             if (e < HV) {
                 if (!active) break;
                 f = je + TT * e;
-                const cd z = v[e];
+                cd z = v[e];
                 cd p;
-                if constexpr (!C::SPLIT) {
+                if constexpr (P == 3) {
+                    // N - f = (M - k) + M (2 - q), or M (3 - q) for k = 0
+                    const int q = (f >= C::M ? 1 : 0) + (f >= 2 * C::M ? 1 : 0), kk = f - q * C::M;
+                    z = d64_dit3_bin<C>(lds, kk, q, h);
+                    p = f == 0 ? z : d64_dit3_bin<C>(lds, kk == 0 ? 0 : C::M - kk, kk == 0 ? 3 - q : 2 - q, h);
+                } else if constexpr (!C::SPLIT) {
                     p = f == 0 ? z : reinterpret_cast<const cd*>(lds)[C::idx(N - f, h)];
                 } else {
                     p = make_double2(zpx[C::SPLIT ? e : 0], f == 0 ? z.y : reinterpret_cast<const double*>(lds)[C::idx(N - f, h)]);
@@ -532,8 +533,9 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
             } else {
                 if (je != 0 || !active) break;
                 f = N / 2;
-                X0 = make_double2(v[HV].x, 0.0);
-                X1 = make_double2(v[HV].y, 0.0);
+                const cd zn = (P == 3) ? d64_dit3_bin<C>(lds, C::M / 2, 1, h) : v[HV];
+                X0 = make_double2(zn.x, 0.0);
+                X1 = make_double2(zn.y, 0.0);
             }
             // complex64 storage, then the float32 normalisation factor (mtmfft.py:104,117-127)
             const float2 s0 = make_float2(__fmul_rn((float)X0.x, a.scale), __fmul_rn((float)X0.y, a.scale));

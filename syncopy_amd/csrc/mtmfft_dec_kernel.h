@@ -141,6 +141,26 @@ __device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int 
     }
 }
 
+// (P = 3) bin k + M q of the length-3M transform from the twiddled sub-transforms in the three LDS regions
+template <class C>
+__device__ __forceinline__ C2 dit3_bin(const float4* lds, int k, int q, int h) {
+    const int ki = C::idx(k, h);
+    C2 g[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const float4 t = lds[rr * C::PL1 * C::G + ki];
+        g[rr].r = v2f{t.x, t.y};
+        g[rr].i = v2f{t.z, t.w};
+    }
+    const float ca = q == 0 ? 1.f : -0.5f;
+    const float cc = q == 0 ? 0.f : (q == 1 ? 0.8660254037844386f : -0.8660254037844386f);
+    const v2f sr = g[1].r + g[2].r, si = g[1].i + g[2].i, dr = g[1].r - g[2].r, di = g[1].i - g[2].i;
+    C2 x;
+    x.r = g[0].r + sr * ca + di * cc;
+    x.i = g[0].i + si * ca - dr * cc;
+    return x;
+}
+
 // OUTK: 0 = power (inlined), 1 = any other real conversion, 2 = complex; MEAN: average over tapers
 template <class C, int OUTK, bool MEAN>
 __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(MtmArgs a) {
@@ -329,7 +349,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
             }
         }
 
-        C2 zpart[C::SPLIT ? HV : 1];      // (SPLIT) the partner bins Z[N - f] of this thread's bins
+        C2 zpart[C::SPLIT ? HV : 1];      // (SPLIT, P = 3) the partner bins Z[N - f] of this thread's bins
         // ---- the passes: radix V from the registers, then R1 (R2, R3); the last one leaves v[e] = Z[j + T e]
         dec_pass<C, V, 1, true, false>(v, lds, j, h, active, a.tw, region);
         dec_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, a.tw, region);
@@ -349,37 +369,10 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
                     lds[region + C::idx(j + T * e, h)] = make_float4(v[e].r[0], v[e].r[1], v[e].i[0], v[e].i[1]);
             }
             __syncthreads();
-            // X[k + M q] = g0 + w3^q g1 + w3^(2q) g2 = g0 + ca (g1 + g2) + cc (-i)(g1 - g2) for this thread's q = r:
-            // ca = 1, cc = 0 (q = 0); ca = -1/2, cc = +-sqrt(3)/2 (q = 1, 2)
-            const float ca = r == 0 ? 1.f : -0.5f;
-            const float cc = r == 0 ? 0.f : (r == 1 ? 0.8660254037844386f : -0.8660254037844386f);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const int ki = C::idx(j + T * e, h);
-                C2 g[3];
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {
-                    const float4 t = lds[rr * C::PL1 * G + ki];
-                    g[rr].r = v2f{t.x, t.y};
-                    g[rr].i = v2f{t.z, t.w};
-                }
-                const v2f sr = g[1].r + g[2].r, si = g[1].i + g[2].i, dr = g[1].r - g[2].r, di = g[1].i - g[2].i;
-                v[e].r = g[0].r + sr * ca + di * cc;
-                v[e].i = g[0].i + si * ca - dr * cc;
-            }
-            __syncthreads();
-            if (active) {                 // natural order over all N bins: idx(k + M r)
-#pragma unroll
-                for (int e = 0; e < V; ++e)
-                    lds[C::idx(j + T * e + C::M * r, h)] = make_float4(v[e].r[0], v[e].r[1], v[e].i[0], v[e].i[1]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e <= HV; ++e) {       // the epilogue's mapping: bins je + TT e
-                const float4 t = lds[C::idx(je + TT * e, h)];
-                v[e].r = v2f{t.x, t.y};
-                v[e].i = v2f{t.z, t.w};
-            }
+            // No second exchange: the epilogue below forms the bins of its mapping, f = je + TT e (e < V / 2, and N / 2 on
+            // je = 0), AND their partners N - f straight from the three regions (dit3_bin).  Measured against a version that
+            // combined per thread (q = r), wrote X in natural order and read bins and partners back: 3000 14.6 -> 13.1,
+            // 6000 33.9 -> 27.4, 7500 40.6 -> 35.6 us/trial (profiles/r4_precision_probe_dit3.txt)
         } else if constexpr (!C::SPLIT) {
             // ---- separate the real channels: partner bin N - f lives in the upper half
             __syncthreads();              // the FFT's last reads of the buffer are done everywhere
@@ -427,10 +420,15 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
             if (e < HV) {
                 if (!active) break;
                 f = je + TT * e;
-                const C2 z = v[e];
+                C2 z = v[e];
+                if constexpr (P == 3) z = dit3_bin<C>(lds, f >= C::M ? f - C::M : f, f >= C::M ? 1 : 0, h);   // (f < N / 2)
                 C2 zp = z;
                 if (f != 0) {
-                    if constexpr (C::SPLIT) {
+                    if constexpr (P == 3) {
+                        // N - f = (M - k) + M (2 - q), or M (3 - q) for k = 0
+                        const int q = f >= C::M ? 1 : 0, kk = f - q * C::M;
+                        zp = dit3_bin<C>(lds, kk == 0 ? 0 : C::M - kk, kk == 0 ? 3 - q : 2 - q, h);
+                    } else if constexpr (C::SPLIT) {
                         zp = zpart[e];
                     } else {
                         const float4 t = lds[C::idx(N - f, h)];
@@ -445,8 +443,9 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
             } else {
                 if (je != 0 || !active) break;
                 f = N / 2;
-                xa.r = v[HV].r * a.scale;
-                xb.r = v[HV].i * a.scale;
+                const C2 zn = (P == 3) ? dit3_bin<C>(lds, C::M / 2, 1, h) : v[HV];
+                xa.r = zn.r * a.scale;
+                xb.r = zn.i * a.scale;
                 xa.i = xb.i = splat(0.f);
             }
             if (MEAN) {

@@ -267,6 +267,8 @@ int emu_mtmfft_dec(int id, const float* data, long long ld, const int* chan_idx,
         case 2001: run_dec_mode<spyfft::CfgD<20, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;
         case 5000: run_dec_mode<spyfft::CfgD<10, 10, 10, 5, 1>>(a, nseg, nchan, outk, mean); break;
         case 600: run_dec_mode<spyfft::CfgD<10, 10, 2, 1, 4, 3>>(a, nseg, nchan, outk, mean); break;
+        case 768: run_dec_mode<spyfft::CfgD<16, 16, 1, 1, 4, 3>>(a, nseg, nchan, outk, mean); break;
+        case 3072: run_dec_mode<spyfft::CfgD<16, 16, 4, 1, 1, 3>>(a, nseg, nchan, outk, mean); break;
         case 10000: run_dec_mode<spyfft::CfgD<20, 20, 5, 5, 1, 1, true>>(a, nseg, nchan, outk, mean); break;
         case 1001: run_dec_mode<spyfft::CfgD<10, 10, 10, 1, 2, 1, true>>(a, nseg, nchan, outk, mean); break;
         case 1500: run_dec_mode<spyfft::CfgD<10, 10, 5, 1, 2, 3>>(a, nseg, nchan, outk, mean); break;

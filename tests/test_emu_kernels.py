@@ -605,6 +605,8 @@ def test_dec_kernel_vs_oracle(dec, nfft, nchan, K, output, keeptapers, detrend, 
     (3000, 4, 2, "fourier", True, 0, False),           # 3 x 1000
     (3000, 3, 2, "abs", False, -1, False),
     (6000, 4, 1, "pow", True, 0, False),               # 3 x 2000
+    (768, 9, 2, "fourier", True, 0, False),            # 3 x 256, 16 values per thread
+    (3072, 4, 2, "pow", False, 0, False),              # 3 x 1024
 ])
 def test_dec_kernel_radix3_decimation(nfft, nchan, K, output, keeptapers, detrend, demean):
     # N = 3 M: three scheduled sub-transforms side by side and one radix-3 combine through LDS (CfgD::P)

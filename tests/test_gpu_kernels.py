@@ -77,6 +77,10 @@ CASES = [
     (1500, 1500, 9, "dpss", {"NW": 2, "Kmax": 3}, "pow", True, 0, True),
     (600, 600, 33, "hann", {}, "fourier", True, 0, False),
     (10000, 10000, 8, "dpss", {"NW": 3, "Kmax": 4}, "pow", False, 0, False),           # split exchanges, 20 values per thread
+    (768, 768, 12, "dpss", {"NW": 2, "Kmax": 3}, "fourier", True, 0, False),           # 3 x 256 ... 3 x 2048
+    (1400, 1536, 6, "hann", {}, "pow", True, 1, False),
+    (3072, 3072, 8, "dpss", {"NW": 4, "Kmax": 7}, "pow", False, 0, True),
+    (6144, 6144, 5, "dpss", {"NW": 2, "Kmax": 2}, "fourier", False, 0, False),
     (9000, 10000, 5, "dpss", {"NW": 2, "Kmax": 2}, "fourier", True, 1, True),
 ]
 

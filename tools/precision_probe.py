@@ -27,7 +27,7 @@ def timed(plan, data, starts, out, reps=3):
     return (time.perf_counter() - t0) / reps
 
 
-for N in [int(a) for a in sys.argv[1:]] or [256, 512, 1024, 2048, 4096, 8192, 16384, 200, 500, 1000, 2000, 2500, 4000, 5000, 10000, 3000, 1009]:
+for N in [int(a) for a in sys.argv[1:]] or [256, 512, 1024, 2048, 4096, 8192, 16384, 200, 500, 1000, 2000, 2500, 4000, 5000, 10000, 1009]:
     T = max(8, min(200, (1 << 27) // (N * C)))
     g = torch.Generator(device="cuda").manual_seed(N)
     data = torch.randn((T * N, C), device="cuda", dtype=torch.float32, generator=g)
