@@ -232,6 +232,24 @@ tfa("mexican_hat_auto", method="wavelet", wavelet="Mexican_hat", toi="all", outp
 tfa("paul4_auto", method="wavelet", wavelet="Paul", order=4, toi="all", keeptrials=False)
 save("wavelet_families", **kw)
 
+# ---------------------------------------------------------------- trial lengths behind the round-4 radix schedules
+# (3 x a scheduled length through the radix-3 decimation, 10000 with split exchanges): mtmfft.py:80-129 takes any nSamples
+kw = {}
+for n in (600, 768, 1500, 3000, 3072, 6000, 10000):
+    d = synthdata.ar2_network(nTrials=3, nSamples=n, AdjMat=np.zeros((4, 4)), seed=n)
+    kw[f"n{n}_data"] = np.stack(trials_of(d))
+    kw[f"n{n}_trialdefinition"] = d.trialdefinition
+    r = spy.freqanalysis(d, method="mtmfft", tapsmofrq=2, keeptrials=False)
+    kw[f"n{n}_pow_avg"] = r.data[()]
+    kw[f"n{n}_freq"] = r.freq
+    r = spy.freqanalysis(d, method="mtmfft", taper="hann", output="fourier", select={"trials": [1]})
+    kw[f"n{n}_fourier_trial1"] = r.data[()]
+    kw[f"n{n}_coh"] = ca(d, method="coh", tapsmofrq=2)
+    r = spy.freqanalysis(d, method="mtmfft", taper="hann", polyremoval=1, foilim=[0, 100],
+                         select={"latency": [-1.0, -1.0 + (n - 37) / 1000.0]}, pad=n / 1000.0)
+    kw[f"n{n}_pow_pad"] = r.data[()]
+save("lengths", **kw)
+
 # ---------------------------------------------------------------- welch = mtmconvol + spy.mean(dim="time") (freqanalysis.py:1054-1056)
 kw = {"data": np.stack(trials_of(tf)), "samplerate": tf.samplerate, "trialdefinition": tf.trialdefinition}
 tfa("welch_hann_half", method="welch", taper="hann", t_ftimwin=0.5, toi=0.5)

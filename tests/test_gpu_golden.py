@@ -8,7 +8,8 @@ import pytest
 import syncopy_amd as spy
 from oracle_routines import ORACLE_CONN, ORACLE_FREQ
 from parity import assert_parity
-from test_oracle_golden import (JACK_VARIANTS, SLT_VARIANTS, TF_VARIANTS, WAVELET_FAMILIES, VARIANTS, WELCH_VARIANTS, chain_checks,
+from test_oracle_golden import (JACK_VARIANTS, LENGTHS, SLT_VARIANTS, TF_VARIANTS, WAVELET_FAMILIES, VARIANTS, WELCH_VARIANTS, chain_checks,
+                                lengths_cases,
                                 check_jackknife, check_superlet, cmb_checks, corr_checks, ppc_checks)
 
 pytestmark = pytest.mark.gpu
@@ -217,6 +218,22 @@ def test_wavelet_families(golden_dir, tf, name, how):
     assert_parity(out.data, ref, what=f"{name} ({how})")
     np.testing.assert_allclose(out.trialdefinition, z[name + "_trialdef"])
     np.testing.assert_allclose(out.freq, z[name + "_freq"])
+
+
+@pytest.mark.parametrize("precision", ["float32", "reference"])
+@pytest.mark.parametrize("how", ["hip", "sequential"])
+@pytest.mark.parametrize("n", LENGTHS)
+def test_lengths_behind_the_radix_schedules(golden_dir, n, how, precision):
+    """3 x (a scheduled length) through the radix-3 decimation and N = 10000 with split exchanges, float32 (K1d) and
+    float64 (K1r2) kernels, batched and per-trial route - against vectors written by the real reference."""
+    z = _load(golden_dir, "lengths")
+    data, cases = lengths_cases(z, n)
+    for name, kind, kw in cases:
+        out = (spy.freqanalysis if kind == "freq" else spy.connectivityanalysis)(data, compute_method=how,
+                                                                                  precision=precision, **kw)
+        ref = z[f"n{n}_{name}"]
+        assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
+        assert_parity(out.data, ref, what=f"n = {n}: {name} ({how}, {precision})")
 
 
 @pytest.mark.parametrize("how", ["hip", "sequential"])

@@ -433,6 +433,36 @@ def test_superlet_variants(golden_dir, name):
     check_superlet(fa(data, **SLT_VARIANTS[name]), z, name)
 
 
+LENGTHS = (600, 768, 1500, 3000, 3072, 6000, 10000)
+
+
+def lengths_cases(z, n):
+    """(name, analysis, keyword arguments) of the `lengths` fixture for trial length n (oracle/gen_golden.py)."""
+    data = spy.AnalogData(np.concatenate(list(z[f"n{n}_data"])), samplerate=1000.0,
+                          trialdefinition=z[f"n{n}_trialdefinition"])
+    return data, [
+        ("pow_avg", "freq", dict(method="mtmfft", tapsmofrq=2, keeptrials=False)),
+        ("fourier_trial1", "freq", dict(method="mtmfft", taper="hann", output="fourier", select={"trials": [1]})),
+        ("coh", "conn", dict(method="coh", tapsmofrq=2)),
+        ("pow_pad", "freq", dict(method="mtmfft", taper="hann", polyremoval=1, foilim=[0, 100],
+                                 select={"latency": [-1.0, -1.0 + (n - 37) / 1000.0]}, pad=n / 1000.0)),
+    ]
+
+
+@pytest.mark.parametrize("n", LENGTHS)
+def test_lengths_behind_the_radix_schedules(golden_dir, n):
+    """Trial lengths 3 x (a scheduled length) and 10000 (mtmfft.py:80-129 takes any nSamples): vectors of the real
+    reference; here the oracle, tests/test_gpu_golden.py the kernels."""
+    z = _load(golden_dir, "lengths")
+    data, cases = lengths_cases(z, n)
+    for name, kind, kw in cases:
+        out = (fa if kind == "freq" else ca)(data, **kw)
+        ref = z[f"n{n}_{name}"]
+        assert out.data.shape == ref.shape and out.data.dtype == ref.dtype
+        assert_parity(out.data, ref, what=f"n = {n}: {name}")
+    np.testing.assert_allclose(fa(data, method="mtmfft", tapsmofrq=2, keeptrials=False).freq, z[f"n{n}_freq"])
+
+
 WELCH_VARIANTS = {
     "welch_hann_half": dict(method="welch", taper="hann", t_ftimwin=0.5, toi=0.5),
     "welch_dpss_avg": dict(method="welch", tapsmofrq=4, t_ftimwin=0.4, toi=0.25, foilim=[0, 150], keeptrials=False),
