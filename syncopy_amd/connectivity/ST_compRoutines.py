@@ -263,8 +263,9 @@ class CrossSpectra(ComputationalRoutine):
         ~5e-7 sqrt(R / N) of error in its coherence (floor of the parity criterion: 1e-6), and 5e-7 sqrt(R) of phase error
         per trial in ppc, where a trial weighs 2 / T in the pair average (floor 5e-6 / sqrt(T)).  R = hs.dynamic_range of
         the float32 spectra of (up to) `sample` of this rank's trials, the largest over the ranks so that every rank
-        takes the same branch.  Costs `sample` trials' transforms and one host synchronisation; AR(2)-type data never
-        asks, line noise 50 dB above the floor or 1/f spectra over four decades do."""
+        takes the same branch.  Costs `sample` trials' transforms and one host synchronisation - once per recording and
+        set of options: the measured ratio is kept on the data object until its array changes (`invalidate`); AR(2)-type
+        data never asks, line noise 50 dB above the floor or 1/f spectra over four decades do."""
         cfg = self.cfg
         dev = data.device_data(partial=True)
         upload = data.upload_in_flight()
@@ -277,13 +278,21 @@ class CrossSpectra(ComputationalRoutine):
         T = len(rows)
         lo, hi = parallel.my_shard(T)
         mine = rows[lo:hi][:sample]
-        ratio, K = 0.0, 1
-        with hs.precision("float32"):
-            for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
-                                                 cfg["demean_taper"], False, pr, None, "fourier", True, reuse=True,
-                                                 upload=upload):
-                ratio = max(ratio, hs.dynamic_range(spec, kept=freq_idx))        # whole axis: see hs.dynamic_range
-                K = spec.shape[1]
+        looks = getattr(data, "_looks", None)
+        key = (tuple(mine), None if chans is None else tuple(int(c) for c in chans), cfg["nSamples"], str(cfg["taper"]),
+               repr(sorted((cfg["taper_opt"] or {}).items())), bool(cfg["demean_taper"]), pr, freq_idx.tobytes())
+        if looks is not None and key in looks:
+            ratio, K = looks[key]
+        else:
+            ratio, K = 0.0, 1
+            with hs.precision("float32"):
+                for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
+                                                     cfg["demean_taper"], False, pr, None, "fourier", True, reuse=True,
+                                                     upload=upload):
+                    ratio = max(ratio, hs.dynamic_range(spec, kept=freq_idx))        # whole axis: see hs.dynamic_range
+                    K = spec.shape[1]
+            if looks is not None:
+                looks[key] = (ratio, K)
         ratio = parallel.allreduce_max(ratio)
         if method == "ppc":
             return bool(5e-7 * np.sqrt(ratio) * 2 / T > 5e-6 / np.sqrt(max(T, 1)))

@@ -62,6 +62,7 @@ class _Base:
         self._upload = None
         self._device = None
         self._device_key = None
+        self._looks = {}                  # what precision="auto" measured on this array (CrossSpectra.needs_float64)
 
     def set_pending(self, thunk, shape, dtype):
         """The host array is `thunk()` - evaluated only if somebody reads `.data`."""
@@ -313,7 +314,7 @@ def trial_rows(data):
     """[(start, stop)] absolute row ranges, in output-trial order, honouring an active selection."""
     si = data.sampleinfo
     if data.selection is None:
-        return [(int(a), int(b)) for a, b in si]
+        return list(zip(si[:, 0].astype(np.int64).tolist(), si[:, 1].astype(np.int64).tolist()))
     out = []
     for t in data.selection.trial_ids:
         a, b = data.selection.time[t]

@@ -57,22 +57,23 @@ class ComputationalRoutine(ABC):
         tax = data.dimord.index("time") if "time" in data.dimord else 0
         shapes, dtp = [], None
         per_trial_args = any(isinstance(a, (list, tuple, np.ndarray)) and len(a) == self.numTrials for a in self.argv)
-        seen = {}                        # dry runs of equally shaped trials are identical (unless argv is per trial)
+        seen = {}                        # dry runs of equally long trials are identical (unless argv is per trial)
+        base = list(data.data_shape)
+        if chans is not None and "channel" in data.dimord:
+            base[data.dimord.index("channel")] = len(chans)
         for k, (a, b) in enumerate(rows):
-            shp = list(data.data_shape)
-            shp[tax] = b - a
-            if chans is not None and "channel" in data.dimord:
-                shp[data.dimord.index("channel")] = len(chans)
-            key = None if per_trial_args else tuple(shp)
-            if key is not None and key in seen:
-                chk, dt = seen[key]
-            else:
+            key = None if per_trial_args else b - a
+            hit = seen.get(key) if key is not None else None
+            if hit is None:
+                shp = list(base)
+                shp[tax] = b - a
                 trial = FauxTrial(shp, data.data_dtype)
                 chk, dt = self.computeFunction(trial, *self._argv(k), noCompute=True, chunkShape=None, **self.cfg)
+                hit = (tuple(int(s) for s in chk), np.dtype(dt))
                 if key is not None:
-                    seen[key] = (chk, dt)
-            shapes.append(tuple(int(s) for s in chk))
-            dtp = np.dtype(dt)
+                    seen[key] = hit
+            shapes.append(hit[0])
+            dtp = hit[1]
         self.targetShapes = shapes
         self.dtype = dtp
         stack = out_stackingdim
@@ -83,11 +84,11 @@ class ComputationalRoutine(ABC):
         else:
             tot = sum(s[stack] for s in shapes)
             first = list(shapes[0])
-            if any(s[:stack] + s[stack + 1:] != shapes[0][:stack] + shapes[0][stack + 1:] for s in shapes):
+            if any(s[:stack] + s[stack + 1:] != shapes[0][:stack] + shapes[0][stack + 1:] for s in set(shapes)):
                 raise SPYValueError("identical non-stacking dimensions of all trial results", varname="data")
             first[stack] = tot
             self.outputShape = tuple(first)
-        self.chunkShape = max(shapes, key=lambda s: int(np.prod(s)))
+        self.chunkShape = max(set(shapes), key=lambda s: int(np.prod(s)))
         self.stackingDim = stack
 
     def _argv(self, k):
