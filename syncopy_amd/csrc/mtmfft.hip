@@ -40,6 +40,10 @@ int dec64_launch_g(hipStream_t stream, const F64Args& a, int nfft, int npairs, i
 int dec64_launch_h(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_i(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_j(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_k(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_l(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_m(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_n(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean);
 int f64_any_launch(hipStream_t stream, F64Args a, long long grid, long long chunk, int outk, bool mean);
 int dec_launch_a(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
@@ -51,6 +55,9 @@ int dec_launch_f(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int
 int dec_launch_g(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_h(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_i(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
+int dec_launch_j(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
+int dec_launch_k(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
+int dec_launch_l(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_c2(hipStream_t stream, const MtmArgs& a, int nquads);
 int pipe_launch(hipStream_t stream, const MtmArgs& a, int log2n, unsigned grid, int outk, bool mean);
 int pipe_max_tapers_demean();
@@ -356,8 +363,10 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         else std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
                            p->log2n, p->G, mode);
         p->kernel_name = buf;
-    } else if ((nfft == 200 || nfft == 500 || nfft == 1000 || nfft == 2000 || nfft == 2500 || nfft == 4000 || nfft == 5000 || nfft == 10000 ||
-                ((nfft == 600 || nfft == 1500 || nfft == 3000 || nfft == 6000 || nfft == 7500 || nfft == 768 || nfft == 1536 || nfft == 3072 ||
+    } else if ((((nfft == 400 || nfft == 800 || nfft == 1200 || nfft == 1600 || nfft == 2400 || nfft == 3200 || nfft == 4800 || nfft == 8000) &&
+                 !std::getenv("SPYHIP_NO_DEC20")) ||
+                nfft == 100 || nfft == 200 || nfft == 500 || nfft == 1000 || nfft == 2000 || nfft == 2500 || nfft == 4000 || nfft == 5000 || nfft == 10000 ||
+                ((nfft == 300 || nfft == 600 || nfft == 1500 || nfft == 3000 || nfft == 6000 || nfft == 7500 || nfft == 768 || nfft == 1536 || nfft == 3072 ||
                   nfft == 6144) && !std::getenv("SPYHIP_NO_DEC3"))) &&
                !std::getenv("SPYHIP_NO_DEC") && !std::getenv("SPYHIP_FORCE_GENERIC") &&
                !std::getenv("SPYHIP_FORCE_LONG") && !std::getenv("SPYHIP_FORCE_MIXED")) {
@@ -540,7 +549,8 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
     SPY_HIP_CHECK(hipSetDevice(p->ctx->device));
     // compile-time radix schedules (mtmfft_dec64_launch.h): the powers of two 256 ... 16384 and the decimal lengths
     static const int dec64_lengths[] = {256, 512, 1024, 2048, 4096, 8192, 16384, 200, 500, 1000, 2000, 2500, 4000, 5000, 10000,
-                                        600, 1500, 3000, 6000, 7500, 768, 1536, 3072, 6144};
+                                        600, 1500, 3000, 6000, 7500, 768, 1536, 3072, 6144,
+                                        100, 400, 800, 1600, 3200, 8000, 300, 1200, 2400, 4800};
     p->f64_dec = false;
     for (int n : dec64_lengths) p->f64_dec = p->f64_dec || (n == p->nfft);
     if (std::getenv("SPYHIP_F64_OLD")) p->f64_dec = false;           // A/B runs against the generic kernels
@@ -684,6 +694,10 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             if ((rc = spyfft::dec64_launch_h(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
             if ((rc = spyfft::dec64_launch_i(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
             if ((rc = spyfft::dec64_launch_j(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_k(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_l(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_m(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_n(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;
             spy::set_error("fft_exec: no reference-precision schedule for nfft = %d", p->nfft);
             return -1;
         }
@@ -759,6 +773,9 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         if ((rc = spyfft::dec_launch_f(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
         if ((rc = spyfft::dec_launch_g(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
         if ((rc = spyfft::dec_launch_i(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_j(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_k(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_l(p->ctx->stream, a, p->nfft, nquads, outk, mean)) != -100) return rc;
         spy::set_error("fft_exec: no decimal-length kernel for nfft = %d", p->nfft);
         return -1;
     }

@@ -34,5 +34,16 @@ using D64_768   = CfgD64<16, 16, 1,  1,  4, false, true, true, 3>;
 using D64_1536  = CfgD64<16, 16, 2,  1,  2, false, true, true, 3>;
 using D64_3072  = CfgD64<16, 16, 4,  1,  1, false, true, true, 3>;
 using D64_6144  = CfgD64<16, 16, 8,  1,  1, false, true, true, 3>;
+// window lengths of sliding-window analyses and the remaining multiples of 100 up to 8000 that factor into the radices
+using D64_100   = CfgD64<10, 10, 1,  1,  16>;
+using D64_400   = CfgD64<20, 20, 1,  1,  8>;
+using D64_800   = CfgD64<20, 20, 2,  1,  4>;
+using D64_1600  = CfgD64<20, 20, 4,  1,  2>;
+using D64_3200  = CfgD64<20, 20, 4,  2,  1>;
+using D64_8000  = CfgD64<20, 20, 20, 1,  1>;
+using D64_300   = CfgD64<10, 10, 1,  1,  8, false, true, true, 3>;
+using D64_1200  = CfgD64<20, 20, 1,  1,  2, false, true, true, 3>;
+using D64_2400  = CfgD64<20, 20, 2,  1,  1, false, true, true, 3>;
+using D64_4800  = CfgD64<20, 20, 4,  1,  1, false, true, true, 3>;
 
 }  // namespace spyfft

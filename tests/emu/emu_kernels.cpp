@@ -267,6 +267,11 @@ int emu_mtmfft_dec(int id, const float* data, long long ld, const int* chan_idx,
         case 2001: run_dec_mode<spyfft::CfgD<20, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;
         case 5000: run_dec_mode<spyfft::CfgD<10, 10, 10, 5, 1>>(a, nseg, nchan, outk, mean); break;
         case 600: run_dec_mode<spyfft::CfgD<10, 10, 2, 1, 4, 3>>(a, nseg, nchan, outk, mean); break;
+        case 100: run_dec_mode<spyfft::CfgD<10, 10, 1, 1, 16>>(a, nseg, nchan, outk, mean); break;
+        case 400: run_dec_mode<spyfft::CfgD<20, 20, 1, 1, 8>>(a, nseg, nchan, outk, mean); break;
+        case 2400: run_dec_mode<spyfft::CfgD<20, 20, 2, 1, 1, 3>>(a, nseg, nchan, outk, mean); break;
+        case 3200: run_dec_mode<spyfft::CfgD<20, 20, 4, 2, 1>>(a, nseg, nchan, outk, mean); break;
+        case 300: run_dec_mode<spyfft::CfgD<10, 10, 1, 1, 8, 3>>(a, nseg, nchan, outk, mean); break;
         case 768: run_dec_mode<spyfft::CfgD<16, 16, 1, 1, 4, 3>>(a, nseg, nchan, outk, mean); break;
         case 3072: run_dec_mode<spyfft::CfgD<16, 16, 4, 1, 1, 3>>(a, nseg, nchan, outk, mean); break;
         case 10000: run_dec_mode<spyfft::CfgD<20, 20, 5, 5, 1, 1, true>>(a, nseg, nchan, outk, mean); break;
@@ -913,6 +918,11 @@ extern "C" int emu_mtmfft_f64(int nfft, int blue_m, const float* data, long long
             case 5000: run_dec64_mode<spyfft::D64_5000>(fa, nseg, nchan, outk, mean); break;
             case 10000: run_dec64_mode<spyfft::D64_10000>(fa, nseg, nchan, outk, mean); break;
             case 600: run_dec64_mode<spyfft::D64_600>(fa, nseg, nchan, outk, mean); break;
+            case 100: run_dec64_mode<spyfft::D64_100>(fa, nseg, nchan, outk, mean); break;
+            case 300: run_dec64_mode<spyfft::D64_300>(fa, nseg, nchan, outk, mean); break;
+            case 400: run_dec64_mode<spyfft::D64_400>(fa, nseg, nchan, outk, mean); break;
+            case 2400: run_dec64_mode<spyfft::D64_2400>(fa, nseg, nchan, outk, mean); break;
+            case 3200: run_dec64_mode<spyfft::D64_3200>(fa, nseg, nchan, outk, mean); break;
             case 768: run_dec64_mode<spyfft::D64_768>(fa, nseg, nchan, outk, mean); break;
             case 1500: run_dec64_mode<spyfft::D64_1500>(fa, nseg, nchan, outk, mean); break;
             case 3000: run_dec64_mode<spyfft::D64_3000>(fa, nseg, nchan, outk, mean); break;

@@ -586,6 +586,9 @@ def test_pipe_kernel_selection_and_padding():
 # ---------------------------------------------------------------------------------------------------------------
 # K1d: compile-time radix schedules (mtmfft_dec_kernel.h)
 @pytest.mark.parametrize("dec,nfft,nchan,K,output,keeptapers,detrend,demean", [
+    (100, 100, 68, 2, "fourier", True, 0, False),      # 10 x 10, sixteen quads per workgroup (+ one padded group)
+    (400, 400, 35, 2, "pow", False, 1, False),         # 20 x 20, eight quads per workgroup
+    (3200, 3200, 4, 1, "fourier", True, 0, False),     # 20 x 20 x 4 x 2
     (1000, 1000, 8, 2, "fourier", True, 0, False),     # 10 x 10 x 10, two quads per workgroup, fast stores
     (1000, 1000, 5, 3, "pow", False, 1, True),         # ragged channels, taper mean, linear detrend, demean_taper
     (2000, 2000, 4, 2, "pow", True, 0, False),         # 10 x 10 x 10 x 2: BASELINE config 1's length
@@ -605,6 +608,8 @@ def test_dec_kernel_vs_oracle(dec, nfft, nchan, K, output, keeptapers, detrend, 
     (3000, 4, 2, "fourier", True, 0, False),           # 3 x 1000
     (3000, 3, 2, "abs", False, -1, False),
     (6000, 4, 1, "pow", True, 0, False),               # 3 x 2000
+    (300, 33, 2, "fourier", True, 0, False),           # 3 x 100, eight quads per workgroup
+    (2400, 4, 2, "abs", True, 0, False),               # 3 x 800, 20 values per thread
     (768, 9, 2, "fourier", True, 0, False),            # 3 x 256, 16 values per thread
     (3072, 4, 2, "pow", False, 0, False),              # 3 x 1024
 ])
@@ -703,7 +708,7 @@ def test_dec64_kernel_long_schedules(nfft):
     _f64_case(nfft, nfft, 2, 1, "fourier", True, 0)
 
 
-@pytest.mark.parametrize("nfft,nchan,K", [(600, 9, 2), (768, 5, 2), (1500, 5, 2), (3000, 3, 2), (3072, 2, 1), (6000, 2, 1),
+@pytest.mark.parametrize("nfft,nchan,K", [(100, 35, 2), (300, 17, 2), (400, 9, 2), (2400, 3, 1), (3200, 2, 1), (600, 9, 2), (768, 5, 2), (1500, 5, 2), (3000, 3, 2), (3072, 2, 1), (6000, 2, 1),
                                           (7500, 2, 1)])
 def test_dec64_kernel_radix3_decimation(nfft, nchan, K):
     # N = 3 M: three scheduled sub-transforms side by side and one radix-3 combine through LDS (CfgD64::P)

@@ -77,6 +77,14 @@ CASES = [
     (1500, 1500, 9, "dpss", {"NW": 2, "Kmax": 3}, "pow", True, 0, True),
     (600, 600, 33, "hann", {}, "fourier", True, 0, False),
     (10000, 10000, 8, "dpss", {"NW": 3, "Kmax": 4}, "pow", False, 0, False),           # split exchanges, 20 values per thread
+    (100, 100, 70, "hann", {}, "pow", True, 0, False),                                 # sliding-window lengths 10 x 10, 3 x 100
+    (400, 400, 36, "hann", {}, "fourier", True, 0, False),                             # 20 values per thread: 400 ... 8000
+    (1100, 1200, 10, "dpss", {"NW": 2, "Kmax": 3}, "pow", False, 1, True),
+    (1600, 1600, 8, "dpss", {"NW": 3, "Kmax": 5}, "fourier", False, 0, False),
+    (3200, 3200, 5, "dpss", {"NW": 2, "Kmax": 2}, "abs", True, None, False),
+    (4800, 4800, 4, "dpss", {"NW": 2, "Kmax": 3}, "pow", False, 0, False),
+    (8000, 8000, 7, "hann", {}, "fourier", True, 0, False),
+    (280, 300, 33, "dpss", {"NW": 2, "Kmax": 3}, "fourier", True, 1, False),
     (768, 768, 12, "dpss", {"NW": 2, "Kmax": 3}, "fourier", True, 0, False),           # 3 x 256 ... 3 x 2048
     (1400, 1536, 6, "hann", {}, "pow", True, 1, False),
     (3072, 3072, 8, "dpss", {"NW": 4, "Kmax": 7}, "pow", False, 0, True),
@@ -522,7 +530,19 @@ def test_reference_precision_resolves_60dB(be):
                                   dict(nsig=700, nfft=768, K=3, output="fourier", keeptapers=True, detrend=0, nchan=9),
                                   dict(nsig=600, nfft=600, K=2, output="pow", keeptapers=True, detrend=0, nchan=17),
                                   dict(nsig=1536, nfft=1536, K=2, output="fourier", keeptapers=True, detrend=0, nchan=5),
-                                  dict(nsig=3072, nfft=3072, K=4, output="real", keeptapers=False, detrend=0, nchan=3)])
+                                  dict(nsig=3072, nfft=3072, K=4, output="real", keeptapers=False, detrend=0, nchan=3),
+                                  # sliding-window lengths and the other multiples of 100 (20 values per thread)
+                                  dict(nsig=100, nfft=100, K=2, output="fourier", keeptapers=True, detrend=0, nchan=37),
+                                  dict(nsig=300, nfft=300, K=2, output="pow", keeptapers=False, detrend=0, nchan=18),
+                                  dict(nsig=350, nfft=400, K=3, output="abs", keeptapers=True, detrend=1, nchan=9),
+                                  dict(nsig=800, nfft=800, K=2, output="abs", keeptapers=True, detrend=-1, nchan=5, demean=True),
+                                  dict(nsig=1200, nfft=1200, K=2, output="fourier", keeptapers=True, detrend=0, nchan=6),
+                                  dict(nsig=1600, nfft=1600, K=4, output="pow", keeptapers=False, detrend=0, nchan=4),
+                                  dict(nsig=2400, nfft=2400, K=2, output="fourier", keeptapers=False, detrend=0, nchan=3,
+                                       freq_idx=[0, 7, 1200, 800, 801]),
+                                  dict(nsig=3200, nfft=3200, K=3, output="fourier", keeptapers=True, detrend=0, nchan=3),
+                                  dict(nsig=4800, nfft=4800, K=2, output="pow", keeptapers=True, detrend=0, nchan=2),
+                                  dict(nsig=8000, nfft=8000, K=2, output="fourier", keeptapers=True, detrend=0, nchan=3)])
 def test_reference_precision_options(be, case):
     """Every option of the plan through the float64 kernel: padding, detrending modes, demean_taper, taper mean,
     conversions, frequency selection, odd channel counts - vs the oracle, which now agrees to complex64 rounding."""

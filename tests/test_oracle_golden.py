@@ -433,7 +433,7 @@ def test_superlet_variants(golden_dir, name):
     check_superlet(fa(data, **SLT_VARIANTS[name]), z, name)
 
 
-LENGTHS = (600, 768, 1500, 3000, 3072, 6000, 10000)
+LENGTHS = (100, 300, 400, 600, 768, 800, 1500, 2400, 3000, 3072, 4800, 6000, 8000, 10000)
 
 
 def lengths_cases(z, n):
