@@ -233,9 +233,10 @@ tfa("paul4_auto", method="wavelet", wavelet="Paul", order=4, toi="all", keeptria
 save("wavelet_families", **kw)
 
 # ---------------------------------------------------------------- trial lengths behind the round-4 radix schedules
-# (3 x a scheduled length through the radix-3 decimation, 10000 with split exchanges): mtmfft.py:80-129 takes any nSamples
+# (3 x a scheduled length through the radix-3 decimation, 10000 with split exchanges, 12000 = 6 x 2000 through HBM):
+# mtmfft.py:80-129 takes any nSamples
 kw = {}
-for n in (100, 300, 400, 600, 768, 800, 1500, 2400, 3000, 3072, 4800, 6000, 8000, 10000):
+for n in (100, 300, 400, 600, 768, 800, 1500, 2400, 3000, 3072, 4800, 6000, 8000, 10000, 12000):
     d = synthdata.ar2_network(nTrials=3, nSamples=n, AdjMat=np.zeros((4, 4)), seed=n)
     kw[f"n{n}_data"] = np.stack(trials_of(d))
     kw[f"n{n}_trialdefinition"] = d.trialdefinition

@@ -59,6 +59,11 @@ int dec_launch_j(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int
 int dec_launch_k(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_l(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_c2(hipStream_t stream, const MtmArgs& a, int nquads);
+// mtmfft_declong_{a,b}.hip: N = P M through HBM (mtmfft_declong.h)
+int declong_group(int M);
+int declong_launch_sub_a(hipStream_t stream, const LongArgs& a, int M, int P, long long nblocks);
+int declong_launch_sub_b(hipStream_t stream, const LongArgs& a, int M, int P, long long nblocks);
+int declong_launch_post(hipStream_t stream, const LongArgs& a, int P, int M, int outk, bool mean);
 int pipe_launch(hipStream_t stream, const MtmArgs& a, int log2n, unsigned grid, int outk, bool mean);
 int pipe_max_tapers_demean();
 int mixed_launch(hipStream_t stream, const MtmArgs& a, const MixPlan& g, int threads, size_t lds, unsigned grid, int outk,
@@ -82,6 +87,7 @@ struct spyhip_fft_plan {
     bool blue = false;          // Bluestein on the packed power-of-two engine (nfft <= 4096, not a power of two)
     bool longp = false;         // Bluestein with four-step length-M transforms through HBM (mtmfft_long.h)
     bool long_direct = false;   // ... or, for power-of-two nfft, one plain four-step transform
+    int dl_P = 0, dl_M = 0;     // N = P M: scheduled sub-transforms of length M + one radix-P pass through HBM (mtmfft_declong.h)
     int l1 = 0, l2 = 0;         // M1 = 2^l1, M2 = 2^l2
     spy::DevBuf<float2> tw1, tw2, twM;
     spy::DevBuf<double> wsum, stats, stats_part;
@@ -277,6 +283,18 @@ int launch_generic(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
     return 0;
 }
 
+// N = P M with M a sub-transform length of mtmfft_declong.h (in order of preference: cost per point of the schedule,
+// then the fewest radix-P terms) and P in {2, 3, 4, 5, 6, 8}
+bool declong_split(int nfft, int* P, int* M) {
+    static const int subs[] = {4096, 2000, 5000, 4000, 10000, 8000};
+    for (int m : subs) {
+        if (nfft % m) continue;
+        const int q = nfft / m;
+        if (q == 2 || q == 3 || q == 4 || q == 5 || q == 6 || q == 8) { *P = q; *M = m; return true; }
+    }
+    return false;
+}
+
 // channel quads interleaved per workgroup of the packed kernel (256 threads up to N = 4096)
 int default_G(int log2n) {
     switch (log2n) {
@@ -424,6 +442,22 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
             p->tw.upload(twiddle_table(M), ctx->stream)) { delete p; return -2; }
         char buf[128];
         std::snprintf(buf, sizeof buf, "mtmfft_blue_kernel<%d, %d, %s>", p->log2n, p->G, mode);
+        p->kernel_name = buf;
+    } else if (nfft > 10240 && !std::getenv("SPYHIP_FORCE_GENERIC") && !std::getenv("SPYHIP_NO_DECLONG") &&
+               declong_split(nfft, &p->dl_P, &p->dl_M)) {
+        // longer than one workgroup's LDS, N = P M with M a scheduled length: decimation in time through HBM
+        std::vector<double> ws((size_t)2 * ntaper);
+        const double mid = 0.5 * (nsig - 1);
+        for (int k = 0; k < ntaper; ++k) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int n = 0; n < nsig; ++n) { const double w = tf[(size_t)k * nsig + n]; s0 += w; s1 += w * (n - mid); }
+            ws[2 * k] = s0;
+            ws[2 * k + 1] = s1;
+        }
+        if (p->tw1.upload(twiddle_table(p->dl_M), ctx->stream) || p->tw2.upload(twiddle_table(p->dl_P), ctx->stream) ||
+            p->twM.upload(twiddle_table(nfft), ctx->stream) || p->wsum.upload(ws, ctx->stream)) { delete p; return -2; }
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "declong<%d x %d, %s>", p->dl_P, p->dl_M, mode);
         p->kernel_name = buf;
     } else if (nfft <= (1 << 19) && !std::getenv("SPYHIP_FORCE_GENERIC") &&
                !(nfft <= 10240 && [&] { int r[spyfft::GEN_MAXFAC], nf2 = 0; return factorize(nfft, r, &nf2); }() &&
@@ -792,6 +826,58 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         const bool mean = !p->keeptapers;
         const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
         return spyfft::mixed_launch(p->ctx->stream, a, p->mix, p->mix_threads, p->lds_bytes, (unsigned)grid, outk, mean);
+    }
+    if (p->dl_P) {
+        spyfft::LongArgs L{};
+        a.nfft = p->nfft;
+        L.m = a;
+        L.M1 = p->nfft; L.M2 = 1;                  // long_post_kernel: natural-order spectrum of length N
+        L.tw1 = p->tw1.p; L.tw2 = p->tw2.p; L.twM = p->twM.p;
+        L.wsum = p->wsum.p;
+        L.direct = 0;
+        L.nquad = (p->nchan + 3) / 4;
+        const size_t N = (size_t)p->nfft;
+        const size_t nstat = (size_t)nseg * p->nchan * (2 + p->ntaper);
+        const int nz = p->demean_taper ? p->ntaper + 1 : 1;
+        if (nstat > p->stats_cap) {
+            if (p->stats.p) { (void)hipFree(p->stats.p); p->stats.p = nullptr; }
+            if (p->stats_part.p) { (void)hipFree(p->stats_part.p); p->stats_part.p = nullptr; }
+            if (p->stats.alloc(nstat) ||
+                p->stats_part.alloc((size_t)nseg * (p->ntaper + 1) * spyfft::LONG_SPLITS * p->nchan * 2)) return -2;
+            p->stats_cap = nstat;
+        }
+        L.stats = p->stats.p;
+        if (p->detrend >= 0 || p->demean_taper) {
+            if (nseg > 65535 || nz * spyfft::LONG_SPLITS > 65535) { spy::set_error("fft_exec: too many segments / tapers per call"); return -1; }
+            hipLaunchKernelGGL(spyfft::long_stats_kernel, dim3((p->nchan + 63) / 64, nseg, nz * spyfft::LONG_SPLITS),
+                               dim3(256), 0, p->ctx->stream, a, p->stats_part.p, nz);
+            hipLaunchKernelGGL(spyfft::long_stats_final_kernel, dim3((unsigned)(((size_t)nseg * p->nchan + 255) / 256)), dim3(256),
+                               0, p->ctx->stream, a, p->stats_part.p, nz, p->stats.p);
+            SPY_HIP_CHECK(hipGetLastError());
+        }
+        const size_t per_seg = (size_t)L.nquad * p->ntaper * N;          // float4 elements
+        size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nseg, (((size_t)2 << 30) / sizeof(float4)) / std::max<size_t>(per_seg, 1)));
+        if (chunk * per_seg > p->scratch_cap) {
+            if (p->scratch.p) { (void)hipFree(p->scratch.p); p->scratch.p = nullptr; }
+            if (p->scratch.alloc(chunk * per_seg)) return -2;
+            p->scratch_cap = chunk * per_seg;
+        }
+        L.scratch = p->scratch.p;
+        const bool mean = !p->keeptapers;
+        const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+        const int G = spyfft::declong_group(p->dl_M);
+        const long long ngrp = (L.nquad + G - 1) / G;
+        for (int s0 = 0; s0 < nseg; s0 += (int)chunk) {
+            L.seg0 = s0;
+            L.nsegc = std::min<int>((int)chunk, nseg - s0);
+            const long long nblocks = (long long)L.nsegc * p->dl_P * ngrp;
+            int rc = spyfft::declong_launch_sub_a(p->ctx->stream, L, p->dl_M, p->dl_P, nblocks);
+            if (rc == -100) rc = spyfft::declong_launch_sub_b(p->ctx->stream, L, p->dl_M, p->dl_P, nblocks);
+            if (rc == -100) { spy::set_error("fft_exec: no sub-transform of length %d", p->dl_M); rc = -1; }
+            if (!rc) rc = spyfft::declong_launch_post(p->ctx->stream, L, p->dl_P, p->dl_M, outk, mean);
+            if (rc) return rc;
+        }
+        return 0;
     }
     if (p->longp) {
         spyfft::LongArgs L{};

@@ -1,0 +1,27 @@
+// declong_sub_kernel instances (mtmfft_declong.h): sub-transform lengths 4000, 8000, 10000 (20 values per thread)
+#include "spy_common.h"
+#include "mtmfft_declong.h"
+
+namespace spyfft {
+
+template <class C>
+static int declong_sub(hipStream_t stream, const LongArgs& a, int P, long long nblocks) {
+    if (nblocks > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", nblocks); return -1; }
+    auto kern = declong_sub_kernel<C>;
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(C::NTHREADS), C::LDS_BYTES, stream, a, P);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int declong_launch_sub_b(hipStream_t stream, const LongArgs& a, int M, int P, long long nblocks) {
+    switch (M) {
+        case 4000: return declong_sub<CfgD<20, 20, 10, 1, 1>>(stream, a, P, nblocks);
+        case 8000: return declong_sub<CfgD<20, 20, 20, 1, 1>>(stream, a, P, nblocks);
+        case 10000: return declong_sub<CfgD<20, 20, 5, 5, 1, 1, true>>(stream, a, P, nblocks);
+        default: return -100;
+    }
+}
+
+}  // namespace spyfft
