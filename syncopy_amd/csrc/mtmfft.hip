@@ -847,7 +847,8 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             p->stats_cap = nstat;
         }
         L.stats = p->stats.p;
-        if (p->detrend >= 0 || p->demean_taper) {
+        // (constant detrending with the reference-order means of seq_mean_kernel needs no sums of its own)
+        if ((p->detrend >= 0 && !(p->detrend == 0 && a.means)) || p->demean_taper) {
             if (nseg > 65535 || nz * spyfft::LONG_SPLITS > 65535) { spy::set_error("fft_exec: too many segments / tapers per call"); return -1; }
             hipLaunchKernelGGL(spyfft::long_stats_kernel, dim3((p->nchan + 63) / 64, nseg, nz * spyfft::LONG_SPLITS),
                                dim3(256), 0, p->ctx->stream, a, p->stats_part.p, nz);
@@ -899,7 +900,8 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             p->stats_cap = nstat;
         }
         L.stats = p->stats.p;
-        if (p->detrend >= 0 || p->demean_taper) {
+        // (constant detrending with the reference-order means of seq_mean_kernel needs no sums of its own)
+        if ((p->detrend >= 0 && !(p->detrend == 0 && a.means)) || p->demean_taper) {
             if (nseg > 65535 || nz * spyfft::LONG_SPLITS > 65535) { spy::set_error("fft_exec: too many segments / tapers per call"); return -1; }
             hipLaunchKernelGGL(spyfft::long_stats_kernel, dim3((p->nchan + 63) / 64, nseg, nz * spyfft::LONG_SPLITS),
                                dim3(256), 0, p->ctx->stream, a, p->stats_part.p, nz);
