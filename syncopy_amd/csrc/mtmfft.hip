@@ -44,6 +44,22 @@ int dec64_launch_k(hipStream_t stream, const F64Args& a, int nfft, int npairs, i
 int dec64_launch_l(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_m(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_n(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+struct Long64Args {           // mtmfft_declong64.h (kept out of this translation unit, as F64Args)
+    MtmArgs m;
+    const double* tapers64;
+    const double2* twM;
+    const double2* twN;
+    const double2* twP;
+    double2* scratch;
+    const double* stats;
+    const double* wsum;
+    int seg0, nsegc;
+    int npair;
+};
+int declong64_group(int M);
+int declong64_launch_sub_a(hipStream_t stream, const Long64Args& a, int M, int P, long long nblocks);
+int declong64_launch_sub_b(hipStream_t stream, const Long64Args& a, int M, int P, long long nblocks);
+int declong64_launch_post(hipStream_t stream, const Long64Args& a, int P, int M, int outk, bool mean);
 int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean);
 int f64_any_launch(hipStream_t stream, F64Args a, long long grid, long long chunk, int outk, bool mean);
 int dec_launch_a(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
@@ -106,6 +122,9 @@ struct spyhip_fft_plan {
     bool f64_any = false;       // ... through the any-length kernel (work arrays in global memory)
     bool f64_dec = false;       // ... through the compile-time-schedule kernel (mtmfft_dec64_kernel.h)
     int f64_blue = 0;           // any-length kernel in its Bluestein form: the length M = 2^m >= 2 nfft - 1
+    bool f64_dl = false;        // ... N = dl_P x dl_M through HBM (mtmfft_declong64.h)
+    spy::DevBuf<double2> tw64_sub, tw64_P, scratch64;
+    size_t scratch64_cap = 0;
     spy::DevBuf<double2> chirp64, bhat64;
     spywil::PlusPlan f64_plan{};
     spy::DevBuf<double2> f64_work;
@@ -588,7 +607,19 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
     p->f64_dec = false;
     for (int n : dec64_lengths) p->f64_dec = p->f64_dec || (n == p->nfft);
     if (std::getenv("SPYHIP_F64_OLD")) p->f64_dec = false;           // A/B runs against the generic kernels
-    p->f64_any = !p->f64_dec && !(p->pow2 && p->log2n >= 8 && p->log2n <= 12);
+    p->f64_dl = !p->f64_dec && p->dl_P > 0 && !std::getenv("SPYHIP_NO_DECLONG64") && !std::getenv("SPYHIP_F64_OLD");
+    p->f64_any = !p->f64_dec && !p->f64_dl && !(p->pow2 && p->log2n >= 8 && p->log2n <= 12);
+    if (p->f64_dl && !p->tw64_sub.p) {
+        auto table = [](int n) {
+            std::vector<double2> t(n);
+            for (int m = 0; m < n; ++m) {
+                const double ang = -2.0 * PI * (double)m / (double)n;
+                t[m] = make_double2(std::cos(ang), std::sin(ang));
+            }
+            return t;
+        };
+        if (p->tw64_sub.upload(table(p->dl_M), p->ctx->stream) || p->tw64_P.upload(table(p->dl_P), p->ctx->stream)) return -2;
+    }
     p->f64_blue = 0;
     int twlen = p->nfft;
     if (p->f64_any) {
@@ -639,7 +670,10 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
     if (!p->precision64) p->fp32_kernel_name = p->kernel_name;
     p->precision64 = true;
     char buf[128];
-    if (p->f64_dec)
+    if (p->f64_dl)
+        std::snprintf(buf, sizeof buf, "declong64_kernel<%d x %d, %d, %s>", p->dl_P, p->dl_M,
+                      p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
+    else if (p->f64_dec)
         std::snprintf(buf, sizeof buf, "mtmfft_dec64_kernel<N = %d, %d, %s>", p->nfft,
                       p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
     else if (p->f64_blue)
@@ -716,6 +750,58 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         fa.scale64 = (double)p->scale;
         const long long grid = (long long)nseg * npairs;
         const int outk64 = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+        if (p->f64_dl) {
+            // N = P M through HBM (mtmfft_declong64.h); trend and post-taper mean from the float64 sums of long_stats_kernel.
+            // (float64 segments of padded sliding windows, seg_f64, are treated as float32 trials here: the nuance is one
+            // rounding of the trend and such windows are not this long)
+            spyfft::Long64Args L{};
+            a.nfft = p->nfft;
+            L.m = a;
+            L.tapers64 = p->tapers64.p;
+            L.twM = p->tw64_sub.p; L.twN = p->tw64.p; L.twP = p->tw64_P.p;
+            L.wsum = p->wsum.p;
+            L.npair = npairs;
+            const size_t N = (size_t)p->nfft;
+            const size_t nstat = (size_t)nseg * p->nchan * (2 + p->ntaper);
+            const int nz = p->demean_taper ? p->ntaper + 1 : 1;
+            if (nstat > p->stats_cap) {
+                if (p->stats.p) { (void)hipFree(p->stats.p); p->stats.p = nullptr; }
+                if (p->stats_part.p) { (void)hipFree(p->stats_part.p); p->stats_part.p = nullptr; }
+                if (p->stats.alloc(nstat) ||
+                    p->stats_part.alloc((size_t)nseg * (p->ntaper + 1) * spyfft::LONG_SPLITS * p->nchan * 2)) return -2;
+                p->stats_cap = nstat;
+            }
+            L.stats = p->stats.p;
+            if ((p->detrend >= 0 && !(p->detrend == 0 && a.means)) || p->demean_taper) {
+                if (nseg > 65535 || nz * spyfft::LONG_SPLITS > 65535) { spy::set_error("fft_exec: too many segments / tapers per call"); return -1; }
+                hipLaunchKernelGGL(spyfft::long_stats_kernel, dim3((p->nchan + 63) / 64, nseg, nz * spyfft::LONG_SPLITS),
+                                   dim3(256), 0, p->ctx->stream, a, p->stats_part.p, nz);
+                hipLaunchKernelGGL(spyfft::long_stats_final_kernel, dim3((unsigned)(((size_t)nseg * p->nchan + 255) / 256)), dim3(256),
+                                   0, p->ctx->stream, a, p->stats_part.p, nz, p->stats.p);
+                SPY_HIP_CHECK(hipGetLastError());
+            }
+            const size_t per_seg = (size_t)npairs * p->ntaper * N;           // double2 elements
+            size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nseg, (((size_t)2 << 30) / sizeof(double2)) / std::max<size_t>(per_seg, 1)));
+            if (chunk * per_seg > p->scratch64_cap) {
+                if (p->scratch64.p) { (void)hipFree(p->scratch64.p); p->scratch64.p = nullptr; }
+                if (p->scratch64.alloc(chunk * per_seg)) return -2;
+                p->scratch64_cap = chunk * per_seg;
+            }
+            L.scratch = p->scratch64.p;
+            const int G = spyfft::declong64_group(p->dl_M);
+            const long long ngrp = (npairs + G - 1) / G;
+            for (int s0 = 0; s0 < nseg; s0 += (int)chunk) {
+                L.seg0 = s0;
+                L.nsegc = std::min<int>((int)chunk, nseg - s0);
+                const long long nblocks = (long long)L.nsegc * p->dl_P * ngrp;
+                int rc = spyfft::declong64_launch_sub_a(p->ctx->stream, L, p->dl_M, p->dl_P, nblocks);
+                if (rc == -100) rc = spyfft::declong64_launch_sub_b(p->ctx->stream, L, p->dl_M, p->dl_P, nblocks);
+                if (rc == -100) { spy::set_error("fft_exec: no float64 sub-transform of length %d", p->dl_M); rc = -1; }
+                if (!rc) rc = spyfft::declong64_launch_post(p->ctx->stream, L, p->dl_P, p->dl_M, outk64, !p->keeptapers);
+                if (rc) return rc;
+            }
+            return 0;
+        }
         if (p->f64_dec) {
             int rc;
             if ((rc = spyfft::dec64_launch_a(p->ctx->stream, fa, p->nfft, npairs, outk64, !p->keeptapers)) != -100) return rc;

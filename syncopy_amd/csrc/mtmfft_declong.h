@@ -127,18 +127,19 @@ __global__ void __launch_bounds__((C::NTHREADS)) declong_sub_kernel(LongArgs a, 
     }
 }
 
-// bin k + M q of the length-N transform from the P twiddled sub-transforms of one (item): sum_r w_P^(r q) F_r[k]
+// bin k + M q of the length-N transform from the P twiddled sub-transforms of one (item): sum_r w_P^(r q) F_r[k].  q is a
+// constant of an unrolled loop at every call: (r q) mod P folds, and the factors 1, -1, -i, +i cost no multiplication
 template <int P>
 __device__ __forceinline__ C2 declong_bin(const C2 (&g)[P], const float2 (&wp)[P], int q) {
     C2 s = g[0];
 #pragma unroll
     for (int r = 1; r < P; ++r) {
-        // (r q) mod P with q known only at run time in the k = 0 thread: a select chain over the P table entries
         const int t = (r * q) % P;
-        float2 w = wp[0];
-#pragma unroll
-        for (int u = 1; u < P; ++u) w = (t == u) ? wp[u] : w;
-        s = cadd(s, cmul_s(g[r], w));
+        if (t == 0) s = cadd(s, g[r]);
+        else if (2 * t == P) s = C2{s.r - g[r].r, s.i - g[r].i};
+        else if (4 * t == P) s = C2{s.r + g[r].i, s.i - g[r].r};           // w = -i
+        else if (4 * t == 3 * P) s = C2{s.r - g[r].i, s.i + g[r].r};       // w = +i
+        else s = cadd(s, cmul_s(g[r], wp[t]));
     }
     return s;
 }
@@ -184,7 +185,10 @@ __global__ void __launch_bounds__(256) declong_post_kernel(LongArgs a, int M) {
             const int fi = m.fpos ? m.fpos[f] : f;
             if (fi < 0) continue;
             const C2 z = declong_bin<P>(ga, wp, q);
-            const C2 zp = declong_bin<P>(gb, wp, kk == 0 ? (P - q) % P : P - 1 - q);
+            // partner N - f = (M - k) + M (P - 1 - q); in the k = 0 thread M (P - q)  (a branch: both indices stay constants)
+            C2 zp;
+            if (kk == 0) zp = declong_bin<P>(gb, wp, (P - q) % P);
+            else zp = declong_bin<P>(gb, wp, P - 1 - q);
             C2 xa, xb;
             xa.r = (z.r + zp.r) * hs;
             xa.i = (z.i - zp.i) * hs;

@@ -552,7 +552,17 @@ def test_reference_precision_resolves_60dB(be):
                                        freq_idx=[0, 7, 1200, 800, 801]),
                                   dict(nsig=3200, nfft=3200, K=3, output="fourier", keeptapers=True, detrend=0, nchan=3),
                                   dict(nsig=4800, nfft=4800, K=2, output="pow", keeptapers=True, detrend=0, nchan=2),
-                                  dict(nsig=8000, nfft=8000, K=2, output="fourier", keeptapers=True, detrend=0, nchan=3)])
+                                  dict(nsig=8000, nfft=8000, K=2, output="fourier", keeptapers=True, detrend=0, nchan=3),
+                                  # beyond one workgroup's LDS: N = P M through HBM (mtmfft_declong64.h)
+                                  dict(nsig=12000, nfft=12000, K=3, output="fourier", keeptapers=True, detrend=0, nchan=5),
+                                  dict(nsig=15000, nfft=15000, K=3, output="pow", keeptapers=False, detrend=1, nchan=4),
+                                  dict(nsig=14000, nfft=16000, K=2, output="fourier", keeptapers=False, detrend=0, nchan=3,
+                                       freq_idx=[0, 5, 7998, 2000, 2001, 7999]),      # (bins M q: the k = 0 thread)
+                                  dict(nsig=20000, nfft=20000, K=2, output="abs", keeptapers=True, detrend=-1, nchan=3,
+                                       demean=True),
+                                  dict(nsig=12288, nfft=12288, K=2, output="fourier", keeptapers=True, detrend=0, nchan=2),
+                                  dict(nsig=24000, nfft=24000, K=2, output="fourier", keeptapers=True, detrend=0, nchan=2),
+                                  dict(nsig=50000, nfft=50000, K=1, output="fourier", keeptapers=True, detrend=-1, nchan=1)])
 def test_reference_precision_options(be, case):
     """Every option of the plan through the float64 kernel: padding, detrending modes, demean_taper, taper mean,
     conversions, frequency selection, odd channel counts - vs the oracle, which now agrees to complex64 rounding."""
