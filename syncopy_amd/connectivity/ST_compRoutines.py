@@ -287,7 +287,7 @@ class CrossSpectra(ComputationalRoutine):
             ratio, K = 0.0, 1
             with hs.precision("float32"):
                 for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
-                                                     cfg["demean_taper"], False, pr, None, "fourier", True, reuse=True,
+                                                     cfg["demean_taper"], False, pr, None, "pow", True, reuse=True,
                                                      upload=upload):
                     ratio = max(ratio, hs.dynamic_range(spec, kept=freq_idx))        # whole axis: see hs.dynamic_range
                     K = spec.shape[1]

@@ -100,19 +100,25 @@ def plan_precision():
 def dynamic_range(spec, kept=None):
     """How far the weakest part of a channel's KEPT spectrum sits below its mean power, judged on tapered spectra
     (B, K, F, C) complex64 of a few trials over the WHOLE frequency axis: max over channels of mean_f P / q_2%(P[kept])
-    with P = the trial- and taper-averaged power.  The mean runs over every bin - an offset nobody removed or a line
+    with P = the trial- and taper-averaged power (`spec`: the power spectra of every taper, or complex spectra).  The mean runs over every bin - an offset nobody removed or a line
     outside the kept band raises the float32 transform's error in the kept bins just the same; the two kept bins next
     to DC are left out of the quantile (they belong to the detrending).  A low percentile, not the minimum: one empty
     bin (a notch, the Nyquist bin of an even filter) is not what the spectrum is like."""
-    p = spec.abs().square().mean(dim=(0, 1))
-    num = p.mean(dim=0)
+    from .. import backend
+    if spec.is_complex():
+        spec = spec.abs().square()
+    # power spectra (B, K, F, C) float32: the mean over trials and tapers with the library's own reduction, the rest on
+    # the host on 2 MB (no torch kernels: the first use of each costs 0.1-0.4 s of code-object loading in a fresh process)
+    F, C = spec.shape[-2], spec.shape[-1]
+    p = backend.trial_mean(spec.reshape(-1, F, C).contiguous()).cpu().numpy().astype(np.float64)
+    num = p.mean(axis=0)
     if kept is not None:
         kept = np.asarray(kept)
         kept = kept[kept >= 2] if (kept >= 2).sum() >= 4 else kept
-        p = p.index_select(0, torch.as_tensor(kept, device=p.device))
+        p = p[kept]
     elif p.shape[0] >= 6:
         p = p[2:]
-    q = torch.quantile(p.float(), 0.02, dim=0).clamp_min(1e-38)
+    q = np.maximum(np.quantile(p, 0.02, axis=0), 1e-38)
     return float((num / q).max())
 
 
