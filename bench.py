@@ -334,9 +334,10 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
                     "bound_us_per_trial": flop / (PEAK_F64_TFLOPS * 1e12) * 1e6,
                     "frac": flop / (PEAK_F64_TFLOPS * 1e12) / (1e-3 * ms64 / T), **_traffic("c2f64", byt)})
     del buf, plan
-    # ---- c2 at trial lengths that are not powers of two (1 kHz x 2 / 3 / 5 / 10 s; BASELINE configs[0] is N = 2000):
-    # the compile-time schedules K1d (3000 = 3 x 1000 through the radix-3 decimation, 10000 with split exchanges)
-    for N2 in (2000, 3000, 5000, 10000):
+    # ---- c2 at trial lengths that are not powers of two (1 kHz x 2 / 3 / 5 / 10 / 12 s; BASELINE configs[0] is N = 2000):
+    # the compile-time schedules K1d (3000 = 3 x 1000 through the radix-3 decimation, 10000 with split exchanges) and,
+    # beyond one workgroup's LDS, K1L2 (12000 = 6 x 2000 through HBM)
+    for N2 in (2000, 3000, 5000, 10000, 12000):
         T2 = 200
         d2 = synthdata.ar2_uncoupled_fast(C, N2, T2, seed=78)
         tp2 = windows.dpss(N2, 1.0 * N2 / 1000.0, K) * np.sqrt(N2)
