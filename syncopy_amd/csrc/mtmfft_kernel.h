@@ -63,7 +63,7 @@ struct MtmArgs {
 // accumulator per channel that takes the samples in time order, then one float32 division by the sample count.
 // That rounding sequence cannot be re-associated, and for channels with an offset its error (~1e-6 of the offset)
 // is what the bins next to DC are made of - so it is reproduced literally: one thread per (segment, channel), a
-// serial chain of v_add_f32 over the rows (loads batched 16 rows ahead; lanes = adjacent channels: coalesced).
+// serial chain of v_add_f32 over the rows (loads batched 64 rows ahead; lanes = adjacent channels: coalesced).
 // Rows outside [seg_lo, seg_hi) count as +0 and leave the sum as it is.
 //
 // ONE channel is the exception: the reference's trial is then an (nSamples, 1) array, contiguous along the axis that is
@@ -111,6 +111,16 @@ static __global__ void __launch_bounds__(256) seq_mean_kernel(MtmArgs a, float* 
     const float* p = a.data + (start + rlo) * a.ld + col;
     float s = 0.f;
     int n = rlo;
+    // 64 rows in flight per thread: with few (segment, channel) threads - a handful of long trials - the chain waits on
+    // memory latency, not on the 64 dependent additions
+    for (; n + 64 <= rhi; n += 64) {
+        float t[64];
+#pragma unroll
+        for (int e = 0; e < 64; ++e) t[e] = p[(long long)e * a.ld];
+#pragma unroll
+        for (int e = 0; e < 64; ++e) s = __fadd_rn(s, t[e]);
+        p += 64 * a.ld;
+    }
     for (; n + 16 <= rhi; n += 16) {
         float t[16];
 #pragma unroll
