@@ -172,13 +172,30 @@ class MultiTaperFFTConvol(ComputationalRoutine):
         cfg = self.cfg
         dev = data.device_data()
         rows, chans = trial_rows(data), selected_channels(data)
-        parts = []
-        for k in self.my_trials():
-            a, b = rows[k]
-            soi, postselect = self._argv(k)
-            parts.append(_mtmconvol_device(dev, a, b - a, soi, postselect, cfg["equidistant"], cfg["toi"], cfg["foi"],
-                                           cfg["keeptapers"], cfg["polyremoval"], cfg["output"],
-                                           cfg["method_kwargs"], chans))
+        mine = list(self.my_trials())
+        if cfg["equidistant"] and mine:
+            # every trial's frames in one launch (the frames of 200 trials x 64 windows are 12800 segments of one plan;
+            # trial by trial the call is 12 x slower than its kernels): stft.py:16-159 / mtmconvol.py:120-150
+            mk = cfg["method_kwargs"]
+            nperseg, noverlap = mk["nperseg"], mk["noverlap"]
+            _, fidx = best_match(np.fft.rfftfreq(nperseg, 1 / mk["samplerate"]), cfg["foi"], squash_duplicates=True)
+            boundary, trials = True, []
+            for k in mine:
+                a, b = rows[k]
+                soi, postselect = self._argv(k)
+                s0, s1, _ = soi.indices(b - a)
+                nTime, boundary = _stft_geometry(s1 - s0, nperseg, noverlap, isinstance(cfg["toi"], np.ndarray))
+                trials.append((a, s0, s1, _frame_ids(max(nTime, 0), postselect)))
+            parts = hs.run_stft_trials(dev, trials, nperseg, nperseg - noverlap, boundary, chans, mk["taper"], mk["taper_opt"],
+                                       cfg["polyremoval"], fidx, cfg["output"], cfg["keeptapers"])
+        else:
+            parts = []
+            for k in mine:
+                a, b = rows[k]
+                soi, postselect = self._argv(k)
+                parts.append(_mtmconvol_device(dev, a, b - a, soi, postselect, cfg["equidistant"], cfg["toi"], cfg["foi"],
+                                               cfg["keeptapers"], cfg["polyremoval"], cfg["output"],
+                                               cfg["method_kwargs"], chans))
         _store_trials(self, out, parts)
 
     def process_metadata(self, data, out):
@@ -441,7 +458,15 @@ def _store_trials(cr, out, parts, stack=False):
         out.data = parallel.gather_trials(local).reshape(cr.outputShape)
         return
     if parts:
-        stacked = torch.stack(parts, dim=0).contiguous()
+        # (results that are consecutive pieces of one device array - trials batched into one launch - are not copied)
+        p0, nb = parts[0], parts[0].numel() * parts[0].element_size()
+        if (len(parts) > 1 and p0.is_contiguous() and p0._base is not None and p0._base.is_contiguous() and
+                all(q._base is p0._base and q.shape == p0.shape and q.data_ptr() == p0.data_ptr() + i * nb
+                    for i, q in enumerate(parts))):
+            first = (p0.data_ptr() - p0._base.data_ptr()) // nb
+            stacked = p0._base.reshape((-1,) + tuple(p0.shape))[first:first + len(parts)]
+        else:
+            stacked = torch.stack(parts, dim=0).contiguous()
         n = stacked.shape[0]
         if stacked.dtype == torch.float32:
             total = hs.backend.trial_mean(stacked) * n

@@ -230,6 +230,42 @@ def run_stft(dev_data, row0, soi_start, soi_stop, frames, nperseg, step, boundar
     return plan.execute(dev_data, starts, lo, hi, chan_idx=ci)
 
 
+def run_stft_trials(dev_data, trials, nperseg, step, boundary, chan_idx, taper, taper_opt, polyremoval, freq_idx, output,
+                    keeptapers, max_bytes=8 << 30):
+    """run_stft for MANY trials in as few launches as `max_bytes` of spectra allow: trials = [(row0, soi_start, soi_stop,
+    frames)]; returns one device tensor (n_frames, Kout, F, C) per trial (views of the batches)."""
+    device = dev_data.device
+    nchan = dev_data.shape[1] if chan_idx is None else len(chan_idx)
+    ci = None if chan_idx is None else torch.tensor(np.asarray(chan_idx), dtype=torch.int32, device=device)
+    opt = dict(taper_opt or {})
+    if taper == "dpss":
+        opt["sym"] = False          # mtmconvol.py:110-111
+    plan = get_plan(nperseg, nperseg, nchan, taper, opt, nperseg, np.sqrt(2) / nperseg, polyremoval, False,
+                    full_freq_idx(freq_idx, nperseg), output, keeptapers, device, whole_trials=False,
+                    float32_frames=not boundary)
+    lead = nperseg // 2 if boundary else 0
+    per_frame = int(np.prod(plan.out_shape(1))) * (8 if plan.kind == 2 else 4)
+    fmax = max(1, int(max_bytes // per_frame))
+    out, k = [None] * len(trials), 0
+    while k < len(trials):
+        k1, nfr = k, 0
+        while k1 < len(trials) and (k1 == k or nfr + len(trials[k1][3]) <= fmax):
+            nfr += len(trials[k1][3])
+            k1 += 1
+        st = np.concatenate([r0 + a + np.asarray(fr, dtype=np.int64) * step - lead for r0, a, _, fr in trials[k:k1]])
+        lo = np.concatenate([np.full(len(fr), r0 + a, dtype=np.int64) for r0, a, _, fr in trials[k:k1]])
+        hi = np.concatenate([np.full(len(fr), r0 + b, dtype=np.int64) for r0, _, b, fr in trials[k:k1]])
+        res = plan.execute(dev_data, torch.from_numpy(st).to(device), torch.from_numpy(lo).to(device),
+                           torch.from_numpy(hi).to(device), chan_idx=ci)
+        off = 0
+        for i in range(k, k1):
+            n = len(trials[i][3])
+            out[i] = res[off:off + n]
+            off += n
+        k = k1
+    return out
+
+
 def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_taper, ft_compat, polyremoval,
                        freq_idx, output, keeptapers, max_bytes=32 << 30, blocked=False, reuse=False, upload=None):
     """Generator over (trial indices, (B, Kout, F, C) device tensor) batches: trials of equal length share a
