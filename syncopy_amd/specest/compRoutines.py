@@ -196,6 +196,13 @@ class MultiTaperFFTConvol(ComputationalRoutine):
                 parts.append(_mtmconvol_device(dev, a, b - a, soi, postselect, cfg["equidistant"], cfg["toi"], cfg["foi"],
                                                cfg["keeptapers"], cfg["polyremoval"], cfg["output"],
                                                cfg["method_kwargs"], chans))
+        if getattr(self, "reduce_time", False) and self.keeptrials and parts and not parallel.collective_active():
+            # method="welch": the time mean of every trial (freqanalysis.py:1054-1056) taken on the device in NumPy's
+            # order (spyhip_axis_nanmean) - the windowed spectra themselves reach the host only if somebody reads them
+            self.time_means = hs.backend.to_host(torch.cat([hs.backend.axis_nanmean(p.contiguous(), 0) for p in parts], dim=0))
+            out.set_pending(lambda: hs.backend.to_host(torch.cat(parts, dim=0)).reshape(self.outputShape), self.outputShape,
+                            self.dtype)
+            return
         _store_trials(self, out, parts)
 
     def process_metadata(self, data, out):

@@ -264,9 +264,11 @@ def _freqanalysis(data, classes, timeAxis, method, output, keeptrials, foi, foil
         if (hs.requested_precision() is None and compute_method in (None, "hip") and hasattr(cr, "compute_hip")
                 and method in ("mtmfft", "mtmconvol", "welch") and _selection_hides_peak(data, cr, method, foi, freqs)):
             stack.enter_context(hs.soft_reference())      # precision="auto": kept bins far below the spectrum's peak
+        if method == "welch":
+            cr.reduce_time = True
         cr.compute(data, out, parallel=False, log_dict=log_dct, method=compute_method)
     if method == "welch":
-        out = _time_mean(out)
+        out = _time_mean(out, getattr(cr, "time_means", None))
     return out
 
 
@@ -356,15 +358,16 @@ def _int_like(val, name, lo, hi):
         raise SPYValueError(f"value to be greater or equals {lo} and less or equals {hi}", varname=name, actual=val)
 
 
-def _time_mean(spec):
+def _time_mean(spec, rows=None):
     """`spy.mean(spec, dim="time")` as freqanalysis.py:1054-1056 applies it for method='welch':
     np.nanmean over the time axis of every trial (statistics/compRoutines.py:36-57, float32 in, float32 out);
     each trial keeps ONE stacked sample (trialdefinition [[k, k+1, 0]], statistics/compRoutines.py:98-117)."""
     td = np.asarray(spec.trialdefinition)
-    rows = [np.nanmean(spec.data[int(a):int(b)], axis=0, keepdims=True) for a, b in td[:, :2]]
+    if rows is None:                  # (`rows`: the same means taken on the device, MultiTaperFFTConvol.compute_hip)
+        rows = np.concatenate([np.nanmean(spec.data[int(a):int(b)], axis=0, keepdims=True) for a, b in td[:, :2]], axis=0)
     n = len(rows)
     k = np.arange(n, dtype=float)[:, None]
-    res = SpectralData(np.concatenate(rows, axis=0).astype(spec.data.dtype, copy=False), samplerate=spec.samplerate,
+    res = SpectralData(np.asarray(rows).astype(spec.data_dtype, copy=False), samplerate=spec.samplerate,
                        trialdefinition=np.hstack((k, k + 1, np.zeros((n, 1)))), dimord=spec.dimord)
     res.freq, res.taper, res.channel = spec.freq, spec.taper, spec.channel
     return res
