@@ -4,7 +4,7 @@
 //   declong_sub_kernel<C>   : (segment, quad) x r < P, tapers in a loop: the scheduled transform of x[P m + r] w_k[P m + r]
 //                             (polynomial removal / demean_taper from the statistics of long_stats_kernel, as long_cols_kernel),
 //                             times W_N^(r k), stored at scratch[item][r M + k]
-//   declong_post_kernel<P>  : per (segment, quad, k < M): the bins k + M q <= N / 2 and their partners from the P regions
+//   declong_post_kernel<P>  : per (segment, quad, k <= M / 2): the bins k + M q, (M - k) + M q <= N / 2 and their partners from the P regions
 //                             (Z[k + M q] = sum_r w_P^(r q) F_r[k]), channel separation, scale, conversion, taper mean, store
 //
 // Against the path this replaces for such lengths (Bluestein with three power-of-two four-step transforms of length
@@ -144,91 +144,111 @@ __device__ __forceinline__ C2 declong_bin(const C2 (&g)[P], const float2 (&wp)[P
     return s;
 }
 
-// ---- radix-P step + channel separation + scale + conversion + taper mean + store, one thread per (segment, quad, k < M):
-// the thread forms the bins f = k + M q <= N / 2 and their partners N - f = (M - k) + M (P - 1 - q) (k = 0: M (P - q)) straight
-// from the P regions of every taper's scratch - the spectrum is never written in natural order.
+// the output bins ko + M q <= N / 2 of one taper from the regions' values at ko (`own`) and at M - ko (`other`): radix-P step for
+// the bin and for its partner N - f = (M - ko) + M (P - 1 - q) (ko = 0: M (P - q), from `own`), channel separation, scale,
+// conversion, then the taper-mean accumulators or the store
 template <int P, int OUTK, bool MEAN>
-__global__ void __launch_bounds__(256) declong_post_kernel(LongArgs a, int M) {
+__device__ __forceinline__ void declong_emit(const MtmArgs& m, const C2 (&own)[P], const C2 (&other)[P], const float2 (&wp)[P],
+                                             int ko, int M, int b, int k, int c0, float2 (&acc)[P / 2 + 1][4]) {
     constexpr bool CPLX = (OUTK == 2);
-    constexpr int NQ = P / 2 + 1;                     // bins per thread: q <= (N / 2 - k) / M
-    const MtmArgs& m = a.m;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long tot = (long long)a.nsegc * a.nquad * M;
-    if (gid >= tot) return;
-    const int kk = (int)(gid % M);
-    const int q4 = (int)((gid / M) % a.nquad);
-    const int bl = (int)(gid / ((long long)M * a.nquad));
-    const int b = a.seg0 + bl, c0 = 4 * q4;
-    const int N = P * M, kb = kk == 0 ? 0 : M - kk;
+    constexpr int NQ = P / 2 + 1;
+    const int N = P * M;
     const float hs = 0.5f * m.scale;
     const int kout = MEAN ? 1 : m.ntaper;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int f = ko + M * q;
+        if (2 * f > N) break;
+        const int fi = m.fpos ? m.fpos[f] : f;
+        if (fi < 0) continue;
+        const C2 z = declong_bin<P>(own, wp, q);
+        C2 zp;                        // (a branch: both indices stay constants of the unrolled loop)
+        if (ko == 0) zp = declong_bin<P>(own, wp, (P - q) % P);
+        else zp = declong_bin<P>(other, wp, P - 1 - q);
+        C2 xa, xb;
+        xa.r = (z.r + zp.r) * hs;
+        xa.i = (z.i - zp.i) * hs;
+        xb.r = (z.i + zp.i) * hs;
+        xb.i = (zp.r - z.r) * hs;
+        const float2 X[4] = {make_float2(xa.r[0], xa.i[0]), make_float2(xa.r[1], xa.i[1]),
+                             make_float2(xb.r[0], xb.i[0]), make_float2(xb.r[1], xb.i[1])};
+        if (MEAN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (CPLX) acc[q][i] = cadd(acc[q][i], X[i]);
+                else acc[q][i].x += convert_real<OUTK>(X[i], m.out_kind);
+            }
+        } else {
+            const size_t o = (((size_t)b * kout + k) * m.nfsel + fi) * m.nchan + c0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c0 + i >= m.nchan) continue;
+                if (CPLX) reinterpret_cast<float2*>(m.out)[o + i] = X[i];
+                else reinterpret_cast<float*>(m.out)[o + i] = convert_real<OUTK>(X[i], m.out_kind);
+            }
+        }
+    }
+}
+
+template <int P, int OUTK>
+__device__ __forceinline__ void declong_store_mean(const MtmArgs& m, int ko, int M, int b, int c0, const float2 (&acc)[P / 2 + 1][4]) {
+    constexpr bool CPLX = (OUTK == 2);
+    const float nt = (float)m.ntaper;
+#pragma unroll
+    for (int q = 0; q < P / 2 + 1; ++q) {
+        const int f = ko + M * q;
+        if (2 * f > P * M) break;
+        const int fi = m.fpos ? m.fpos[f] : f;
+        if (fi < 0) continue;
+        const size_t o = ((size_t)b * m.nfsel + fi) * m.nchan + c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (c0 + i >= m.nchan) continue;
+            if (CPLX) reinterpret_cast<float2*>(m.out)[o + i] = make_float2(acc[q][i].x / nt, acc[q][i].y / nt);
+            else reinterpret_cast<float*>(m.out)[o + i] = acc[q][i].x / nt;
+        }
+    }
+}
+
+// ---- radix-P step + channel separation + scale + conversion + taper mean + store, one thread per (segment, quad, k <= M / 2):
+// the thread reads the P regions at k and at M - k ONCE per taper and forms the bins k + M q and (M - k) + M q that lie in
+// [0, N / 2] - each with its partner, which is a bin of the other index - the spectrum is never written in natural order.
+template <int P, int OUTK, bool MEAN>
+__global__ void __launch_bounds__(256) declong_post_kernel(LongArgs a, int M) {
+    constexpr int NQ = P / 2 + 1;                     // bins per index: q <= (N / 2 - k) / M
+    const MtmArgs& m = a.m;
+    const int Mh = M / 2 + 1;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tot = (long long)a.nsegc * a.nquad * Mh;
+    if (gid >= tot) return;
+    const int kk = (int)(gid % Mh);
+    const int q4 = (int)((gid / Mh) % a.nquad);
+    const int bl = (int)(gid / ((long long)Mh * a.nquad));
+    const int b = a.seg0 + bl, c0 = 4 * q4;
+    const int kb = kk == 0 ? 0 : M - kk;
+    const bool both = kk != 0 && 2 * kk != M;         // (k = 0 and k = M / 2 are their own mirror index)
     float2 wp[P];
 #pragma unroll
     for (int r = 0; r < P; ++r) wp[r] = a.tw2[r];
-    float2 acc[NQ][4];
+    float2 acca[NQ][4], accb[NQ][4];
 #pragma unroll
     for (int s = 0; s < NQ; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[s][i] = make_float2(0.f, 0.f);
+        for (int i = 0; i < 4; ++i) acca[s][i] = accb[s][i] = make_float2(0.f, 0.f);
     for (int k = 0; k < m.ntaper; ++k) {
-        const float4* const base = a.scratch + (((size_t)bl * a.nquad + q4) * m.ntaper + k) * (size_t)N;
+        const float4* const base = a.scratch + (((size_t)bl * a.nquad + q4) * m.ntaper + k) * ((size_t)P * M);
         C2 ga[P], gb[P];
 #pragma unroll
         for (int r = 0; r < P; ++r) {
             ga[r] = ld_c2(base + (size_t)r * M + kk);
             gb[r] = ld_c2(base + (size_t)r * M + kb);
         }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int f = kk + M * q;
-            if (2 * f > N) break;
-            const int fi = m.fpos ? m.fpos[f] : f;
-            if (fi < 0) continue;
-            const C2 z = declong_bin<P>(ga, wp, q);
-            // partner N - f = (M - k) + M (P - 1 - q); in the k = 0 thread M (P - q)  (a branch: both indices stay constants)
-            C2 zp;
-            if (kk == 0) zp = declong_bin<P>(gb, wp, (P - q) % P);
-            else zp = declong_bin<P>(gb, wp, P - 1 - q);
-            C2 xa, xb;
-            xa.r = (z.r + zp.r) * hs;
-            xa.i = (z.i - zp.i) * hs;
-            xb.r = (z.i + zp.i) * hs;
-            xb.i = (zp.r - z.r) * hs;
-            const float2 X[4] = {make_float2(xa.r[0], xa.i[0]), make_float2(xa.r[1], xa.i[1]),
-                                 make_float2(xb.r[0], xb.i[0]), make_float2(xb.r[1], xb.i[1])};
-            if (MEAN) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (CPLX) acc[q][i] = cadd(acc[q][i], X[i]);
-                    else acc[q][i].x += convert_real<OUTK>(X[i], m.out_kind);
-                }
-            } else {
-                const size_t o = (((size_t)b * kout + k) * m.nfsel + fi) * m.nchan + c0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (c0 + i >= m.nchan) continue;
-                    if (CPLX) reinterpret_cast<float2*>(m.out)[o + i] = X[i];
-                    else reinterpret_cast<float*>(m.out)[o + i] = convert_real<OUTK>(X[i], m.out_kind);
-                }
-            }
-        }
+        declong_emit<P, OUTK, MEAN>(m, ga, gb, wp, kk, M, b, k, c0, acca);
+        if (both) declong_emit<P, OUTK, MEAN>(m, gb, ga, wp, kb, M, b, k, c0, accb);
     }
     if (MEAN) {
-        const float nt = (float)m.ntaper;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int f = kk + M * q;
-            if (2 * f > N) break;
-            const int fi = m.fpos ? m.fpos[f] : f;
-            if (fi < 0) continue;
-            const size_t o = ((size_t)b * m.nfsel + fi) * m.nchan + c0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (c0 + i >= m.nchan) continue;
-                if (CPLX) reinterpret_cast<float2*>(m.out)[o + i] = make_float2(acc[q][i].x / nt, acc[q][i].y / nt);
-                else reinterpret_cast<float*>(m.out)[o + i] = acc[q][i].x / nt;
-            }
-        }
+        declong_store_mean<P, OUTK>(m, kk, M, b, c0, acca);
+        if (both) declong_store_mean<P, OUTK>(m, kb, M, b, c0, accb);
     }
 }
 

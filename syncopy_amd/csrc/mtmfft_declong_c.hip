@@ -6,7 +6,7 @@ namespace spyfft {
 
 template <int P, int OUTK, bool MEAN>
 static int declong_post(hipStream_t stream, const LongArgs& a, int M) {
-    const long long tot = (long long)a.nsegc * a.nquad * M;
+    const long long tot = (long long)a.nsegc * a.nquad * (M / 2 + 1);
     const long long nb = (tot + 255) / 256;
     if (nb > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", nb); return -1; }
     hipLaunchKernelGGL((declong_post_kernel<P, OUTK, MEAN>), dim3((unsigned)nb), dim3(256), 0, stream, a, M);
