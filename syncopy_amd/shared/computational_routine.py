@@ -28,6 +28,21 @@ def parse_cF_returns(res):
     return res, None
 
 
+def _arg_key(v):
+    """Hashable stand-in of a compute-function argument (slices, index arrays, nested lists) for the dry-run cache."""
+    if isinstance(v, slice):
+        return ("slice", v.start, v.stop, v.step)
+    if isinstance(v, np.ndarray):
+        return ("array", v.shape, v.dtype.str, v.tobytes())
+    if isinstance(v, (list, tuple)):
+        return ("seq",) + tuple(_arg_key(x) for x in v)
+    try:
+        hash(v)
+        return v
+    except TypeError:
+        return ("id", id(v))
+
+
 class ComputationalRoutine(ABC):
     computeFunction = None
     valid_kws = []
@@ -62,7 +77,9 @@ class ComputationalRoutine(ABC):
         if chans is not None and "channel" in data.dimord:
             base[data.dimord.index("channel")] = len(chans)
         for k, (a, b) in enumerate(rows):
-            key = None if per_trial_args else b - a
+            # (per-trial arguments - the sample and frame selections of the time-frequency methods - are usually the same
+            # few values over and over: they join the key instead of forcing one dry run per trial)
+            key = (b - a, tuple(_arg_key(v) for v in self._argv(k))) if per_trial_args else b - a
             hit = seen.get(key) if key is not None else None
             if hit is None:
                 shp = list(base)
