@@ -188,14 +188,35 @@ class MultiTaperFFTConvol(ComputationalRoutine):
                 trials.append((a, s0, s1, _frame_ids(max(nTime, 0), postselect)))
             parts = hs.run_stft_trials(dev, trials, nperseg, nperseg - noverlap, boundary, chans, mk["taper"], mk["taper_opt"],
                                        cfg["polyremoval"], fidx, cfg["output"], cfg["keeptapers"])
+        elif mine:
+            # one window per soi entry (compRoutines.py:392-408: plain, un-detrended, un-padded mtmfft per window): the windows
+            # of ALL trials by length, one launch per length
+            mk = cfg["method_kwargs"]
+            wins, owner = [], []
+            for i, k in enumerate(mine):
+                a, b = rows[k]
+                soi, _ = self._argv(k)
+                for sl in soi:
+                    s0, s1, _ = sl.indices(b - a)
+                    wins.append((a + s0, a + max(s0, s1)))
+                    owner.append(i)
+            lens = sorted({w1 - w0 for w0, w1 in wins})
+            fidx = {n: best_match(np.fft.rfftfreq(n, 1 / mk["samplerate"]), cfg["foi"], squash_duplicates=True)[1] for n in lens}
+            if len({v.size for v in fidx.values()}) != 1:
+                raise ValueError("analysis windows of different lengths select different numbers of frequencies")
+            res = [None] * len(wins)
+            for n in lens:
+                which = [i for i, (w0, w1) in enumerate(wins) if w1 - w0 == n]
+                part = hs.run_mtmfft(dev, [wins[i] for i in which], chans, None, mk["taper"], mk["taper_opt"], False, False, None,
+                                     fidx[n], cfg["output"], cfg["keeptapers"])
+                for i, r in zip(which, part):
+                    res[i] = r
+            per_trial = [[] for _ in mine]
+            for r, o in zip(res, owner):
+                per_trial[o].append(r)
+            parts = [torch.stack(p, dim=0) for p in per_trial]
         else:
             parts = []
-            for k in mine:
-                a, b = rows[k]
-                soi, postselect = self._argv(k)
-                parts.append(_mtmconvol_device(dev, a, b - a, soi, postselect, cfg["equidistant"], cfg["toi"], cfg["foi"],
-                                               cfg["keeptapers"], cfg["polyremoval"], cfg["output"],
-                                               cfg["method_kwargs"], chans))
         if getattr(self, "reduce_time", False) and self.keeptrials and parts and not parallel.collective_active():
             # method="welch": the time mean of every trial (freqanalysis.py:1054-1056) taken on the device in NumPy's
             # order (spyhip_axis_nanmean) - the windowed spectra themselves reach the host only if somebody reads them
