@@ -298,6 +298,49 @@ def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detren
     return out
 
 
+def fft_exec_declong(data, seg_start, seg_lo, seg_hi, nsig, P, M, tapers, scale, detrend=-1, demean_taper=False, freq_idx=None,
+                     output="pow", keeptapers=True, chan_idx=None, reference_mean=False):
+    """Emulated spyhip_fft_exec of a K1L2 plan (mtmfft_declong.h): nfft = P M, tables as spyhip_fft_plan_create builds them."""
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    nfft = P * M
+    ld = data.shape[1]
+    nchan = ld if chan_idx is None else len(chan_idx)
+    ci = None if chan_idx is None else np.ascontiguousarray(chan_idx, dtype=np.int32)
+    ss = np.ascontiguousarray(seg_start, dtype=np.int64)
+    sl = np.ascontiguousarray(seg_lo, dtype=np.int64)
+    sh = np.ascontiguousarray(seg_hi, dtype=np.int64)
+    nseg, K = len(ss), tapers.shape[0]
+    tp = np.ascontiguousarray(tapers, dtype=np.float32)
+    nf = nfft // 2 + 1
+    if freq_idx is None:
+        fpos, nfsel = None, nf
+    else:
+        fi = np.asarray(freq_idx, dtype=np.int64)
+        nfsel = len(fi)
+        fpos = np.full(nf, -1, dtype=np.int32)
+        fpos[fi] = np.arange(nfsel, dtype=np.int32)
+    kind = OUT_KINDS[output]
+    out = np.full((nseg, K if keeptapers else 1, nfsel, nchan), np.nan, dtype=np.complex64 if kind == 2 else np.float32)
+    mid = 0.5 * (nsig - 1)
+    t64 = np.asarray(tapers, dtype=np.float64)
+    wsum = np.ascontiguousarray(np.stack([t64.sum(axis=1), (t64 * (np.arange(nsig) - mid)).sum(axis=1)], axis=1))
+    means = None
+    if reference_mean and detrend == 0:
+        means = seq_mean(data, ss, sl, sh, nsig, chan_idx)
+    lib().emu_set_means(_p(means, C.c_float) if means is not None else None)
+    tws, twn, twp = twiddles(M), twiddles(nfft), twiddles(P)
+    rc = lib().emu_mtmfft_declong(
+        C.c_int(P), C.c_int(M), _p(tws, C.c_float), _p(twn, C.c_float), _p(twp, C.c_float), _p(wsum, C.c_double),
+        _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int), _p(ss, C.c_longlong), _p(sl, C.c_longlong),
+        _p(sh, C.c_longlong), C.c_int(nseg), C.c_int(nsig), C.c_int(nchan), C.c_int(K), _p(tp, C.c_float),
+        C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), _p(fpos, C.c_int), C.c_int(nfsel), C.c_int(kind),
+        C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
+    lib().emu_set_means(None)
+    if rc != 0:
+        raise RuntimeError(f"emu_mtmfft_declong({P}, {M}) -> {rc}")
+    return out
+
+
 def set_blocked(on):
     """Channel-blocked hand-over layout for the following fft_exec / csd_accumulate calls."""
     lib().emu_set_blocked(C.c_int(int(bool(on))))

@@ -26,6 +26,7 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_mixed.h"
 #include "../../syncopy_amd/csrc/mtmfft_long.h"
+#include "../../syncopy_amd/csrc/mtmfft_declong.h"
 #include "../../syncopy_amd/csrc/cwt_kernel.h"
 #include "../../syncopy_amd/csrc/granger_kernels.h"
 #include "../../syncopy_amd/csrc/wilson_plus_kernel.h"
@@ -168,6 +169,25 @@ void run_plus4(const double* g, int F, int n, const double* tw, double* gp, doub
     emu::launch(dim3((unsigned)spywil::plus4_grid((long long)n * n)), dim3(C::T), C::LDS_BYTES, [&] {
         spywil::plus4_kernel<LOG2L>(reinterpret_cast<const spywil::cd*>(g), F, (long long)n * n, reinterpret_cast<const spywil::cd*>(tw),
                                     reinterpret_cast<spywil::cd*>(gp), reinterpret_cast<spywil::cd*>(g0)); });
+}
+
+// K1L2 (mtmfft_declong.h): N = P M through scratch memory - statistics, scheduled sub-transforms of the decimated samples,
+// radix-P step + separation + conversion.  (P, M) = (6, 2000), (3, 4096), (4, 5000), (2, 10000)
+template <class C, int P>
+static void run_declong(spyfft::LongArgs& L, int outk, bool mean) {
+    constexpr int M = C::N, G = C::G;
+    const int ngrp = (L.nquad + G - 1) / G;
+    emu::launch(dim3((unsigned)((long long)L.nsegc * P * ngrp)), dim3(C::NTHREADS), C::LDS_BYTES,
+                [&] { spyfft::declong_sub_kernel<C>(L, P); });
+    const unsigned grid = (unsigned)(((long long)L.nsegc * L.nquad * (M / 2 + 1) + 255) / 256);
+    switch (outk * 2 + (mean ? 1 : 0)) {
+        case 0: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::declong_post_kernel<P, 0, false>(L, M); }); break;
+        case 1: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::declong_post_kernel<P, 0, true>(L, M); }); break;
+        case 2: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::declong_post_kernel<P, 1, false>(L, M); }); break;
+        case 3: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::declong_post_kernel<P, 1, true>(L, M); }); break;
+        case 4: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::declong_post_kernel<P, 2, false>(L, M); }); break;
+        default: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::declong_post_kernel<P, 2, true>(L, M); }); break;
+    }
 }
 
 extern "C" {
@@ -368,6 +388,47 @@ int emu_mtmfft_long(int l1, int l2, int nfft, const float* chirp, const float* b
         case 4: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::long_post_kernel<2, false>(L); }); break;
         default: emu::launch(dim3(grid), dim3(256), 0, [&] { spyfft::long_post_kernel<2, true>(L); }); break;
     }
+    return 0;
+}
+
+int emu_mtmfft_declong(int P, int M, const float* twsub, const float* twN, const float* twP, const double* wsum,
+                       const float* data, long long ld, const int* chan_idx, const long long* seg_start,
+                       const long long* seg_lo, const long long* seg_hi, int nseg, int nsig, int nchan, int ntaper,
+                       const float* tapers, float scale, int detrend, int demean_taper, const int* fpos, int nfsel,
+                       int out_kind, int keeptapers, void* out) {
+    MtmArgs a{};
+    a.data = data; a.ld = ld; a.chan_idx = chan_idx;
+    a.seg_start = seg_start; a.seg_lo = seg_lo; a.seg_hi = seg_hi;
+    a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.ntaper = ntaper;
+    a.tapers = tapers; a.scale = scale; a.detrend = detrend; a.demean_taper = demean_taper;
+    a.fpos = fpos; a.nfsel = nfsel; a.out_kind = out_kind; a.out = out; a.nfft = P * M;
+    a.means = g_means;
+    spyfft::LongArgs L{};
+    L.m = a;
+    L.M1 = P * M; L.M2 = 1;
+    L.tw1 = reinterpret_cast<const float2*>(twsub); L.tw2 = reinterpret_cast<const float2*>(twP);
+    L.twM = reinterpret_cast<const float2*>(twN); L.wsum = wsum;
+    L.nquad = (nchan + 3) / 4;
+    std::vector<double> stats((size_t)nseg * nchan * (2 + ntaper), 0.0);
+    L.stats = stats.data();
+    if ((detrend >= 0 && !(detrend == 0 && a.means)) || demean_taper) {
+        const int nz = demean_taper ? ntaper + 1 : 1;
+        std::vector<double> part((size_t)nseg * nz * spyfft::LONG_SPLITS * nchan * 2, 0.0);
+        emu::launch(dim3((nchan + 63) / 64, nseg, nz * spyfft::LONG_SPLITS), dim3(256), 0,
+                    [&] { spyfft::long_stats_kernel(a, part.data(), nz); });
+        emu::launch(dim3((unsigned)(((size_t)nseg * nchan + 255) / 256)), dim3(256), 0,
+                    [&] { spyfft::long_stats_final_kernel(a, part.data(), nz, stats.data()); });
+    }
+    std::vector<float4> scratch((size_t)nseg * L.nquad * ntaper * (size_t)P * M);
+    L.scratch = scratch.data();
+    L.seg0 = 0; L.nsegc = nseg;
+    const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    const bool mean = !keeptapers;
+    if (P == 6 && M == 2000) run_declong<spyfft::CfgD<10, 10, 10, 2, 1>, 6>(L, outk, mean);
+    else if (P == 3 && M == 4096) run_declong<spyfft::CfgD<16, 16, 16, 1, 1>, 3>(L, outk, mean);
+    else if (P == 4 && M == 5000) run_declong<spyfft::CfgD<10, 10, 10, 5, 1>, 4>(L, outk, mean);
+    else if (P == 2 && M == 10000) run_declong<spyfft::CfgD<20, 20, 5, 5, 1, 1, true>, 2>(L, outk, mean);
+    else return -1;
     return 0;
 }
 

@@ -634,6 +634,31 @@ def test_dec_kernel_radix3_padding_and_selection():
     _fft_case(1400, 1500, 4, 2, "fourier", True, 1, dec=1500, nseg=2)
 
 
+@pytest.mark.parametrize("P,M,nsig,nchan,K,output,keeptapers,detrend,demean,refmean", [
+    (6, 2000, 12000, 5, 2, "fourier", True, 0, False, True),       # ragged quads, reference-order mean
+    (6, 2000, 11000, 4, 2, "pow", False, 1, True, False),          # zero padding, line fit and demean_taper from the statistics
+    (3, 4096, 12288, 3, 1, "abs", True, -1, False, False),         # 16 values per thread in the sub-transform
+    (4, 5000, 20000, 2, 1, "fourier", False, 0, False, True),      # radix 4: the factors +-1, +-i
+])
+def test_long_trials_through_scratch_memory(P, M, nsig, nchan, K, output, keeptapers, detrend, demean, refmean):
+    """K1L2 (mtmfft_declong.h): N = P M beyond one workgroup's LDS - statistics, scheduled sub-transforms of the samples
+    P m + r, radix-P step + separation + conversion, against the oracle."""
+    nfft = P * M
+    rng = np.random.default_rng(P * M + nchan)
+    data = (rng.normal(size=(nsig + 9, nchan)) + (5.0 if detrend == 0 else 0.0)).astype("f4")
+    ss = np.array([4])
+    taper, topt = ("dpss", {"NW": (K + 1) / 2, "Kmax": K}) if K > 1 else ("hann", {})
+    tapers = O.taper_table(taper, nsig, nfft, topt)
+    fi = np.array([0, 1, M - 1, M, M + 1, nfft // 2 - 1, nfft // 2, 37]) if output == "abs" else None
+    out = E.fft_exec_declong(data, ss, ss, ss + nsig, nsig, P, M, tapers, O.spec_scale(nsig, nfft), detrend, demean, fi, output,
+                             keeptapers, reference_mean=refmean)
+    freqs = np.fft.rfftfreq(nfft, 1e-3)
+    ref, _ = O.mtmfft_cF(np.array(data[4:4 + nsig]), foi=freqs if fi is None else freqs[fi], keeptapers=keeptapers,
+                         polyremoval=None if detrend < 0 else detrend, output=output,
+                         method_kwargs=dict(samplerate=1000.0, taper=taper, taper_opt=topt, nSamples=nfft, demean_taper=demean))
+    assert_parity(out[0], ref[0], what=f"{P} x {M}")
+
+
 def test_dec_kernel_padding_and_selection():
     _fft_case(1700, 2000, 6, 2, "pow", True, 0, dec=2000, nseg=1, freq_idx=np.array([0, 1, 999, 1000, 37]),
               chan_idx=np.array([5, 0, 2, 2]))
