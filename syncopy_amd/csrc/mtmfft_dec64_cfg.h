@@ -36,7 +36,7 @@ using D64_3072  = CfgD64<16, 16, 4,  1,  1, false, true, true, 3>;
 using D64_6144  = CfgD64<16, 16, 8,  1,  1, false, true, true, 3>;
 // window lengths of sliding-window analyses and the remaining multiples of 100 up to 8000 that factor into the radices
 using D64_100   = CfgD64<10, 10, 1,  1,  16>;
-using D64_400   = CfgD64<20, 20, 1,  1,  8>;
+using D64_400   = CfgD64<20, 20, 1,  1,  8>;      // (10 x 10 x 2 x 2, the float32 choice, measured 2.5 vs 2.2 us/trial here)
 using D64_800   = CfgD64<20, 20, 2,  1,  4>;
 using D64_1600  = CfgD64<20, 20, 4,  1,  2>;
 using D64_3200  = CfgD64<20, 20, 4,  2,  1>;

@@ -288,7 +288,7 @@ int emu_mtmfft_dec(int id, const float* data, long long ld, const int* chan_idx,
         case 5000: run_dec_mode<spyfft::CfgD<10, 10, 10, 5, 1>>(a, nseg, nchan, outk, mean); break;
         case 600: run_dec_mode<spyfft::CfgD<10, 10, 2, 1, 4, 3>>(a, nseg, nchan, outk, mean); break;
         case 100: run_dec_mode<spyfft::CfgD<10, 10, 1, 1, 16>>(a, nseg, nchan, outk, mean); break;
-        case 400: run_dec_mode<spyfft::CfgD<20, 20, 1, 1, 8>>(a, nseg, nchan, outk, mean); break;
+        case 400: run_dec_mode<spyfft::CfgD<10, 10, 2, 2, 8>>(a, nseg, nchan, outk, mean); break;
         case 2400: run_dec_mode<spyfft::CfgD<20, 20, 2, 1, 1, 3>>(a, nseg, nchan, outk, mean); break;
         case 3200: run_dec_mode<spyfft::CfgD<20, 20, 4, 2, 1>>(a, nseg, nchan, outk, mean); break;
         case 300: run_dec_mode<spyfft::CfgD<10, 10, 1, 1, 8, 3>>(a, nseg, nchan, outk, mean); break;

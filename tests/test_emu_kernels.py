@@ -587,7 +587,7 @@ def test_pipe_kernel_selection_and_padding():
 # K1d: compile-time radix schedules (mtmfft_dec_kernel.h)
 @pytest.mark.parametrize("dec,nfft,nchan,K,output,keeptapers,detrend,demean", [
     (100, 100, 68, 2, "fourier", True, 0, False),      # 10 x 10, sixteen quads per workgroup (+ one padded group)
-    (400, 400, 35, 2, "pow", False, 1, False),         # 20 x 20, eight quads per workgroup
+    (400, 400, 35, 2, "pow", False, 1, False),         # 10 x 10 x 2 x 2, eight quads per workgroup
     (3200, 3200, 4, 1, "fourier", True, 0, False),     # 20 x 20 x 4 x 2
     (1000, 1000, 8, 2, "fourier", True, 0, False),     # 10 x 10 x 10, two quads per workgroup, fast stores
     (1000, 1000, 5, 3, "pow", False, 1, True),         # ragged channels, taper mean, linear detrend, demean_taper
