@@ -328,9 +328,13 @@ def _run_stages(data, classes, st, method, keeptrials, output, compute_method, j
     from ..specest import hip_spectral as hs
     batched = compute_method in (None, "hip")
     with ExitStack() as stack:
-        if (batched and hs.requested_precision() is None and method in ("coh", "granger", "ppc")
-                and isinstance(data, AnalogData) and hasattr(st, "needs_float64") and st.needs_float64(data, method)):
-            stack.enter_context(hs.soft_reference())          # precision="auto": the data ask for float64 transforms
+        # precision="auto": float64 transforms when the OUTPUT isolates a part of the complex coherency (its imaginary or real
+        # part, its phase: 1.5e-7 of the modulus is not small against a part that nearly vanishes - as freqanalysis decides for
+        # its own outputs), or when the DATA ask for them (CrossSpectra.needs_float64)
+        if (batched and hs.requested_precision() is None and method in ("coh", "granger", "ppc") and isinstance(data, AnalogData)
+                and ((method == "coh" and output in ("imag", "angle", "real"))
+                     or (hasattr(st, "needs_float64") and st.needs_float64(data, method)))):
+            stack.enter_context(hs.soft_reference())
         if method == "coh" and output in ("imag", "angle") and batched:
             from .. import backend
             stack.enter_context(backend.csd_phase_exact(True))

@@ -252,6 +252,12 @@ def run_stft_trials(dev_data, trials, nperseg, step, boundary, chan_idx, taper, 
         while k1 < len(trials) and (k1 == k or nfr + len(trials[k1][3]) <= fmax):
             nfr += len(trials[k1][3])
             k1 += 1
+        if nfr == 0:                  # (no window fits these trials: empty results - the caller's shape check speaks, as before)
+            for i in range(k, k1):
+                out[i] = torch.empty((0,) + tuple(plan.out_shape(1)[1:]), device=device,
+                                     dtype=torch.complex64 if plan.kind == 2 else torch.float32)
+            k = k1
+            continue
         st = np.concatenate([r0 + a + np.asarray(fr, dtype=np.int64) * step - lead for r0, a, _, fr in trials[k:k1]])
         lo = np.concatenate([np.full(len(fr), r0 + a, dtype=np.int64) for r0, a, _, fr in trials[k:k1]])
         hi = np.concatenate([np.full(len(fr), r0 + b, dtype=np.int64) for r0, _, b, fr in trials[k:k1]])
