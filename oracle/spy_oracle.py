@@ -318,7 +318,8 @@ def mtmconvol_cF(trl, soi, postselect, equidistant=True, toi=None, foi=None, nTa
         spec = np.full((n_time, nTaper, foi.size, dat.shape[1]), np.nan, dtype=OUT_DTYPE[output])
         for tk in range(len(soi)):
             ftr, freqs = mtmfft(dat[soi[tk], :], fs, taper=taper, taper_opt=taper_opt)
-            _, fidx = best_match(freqs, foi, squash_duplicates=True)
+            if tk == 0:       # compRoutines.py:403-408: the bin indices of the FIRST window serve every window of the trial
+                _, fidx = best_match(freqs, foi, squash_duplicates=True)
             spec[tk] = convert_output(ftr[:, fidx, :], output)
     if not keeptapers:
         return np.nanmean(spec, axis=1, keepdims=True)

@@ -123,17 +123,21 @@ def _mtmconvol_device(dev, row0, nsamp, soi, postselect, equidistant, toi, foi, 
     for sl in soi:
         a, b, _ = sl.indices(nsamp)
         rows.append((row0 + a, row0 + max(a, b)))
-    lens = {b - a for a, b in rows}
-    fidx = {}
-    for n in lens:
-        _, fidx[n] = best_match(np.fft.rfftfreq(n, 1 / fs), foi, squash_duplicates=True)
-    if len({v.size for v in fidx.values()}) != 1:
-        raise ValueError("analysis windows of different lengths select different numbers of frequencies")
+    # compRoutines.py:403-408: the bin indices matched on the FIRST window serve every window of the trial
+    _, fi = best_match(np.fft.rfftfreq(rows[0][1] - rows[0][0], 1 / fs), foi, squash_duplicates=True)
+    lens, seen_len = {b - a for a, b in rows}, set()
+    for a, b in rows:                 # (in window order: the first offending window speaks)
+        n = b - a
+        if n not in seen_len:
+            seen_len.add(n)
+            hs.taper_table(taper, n, n, taper_opt)                                      # the window function's own checks
+        if fi.size and int(fi.max()) >= n // 2 + 1:
+            raise IndexError(f"index {int(fi.max())} is out of bounds for axis 1 with size {n // 2 + 1}")
     res = [None] * len(rows)
     for n in lens:
         which = [i for i, (a, b) in enumerate(rows) if b - a == n]
         part = hs.run_mtmfft(dev, [rows[i] for i in which], chans, None, taper, taper_opt, False, False, None,
-                             fidx[n], output, keeptapers)
+                             fi, output, keeptapers)
         for i, r in zip(which, part):
             res[i] = r
     return torch.stack(res, dim=0)
@@ -200,15 +204,24 @@ class MultiTaperFFTConvol(ComputationalRoutine):
                     s0, s1, _ = sl.indices(b - a)
                     wins.append((a + s0, a + max(s0, s1)))
                     owner.append(i)
-            lens = sorted({w1 - w0 for w0, w1 in wins})
-            fidx = {n: best_match(np.fft.rfftfreq(n, 1 / mk["samplerate"]), cfg["foi"], squash_duplicates=True)[1] for n in lens}
-            if len({v.size for v in fidx.values()}) != 1:
-                raise ValueError("analysis windows of different lengths select different numbers of frequencies")
+            # compRoutines.py:403-408: the bin indices matched on the FIRST window of a trial serve all of its windows (windows
+            # cut short at a trial edge then read the same indices of a coarser frequency axis - or fall off its end)
+            fs, first, groups, seen_len = mk["samplerate"], {}, {}, set()
+            for i, ((w0, w1), o) in enumerate(zip(wins, owner)):      # (in window order: the first offending window speaks)
+                if w1 - w0 not in seen_len:
+                    seen_len.add(w1 - w0)
+                    hs.taper_table(mk["taper"], w1 - w0, w1 - w0, mk["taper_opt"])      # the window function's own checks
+                if o not in first:
+                    first[o] = best_match(np.fft.rfftfreq(w1 - w0, 1 / fs), cfg["foi"], squash_duplicates=True)[1]
+                fi = first[o]
+                nf = (w1 - w0) // 2 + 1
+                if fi.size and int(fi.max()) >= nf:
+                    raise IndexError(f"index {int(fi.max())} is out of bounds for axis 1 with size {nf}")
+                groups.setdefault((w1 - w0, fi.tobytes()), (fi, []))[1].append(i)
             res = [None] * len(wins)
-            for n in lens:
-                which = [i for i, (w0, w1) in enumerate(wins) if w1 - w0 == n]
+            for (n, _), (fi, which) in groups.items():
                 part = hs.run_mtmfft(dev, [wins[i] for i in which], chans, None, mk["taper"], mk["taper_opt"], False, False, None,
-                                     fidx[n], cfg["output"], cfg["keeptapers"])
+                                     fi, cfg["output"], cfg["keeptapers"])
                 for i, r in zip(which, part):
                     res[i] = r
             per_trial = [[] for _ in mine]
