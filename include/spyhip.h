@@ -332,7 +332,9 @@ int spyhip_cwt_exec(spyhip_cwt_plan* plan, const float* data_d, int64_t ld,
  * (connectivity/AV_compRoutines.py:293-412).  csd_d: complex64 (nfreq, C, C)
  * trial-averaged CSD.  granger_d: float32 (nfreq, C, C).  info (host, 4
  * doubles): converged, max rel. err, reg. factor, initial cond. num.
- * H_d / Sigma_d (complex128 (nfreq,C,C) / complex128 (C,C)) may be NULL. */
+ * H_d / Sigma_d (complex128 (nfreq,C,C) / complex128 (C,C)) may be NULL.
+ * Return -6: a Cholesky factorisation met a matrix that is not positive definite (np.linalg.cholesky's LinAlgError at
+ * wilson_sf.py:76,144-151; the Python host mirror raises that type). */
 int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int nchan, double rtol, int niter,
                    double cond_max, double eps_max, void* granger_d, void* H_d, void* Sigma_d,
                    double* info);

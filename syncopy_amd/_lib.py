@@ -129,4 +129,9 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().spyhip_last_error().decode("utf-8", "replace")
+        if rc == -6:
+            # a Cholesky factorisation met a matrix that is not positive definite (granger.hip: check_info): the reference's
+            # np.linalg.cholesky raises this type with this text (wilson_sf.py:76,144-151)
+            import numpy as np
+            raise np.linalg.LinAlgError("Matrix is not positive definite") from SpyHipError(f"{what} failed (code {rc}): {msg}")
         raise SpyHipError(f"{what} failed (code {rc}): {msg}")

@@ -384,6 +384,8 @@ def test_granger_random_networks(seed):
     if rng.integers(0, 2):
         kw["pad"] = "nextpow2"
     got, ref, _ = _run_both(spy.connectivityanalysis, data, ORACLE_CONN, kw)
+    if got is None:                            # both sides refused with the same error (a CSD that is not positive definite:
+        return                                 # np.linalg.LinAlgError on both, wilson_sf.py:76)
     # Both sides stop iterating when the reconstruction error max|S - psi psi^H| / |S| falls below rtol = 5e-6; at that
     # point the estimate still sits 1e-3 ... 3e-3 from the fully converged factorisation (measured: the oracle's loop
     # run to 1e-12 on the same cross-spectral matrix), and the two sides - complex128 kernels on an exactly Hermitian
