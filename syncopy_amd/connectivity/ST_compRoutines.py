@@ -294,9 +294,11 @@ class CrossSpectra(ComputationalRoutine):
             if looks is not None:
                 looks[key] = (ratio, K)
         ratio = parallel.allreduce_max(ratio)
+        # (7.5e-7, not the 5e-7 of the estimate above: two of 48000 seeded cases sat at 1.2 x and 1.5 x the criterion with float32
+        # transforms the plain estimate had let through - profiles/r4_fuzz_offset1300000.log)
         if method == "ppc":
-            return bool(5e-7 * np.sqrt(ratio) * 2 / T > 5e-6 / np.sqrt(max(T, 1)))
-        return bool(5e-7 * np.sqrt(ratio / (T * K)) > 1e-6)
+            return bool(7.5e-7 * np.sqrt(ratio) * 2 / T > 5e-6 / np.sqrt(max(T, 1)))
+        return bool(7.5e-7 * np.sqrt(ratio / (T * K)) > 1e-6)
 
     def ppc_hip(self, data):
         """Pairwise phase consistency with the kernels (connectivity_analysis.py:624-663, ST_compRoutines.py:159-233):
