@@ -104,6 +104,18 @@ def _stft_geometry(nsamp, nperseg, noverlap, toi_is_array):
     return nTime, True
 
 
+def _first_window_bins(n0, fs, foi, n_chan):
+    """Bin indices matched on the first window of a trial (compRoutines.py:402-404).  The reference writes the selected bins
+    into a block of foi.size frequencies: another count does not fit (NumPy's broadcast error), a single bin fills the block."""
+    _, fi = best_match(np.fft.rfftfreq(n0, 1 / fs), foi, squash_duplicates=True)
+    if fi.size != foi.size:
+        if fi.size != 1:
+            raise ValueError(f"could not broadcast input array from shape (1,{fi.size},{n_chan}) into shape "
+                             f"(1,{foi.size},{n_chan})")
+        fi = np.repeat(fi, foi.size)
+    return fi
+
+
 def _mtmconvol_device(dev, row0, nsamp, soi, postselect, equidistant, toi, foi, keeptapers, polyremoval, output,
                       method_kwargs, chans):
     """Time-frequency spectrum of one trial (rows [row0, row0+nsamp) of `dev`) -> device tensor."""
@@ -124,13 +136,16 @@ def _mtmconvol_device(dev, row0, nsamp, soi, postselect, equidistant, toi, foi, 
         a, b, _ = sl.indices(nsamp)
         rows.append((row0 + a, row0 + max(a, b)))
     # compRoutines.py:403-408: the bin indices matched on the FIRST window serve every window of the trial
-    _, fi = best_match(np.fft.rfftfreq(rows[0][1] - rows[0][0], 1 / fs), foi, squash_duplicates=True)
-    lens, seen_len = {b - a for a, b in rows}, set()
+    if not rows:
+        raise IndexError("list index out of range")
+    lens, seen_len, fi = {b - a for a, b in rows}, set(), None
     for a, b in rows:                 # (in window order: the first offending window speaks)
         n = b - a
         if n not in seen_len:
             seen_len.add(n)
             hs.taper_table(taper, n, n, taper_opt)                                      # the window function's own checks
+        if fi is None:
+            fi = _first_window_bins(n, fs, foi, dev.shape[1] if chans is None else len(chans))
         if fi.size and int(fi.max()) >= n // 2 + 1:
             raise IndexError(f"index {int(fi.max())} is out of bounds for axis 1 with size {n // 2 + 1}")
     res = [None] * len(rows)
@@ -212,7 +227,7 @@ class MultiTaperFFTConvol(ComputationalRoutine):
                     seen_len.add(w1 - w0)
                     hs.taper_table(mk["taper"], w1 - w0, w1 - w0, mk["taper_opt"])      # the window function's own checks
                 if o not in first:
-                    first[o] = best_match(np.fft.rfftfreq(w1 - w0, 1 / fs), cfg["foi"], squash_duplicates=True)[1]
+                    first[o] = _first_window_bins(w1 - w0, fs, cfg["foi"], dev.shape[1] if chans is None else len(chans))
                 fi = first[o]
                 nf = (w1 - w0) // 2 + 1
                 if fi.size and int(fi.max()) >= nf:

@@ -119,3 +119,20 @@ def test_mtmconvol_tiny_window():
     kw = dict(method="mtmconvol", taper="hann", t_ftimwin=0.016, toi=0.5, output="abs", keeptrials=True)
     got, ref = _both(spy.freqanalysis, data, ORACLE_FREQ, **kw)
     assert_parity(got.data, ref.data, what="mtmconvol, 16-sample windows")
+
+
+@pytest.mark.parametrize("per_trial", [False, True])
+def test_mtmconvol_first_window_cut_short_at_the_trial_edge(per_trial):
+    """Irregular toi whose first window overhangs the trial: the reference matches the bins on that shortened window
+    (compRoutines.py:402-404) and cannot write 117 of them into a block of 129 - NumPy's broadcast ValueError, before any
+    later (still shorter) window could run off the frequency axis."""
+    data = _data(300, 3, 3, seed=11)
+    trl = data.trialdefinition.copy()
+    trl[:, 2] = -75                                   # 75 samples before time zero: the first window ends at the trial's end
+    data = spy.AnalogData(data.data, samplerate=1000.0, trialdefinition=trl)
+    kw = dict(method="mtmconvol", taper="hann", t_ftimwin=0.256, toi=np.array([0.1214, 0.1323, 0.1556, 0.1889]),
+              output="abs", keeptrials=True)
+    with pytest.raises(ValueError, match="could not broadcast"):
+        spy.freqanalysis(data, compute_method="sequential", routine_classes=ORACLE_FREQ, **kw)
+    with pytest.raises(ValueError, match="could not broadcast"):
+        spy.freqanalysis(data, **({"compute_method": "sequential"} if per_trial else {}), **kw)
