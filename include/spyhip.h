@@ -167,6 +167,12 @@ int spyhip_fft_plan_set_precision(spyhip_fft_plan* plan, int reference);
  * holds these segments as FLOAT64 arrays (zero-extended / padded windows): the reference-precision kernels
  * (spyhip_fft_plan_set_precision) then subtract the trend in float64 instead of rounding the samples to float32. */
 int spyhip_fft_plan_set_reference_mean(spyhip_fft_plan* plan, int on);
+/* Range of the spectra for spyhip_csd_accumulate_split: with absmax_d != NULL (nchan floats on the device, zeroed by the
+ * caller) every spyhip_fft_exec of a FOURIER / keeptapers=1 plan raises absmax_d[c] to the largest |re|, |im| it wrote
+ * for channel c (the values are in registers anyway: one v_max3_f32 per value and a handful of atomics per workgroup).
+ * Returns -3 (and stores nothing) for plans whose kernel family does not deliver it - float32 transforms of a power-of-two
+ * length 256 ... 8192 in the standard layout do; NULL switches it off. */
+int spyhip_fft_plan_set_absmax(spyhip_fft_plan* plan, float* absmax_d);
 /* name of the dominant kernel a plan launches (for rocprof matching) */
 const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* plan);
 
@@ -192,6 +198,22 @@ int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, in
  * summed directly like the reference's complex64 products (connectivity/csd.py:98-102) - what the front ends select
  * for output = "imag" / "angle".  Per context; costs ~25 % of K4's throughput at 256 channels. */
 int spyhip_csd_set_phase_exact(spyhip_ctx* ctx, int on);
+/* The same accumulation on the HALF-PRECISION matrix cores (K4h, csrc/csdh_kernel.h) for nchan = 256: every float32
+ * operand, scaled by a power of two per channel, is split once into an fp16 pair hi + lo (22 significant bits) and a
+ * real product is hi hi' + hi lo' + lo hi' with float32 accumulation - float32-class products at 5.3 x less matrix time
+ * than the float32 instructions, with the plain 4-multiplication complex product (the imaginary part is summed directly:
+ * this path also serves spyhip_csd_set_phase_exact contexts).  absmax_d: 256 floats on the device, per channel an upper
+ * bound of |re| and |im| over the spectra of this call - what spyhip_fft_plan_set_absmax makes spyhip_fft_exec deliver
+ * for free - or NULL: the library takes one extra pass over the spectra.  A frequency where a channel's rms sits more
+ * than ~2^18 below that bound (or that holds Inf / NaN) is left to the float32 kernels by the half-precision kernel
+ * itself (checked on the diagonal it accumulated, before anything is added): results never depend on the data's dynamic
+ * range, only the speed does.  Other channel counts, and SPYHIP_CSD_F32=1 in the environment: identical to
+ * spyhip_csd_accumulate.  Same reference lines (connectivity/csd.py:94-102). */
+int spyhip_csd_accumulate_split(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                                void* acc_d, const float* absmax_d);
+/* number of frequencies the last spyhip_csd_accumulate_split call of this context handed to the float32 kernels
+ * (synchronises the stream; for tests and benchmarks) */
+int spyhip_csd_split_fallbacks(spyhip_ctx* ctx, int* count);
 /* same accumulation from spectra in the channel-blocked layout of spyhip_fft_plan_set_blocked:
  * spec_d = (nrows, ceil(nchan/4), nfreq, 4) complex64.  Bit-identical results. */
 int spyhip_csd_accumulate_blocked(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,

@@ -349,8 +349,11 @@ class FFTPlan:
             return (nseg * self.kout, (self.nchan + 3) // 4, self.nfsel, 4)
         return (nseg, self.kout, self.nfsel, self.nchan)
 
-    def execute(self, data, seg_start, seg_lo=None, seg_hi=None, chan_idx=None, out=None):
-        """data: (rows, ld) float32 cuda tensor; seg_*: int64 cuda tensors of equal length."""
+    def execute(self, data, seg_start, seg_lo=None, seg_hi=None, chan_idx=None, out=None, absmax=None):
+        """data: (rows, ld) float32 cuda tensor; seg_*: int64 cuda tensors of equal length.
+        `absmax`: (nchan,) float32 cuda tensor that every call RAISES to the largest |re|, |im| written per channel - the
+        range csd_accumulate(..., absmax=) scales by (spyhip_fft_plan_set_absmax); `self.tracked_absmax` says whether
+        this plan's kernel delivered it (False: the tensor is untouched, pass absmax=None to csd_accumulate)."""
         assert data.is_cuda and data.dtype == torch.float32 and data.dim() == 2 and data.is_contiguous()
         dev = data.device
         nseg = int(seg_start.numel())
@@ -370,9 +373,17 @@ class FFTPlan:
             assert out.is_cuda and out.is_contiguous() and out.dtype == self.out_dtype
             assert tuple(out.shape) == self.out_shape(nseg), (tuple(out.shape), self.out_shape(nseg))
         self.ctx.bind_stream()
-        check(self.ctx.lib.spyhip_fft_exec(self.handle, _ptr(data), int(data.shape[1]), _ptr(chan_idx),
-                                           _ptr(seg_start), _ptr(seg_lo), _ptr(seg_hi), nseg, _ptr(out)),
-              "spyhip_fft_exec")
+        self.tracked_absmax = False
+        if absmax is not None:
+            assert absmax.is_cuda and absmax.dtype == torch.float32 and absmax.numel() == self.nchan and absmax.is_contiguous()
+            self.tracked_absmax = self.ctx.lib.spyhip_fft_plan_set_absmax(self.handle, _ptr(absmax)) == 0
+        try:
+            check(self.ctx.lib.spyhip_fft_exec(self.handle, _ptr(data), int(data.shape[1]), _ptr(chan_idx),
+                                               _ptr(seg_start), _ptr(seg_lo), _ptr(seg_hi), nseg, _ptr(out)),
+                  "spyhip_fft_exec")
+        finally:
+            if self.tracked_absmax:
+                self.ctx.lib.spyhip_fft_plan_set_absmax(self.handle, None)
         return out
 
     def __del__(self):
@@ -483,10 +494,13 @@ class csd_phase_exact:
         return False
 
 
-def csd_accumulate(spec, acc, blocked=False):
+def csd_accumulate(spec, acc, blocked=False, absmax=None):
     """acc[f,i,j] += sum_r spec[r,f,i] conj(spec[r,f,j]) on the lower triangle (MFMA).
     spec: (..., F, C) complex64 (leading dims flattened to rows), or with blocked=True the hand-over layout
-    (rows, ceil(C/4), F, 4) of FFTPlan.set_blocked; acc: (F, C, C) complex64."""
+    (rows, ceil(C/4), F, 4) of FFTPlan.set_blocked; acc: (F, C, C) complex64.
+    256 channels in the standard layout run on the half-precision matrix cores with split operands
+    (spyhip_csd_accumulate_split); `absmax`: (256,) float32 bound of |re|, |im| per channel as FFTPlan.execute(...,
+    absmax=) leaves it, or None: the library takes its own pass over the spectra first."""
     assert spec.is_cuda and spec.dtype == torch.complex64 and spec.is_contiguous()
     assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous()
     ctx = context(spec.device)
@@ -501,8 +515,23 @@ def csd_accumulate(spec, acc, blocked=False):
     F, Cn = spec.shape[-2], spec.shape[-1]
     assert tuple(acc.shape) == (F, Cn, Cn), (tuple(acc.shape), (F, Cn, Cn))
     nrows = spec.numel() // (F * Cn)
+    if Cn == 256 and nrows > 0:
+        if absmax is not None:
+            assert absmax.is_cuda and absmax.dtype == torch.float32 and absmax.numel() == 256 and absmax.is_contiguous()
+        check(ctx.lib.spyhip_csd_accumulate_split(ctx.handle, _ptr(spec), nrows, F, Cn, _ptr(acc), _ptr(absmax)),
+              "spyhip_csd_accumulate_split")
+        return acc
     check(ctx.lib.spyhip_csd_accumulate(ctx.handle, _ptr(spec), nrows, F, Cn, _ptr(acc)), "spyhip_csd_accumulate")
     return acc
+
+
+def csd_split_fallbacks(device=None):
+    """Frequencies the last 256-channel csd_accumulate of this device's context left to the float32 kernels
+    (spyhip_csd_split_fallbacks; synchronises)."""
+    ctx = context(device)
+    n = C.c_int(0)
+    check(ctx.lib.spyhip_csd_split_fallbacks(ctx.handle, C.byref(n)), "spyhip_csd_split_fallbacks")
+    return int(n.value)
 
 
 def csd_kernel_name(nchan, blocked=False):
@@ -511,6 +540,8 @@ def csd_kernel_name(nchan, blocked=False):
     nt = (nchan + 31) // 32
     ntiles = nt * (nt + 1) // 2
     import os
+    if nchan == 256 and not blocked and not os.environ.get("SPYHIP_CSD_F32"):
+        return "spycsd::csdh_kernel"
     if nchan == 256 and not os.environ.get("SPYHIP_CSD_4M"):
         return "spycsd::csd3m_kernel<256, 8, true, false, false>"
     if nchan <= 512 and not blocked and not os.environ.get("SPYHIP_CSD_4M"):

@@ -47,6 +47,7 @@ extern "C" int spyhip_ctx_destroy(spyhip_ctx* ctx) {
         if (ctx->scratch) (void)hipFree(ctx->scratch);
         if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
         if (ctx->arena) (void)hipFree(ctx->arena);
+        if (ctx->k4h_buf) (void)hipFree(ctx->k4h_buf);
     }
     delete ctx;
     return 0;

@@ -7,6 +7,7 @@
 #include "spy_common.h"
 #include "csd_kernel.h"
 #include "csd3m_launch.h"
+#include "csdh_launch.h"
 
 using spycsd::CsdArgs;
 
@@ -121,6 +122,59 @@ extern "C" int spyhip_csd_set_phase_exact(spyhip_ctx* ctx, int on) {
 extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
                                      void* acc_d) {
     return csd_accumulate_impl(ctx, spec_d, nrows, nfreq, nchan, acc_d, 0);
+}
+
+// K4h (csdh_kernel.h): 256 channels on the half-precision matrix cores with split float32 operands.  The frequencies
+// beyond the last full round of workgroups go to the re-cut float32 tail like on the other paths.
+extern "C" int spyhip_csd_accumulate_split(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                                           void* acc_d, const float* absmax_d) {
+    static const bool env_f32 = std::getenv("SPYHIP_CSD_F32") != nullptr;
+    if (!ctx || nchan != 256 || nrows < 1 || env_f32)
+        return csd_accumulate_impl(ctx, spec_d, nrows, nfreq, nchan, acc_d, 0);
+    if (!spec_d || !acc_d || nfreq < 1) { spy::set_error("csd_accumulate_split: null argument / bad shape"); return -1; }
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t need = (size_t)nfreq * sizeof(int) + 256 * sizeof(float);
+    if (need > ctx->k4h_bytes) {
+        if (ctx->k4h_buf) { SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->k4h_buf); ctx->k4h_buf = nullptr; ctx->k4h_bytes = 0; }
+        SPY_HIP_CHECK(hipMalloc(&ctx->k4h_buf, need));
+        ctx->k4h_bytes = need;
+    }
+    float* const own_max = reinterpret_cast<float*>(ctx->k4h_buf);
+    int* const flags = reinterpret_cast<int*>(own_max + 256);
+    const float2* spec = reinterpret_cast<const float2*>(spec_d);
+    if (!absmax_d) {
+        SPY_HIP_CHECK(hipMemsetAsync(own_max, 0, 256 * sizeof(float), ctx->stream));
+        int rc = spycsd::csdh_absmax(ctx->stream, spec, (long long)nrows * nfreq * 256, 256, own_max);
+        if (rc) return rc;
+        absmax_d = own_max;
+    }
+    const long long rem = nfreq % ctx->num_cu;
+    int f_main = nfreq;
+    if (nfreq > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) f_main = nfreq - (int)rem;
+    int rc = spycsd::csdh_run(ctx->stream, spec, nrows, nfreq, reinterpret_cast<float2*>(acc_d), absmax_d, flags, f_main,
+                              ctx->csd_phase_exact != 0);
+    ctx->k4h_nf = f_main;
+    if (rc || f_main == nfreq) return rc;
+    CsdArgs a{};
+    a.spec = spec;
+    a.nrows = nrows; a.F = nfreq; a.C = 256;
+    a.acc = reinterpret_cast<float2*>(acc_d);
+    a.nt = 8; a.ntiles = 36; a.nitems = (long long)nfreq * 36; a.cpad = 256;
+    a.fast_per = 36;
+    return launch_tail(ctx, a, (long long)f_main * 36, nrows, nfreq, 256);
+}
+
+extern "C" int spyhip_csd_split_fallbacks(spyhip_ctx* ctx, int* count) {
+    if (!ctx || !count) { spy::set_error("csd_split_fallbacks: null argument"); return -1; }
+    *count = 0;
+    if (!ctx->k4h_buf || ctx->k4h_nf <= 0) return 0;
+    SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<int> h((size_t)ctx->k4h_nf);
+    SPY_HIP_CHECK(hipMemcpyAsync(h.data(), reinterpret_cast<const char*>(ctx->k4h_buf) + 256 * sizeof(float), h.size() * sizeof(int),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int v : h) *count += v != 0;
+    return 0;
 }
 
 extern "C" int spyhip_csd_accumulate_blocked(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,

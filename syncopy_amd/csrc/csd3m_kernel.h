@@ -544,6 +544,7 @@ __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdAr
     }
     f += (int)(a.item_base / M3_TILES_PER_F);
     if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
+    if (CH == 256 && EXACT && a.only_flagged && !a.only_flagged[f]) return;      // (wave-uniform)
     m3_dispatch<CH, WPG, EXACT, RECT, M4, 0, (WPG == 4 ? 8 : M3Tab<CH, RECT>::NW)>(g, a, Xb, f, lane);
 }
 

@@ -33,6 +33,8 @@ struct CsdArgs {
     // channel sub-ranges of the 3-multiplication kernel (more than 512 channels; 0 = the whole rows): rows are `ctot`
     // channels wide, the launch works on n0 channels from ch0 (and, for a rectangle, n1 channels from ch1)
     int ctot, ch0, n0, ch1, n1;
+    // csd3m_kernel<256, 8> as the float32 stand-in of csdh_kernel (csdh_kernel.h): only frequencies f with only_flagged[f] != 0
+    const int* only_flagged;
 };
 
 }  // namespace spycsd

@@ -118,6 +118,7 @@ struct spyhip_fft_plan {
     spy::DevBuf<int> fpos;
     bool identity_freq = true;
     bool blocked = false;
+    unsigned* absmax = nullptr;  // spyhip_fft_plan_set_absmax: where the exec calls leave the range of the spectra
     bool precision64 = false;   // float64 taper product + FFT, complex64 rounding where the reference rounds (mtmfft_f64_kernel.h)
     bool f64_any = false;       // ... through the any-length kernel (work arrays in global memory)
     bool f64_dec = false;       // ... through the compile-time-schedule kernel (mtmfft_dec64_kernel.h)
@@ -588,6 +589,21 @@ extern "C" int spyhip_fft_plan_set_blocked(spyhip_fft_plan* p, int on) {
     return 0;
 }
 
+extern "C" int spyhip_fft_plan_set_absmax(spyhip_fft_plan* p, float* absmax_d) {
+    if (!p) { spy::set_error("fft_plan_set_absmax: null plan"); return -1; }
+    if (!absmax_d) { p->absmax = nullptr; return 0; }
+    // the packed power-of-two kernel (mtmfft2_kernel.h) tracks it; the other families do not (yet)
+    const bool ok = p->pow2 && !p->pipe && p->log2n >= 8 && p->log2n <= 13 && !p->precision64 && !p->blocked &&
+                    p->output == SPYHIP_OUT_FOURIER && p->keeptapers;
+    if (!ok) {
+        p->absmax = nullptr;
+        spy::set_error("fft_plan_set_absmax: this plan's kernel does not deliver the range of its spectra");
+        return -3;
+    }
+    p->absmax = reinterpret_cast<unsigned*>(absmax_d);
+    return 0;
+}
+
 extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) {
     if (!p) { spy::set_error("fft_plan_set_precision: null plan"); return -1; }
     if (!reference) {
@@ -721,6 +737,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     a.blocked = p->blocked ? 1 : 0;
     a.means = nullptr;
     a.seg_f64 = p->seg_f64 ? 1 : 0;
+    a.absmax = (p->absmax && !p->blocked && !p->precision64 && !p->pipe) ? p->absmax : nullptr;
     if (p->ref_mean && p->detrend == 0) {
         // the per-channel means of every segment in the reference's summation order, ahead of the transform
         const size_t need = (size_t)nseg * p->nchan;

@@ -29,6 +29,9 @@ struct spyhip_ctx {
     size_t comm_buf_bytes = 0;
     void* arena = nullptr;          // work arrays of spyhip_granger (5 x F n^2 complex128 ...): kept between calls - a
     size_t arena_bytes = 0;         // hipMalloc + hipFree of 11 GB per call cost 0.05 ... 1 s; spyhip_ctx_trim frees it
+    void* k4h_buf = nullptr;        // spyhip_csd_accumulate_split: 256 floats (the library's own range pass) + one flag per frequency
+    size_t k4h_bytes = 0;
+    int k4h_nf = 0;                 // frequencies the half-precision kernel was launched on in the last call
 #endif
     int csd_phase_exact = 0;        // spyhip_csd_set_phase_exact: 4-multiplication K4 kernels only (csd.hip)
     int granger_iters = 0;          // Wilson iterations of the last spyhip_granger call on this context
