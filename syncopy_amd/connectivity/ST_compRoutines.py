@@ -44,12 +44,13 @@ def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, pol
         groups = {}
         for k, i in enumerate(sel):
             groups.setdefault(id(acc_of_trial(i)), (acc_of_trial(i), []))[1].append(k)
+        am = getattr(spec, "spyhip_absmax", None)       # range of the whole batch: a bound for each of its trials too
         for acc, ks in groups.values():
             if len(ks) == spec.shape[0]:
-                backend.csd_accumulate(spec, acc)
+                backend.csd_accumulate(spec, acc, absmax=am)
             else:
                 for k in ks:
-                    backend.csd_accumulate(spec[k], acc)
+                    backend.csd_accumulate(spec[k], acc, absmax=am)
     return ntaper
 
 
@@ -354,7 +355,7 @@ class CrossSpectra(ComputationalRoutine):
         K = 1
         for _, spec in batches(mine):
             K = spec.spyhip_ntaper
-            backend.csd_accumulate(spec, S)
+            backend.csd_accumulate(spec, S, absmax=getattr(spec, "spyhip_absmax", None))
         K = int(cfg["taper_opt"].get("Kmax", K)) if cfg["taper_opt"] else K
         backend.csd_allreduce_(S)
         backend.csd_finalize(S, 1.0 / (K * T))
@@ -371,7 +372,7 @@ class CrossSpectra(ComputationalRoutine):
                 continue
             for t in range(spec.shape[0]):
                 St.zero_()
-                backend.csd_accumulate(spec[t], St)
+                backend.csd_accumulate(spec[t], St, absmax=getattr(spec, "spyhip_absmax", None))
                 backend.csd_finalize(St, 1.0 / K)
                 loo = T * S - St                       # complex64, the reference's operation order
                 loo /= T - 1

@@ -34,7 +34,7 @@
 //
 // Validity: a channel whose rms at this frequency sits more than 2^18 below the channel's batch-wide peak would see
 // lo go subnormal for its TYPICAL value (absolute error 2^-25 against an rms below 2^-3).  The workgroup checks the
-// diagonal of what it accumulated (sum |y|^2 >= rows 2^-6, or exactly 0, and finite) BEFORE committing; a frequency
+// diagonal of what it accumulated (sum |y|^2 >= rows 2^-6 and finite, or 0 for a channel whose range is 0) BEFORE committing; a frequency
 // that fails is left untouched and flagged, and the float32 kernel (csd3m_kernel<256, 8> with CsdArgs::only_flagged)
 // redoes exactly those.  Non-finite input takes the same route, so NaN / Inf propagate as before.
 #pragma once
@@ -307,11 +307,14 @@ __device__ __forceinline__ void csdh_wave(const CsdhArgs& a, char* lds, int f, i
         m3_for<0, NT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             if constexpr (TAB::blk(G, TAB::ta(G, t)) == TAB::blk(G, TAB::tb(G, t))) {
+                // an all-zero diagonal entry is only innocent for a channel that IS zero (a scale of 2^-114 for an
+                // Inf "maximum" would flush a whole channel to zero otherwise)
+                const bool dead = a.absmax[TAB::blk(G, TAB::ta(G, t)) * 16 + l15] == 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (4 * lq + r == l15) {
                         const float v = re[t][r];
-                        bad = bad || !((v >= floor2 && v < __builtin_inff()) || v == 0.f);
+                        bad = bad || !((v >= floor2 && v < __builtin_inff()) || (v == 0.f && dead));
                     }
             }
         });

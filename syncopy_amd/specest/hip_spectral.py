@@ -302,7 +302,13 @@ def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_
             # reuse=True: the consumer is done with a batch before it asks for the next one (stream order), so all
             # batches - and all later calls of the same shape - share one device buffer
             buf = backend.handover_buffer(plan.out_shape(len(sel)), device) if reuse and plan.kind == 2 else None
-            spec = plan.execute(dev_data, starts, chan_idx=ci, out=buf)
+            # complex all-taper spectra of 256 channels are what K4h consumes (backend.csd_accumulate): let the transform
+            # kernel leave the per-channel range it scales by (fresh per batch; None where the kernel family cannot)
+            am = None
+            if nchan == 256 and plan.kind == 2 and keeptapers and not plan.blocked:
+                am = torch.zeros(256, dtype=torch.float32, device=device)
+            spec = plan.execute(dev_data, starts, chan_idx=ci, out=buf, absmax=am)
             spec.spyhip_blocked = plan.blocked
             spec.spyhip_ntaper = plan.kout
+            spec.spyhip_absmax = am if plan.tracked_absmax else None
             yield sel, spec

@@ -57,7 +57,7 @@ def _patch():
         spec.spyhip_ntaper = spec.shape[1]
         yield np.arange(len(rows)), spec
 
-    def csd_accumulate(spec, acc, blocked=False):
+    def csd_accumulate(spec, acc, blocked=False, absmax=None):
         s = spec.reshape(-1, spec.shape[-2], spec.shape[-1])
         acc += torch.einsum("rfi,rfj->fij", s, s.conj())
         return acc

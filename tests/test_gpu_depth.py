@@ -65,7 +65,7 @@ def _reference(spec, f):
 
 @pytest.mark.parametrize("kind", ["noise", "coherent"])
 def test_csd_accumulate_at_production_depth(be, kind):
-    """One launch of the bench shape (7000 x 2049 x 256, `csd3m_kernel<256, 8>` + row-split tail) against complex128
+    """One launch of the bench shape (7000 x 2049 x 256, `csdh_kernel` + row-split tail) against complex128
     products at 16 frequencies incl. 0, 2047 and 2048 (the tail)."""
     spec = _spectra(kind)
     R, F, C = spec.shape
@@ -91,11 +91,14 @@ def test_csd_accumulate_at_production_depth(be, kind):
         assert_parity(coh[f].cpu().numpy(), (np.abs(ref) / np.outer(d, d)).astype(np.float32), what=f"{kind} coh f={f}")
 
 
-def test_imaginary_part_needs_phase_exact_kernels(be):
-    """Strongly coherent pairs near zero lag at full depth: the imaginary part of the default (3M) accumulator misses
-    the criterion by orders of magnitude, the phase-exact kernels meet it - which is why the front ends select them
-    for output='imag' / 'angle'.  If the default kernels ever pass here the routing can go."""
-    spec = _spectra("coherent")
+@pytest.mark.parametrize("C", [256, 128])
+def test_imaginary_part_needs_phase_exact_kernels(be, C):
+    """Strongly coherent pairs near zero lag at full depth: the imaginary part of the float32 3-multiplication
+    accumulator (every channel count but 256) misses the criterion by orders of magnitude, the phase-exact kernels meet
+    it - which is why the front ends select them for output='imag' / 'angle'.  256 channels run the half-precision
+    kernel (csdh_kernel.h), a 4-multiplication product whose imaginary part is summed directly: it meets the criterion
+    in either mode.  If the 3M kernels ever pass here the routing can go."""
+    spec = _spectra("coherent", C=C, F=2049 if C == 256 else 1025)
     R, F, C = spec.shape
     il = np.tril_indices(C, -1)
     res = {}
@@ -104,7 +107,7 @@ def test_imaginary_part_needs_phase_exact_kernels(be):
         with be.csd_phase_exact(exact):
             be.csd_accumulate(spec, acc)
         worst = 0.0
-        for f in FSEL:
+        for f in (f for f in FSEL if f < F):
             ref = _reference(spec, f)
             d = np.sqrt(np.real(np.diag(ref)))
             cref = ref / np.outer(d, d)
@@ -113,11 +116,15 @@ def test_imaginary_part_needs_phase_exact_kernels(be):
                 worst = max(worst, excess_abs(got[il], r[il]))
         res[exact] = worst
         del acc
-    print(f"[depth] coherence imag / angle of coherent pairs (|d| <= 1e-5 |b| + {IMAG_ATOL:g}): default kernels err/tol = "
-          f"{res[False]:.3g}, phase-exact kernels {res[True]:.3g}")
+    print(f"[depth] {C} channels, coherence imag / angle of coherent pairs (|d| <= 1e-5 |b| + {IMAG_ATOL:g}): default kernels "
+          f"err/tol = {res[False]:.3g}, phase-exact kernels {res[True]:.3g}")
     assert res[True] <= 1.0, res
-    assert res[False] > 1.0, ("the 3-multiplication kernels now meet the criterion on imaginary parts: "
-                              "drop the phase-exact routing", res)
+    if C == 256:
+        assert res[False] <= 1.0, ("the half-precision kernel sums the imaginary part directly", res)
+        assert be.csd_split_fallbacks() == 0, "no frequency of this data should need the float32 kernels"
+    else:
+        assert res[False] > 1.0, ("the 3-multiplication kernels now meet the criterion on imaginary parts: "
+                                  "drop the phase-exact routing", res)
 
 
 def test_coherence_imag_angle_256_channels_vs_oracle():
