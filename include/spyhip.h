@@ -168,8 +168,11 @@ int spyhip_fft_plan_set_precision(spyhip_fft_plan* plan, int reference);
  * (spyhip_fft_plan_set_precision) then subtract the trend in float64 instead of rounding the samples to float32. */
 int spyhip_fft_plan_set_reference_mean(spyhip_fft_plan* plan, int on);
 /* Range of the spectra for spyhip_csd_accumulate_split: with absmax_d != NULL (nchan floats on the device, zeroed by the
- * caller) every spyhip_fft_exec of a FOURIER / keeptapers=1 plan raises absmax_d[c] to the largest |re|, |im| it wrote
- * for channel c (the values are in registers anyway: one v_max3_f32 per value and a handful of atomics per workgroup).
+ * caller) every spyhip_fft_exec of a FOURIER / keeptapers=1 plan raises absmax_d[c] to a BOUND of every |re|, |im| it
+ * writes for channel c: max over tapers of ||w scale||_2 times the 2-norm of the detrended segment (Cauchy-Schwarz; one sum
+ * of squares per segment from samples that are in registers anyway - a maximum over the values written costs the
+ * transform kernel 6 %).  The bound sits sqrt(nsig) / (crest factor) above the largest bin of noise-like data (3-4 bits of
+ * the ~18 the half-precision kernel has) and is tight for offset- or line-dominated channels, where the bits matter.
  * Returns -3 (and stores nothing) for plans whose kernel family does not deliver it - float32 transforms of a power-of-two
  * length 256 ... 8192 in the standard layout do; NULL switches it off. */
 int spyhip_fft_plan_set_absmax(spyhip_fft_plan* plan, float* absmax_d);

@@ -40,22 +40,25 @@
 #pragma once
 #include "csd3m_kernel.h"
 
-#ifndef CSDH_NT
-#define CSDH_NT 0
-#endif
-#ifndef CSDH_APP
-#define CSDH_APP 1      // two A fragment slots (ping-pong); 0: one
-#endif
-#ifndef CSDH_DEEP
-#define CSDH_DEEP 0
+#ifndef CSDH_FENCE
+#define CSDH_FENCE 0x78f    // __builtin_amdgcn_sched_barrier mask behind the loader's fetches: everything but vector memory may cross
 #endif
 #ifndef CSDH_S1
 #define CSDH_S1 7
 #define CSDH_S2 15
 #endif
+
 #ifndef CSDH_ABL
 #define CSDH_ABL 0      // development ablations (tools/csdh_probe.hip): 1 no global loads, 2 no conversion, 4 no LDS writes,
 #endif                  // 8 no fragment reads, 16 no barrier, 32 no negation
+
+#ifdef CSDH_STAMPS
+#define CSDH_STAMP(k) do { if (blockIdx.x == 0 && c >= 20 && c < 24) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        const unsigned long long t__ = __builtin_readcyclecounter(); \
+        if (lane == 0) a.stamps[((c - 20) * 8 + G) * 8 + (k)] = t__; } } while (0)
+#else
+#define CSDH_STAMP(k) do { } while (0)
+#endif
 
 namespace spycsd {
 
@@ -73,6 +76,7 @@ struct CsdhArgs {
     int* flags;             // [F]: 1 = this launch did NOT add frequency f (float32 kernel must), 0 = added
     int f0;                 // block b -> frequency f0 + b
     int nf;                 // frequencies of this launch
+    unsigned long long* stamps;   // development timeline (tools/csdh_probe.hip, -DCSDH_STAMPS): [4 chunks][8 waves][8 points]
     long long rs, fs;       // strides (complex elements) between rows and between frequencies: (nrows, F, 256) -> F * 256, 256
 };
 
@@ -116,11 +120,7 @@ struct HPlan {
             p.bblk[s] = y;
             if (ac[0] == x) { p.aslot[s] = 0; p.aload[s] = false; }
             else if (ac[1] == x) { p.aslot[s] = 1; p.aload[s] = false; }
-            else {
-                const int v = CSDH_APP ? 1 - alast : 0;
-                p.aslot[s] = v; p.aload[s] = true; ac[v] = x;
-                if (!CSDH_APP) ac[1] = -1;
-            }
+            else { p.aslot[s] = 1 - alast; p.aload[s] = true; ac[1 - alast] = x; }
             alast = p.aslot[s];
             if (x == y) { p.bslot[s] = 2; p.bload[s] = false; }
             else {
@@ -163,63 +163,91 @@ __device__ __forceinline__ void csdh_wave(const CsdhArgs& a, char* lds, int f, i
     const int nchunk = (int)((nrows + CSDH_KROWS - 1) / CSDH_KROWS);
     const size_t rowstride = (size_t)a.rs;                            // float2 elements between rows
 
-    // ---- loader: phase ph = channel lc0 + 64 ph, 8 rows; one staging set per phase so that BOTH phases of chunk c + 1
-    // are in flight for most of chunk c (the waves of a workgroup run in step: a wait is a wait for all of them)
-    f32x2 stA[8];
-#if CSDH_DEEP
-    f32x2 stB[8];
-#else
-    f32x2 (&stB)[8] = stA;
-#endif
+    // ---- loader: phase ph = channel lc0 + 64 ph, 8 rows.  Everything that is not a matrix instruction competes with the
+    // matrix instructions of BOTH waves of the SIMD for its one issue port (the timeline of tools/csdh_probe.hip
+    // -DCSDH_STAMPS: the wave that loses the arbitration finishes a chunk 2500 cycles after its partner), so the
+    // common case - all 32 rows of the chunk exist - is kept lean: row addresses = one scalar pointer per chunk + i row
+    // strides, two v_fma_mix per value for the split (product with the scale, rounding to fp16 and packing in one
+    // instruction; the residual the same way), no per-row selects.  Only the last one or two chunks of a launch take
+    // the general path (rows past the end are fetched from the last row and given the scale 0).
+    f32x2 st[8];
     const int nrows_i = (int)nrows;                  // (the host keeps launches below 2^31 rows)
+    const int nfull = nrows_i / CSDH_KROWS;          // chunks whose 32 rows all exist
     const char* const gb = reinterpret_cast<const char*>(a.spec) + ((size_t)f * a.fs + 128 * CHH) * 8;   // wave-uniform
+    const size_t rowbytes = rowstride * 8;
     const unsigned voff = (unsigned)lane * 8u;
-    // rows past the end of the spectra (ragged last chunk, and the look-ahead of the last iteration) are fetched from
-    // the last row instead and given the scale 0 in convert: no branches, no second code path
-    auto fetch = [&](int c, int ph, f32x2 (&st)[8]) {
-        const int r0 = c * CSDH_KROWS + 8 * KG;
+    const char* nextp = gb + (size_t)(CSDH_KROWS + 8 * KG) * rowbytes;       // rows 8 KG ... of the chunk fetched next
+    auto fetch = [&](int c, int ph) {
+        if (c < nfull) {                                                      // (uniform) nextp points at chunk c
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = min(r0 + i, nrows_i - 1);
-            const char* const rp = gb + ((size_t)r * rowstride + 64 * ph) * 8;                           // wave-uniform
-            if (CSDH_ABL & 1) st[i] = f32x2{(float)(r + lane), (float)(c - lane)};
-            else if (CSDH_NT) st[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(rp + voff));
-            else st[i] = *reinterpret_cast<const f32x2*>(rp + voff);
+            for (int i = 0; i < 8; ++i) {
+                if (CSDH_ABL & 1) st[i] = f32x2{(float)(i + lane), (float)(c - lane)};
+                else if ((CSDH_ABL & 128) && c > 2) asm volatile("" : "+v"(st[i]));      // keep the (real) values of chunk 2
+                else st[i] = *reinterpret_cast<const f32x2*>(nextp + i * rowbytes + 512 * ph + voff);
+            }
+        } else {
+            const int r0 = c * CSDH_KROWS + 8 * KG;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = min(r0 + i, nrows_i - 1);
+                st[i] = *reinterpret_cast<const f32x2*>(gb + (size_t)r * rowbytes + 512 * ph + voff);
+            }
         }
     };
+    // (hi, lo) fp16 pairs of x0 s and x1 s, packed (x0 in the low halves): hi = fp16(x s), lo = fp16(x s - hi)
+    auto split2 = [](float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+        asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+            "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+            "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(hi), "=&v"(lo)
+            : "v"(x0), "v"(x1), "v"(s));
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // chunk c lives in buffer c & 1 with the planes (re, im) in the order (c & 1) ? (im, re) : (re, im)
-    auto convert = [&](int c, int ph, f32x2 (&st)[8]) {
-        const int r0 = c * CSDH_KROWS + 8 * KG;
+    auto convert = [&](int c, int ph) {
         const float sc = ph ? s1 : s0;
-        f16x8 rh, rl, ih, il;
+        u32x4 rh, rl, ih, il;
         if (CSDH_ABL & 2) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { rh[i] = rl[i] = (_Float16)st[i][0]; ih[i] = il[i] = (_Float16)st[i][1]; }
-        } else
+            for (int i = 0; i < 4; ++i) { rh[i] = rl[i] = __float_as_uint(st[2 * i][0]); ih[i] = il[i] = __float_as_uint(st[2 * i + 1][1]); }
+        } else if (c < nfull) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4; ++i) {
+                unsigned h, l;
+                split2(st[2 * i][0], st[2 * i + 1][0], sc, h, l);
+                rh[i] = h; rl[i] = l;
+                split2(st[2 * i][1], st[2 * i + 1][1], sc, h, l);
+                ih[i] = h; il[i] = l;
+            }
+        } else {
             // (a row past the end was fetched from the last row: scale 0 - if that row holds Inf / NaN the product is NaN,
             // in channels that the row itself has already made non-finite)
-            const float s = (r0 + i < nrows_i) ? sc : 0.f;
-            const float yr = st[i][0] * s, yi = st[i][1] * s;
-            const _Float16 hr = (_Float16)yr, hi = (_Float16)yi;
-            rh[i] = hr;
-            ih[i] = hi;
-            rl[i] = (_Float16)(yr - (float)hr);
-            il[i] = (_Float16)(yi - (float)hi);
+            const int r0 = c * CSDH_KROWS + 8 * KG;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sa = (r0 + 2 * i < nrows_i) ? sc : 0.f, sb = (r0 + 2 * i + 1 < nrows_i) ? sc : 0.f;
+                unsigned h0, l0, h1, l1;
+                split2(st[2 * i][0], st[2 * i][1], sa, h0, l0);            // (re, im) of row 2 i
+                split2(st[2 * i + 1][0], st[2 * i + 1][1], sb, h1, l1);    // (re, im) of row 2 i + 1
+                rh[i] = (h0 & 0xffffu) | (h1 << 16);
+                rl[i] = (l0 & 0xffffu) | (l1 << 16);
+                ih[i] = (h0 >> 16) | (h1 & 0xffff0000u);
+                il[i] = (l0 >> 16) | (l1 & 0xffff0000u);
+            }
         }
         const int odd = c & 1;
         char* const w = lds + odd * CSDH_BUF + KG * 4096 + (lc0 + 64 * ph) * 16;
         char* const wr = w + (odd ? 2 * CSDH_PLANE : 0);
         char* const wi = w + (odd ? 0 : 2 * CSDH_PLANE);
         if (CSDH_ABL & 4) {
-            if (rh[0] + rl[1] + ih[2] + il[3] == (_Float16)123.25f) *reinterpret_cast<f16x8*>(wr) = rh;
+            if (rh[0] + rl[1] + ih[2] + il[3] == 123456u) *reinterpret_cast<u32x4*>(wr) = rh;
             return;
         }
-        *reinterpret_cast<f16x8*>(wr) = rh;
-        *reinterpret_cast<f16x8*>(wr + CSDH_PLANE) = rl;
-        *reinterpret_cast<f16x8*>(wi) = ih;
-        *reinterpret_cast<f16x8*>(wi + CSDH_PLANE) = il;
+        *reinterpret_cast<u32x4*>(wr) = rh;
+        *reinterpret_cast<u32x4*>(wr + CSDH_PLANE) = rl;
+        *reinterpret_cast<u32x4*>(wi) = ih;
+        *reinterpret_cast<u32x4*>(wi + CSDH_PLANE) = il;
     };
 
     f32x4 re[NT], im[NT];
@@ -228,15 +256,18 @@ __device__ __forceinline__ void csdh_wave(const CsdhArgs& a, char* lds, int f, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) { re[t][r] = 0.f; im[t][r] = 0.f; }
 
-    fetch(0, 0, stA);
-    convert(0, 0, stA);
-    fetch(0, 1, stB);
-    convert(0, 1, stB);
+    nextp -= (size_t)CSDH_KROWS * rowbytes;      // chunk 0
+    fetch(0, 0);
+    convert(0, 0);
+    fetch(0, 1);
+    convert(0, 1);
+    nextp += (size_t)CSDH_KROWS * rowbytes;
     __syncthreads();
 
     // fragment slots: [plane 0 hi, plane 0 lo, plane 1 hi, plane 1 lo]
-    f16x8 A[CSDH_APP ? 2 : 1][4], B[2][4];
+    f16x8 A[2][4], B[2][4];
     unsigned rb = (unsigned)(lq * 4096 + l15 * 16);          // this lane's fragment base in the current buffer
+    bool nofrag = false;
     auto ldfrag = [&](f16x8 (&dst)[4], int blk) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -244,28 +275,29 @@ __device__ __forceinline__ void csdh_wave(const CsdhArgs& a, char* lds, int f, i
                 asm volatile("" : "+v"(dst[p]));            // keep the registers alive, read nothing
                 continue;
             }
+            if ((CSDH_ABL & 64) && nofrag) continue;        // real operand bits, fetched in the first chunk only
             dst[p] = *reinterpret_cast<const f16x8*>(lds + rb + p * CSDH_PLANE + blk * 256);
         }
     };
     constexpr int S1 = CSDH_S1, S2 = CSDH_S2;                 // the conversions go behind these steps
 
     for (int c = 0; c < nchunk; ++c) {
+        CSDH_STAMP(0);
         ldfrag(A[PL::T.aslot[0]], PL::T.ablk[0]);
         if constexpr (PL::T.bload[0]) ldfrag(B[PL::T.bslot[0] & 1], PL::T.bblk[0]);
-        fetch(c + 1, 0, stA);     // (the last iteration converts rows that do not exist into the idle buffer: zeros)
-        if (CSDH_DEEP) fetch(c + 1, 1, stB);
-        __builtin_amdgcn_sched_barrier(0);         // the loads are issued HERE, ahead of the chunk's matrix work
+        fetch(c + 1, 0);          // (the last iteration converts rows that do not exist into the idle buffer: zeros)
+        __builtin_amdgcn_sched_barrier(CSDH_FENCE);      // the loads are issued HERE, ahead of the chunk's matrix work
         m3_for<0, NT>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int t = PL::T.tile[s];
             // operands of the next step land while this one multiplies
             if constexpr (s + 1 < NT) {
-                if constexpr (CSDH_APP && PL::T.aload[s + 1]) ldfrag(A[PL::T.aslot[s + 1]], PL::T.ablk[s + 1]);
+                if constexpr (PL::T.aload[s + 1]) ldfrag(A[PL::T.aslot[s + 1]], PL::T.ablk[s + 1]);
                 if constexpr (PL::T.bload[s + 1]) ldfrag(B[PL::T.bslot[s + 1]], PL::T.bblk[s + 1]);
             }
-            if constexpr (!CSDH_APP && s > 0 && PL::T.aload[s]) ldfrag(A[0], PL::T.ablk[s]);
             const f16x8(&X)[4] = A[PL::T.aslot[s]];
             const f16x8(&Y)[4] = PL::T.bslot[s] == 2 ? A[PL::T.aslot[s]] : B[PL::T.bslot[s] & 1];
+            __builtin_amdgcn_s_setprio(1);            // the matrix instructions of a sub-tile ahead of the partner wave's vector work
             // Im, first group: plane 1 of A x plane 0 of B
             im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[0], im[t], 0, 0, 0);
             im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[1], im[t], 0, 0, 0);
@@ -282,17 +314,33 @@ __device__ __forceinline__ void csdh_wave(const CsdhArgs& a, char* lds, int f, i
             im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[2], im[t], 0, 0, 0);
             im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[3], im[t], 0, 0, 0);
             im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[1], Y[2], im[t], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
             if constexpr (s == S1) {
-                convert(c + 1, 0, stA);
-                if (!CSDH_DEEP) {
-                    fetch(c + 1, 1, stB);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                CSDH_STAMP(2);
+#ifdef CSDH_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                CSDH_STAMP(3);
+                convert(c + 1, 0);
+                fetch(c + 1, 1);
+                __builtin_amdgcn_sched_barrier(CSDH_FENCE);
+                CSDH_STAMP(4);
             }
-            if constexpr (s == S2) convert(c + 1, 1, stB);
+            if constexpr (s == 0) CSDH_STAMP(1);
+            if constexpr (s == S2) {
+                CSDH_STAMP(5);
+#ifdef CSDH_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                CSDH_STAMP(6);
+                convert(c + 1, 1);
+            }
         });
+        CSDH_STAMP(7);
         if (!(CSDH_ABL & 16)) __syncthreads();
+        if (CSDH_ABL & 64) nofrag = true;
         rb ^= (unsigned)CSDH_BUF;
+        nextp += (size_t)CSDH_KROWS * rowbytes;
     }
 
     // ---- the Im accumulators carry the sign (-1)^nchunk relative to (even chunks) Im = Ai Br - Ar Bi ... :

@@ -119,6 +119,7 @@ struct spyhip_fft_plan {
     bool identity_freq = true;
     bool blocked = false;
     unsigned* absmax = nullptr;  // spyhip_fft_plan_set_absmax: where the exec calls leave the range of the spectra
+    float wnorm = 0.f;           // max_k || w_k scale ||_2
     bool precision64 = false;   // float64 taper product + FFT, complex64 rounding where the reference rounds (mtmfft_f64_kernel.h)
     bool f64_any = false;       // ... through the any-length kernel (work arrays in global memory)
     bool f64_dec = false;       // ... through the compile-time-schedule kernel (mtmfft_dec64_kernel.h)
@@ -349,6 +350,15 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
     p->scale = (float)scale;
     SPY_HIP_CHECK(hipSetDevice(ctx->device));
 
+    {
+        double wmax = 0.0;
+        for (int k = 0; k < ntaper; ++k) {
+            double q = 0.0;
+            for (int n = 0; n < nsig; ++n) q += tapers[(size_t)k * nsig + n] * tapers[(size_t)k * nsig + n];
+            wmax = std::max(wmax, q);
+        }
+        p->wnorm = (float)(std::sqrt(wmax) * std::fabs(scale) * (1.0 + 1e-6));
+    }
     std::vector<float> tf((size_t)ntaper * nsig);
     for (size_t i = 0; i < tf.size(); ++i) tf[i] = (float)tapers[i];
     if (p->tapers.upload(tf, ctx->stream)) { delete p; return -2; }
@@ -738,6 +748,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     a.means = nullptr;
     a.seg_f64 = p->seg_f64 ? 1 : 0;
     a.absmax = (p->absmax && !p->blocked && !p->precision64 && !p->pipe) ? p->absmax : nullptr;
+    a.wnorm = p->wnorm;
     if (p->ref_mean && p->detrend == 0) {
         // the per-channel means of every segment in the reference's summation order, ahead of the transform
         const size_t need = (size_t)nseg * p->nchan;

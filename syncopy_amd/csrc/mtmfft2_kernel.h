@@ -202,9 +202,30 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
     const bool fast = full && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) &&
                       ((a.nchan & (CPLX ? 1 : 3)) == 0);
 
-    // largest |re|, |im| written per channel (complex all-taper output only; a.absmax may be null)
-    float amx[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool track = CPLX && !MEAN && a.absmax != nullptr;      // uniform
+    // ---- range of the spectra for K4h (spyhip_fft_plan_set_absmax; complex all-taper output only): every bin of channel c
+    // obeys |X_c(f)| = |sum_n w[n] x_c[n] e^(...)| <= ||w||_2 ||x_c||_2, so ONE sum of squares of the detrended samples
+    // per segment (they are in registers) bounds all tapers and all bins - 32 packed multiply-adds per thread and segment
+    // instead of a maximum over every value written.  a.wnorm = max over the tapers of ||w scale||_2 (a per-taper mean
+    // removed after the product, demean_taper, only shrinks the norm).
+    if (CPLX && !MEAN && a.absmax != nullptr) {                   // uniform
+        v2f qr = splat(0.f), qi = splat(0.f);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            qr += x[e].r * x[e].r;
+            qi += x[e].i * x[e].i;
+        }
+        double q[4] = {(double)qr[0], (double)qr[1], (double)qi[0], (double)qi[1]};
+        block_sum<C::NTHREADS, G, 4>(q, reinterpret_cast<double*>(lds), tid, h);
+        if (j0 == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (has[i]) {
+                    // (float32 partial sums: 1e-6 relative; the margin covers them and the rounding of the product)
+                    const float bound = sqrtf((float)q[i]) * a.wnorm * 1.001f;
+                    atomicMax(a.absmax + c0 + i, __float_as_uint(bound));    // non-negative floats order like their bits
+                }
+        }
+    }
 
     // taper weights of the first taper; later tapers are prefetched while the previous FFT runs
     float wn[16];
@@ -343,12 +364,6 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                 if (CPLX) {
                     const float4 lo = make_float4(xa.r[0], xa.i[0], xa.r[1], xa.i[1]);
                     const float4 hi = make_float4(xb.r[0], xb.i[0], xb.r[1], xb.i[1]);
-                    if (track) {
-                        amx[0] = fmaxf(amx[0], fmaxf(fabsf(lo.x), fabsf(lo.y)));
-                        amx[1] = fmaxf(amx[1], fmaxf(fabsf(lo.z), fabsf(lo.w)));
-                        amx[2] = fmaxf(amx[2], fmaxf(fabsf(hi.x), fabsf(hi.y)));
-                        amx[3] = fmaxf(amx[3], fmaxf(fabsf(hi.z), fabsf(hi.w)));
-                    }
                     if (G == 1 && e < 8) {
                         // The L2 accepts one write request per line and clock whatever its size, and every lane
                         // owns a different row (bin): let lanes (2i, 2i+1) write the two 16-byte halves of the
@@ -384,7 +399,6 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (!has[i]) continue;
-                        if (track) amx[i] = fmaxf(amx[i], fmaxf(fabsf(X[i].x), fabsf(X[i].y)));
                         if (CPLX) stg<float2>(slab, o + i * OSZ, X[i]);
                         else stg<float>(slab, o + i * OSZ, convert_real<OUTK>(X[i], a.out_kind));
                     }
@@ -393,28 +407,6 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         }
         // no barrier here: the next taper's first LDS write sits behind one (fft2_forward / block_sum)
         SPY_STAMP(sn);
-    }
-
-    if (track) {
-        // threads tid = G j + h share the quad h: maximum over the lanes of a wave that hold the same quad (lane strides of
-        // G), over the waves through LDS, then one atomic per channel and workgroup (non-negative floats order like their
-        // bit patterns; a NaN is dropped by the maximum - NaN spectra fail K4h's own validity check instead)
-        __syncthreads();
-        unsigned* const sm = reinterpret_cast<unsigned*>(lds);
-        if (tid < 4 * G) sm[tid] = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float m = amx[i];
-#pragma unroll
-            for (int d = 32; d >= G && d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-            if ((tid & 63) < G) atomicMax(&sm[4 * h + i], __float_as_uint(m));
-        }
-        __syncthreads();
-        if (tid < 4 * G) {
-            const int c = 4 * pg * G + tid;
-            if (c < a.nchan) atomicMax(a.absmax + c, sm[tid]);
-        }
     }
 
     if (MEAN) {

@@ -55,8 +55,9 @@ struct MtmArgs {
                                 // (seq_mean_kernel) used for detrend == 0, or nullptr: float64 block sums
     int seg_f64;                // the segments are FLOAT64 arrays in the reference (zero-extended / padded sliding windows,
                                 // stft.py:101-117): the float64 kernels then subtract the trend in float64 as well
-    unsigned* absmax;           // nullptr, or nchan bit patterns of non-negative floats raised to the largest |re|, |im| of every
+    unsigned* absmax;           // nullptr, or nchan bit patterns of non-negative floats raised to a bound of |re|, |im| of every
                                 // complex value written for the channel (spyhip_fft_plan_set_absmax: the range K4h scales by)
+    float wnorm;                // max over the tapers of || w * scale ||_2 (the bound is wnorm * ||detrended segment||_2)
 };
 
 // Per-channel mean of a segment exactly as the reference takes it.  scipy.signal.detrend(type="constant") on the

@@ -141,8 +141,9 @@ def test_nonfinite_values_propagate(be):
 
 @pytest.mark.parametrize("N,nchan,K", [(256, 256, 2), (1024, 37, 3), (4096, 256, 7), (8192, 8, 1)])
 def test_fft_plan_delivers_the_range(be, N, nchan, K):
-    """spyhip_fft_plan_set_absmax: every exec raises absmax[c] to the largest |re|, |im| it wrote for channel c - bit
-    for bit the maximum over the spectra it returns, for every power-of-two length of the packed kernel."""
+    """spyhip_fft_plan_set_absmax: every exec raises absmax[c] to a bound of the |re|, |im| it wrote for channel c
+    (taper norm x 2-norm of the detrended segment): never below the true maximum, within sqrt(N) of it on noise, for
+    every power-of-two length of the packed kernel."""
     B = 5
     rng = np.random.default_rng(N + nchan)
     data = rng.normal(size=(B * N, nchan)).astype(np.float32) * np.logspace(-3, 3, nchan).astype(np.float32)
@@ -154,10 +155,18 @@ def test_fft_plan_delivers_the_range(be, N, nchan, K):
     spec = plan.execute(d, starts[:3], absmax=am)
     assert plan.tracked_absmax
     ref = torch.view_as_real(spec).abs().amax(dim=(0, 1, 2, 4))
-    assert torch.equal(am, ref)
+    assert bool((am >= ref).all()) and bool((am <= ref * np.sqrt(N)).all()), (am / ref).cpu().numpy()
+    first = am.clone()
     spec2 = plan.execute(d, starts[3:], absmax=am)          # a second call only raises it
     ref2 = torch.maximum(ref, torch.view_as_real(spec2).abs().amax(dim=(0, 1, 2, 4)))
-    assert torch.equal(am, ref2)
+    assert bool((am >= first).all()) and bool((am >= ref2).all()) and bool((am <= ref2 * np.sqrt(N)).all())
+    # a channel riding on an offset nobody removes: the DC bin IS the bound (tight where the bits are needed)
+    if K == 1:
+        off = be.FFTPlan(N, N, nchan, tapers, np.sqrt(2) / N, None, False, None, "fourier", True)
+        am0 = torch.zeros(nchan, dtype=torch.float32, device="cuda")
+        s0 = off.execute(d + 1000.0 * float(np.abs(data).max()), starts[:2], absmax=am0)
+        r0 = torch.view_as_real(s0).abs().amax(dim=(0, 1, 2, 4))
+        assert bool((am0 >= r0).all()) and bool((am0 <= 1.5 * r0).all()), (am0 / r0).cpu().numpy()
     plain = plan.execute(d, starts[:3])                     # and without it the spectra are the same bits
     assert torch.equal(torch.view_as_real(plain), torch.view_as_real(spec))
     if nchan == 256:

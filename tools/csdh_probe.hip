@@ -87,11 +87,29 @@ int main(int argc, char** argv) {
     a.spec = spec; a.nrows = rows; a.F = F; a.acc = acc; a.absmax = absmax; a.flags = flags; a.f0 = 0; a.nf = F; a.rs = (long long)F * 256; a.fs = 256;
     if (getenv("CSDH_FMAJOR")) { a.rs = 256; a.fs = rows * 256; }
     if (getenv("CSDH_BLOCKED")) { a.rs = 256; a.fs = 32 * 256; /* rows of a 32-row block contiguous; blocks overlap: timing only */ }
+    unsigned long long* stamps;
+    hipMalloc(&stamps, 4 * 8 * 8 * 8);
+    hipMemset(stamps, 0, 4 * 8 * 8 * 8);
+    a.stamps = stamps;
     hipFuncSetAttribute((const void*)spycsd::csdh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, spycsd::CSDH_LDS_BYTES);
     spycsd::csdh_kernel<<<F, 512, spycsd::CSDH_LDS_BYTES>>>(a);
     hipDeviceSynchronize();
     printf("csdh first launch: %s\n", hipGetErrorString(hipGetLastError()));
 
+#ifdef CSDH_STAMPS
+    {
+        std::vector<unsigned long long> h(4 * 8 * 8);
+        hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        const unsigned long long t0 = h[0];
+        printf("timeline of block 0 (cycles since wave 0 entered chunk 20): points 0 chunk start, 1 after first tile, 2 before / 3 after the wait for loads A, 4 after conversion A + issue of loads B, 5 before / 6 after the wait for loads B, 7 before the barrier\n");
+        for (int c = 0; c < 4; ++c)
+            for (int g = 0; g < 8; ++g) {
+                printf("chunk %d wave %d:", 20 + c, g);
+                for (int k = 0; k < 8; ++k) printf(" %7lld", (long long)(h[(c * 8 + g) * 8 + k] - t0));
+                printf("\n");
+            }
+    }
+#endif
     // float32 3M kernel for comparison
     spycsd::CsdArgs b{};
     b.spec = spec; b.nrows = rows; b.F = F; b.C = 256; b.acc = acc3;
