@@ -29,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_MFMA_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16 / FP16 MFMA, dense (2:1 sparsity figures are not a peak)
+PROFILE_ROUND = "r5"            # profiles/<round>_* written by tools/final_bench.sh on the code of this round
 PEAK_F64_TFLOPS = 78.6          # MI355X_MICROARCH.md: FP64 vector / matrix
 PEAK_HBM_GBS = 8000.0
 # SURVEY 8(d) bound of the headline on one GPU: K4's 3.775e9 algorithmic flops per trial at 157.3 TFLOP/s = 24.0 us
@@ -185,7 +187,7 @@ def k4_sources_sha():
     other kernel code are not reported."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("csd3m_kernel.h", "csd3m_launch_impl.h", "csd.hip", "csd_kernel.h", "csd_args.h"):
+    for name in ("csdh_kernel.h", "csdh.hip", "csd3m_kernel.h", "csd3m_launch_impl.h", "csd.hip", "csd_kernel.h", "csd_args.h"):
         with open(os.path.join(ROOT, "syncopy_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -199,7 +201,7 @@ def pmc_traffic(nrows, nfreq, nchan):
     (bytes or None, provenance): the counters are only reported for the launch shape AND the kernel sources they were
     taken on (first line of the file: shape and `k4_sources_sha`)."""
     sha = k4_sources_sha()
-    for name in ("r4_pmc_headline.txt", "r3_pmc_counters_final.txt", "r2_pmc_counters_final.txt", "r1_pmc_counters_final.txt"):
+    for name in (PROFILE_ROUND + "_pmc_headline.txt", "r4_pmc_headline.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -219,7 +221,7 @@ def pmc_traffic(nrows, nfreq, nchan):
         if not ln.startswith(" "):
             cur = ln.strip()
             continue
-        if cur is None or not any(k in cur for k in ("csd_accum_kernel", "csd_reduce_parts", "csd3m_kernel")):
+        if cur is None or not any(k in cur for k in ("csd_accum_kernel", "csd_reduce_parts", "csd3m_kernel", "csdh_kernel")):
             continue
         name, rest = ln.split()[0], ln.split("mean=")[1]
         if name == "FETCH_SIZE":
@@ -229,11 +231,11 @@ def pmc_traffic(nrows, nfreq, nchan):
     return (total or None), prov
 
 
-PMC_SECONDARY = "r4_pmc_secondary.txt"
+PMC_SECONDARY = PROFILE_ROUND + "_pmc_secondary.txt"
 
 
 def pmc_secondary(mode):
-    """HBM bytes per trial of one `secondary` workload from the committed counter file (profiles/r4_pmc_secondary.txt,
+    """HBM bytes per trial of one `secondary` workload from the committed counter file (profiles/<round>_pmc_secondary.txt,
     written by tools/final_bench.sh through the torch-free tools/pmc_harness2.cpp - same plans, shapes and launch
     arguments): sum over the workload's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x 1024 x dispatches, divided by the
     repetitions and trials of the harness run (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
@@ -298,10 +300,10 @@ def _event_ms(torch, fn, reps=3):
 
 def _traffic(mode, algorithmic_bytes):
     """`traffic` fields of a secondary entry: counter bytes per trial, their ratio to the algorithmic bytes, the files a
-    reader needs to recompute the entry (kernel durations: profiles/r4_secondary_kernel_stats.txt, section `mode`)."""
+    reader needs to recompute the entry (kernel durations: profiles/<round>_secondary_kernel_stats.txt, section `mode`)."""
     t, prov = pmc_secondary(mode)
     return {"traffic_bytes_per_trial": t, "traffic_over_algorithmic": (t / algorithmic_bytes) if t else None,
-            "traffic_source": prov, "kernel_stats": "profiles/r4_secondary_kernel_stats.txt#" + mode}
+            "traffic_source": prov, "kernel_stats": "profiles/" + PROFILE_ROUND + "_secondary_kernel_stats.txt#" + mode}
 
 
 def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
@@ -497,7 +499,7 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
              "kernel": "spywil::zinv_mfma_kernel / zgemm_mfma_kernel<0..3> / plus4_kernel", "bound": "fp64 %.1f TFLOP/s" % PEAK_F64_TFLOPS,
              "flop_per_iteration": flop_it, "executed_flop_per_iteration": flop_it_exec,
              "st_stage_s": dt_st, "st_trials": Tg, "st_plus_av_s": dt_st + dt, "first_call_s": dt_first,
-             "kernel_stats": "profiles/r4_wilson_kernel_stats.csv", "counters": "profiles/r4_wilson_pmc.txt",
+             "kernel_stats": "profiles/" + PROFILE_ROUND + "_wilson_kernel_stats.csv", "counters": "profiles/" + PROFILE_ROUND + "_wilson_pmc.txt",
              "note": "frac prices the flops the kernels execute (conjugate symmetry: F of the reference's 2(F-1) bins) "
                      "against the fp64 matrix peak; algorithmic_frac uses SURVEY 8(d)'s count for the full spectrum"}
     if iters:
@@ -713,17 +715,85 @@ def main():
             blocks = [min(256, C - 256 * i) for i in range((C + 255) // 256)]
             nsub = sum(((b + 15) // 16) * ((b + 15) // 16 + 1) // 2 for b in blocks) + 256 * (len(blocks) * (len(blocks) - 1) // 2)
         executed = ((rows[0] + 3) // 4) * F * nsub * 3 * 2048.0 if is3m else None
+        # K4h (256 channels, standard layout): 12 v_mfma_f32_16x16x32_f16 (16384 flop) per 16 x 16 sub-tile and chunk of 32
+        # rows on the frequencies of the full rounds of workgroups; the frequencies beyond them run the float32 tail
+        k4h = C == 256 and not blocked and not os.environ.get("SPYHIP_CSD_F32")
+        if k4h:
+            ncu = torch.cuda.get_device_properties(0).multi_processor_count
+            rem = F % ncu
+            f_main = F - rem if (F > ncu and 0 < rem and 4 * rem <= ncu) else F
+            executed = ((rows[0] + 31) // 32) * f_main * 136 * 12 * 16384.0
+            fallbacks = be.csd_split_fallbacks()
         value = world * T * args.steps / el
         coll = {"executed": bool(dist_on), "backend": "RCCL, library communicator (spyhip_allreduce_csd)" if dist_on else None}
         if ev_coll:
             coll.update({"bytes": ev_coll[0][2], "pack_allreduce_unpack_ms": float(np.mean([a.elapsed_time(b) for a, b, _ in ev_coll]))})
         traffic, traffic_prov = pmc_traffic(rows[0], F, C)
+        avg_ms = float(np.mean(csd_ms))
+        hbm_bytes = rows[0] * F * C * 8 + (2 * F * nsub * 256 * 8 if (is3m or k4h) else 2 * F * (((C + 31) // 32) * ((C + 31) // 32 + 1) // 2) * 1024 * 8)
+        if k4h:
+            ex_tf = executed / (avg_ms * 1e-3) / 1e12
+            roofline = {
+                "bound": "mfma",
+                "kernel": "spycsd::csdh_kernel (+ its float32 stand-in on flagged frequencies, the row-split <1, 1> tail and its reduction)",
+                # what the half-precision matrix pipe executes: 3 fp16 products per real product, 4 real products per complex one
+                "achieved": ex_tf,
+                "peak": PEAK_MFMA_F16_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ex_tf / PEAK_MFMA_F16_TFLOPS,
+                "executed_mfma_flop_per_launch": executed,
+                # the same launch in the units of SURVEY 8(d): 8 flop per complex multiply-accumulate on the Hermitian-
+                # minimal triangle, against the float32 matrix peak the survey priced K4 with
+                "algorithmic_TFLOPs": achieved,
+                "flop_per_launch": flops[0],
+                "fp32_equivalent_frac": achieved / PEAK_MFMA_F32_TFLOPS,
+                "fp32_peak": PEAK_MFMA_F32_TFLOPS,
+                "frequencies_left_to_float32_kernels": fallbacks,
+                "note": "achieved = executed fp16 matrix flops per launch / avg_launch_ms: ceil(rows / 32) chunks x frequencies of "
+                        "the full rounds x 136 sub-tiles x 12 v_mfma_f32_16x16x32_f16 x 16384 flop (= SQ_INSTS_VALU_MFMA_F16 / "
+                        "SQ_INSTS_MFMA x 16384 of profiles/%s_pmc_headline.txt); peak = dense FP16 / BF16 MFMA.  The chip does not "
+                        "hold 2.4 GHz under this load: GRBM_GUI_ACTIVE / duration in the same file gives the clock the fraction "
+                        "should also be read against." % PROFILE_ROUND,
+                "kernel_stats": "profiles/%s_bench_final_kernel_stats.csv (Name = spycsd::csdh_kernel; AverageNs + the tail rows must agree with avg_launch_ms)" % PROFILE_ROUND,
+                "avg_launch_ms": avg_ms,
+                "algorithmic_hbm_bytes_per_launch": hbm_bytes,
+                "hbm_GBps": hbm_bytes / (avg_ms * 1e-3) / 1e9,
+                "hbm_frac": hbm_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "traffic": traffic,
+                "traffic_source": traffic_prov,
+            }
+        else:
+            roofline = {
+                "bound": "mfma",
+                "kernel": be.csd_kernel_name(C, blocked) + " (+ row-split <1, 1> tail and its reduction)",
+                "achieved": achieved,
+                "peak": PEAK_MFMA_F32_TFLOPS,
+                "unit": "TFLOP/s",
+                # frac = what the matrix pipe really does: flops the kernel EXECUTES per launch / duration / peak (<= 1);
+                # algorithmic_frac = SURVEY 8(d)'s credited flops (8 per complex multiply-accumulate on the Hermitian-
+                # minimal triangle) / duration / peak - above frac because the 3-multiplication product executes 3/4 of them
+                "frac": ((executed / flops[0]) if executed else 1.0) * achieved / PEAK_MFMA_F32_TFLOPS,
+                "algorithmic_frac": achieved / PEAK_MFMA_F32_TFLOPS,
+                "flop_per_launch": flops[0],
+                "executed_mfma_flop_per_launch": executed,
+                "executed_TFLOPs": ((executed / flops[0]) if executed else 1.0) * achieved,
+                "note": "achieved = algorithmic flops (8 per complex multiply-accumulate on the Hermitian-minimal triangle, "
+                        "SURVEY 8d) / avg_launch_ms; executed_mfma_flop_per_launch = ceil(rows / 4) x F x sub-tiles x 3 MFMAs x "
+                        "2048 flop; frac = executed / avg_launch_ms / peak",
+                "avg_launch_ms": avg_ms,
+                "algorithmic_hbm_bytes_per_launch": hbm_bytes,
+                "traffic": traffic,
+                "traffic_source": traffic_prov,
+            }
         line = {
             "metric": "trials/sec for mtmfft+coherence (256 ch x 4096 samples, 7 DPSS tapers, full CSD)",
             "value": value,
             "unit": "trials/s",
-            # whole step against SURVEY 8(d)'s bound of 41.7 k trials/s per GPU (K4's matrix bound)
+            # whole step against SURVEY 8(d)'s bound of 41.7 k trials/s per GPU (K4 priced at the FLOAT32 matrix peak: the
+            # half-precision formulation of K4 is not bound by it) and against what binds the path now: the 4.19 MB in +
+            # 29.4 MB of spectra written by K1 and read by K4 per trial at the HBM peak
             "headline_frac": value / (world * HEADLINE_BOUND_TRIALS_PER_S),
+            "headline_hbm_frac": value / (world * PEAK_HBM_GBS * 1e9 / (N * C * 4 + 2 * K * F * C * 8)),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -747,31 +817,7 @@ def main():
                 "csd_ms_per_trial": sum(csd_ms) / (T * args.steps),
                 "collective": coll,
             },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": be.csd_kernel_name(C, blocked) + " (+ row-split <1, 1> tail and its reduction)",
-                "achieved": achieved,
-                "peak": PEAK_MFMA_F32_TFLOPS,
-                "unit": "TFLOP/s",
-                # frac = what the matrix pipe really does: flops the kernel EXECUTES per launch / duration / peak (<= 1);
-                # algorithmic_frac = SURVEY 8(d)'s credited flops (8 per complex multiply-accumulate on the Hermitian-
-                # minimal triangle) / duration / peak - above frac because the 3-multiplication product executes 3/4 of them
-                "frac": ((executed / flops[0]) if executed else 1.0) * achieved / PEAK_MFMA_F32_TFLOPS,
-                "algorithmic_frac": achieved / PEAK_MFMA_F32_TFLOPS,
-                "flop_per_launch": flops[0],
-                "executed_mfma_flop_per_launch": executed,
-                "executed_TFLOPs": ((executed / flops[0]) if executed else 1.0) * achieved,
-                "note": "achieved = algorithmic flops (8 per complex multiply-accumulate on the Hermitian-minimal triangle, "
-                        "SURVEY 8d) / avg_launch_ms; executed_mfma_flop_per_launch = ceil(rows / 4) x F x sub-tiles x 3 MFMAs x "
-                        "2048 flop (= SQ_INSTS_MFMA x 2048 of profiles/r4_pmc_headline.txt); frac = executed / avg_launch_ms / peak",
-                "kernel_stats": "profiles/r4_bench_final_kernel_stats.csv (Name = the kernel above; AverageNs must agree with avg_launch_ms)",
-                "avg_launch_ms": float(np.mean(csd_ms)),
-                # spectra once + read-modify-write of the accumulator's lower triangle (16 x 16 sub-tiles for the
-                # 3-multiplication kernel, 32 x 32 tiles otherwise)
-                "algorithmic_hbm_bytes_per_launch": rows[0] * F * C * 8 + (2 * F * nsub * 256 * 8 if is3m else 2 * F * (((C + 31) // 32) * ((C + 31) // 32 + 1) // 2) * 1024 * 8),
-                "traffic": traffic,
-                "traffic_source": traffic_prov,
-            },
+            "roofline": roofline,
         }
         if world == 1 and not args.no_secondary:
             del spec

@@ -1,6 +1,7 @@
 #!/bin/bash
 # ONE script behind every figure of the bench line (VERDICT r3 "next" 3).  On the GPU box:  bash tools/final_bench.sh
-# Everything lands in gpurun_out/final/ (summaries only: traces stay in /tmp); the files are then copied to profiles/r4_*.
+# Everything lands in gpurun_out/final/ (summaries only: traces stay in /tmp); the files are then copied to profiles/r5_*
+# (bench.py: PROFILE_ROUND).
 #   bench.json                      python bench.py (the line the driver also produces)
 #   bench_kernel_stats.csv          rocprofv3 --kernel-trace --stats of the headline-only run (K0 / K1 / K4 / K5 rows)
 #   bench_under_rocprof.json        that run's own line (HIP-event averages inside the profiled process)

@@ -1,6 +1,7 @@
 // Torch-free driver of the C ABI for rocprofv3 counter passes (PMC collection crashes inside
 // torch's own kernels on this image).  Runs the coherence front half on synthetic trials:
-//   spyhip_fft_exec (fourier, all tapers) -> spyhip_csd_accumulate[_blocked], `reps` times;
+//   spyhip_fft_exec (fourier, all tapers; leaves the range of the spectra) -> spyhip_csd_accumulate_split (K4h on the
+//   half-precision matrix cores; SPYHIP_CSD_F32=1: the float32 kernels) or spyhip_csd_accumulate_blocked, `reps` times;
 //   which & 4: the trials are 64 distinct AR(2) realisations (alphas 0.55, -0.8 as synthdata.ar2_network), and the
 //   averaged CSD goes through spyhip_granger afterwards (K6 at 256 channels x 2049 frequencies).
 // build: hipcc -O2 tools/pmc_harness.cpp -Iinclude -Lsyncopy_amd -lspyhip -Wl,-rpath,$PWD/syncopy_amd -o gpurun_out/pmc_harness
@@ -52,6 +53,10 @@ int main(int argc, char** argv) {
     SK(spyhip_fft_plan_set_reference_mean(plan, 1));     // as the front ends do for whole trials
     if (blocked) SK(spyhip_fft_plan_set_blocked(plan, 1));
     void *spec, *acc;
+    float* absmax;
+    CK(hipMalloc(&absmax, C * sizeof(float)));
+    CK(hipMemset(absmax, 0, C * sizeof(float)));
+    const bool ranged = !blocked && spyhip_fft_plan_set_absmax(plan, absmax) == 0;
     CK(hipMalloc(&spec, (size_t)B * K * F * C * 8));
     CK(hipMalloc(&acc, (size_t)F * C * C * 8));
     CK(hipMemset(acc, 0, (size_t)F * C * C * 8));
@@ -59,7 +64,12 @@ int main(int argc, char** argv) {
     for (int r = 0; r < reps; ++r) {
         if (which & 1) SK(spyhip_fft_exec(plan, data, C, nullptr, dst, dst, dhi, B, spec));
         if (which & 2) SK(blocked ? spyhip_csd_accumulate_blocked(ctx, spec, (int64_t)B * K, F, C, acc)
-                               : spyhip_csd_accumulate(ctx, spec, (int64_t)B * K, F, C, acc));
+                               : spyhip_csd_accumulate_split(ctx, spec, (int64_t)B * K, F, C, acc, ranged ? absmax : nullptr));
+    }
+    if ((which & 2) && !blocked) {
+        int nfb = 0;
+        SK(spyhip_csd_split_fallbacks(ctx, &nfb));
+        printf("frequencies left to the float32 kernels: %d\n", nfb);
     }
     if (which & 4) {
         SK(spyhip_csd_finalize(ctx, acc, F, C, 1.0 / ((double)B * K * reps)));
