@@ -164,10 +164,14 @@ class Upload:
     ones are still on the bus.  `finish()` waits for everything (what `AnalogData.device_data()` does for callers that
     do not know about uploads in flight)."""
 
-    def __init__(self, host, dev, time_axis):
+    def __init__(self, host, dev, time_axis, row0=0):
         import threading
         self.dev, self.host, self.time_axis = dev, host, time_axis
+        self.row0 = int(row0)                # host row of the tensor's first row (a rank stages only its own span)
         self.nrows = dev.shape[0]
+        # `dev` was allocated on the caller's current stream: the caching allocator may have handed out a block whose
+        # previous owner still has kernels queued there - the copy stream must not overtake them
+        self.alloc_stream = torch.cuda.current_stream(dev.device)
         self.marks = []                      # [(row_end, event)] in row order
         self.cond = threading.Condition()
         self.error = None
@@ -193,14 +197,17 @@ class Upload:
         stage = _staging("h2d", _H2D_CHUNK)
         rows_per = self.chunk_rows()
         stream = torch.cuda.Stream(device=dev.device)
+        stream.wait_stream(self.alloc_stream)
+        dev.record_stream(stream)
         busy = [None, None]
+        h0 = self.row0
         for k, r0 in enumerate(range(0, ntime, rows_per)):
             r1 = min(ntime, r0 + rows_per)
             buf = stage[k & 1]
             if busy[k & 1] is not None:
                 busy[k & 1].synchronize()              # the copy that last used this buffer has left it
             pinned = buf[:(r1 - r0) * nchan * 4].view(torch.float32).view(r1 - r0, nchan)
-            _staged_fill(pinned.numpy(), host[r0:r1] if self.time_axis == 0 else host[:, r0:r1].T)
+            _staged_fill(pinned.numpy(), host[h0 + r0:h0 + r1] if self.time_axis == 0 else host[:, h0 + r0:h0 + r1].T)
             with torch.cuda.stream(stream):
                 dev[r0:r1].copy_(pinned, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -236,8 +243,10 @@ class Upload:
         self.host = None
 
 
-def to_device(host, device, time_axis=0, background=False):
+def to_device(host, device, time_axis=0, background=False, rows=None):
     """Host recording -> (time x channel) float32 matrix in HBM: the ingress of the in-HBM trial queue.
+    `rows` = (lo, hi): only that span of the recording's rows (a rank's trial shard, AnalogData.shard_span) - the
+    tensor's row 0 is then host row lo.
     `host` may be an np.memmap onto a `.spy` data file (io/spy_container.py) of any size: blocks of rows are read
     (and, if needed, converted to float32 / transposed - dimord ["channel", "time"], compRoutines.py:143-146) straight
     into two alternating pinned staging buffers and copied to the device asynchronously, so the file is never held in
@@ -245,14 +254,18 @@ def to_device(host, device, time_axis=0, background=False):
     `background=True` returns (tensor, Upload or None) at once: the copy proceeds on a thread and a stream of its own
     (class Upload) - None when the recording is small enough for one plain copy."""
     ntime, nchan = (host.shape if time_axis == 0 else host.shape[::-1])
-    dev = torch.empty((ntime, nchan), dtype=torch.float32, device=device)
-    nbytes = ntime * nchan * 4
+    lo, hi = (0, ntime) if rows is None else (int(rows[0]), int(rows[1]))
+    assert 0 <= lo <= hi <= ntime, (lo, hi, ntime)
+    dev = torch.empty((hi - lo, nchan), dtype=torch.float32, device=device)
+    nbytes = (hi - lo) * nchan * 4
+    if nbytes == 0:
+        return (dev, None) if background else dev
     direct = (time_axis == 0 and host.dtype == np.float32 and host.flags["C_CONTIGUOUS"]
               and not isinstance(host, np.memmap))
     if direct and nbytes < (64 << 20):
-        dev.copy_(torch.from_numpy(host))
+        dev.copy_(torch.from_numpy(host[lo:hi]))
         return (dev, None) if background else dev
-    up = Upload(host, dev, time_axis)
+    up = Upload(host, dev, time_axis, row0=lo)
     if background:
         return dev, up
     up.finish()

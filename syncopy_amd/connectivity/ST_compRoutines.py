@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from .. import backend, parallel
-from ..datatype import selected_channels, trial_rows
+from ..datatype import device_rows, selected_channels, trial_rows
 from ..shared.computational_routine import ComputationalRoutine, propagate_properties
 from ..shared.const_def import spectralDTypes
 from ..shared.errors import SPYValueError
@@ -213,7 +213,7 @@ class CrossSpectra(ComputationalRoutine):
         cfg = self.cfg
         dev = data.device_data(partial=True)
         upload = data.upload_in_flight()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
         freqs, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
         pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
@@ -270,7 +270,7 @@ class CrossSpectra(ComputationalRoutine):
         cfg = self.cfg
         dev = data.device_data(partial=True)
         upload = data.upload_in_flight()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
         _, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
         if freq_idx.size < 4:
@@ -309,7 +309,7 @@ class CrossSpectra(ComputationalRoutine):
         and visits T(T-1)/2 pairs).  Returns the (F, C, C) float32 device tensor."""
         cfg = self.cfg
         dev = data.device_data()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
         freqs, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
         pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
@@ -337,7 +337,7 @@ class CrossSpectra(ComputationalRoutine):
         trials (NormalizeCrossSpectra.jackknife_accumulate)."""
         cfg = self.cfg
         dev = data.device_data()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         nS = cfg["nSamples"] if cfg["nSamples"] is not None else rows[0][1] - rows[0][0]
         freqs, freq_idx = _freq_selection(nS, cfg["samplerate"], cfg["foi"])
         pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
@@ -454,7 +454,7 @@ class CrossCovariance(ComputationalRoutine):
         reference's per-trial, per-pair convolutions never happen.  Kept trials: the same per trial."""
         cfg = self.cfg
         dev = data.device_data()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         pr = cfg["polyremoval"] if cfg["polyremoval"] in (0, 1) and cfg["polyremoval"] is not False else None
         T = self.numTrials
         mine = [rows[k] for k in self.my_trials()]

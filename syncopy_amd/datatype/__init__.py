@@ -144,23 +144,48 @@ class AnalogData(_Base):
             channel = ["channel" + str(i + 1).zfill(len(str(nchan))) for i in range(nchan)]
         self.channel = np.array(channel)
 
+    def shard_span(self):
+        """[lo, hi) of the host rows this rank's trials live in: the whole recording without a process group, else the
+        rows from the first to the last sample of the rank's contiguous trial shard (parallel.my_shard over the selected
+        trials, exactly the shard every compute_hip works on) - a worker of the reference reads only its own slab too
+        (shared/kwarg_decorators.py:684-735).  Trials that overlap or are listed out of order make the span cover rows
+        nobody on this rank needs; nothing outside it is ever staged."""
+        from .. import parallel
+        ntime = self.data.shape[self.dimord.index("time")]
+        if parallel.world()[1] == 1:
+            return 0, int(ntime)
+        rows = trial_rows(self)
+        lo, hi = parallel.my_shard(len(rows))
+        mine = rows[lo:hi]
+        if not mine:
+            return 0, 0
+        return int(min(a for a, _ in mine)), int(min(ntime, max(b for _, b in mine)))
+
     def device_data(self, device=None, partial=False):
-        """The (time x channel) float32 matrix in HBM (uploaded once, C-order, channel fastest).
+        """This rank's part of the (time x channel) float32 matrix in HBM (uploaded once, C-order, channel fastest): the
+        rows `shard_span()`; `device_rows(data)` gives the trials in ITS row coordinates.
         `partial=True`: do not wait for an upload in flight - the caller walks the trials in order and asks
         `upload_in_flight().wait_rows(row_end)` before it touches rows (backend.Upload): kernels on the first trials
         overlap the PCIe copy of the later ones."""
         import torch
-        from ..backend import require_gpu
-        require_gpu()                      # loud failure: there is no CPU path
+        from .. import backend
+        backend.require_gpu()              # loud failure: there is no CPU path
         dev = torch.device("cuda" if device is None else device)
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
-        # the copy belongs to one host array in one orientation: a new array object, shape or dimord uploads again
-        key = (id(self._data), self._data.shape, tuple(self.dimord), str(dev))
+        span = self.shard_span()
+        # the copy belongs to one host array in one orientation and one row span: a new array object, shape, dimord or
+        # shard uploads again
+        key = (id(self._data), self._data.shape, tuple(self.dimord), str(dev), span)
         if self._device is None or self._device_key != key:
-            from ..backend import to_device
-            self._device, self._upload = to_device(self.data, dev, time_axis=self.dimord.index("time"), background=True)
+            if getattr(self, "_upload", None) is not None:
+                self._upload.finish()      # a copy thread still writing into the tensor that is about to be dropped
+                self._upload = None
+            self._device, self._upload = backend.to_device(self.data, dev, time_axis=self.dimord.index("time"),
+                                                           background=True, rows=span)
             self._device_key = key
+            self._row_origin = span[0]
+            self.staged_rows = span        # (what tests and tests/nccl_worker.py report)
         if not partial and getattr(self, "_upload", None) is not None:
             self._upload.finish()
             self._upload = None
@@ -320,6 +345,12 @@ def trial_rows(data):
         a, b = data.selection.time[t]
         out.append((int(si[t, 0] + a), int(si[t, 0] + b)))
     return out
+
+
+def device_rows(data):
+    """trial_rows in the row coordinates of `data.device_data()` (which must have been called: it decides the span)."""
+    o = getattr(data, "_row_origin", 0) or 0
+    return [(a - o, b - o) for a, b in trial_rows(data)] if o else trial_rows(data)
 
 
 def selected_channels(data):

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import parallel
-from ..datatype import selected_channels, trial_rows
+from ..datatype import device_rows, selected_channels, trial_rows
 from ..shared.computational_routine import ComputationalRoutine, propagate_properties
 from ..shared.const_def import spectralDTypes
 from ..shared.tools import best_match
@@ -63,7 +63,7 @@ class MultiTaperFFT(ComputationalRoutine):
         """All trials from the in-HBM queue; trial mean (keeptrials=False) in the reference's order."""
         mk, cfg = self.cfg["method_kwargs"], self.cfg
         dev = data.device_data()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         lengths = [b - a for a, b in rows]
         freqs = np.fft.rfftfreq(mk["nSamples"] if mk["nSamples"] is not None else lengths[0], 1 / mk["samplerate"])
         _, freq_idx = best_match(freqs, cfg["foi"], squash_duplicates=True)
@@ -190,7 +190,7 @@ class MultiTaperFFTConvol(ComputationalRoutine):
     def compute_hip(self, data, out):
         cfg = self.cfg
         dev = data.device_data()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         mine = list(self.my_trials())
         if cfg["equidistant"] and mine:
             # every trial's frames in one launch (the frames of 200 trials x 64 windows are 12800 segments of one plan;
@@ -368,7 +368,7 @@ class WaveletTransform(ComputationalRoutine):
     def compute_hip(self, data, out):
         cfg = self.cfg
         dev = data.device_data()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         mine = list(self.my_trials())
         pre = [self._argv(k)[0] for k in mine]
         post = [self._argv(k)[1] for k in mine]
@@ -481,7 +481,7 @@ class SuperletTransform(ComputationalRoutine):
     def compute_hip(self, data, out):
         cfg = self.cfg
         dev = data.device_data()
-        rows, chans = trial_rows(data), selected_channels(data)
+        rows, chans = device_rows(data), selected_channels(data)
         mine = list(self.my_trials())
         pre = [self._argv(k)[0] for k in mine]
         post = [self._argv(k)[1] for k in mine]

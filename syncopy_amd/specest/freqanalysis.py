@@ -276,12 +276,13 @@ def _selection_hides_peak(data, cr, method, foi, freqs):
     """See hip_spectral.selection_hides_peak: a handful of this rank's trials (mtmfft) or of the first trial's windows
     (mtmconvol / welch) through the float32 kernels, whole axis, against the bins the call keeps."""
     from .. import parallel
-    from ..datatype import selected_channels, trial_rows
+    from ..datatype import device_rows, selected_channels
     from . import hip_spectral as hs
     if foi is None or freqs is None or len(foi) >= len(freqs):
         return False
     _, fidx = best_match(freqs, foi, squash_duplicates=True)
-    rows, chans = trial_rows(data), selected_channels(data)
+    dev = data.device_data()
+    rows, chans = device_rows(data), selected_channels(data)
     lo, hi = parallel.my_shard(len(rows))
     mine = rows[lo:hi]
     mk = cr.cfg["method_kwargs"]
@@ -295,7 +296,7 @@ def _selection_hides_peak(data, cr, method, foi, freqs):
         nfft, opt = n, dict(mk["taper_opt"] or {})
         if mk["taper"] == "dpss":
             opt["sym"] = False
-    return hs.selection_hides_peak(data.device_data(), seg, chans, nfft, mk["taper"], opt, pr, fidx, len(freqs))
+    return hs.selection_hides_peak(dev, seg, chans, nfft, mk["taper"], opt, pr, fidx, len(freqs))
 
 
 def _windows_at(toi, even, nperseg, fs, tStart):

@@ -131,16 +131,21 @@ def selection_hides_peak(dev_data, rows, chan_idx, nfft, taper, taper_opt, polyr
     transforms from a factor 3 on.  Judged on the float32 power spectra of the segments `rows` (equal length, a
     handful), the largest ratio over the ranks decides."""
     from .. import parallel
-    if freq_idx is None or len(freq_idx) >= nfull or len(rows) == 0:
+    # only rank-INDEPENDENT early-outs ahead of the collective: a rank whose shard is empty (more ranks than trials, a
+    # first trial shorter than the window) contributes the ratio 0 and still takes part, so that every rank enters the
+    # same all-reduce and picks the same precision
+    if freq_idx is None or len(freq_idx) >= nfull:
         return False
-    n = rows[0][1] - rows[0][0]
-    rows = [r for r in rows if r[1] - r[0] == n][:16]
-    N = n if nfft is None else int(nfft)
-    with precision("float32"):
-        spec = run_mtmfft(dev_data, rows, chan_idx, N, taper, taper_opt, False, False, polyremoval, None, "pow", False)
-    p = torch.stack(spec, dim=0)[:, 0]                                    # (B, F, C)
-    kept = p.index_select(1, torch.as_tensor(np.asarray(freq_idx), device=p.device))
-    ratio = float((p.amax(dim=(0, 1)) / kept.amax(dim=(0, 1)).clamp_min(1e-38)).max()) if kept.numel() else 0.0
+    ratio = 0.0
+    if len(rows):
+        n = rows[0][1] - rows[0][0]
+        rows = [r for r in rows if r[1] - r[0] == n][:16]
+        N = n if nfft is None else int(nfft)
+        with precision("float32"):
+            spec = run_mtmfft(dev_data, rows, chan_idx, N, taper, taper_opt, False, False, polyremoval, None, "pow", False)
+        p = torch.stack(spec, dim=0)[:, 0]                                    # (B, F, C)
+        kept = p.index_select(1, torch.as_tensor(np.asarray(freq_idx), device=p.device))
+        ratio = float((p.amax(dim=(0, 1)) / kept.amax(dim=(0, 1)).clamp_min(1e-38)).max()) if kept.numel() else 0.0
     ratio = parallel.allreduce_max(ratio)
     return bool(np.sqrt(ratio) > 3.0)
 
@@ -166,9 +171,15 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
                                keeptapers, device=device,
                                reference_mean=(1 if detrend == 0 else 0) if (whole_trials or float32_frames) else 2)
         if plan_precision() == "reference":
-            if not plan.set_precision(True) and _precision[-1] == "reference":
-                raise PrecisionUnavailable("a transform length up to 2^20 for float64 transforms", varname="precision",
-                                           actual=f"nfft = {int(nfft)}")
+            if not plan.set_precision(True):
+                if _precision[-1] == "reference":
+                    raise PrecisionUnavailable("a transform length up to 2^20 for float64 transforms", varname="precision",
+                                               actual=f"nfft = {int(nfft)}")
+                # the soft request ("reference?") falls back to float32: that plan must not sit under the "reference" key,
+                # where a later explicit precision="reference" would take it for a float64 plan
+                key = key[:-1] + ("float32",)
+                if blocked:
+                    plan.set_blocked(True)
         elif blocked:
             plan.set_blocked(True)
         _bounded_put(_plan_cache, key, plan)

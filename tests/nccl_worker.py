@@ -73,6 +73,14 @@ def main(out_path):
             res["c5_sample"] = np.ascontiguousarray(g5.data[0, ::64, :16, :16])
             del big, g5
             spy.release_device_buffers()
+        # what this rank staged into HBM for the analyses above: only the rows of its own trial shard
+        # (AnalogData.shard_span: the reference's workers read only their slab, kwarg_decorators.py:684-735)
+        lo, hi = data.staged_rows
+        mine = torch.tensor([lo, hi, (hi - lo) * data.data.shape[1] * 4], dtype=torch.int64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        res["staged_rows_and_bytes_per_rank"] = torch.stack(allr).cpu().numpy()
+        res["recording_rows"] = np.array(data.data.shape[0])
         res["world"] = np.array(world)
         torch.cuda.synchronize()
         if dist.get_rank() == 0:

@@ -36,14 +36,20 @@ def _patch():
     from syncopy_amd import backend, parallel
     from syncopy_amd.datatype import AnalogData
     from syncopy_amd.specest import hip_spectral as hs
-    calls = {"rows": []}
+    calls = {"rows": [], "staged": []}
 
     def device_data(self, device=None, partial=False):
-        return torch.from_numpy(np.ascontiguousarray(self.data, dtype=np.float32))
+        # the product's own span / origin logic (AnalogData.shard_span, datatype.device_rows), a host tensor instead of
+        # the upload: only this rank's rows exist in it, so every index below must be shard-local
+        span = self.shard_span()
+        self._row_origin, self.staged_rows = span[0], span
+        calls["staged"].append(span)
+        return torch.from_numpy(np.ascontiguousarray(self.data[span[0]:span[1]], dtype=np.float32))
 
     def run_mtmfft_batches(dev, rows, chans, nfft, taper, taper_opt, demean_taper, ft_compat, polyremoval, freq_idx, output,
                            keeptapers, max_bytes=0, blocked=False, reuse=False, upload=None):
         calls["rows"].extend(rows)
+        assert all(0 <= a and b <= dev.shape[0] for a, b in rows), (rows, dev.shape)
         x = dev.numpy()
         specs = []
         for a, b in rows:
@@ -89,7 +95,9 @@ def _st_stage(keeptrials):
     out = CrossSpectralData(dimord=CrossSpectra.dimord)
     st.initialize(data, out._stackingDim, chan_per_worker=None, keeptrials=keeptrials)
     st.compute(data, out, parallel=False, log_dict={}, method="hip")
-    return np.asarray(out.data), calls["rows"], trial_rows(data), list(st.my_trials())
+    o = data._row_origin
+    return (np.asarray(out.data), [(a + o, b + o) for a, b in calls["rows"]], trial_rows(data), list(st.my_trials()),
+            calls["staged"][-1])
 
 
 def _worker(rank, world, port, tmp):
@@ -99,7 +107,8 @@ def _worker(rank, world, port, tmp):
     try:
         res = {}
         for kt in (False, True):
-            val, rows, all_rows, mine = _st_stage(kt)
+            val, rows, all_rows, mine, staged = _st_stage(kt)
+            res[f"staged{int(kt)}"] = np.array(staged)
             res[f"val{int(kt)}"] = val
             res[f"rows{int(kt)}"] = np.array(rows)
             res[f"mine{int(kt)}"] = np.array(mine)
@@ -132,6 +141,13 @@ def test_compute_hip_shards_trials_and_sums_once(tmp_path, world):
         assert sum(mine, []) == list(range(len(all_rows)))
         for r in range(world):
             assert [tuple(x) for x in z[r][f"rows{kt}"]] == [all_rows[k] for k in mine[r]]
+        # what each rank staged: exactly the rows of its own trials - pairwise disjoint, in rank order, and together the
+        # whole recording (these trials neither overlap nor leave gaps)
+        staged = [tuple(int(v) for v in z[r][f"staged{kt}"]) for r in range(world)]
+        for r in range(world):
+            assert staged[r] == (all_rows[mine[r][0]][0], all_rows[mine[r][-1]][1])
+        assert staged[0][0] == 0 and staged[-1][1] == all_rows[-1][1]
+        assert all(staged[r][1] == staged[r + 1][0] for r in range(world - 1))
         ref = _reference(bool(kt)).astype(np.complex64)
         for r in range(world):
             assert z[r][f"val{kt}"].shape == ref.shape

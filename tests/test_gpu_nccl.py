@@ -47,6 +47,12 @@ def test_front_ends_under_nccl_group(tmp_path):
     z = np.load(out)
     assert int(z["world"]) == n and bool(z["pack_allreduce_unpack_bit_exact"])
     assert bool(z["library_comm_up"]) and bool(z["library_allreduce_bit_exact"])
+    # every rank staged the rows of its own trial shard and nothing else: disjoint spans in rank order, together the
+    # recording; the bytes over PCIe add up to ONE copy of it (not one per rank)
+    st = z["staged_rows_and_bytes_per_rank"]
+    assert st.shape == (n, 3) and st[0, 0] == 0 and st[-1, 1] == int(z["recording_rows"])
+    assert all(st[r, 1] == st[r + 1, 0] for r in range(n - 1))
+    assert int(st[:, 2].sum()) == int(z["recording_rows"]) * 37 * 4
     adj = np.zeros((37, 37))
     adj[0, 1] = adj[5, 30] = 0.3
     data = spy.synthdata.ar2_network(AdjMat=adj, nSamples=1024, nTrials=11, seed=3, samplerate=500)
