@@ -173,8 +173,9 @@ int spyhip_fft_plan_set_reference_mean(spyhip_fft_plan* plan, int on);
  * of squares per segment from samples that are in registers anyway - a maximum over the values written costs the
  * transform kernel 6 %).  The bound sits sqrt(nsig) / (crest factor) above the largest bin of noise-like data (3-4 bits of
  * the ~18 the half-precision kernel has) and is tight for offset- or line-dominated channels, where the bits matter.
- * Returns -3 (and stores nothing) for plans whose kernel family does not deliver it - float32 transforms of a power-of-two
- * length 256 ... 8192 in the standard layout do; NULL switches it off. */
+ * Float32 transforms of a power-of-two length 256 ... 8192 form it inside the transform kernel; every other length and the
+ * float64 transforms (spyhip_fft_plan_set_precision) take one pass over the segments ahead of the transform.  Returns -3
+ * (and stores nothing) for plans that do not write complex all-taper spectra in the standard layout; NULL switches it off. */
 int spyhip_fft_plan_set_absmax(spyhip_fft_plan* plan, float* absmax_d);
 /* name of the dominant kernel a plan launches (for rocprof matching) */
 const char* spyhip_fft_plan_kernel_name(const spyhip_fft_plan* plan);

@@ -602,9 +602,9 @@ extern "C" int spyhip_fft_plan_set_blocked(spyhip_fft_plan* p, int on) {
 extern "C" int spyhip_fft_plan_set_absmax(spyhip_fft_plan* p, float* absmax_d) {
     if (!p) { spy::set_error("fft_plan_set_absmax: null plan"); return -1; }
     if (!absmax_d) { p->absmax = nullptr; return 0; }
-    // the packed power-of-two kernel (mtmfft2_kernel.h) tracks it; the other families do not (yet)
-    const bool ok = p->pow2 && !p->pipe && p->log2n >= 8 && p->log2n <= 13 && !p->precision64 && !p->blocked &&
-                    p->output == SPYHIP_OUT_FOURIER && p->keeptapers;
+    // the packed power-of-two kernel (mtmfft2_kernel.h) bounds its spectra from the samples it holds; every other family
+    // (other lengths, float64 transforms) gets a pass over the segments ahead of the transform (seg_range_kernel)
+    const bool ok = !p->blocked && p->output == SPYHIP_OUT_FOURIER && p->keeptapers;
     if (!ok) {
         p->absmax = nullptr;
         spy::set_error("fft_plan_set_absmax: this plan's kernel does not deliver the range of its spectra");
@@ -747,8 +747,21 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     a.blocked = p->blocked ? 1 : 0;
     a.means = nullptr;
     a.seg_f64 = p->seg_f64 ? 1 : 0;
-    a.absmax = (p->absmax && !p->blocked && !p->precision64 && !p->pipe) ? p->absmax : nullptr;
+    a.absmax = (p->absmax && !p->blocked) ? p->absmax : nullptr;
     a.wnorm = p->wnorm;
+    if (a.absmax && !(p->pow2 && !p->pipe && p->log2n <= 13 && !p->precision64)) {
+        // every family but the packed power-of-two kernel (which bounds its spectra from the samples it holds): a pass
+        // over the segments ahead of the transform
+        const int bt = std::min(256, ((p->nchan + 63) / 64) * 64);
+        const int ncb = (p->nchan + bt - 1) / bt;
+        for (int s0 = 0; s0 < nseg; s0 += 65535) {
+            MtmArgs m = a;
+            m.seg_start += s0; m.seg_lo += s0; m.seg_hi += s0;
+            hipLaunchKernelGGL(spyfft::seg_range_kernel, dim3(ncb, std::min(65535, nseg - s0)), dim3(bt), 0, p->ctx->stream, m);
+        }
+        SPY_HIP_CHECK(hipGetLastError());
+        a.absmax = nullptr;                      // (the transform kernels of these families do not look at it)
+    }
     if (p->ref_mean && p->detrend == 0) {
         // the per-channel means of every segment in the reference's summation order, ahead of the transform
         const size_t need = (size_t)nseg * p->nchan;

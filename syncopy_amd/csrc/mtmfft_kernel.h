@@ -139,6 +139,45 @@ static __global__ void __launch_bounds__(256) seq_mean_kernel(MtmArgs a, float* 
     means[(size_t)b * a.nchan + c] = __fdiv_rn(s, (float)a.nsig);
 }
 
+// Range of the spectra a plan is about to write (spyhip_fft_plan_set_absmax) for the kernel families that do not form it
+// from the samples they hold anyway: every bin of channel c obeys |X_c(f)| <= ||w scale||_2 ||x_c||_2 (Cauchy-Schwarz), and
+// removing a mean or a line (orthogonal projections) or a taper-wise mean only shrinks the 2-norm - so the norm of the
+// samples minus their mean (detrend >= 0; float64 sums) or of the samples as they are bounds all tapers and all bins.
+// One thread per (segment, channel), adjacent lanes = adjacent channels (coalesced), 16 rows in flight.
+static __global__ void __launch_bounds__(256) seg_range_kernel(MtmArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= a.nchan) return;
+    const long long col = a.chan_idx ? a.chan_idx[c] : c;
+    const long long start = a.seg_start[b];
+    const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
+    const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
+    const int rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
+    const float* p = a.data + (start + rlo) * a.ld + col;
+    double s1 = 0.0, s2 = 0.0;
+    int n = rlo;
+    for (; n + 16 <= rhi; n += 16) {
+        float t[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t[e] = p[(long long)e * a.ld];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s1 += (double)t[e]; s2 += (double)t[e] * (double)t[e]; }
+        p += 16 * a.ld;
+    }
+    for (; n < rhi; ++n) {
+        const double v = (double)*p;
+        s1 += v;
+        s2 += v * v;
+        p += a.ld;
+    }
+    // (the mean is taken over the nsig samples of the window, zeros outside the trial included: compRoutines.py:169-172)
+    double q = a.detrend >= 0 ? s2 - s1 * s1 / (double)a.nsig : s2;
+    q = q > 0.0 ? q : 0.0;
+    // cancellation in s2 - s1^2 / n leaves ~1e-16 s2 of doubt: part of the bound
+    const float bound = (float)((sqrt(q) + 1e-7 * sqrt(s2)) * (double)a.wnorm * 1.001);
+    atomicMax(a.absmax + c, __float_as_uint(bound));
+}
+
 // output conversions of const_def.py:25-37; `kind` is wave-uniform.  Kept out of
 // line so that the compiler branches on `kind` instead of evaluating sqrt and
 // atan2 for every bin and selecting afterwards.

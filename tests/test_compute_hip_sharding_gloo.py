@@ -153,3 +153,37 @@ def test_compute_hip_shards_trials_and_sums_once(tmp_path, world):
             assert z[r][f"val{kt}"].shape == ref.shape
             assert_parity(z[r][f"val{kt}"], ref, what=f"rank {r} keeptrials={kt}")
             assert np.array_equal(z[r][f"val{kt}"], z[0][f"val{kt}"])          # every rank holds the same result
+
+
+def _peak_worker(rank, world, port, tmp):
+    """precision="auto" look of freqanalysis with more ranks than trials: the rank with an empty shard must still enter
+    the all-reduce of the ratio (it used to return early and the others' MAX met its next SUM)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syncopy_amd import parallel
+        from syncopy_amd.specest import hip_spectral as hs
+
+        def run_mtmfft(dev, rows, chans, nfft, *a, **k):          # power spectra with a peak outside the kept band
+            p = torch.ones((1, 65, 4))
+            p[0, 3] = 1e4
+            return [p.clone() for _ in rows]
+
+        hs.run_mtmfft = run_mtmfft
+        rows = [(0, 128), (128, 256)]                              # two trials, three ranks: rank 2 has none
+        lo, hi = parallel.my_shard(len(rows))
+        ans = hs.selection_hides_peak(None, rows[lo:hi], None, None, "hann", None, 0, np.arange(20, 40), 65)
+        t = torch.tensor([1.0 if ans else 0.0])
+        parallel.allreduce_sum_(t)                                  # the next collective of the real call sequence
+        np.savez(os.path.join(tmp, f"peak{rank}.npz"), ans=np.array(ans), total=t.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_precision_look_with_an_empty_shard(tmp_path):
+    world = 3
+    mp.spawn(_peak_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(tmp_path / f"peak{r}.npz") for r in range(world)]
+    assert all(bool(x["ans"]) for x in z), "every rank takes the same (float64) branch"
+    assert all(float(x["total"][0]) == world for x in z)

@@ -180,16 +180,31 @@ def test_fft_plan_delivers_the_range(be, N, nchan, K):
         _check(spec.reshape(-1, F, C), own, [0, 1, F // 2, F - 1], "range from the library's own pass")
 
 
-def test_plans_without_range_tracking_say_so(be):
-    """Kernel families that do not deliver the range leave the tensor alone and report it; csd_accumulate then takes its
-    own pass (absmax=None)."""
-    N = 2000
+@pytest.mark.parametrize("N,reference", [(2000, False), (3000, False), (12000, False), (4096, True), (2000, True)])
+def test_range_for_every_kernel_family(be, N, reference):
+    """Lengths without an in-kernel bound (decimal schedules, N = P M through HBM) and float64 transforms take a pass over
+    the segments ahead of the transform: still a bound, still within sqrt(N) of the truth, with a mean removed or not."""
+    nchan, B = 12, 3
+    rng = np.random.default_rng(N)
+    data = (rng.normal(size=(B * N, nchan)) * np.logspace(-2, 2, nchan) + 50.0).astype(np.float32)
+    d = torch.from_numpy(data).cuda()
+    starts = torch.arange(B, device="cuda", dtype=torch.int64) * N
     tapers = O.taper_table("hann", N, N)
-    plan = be.FFTPlan(N, N, 8, tapers, np.sqrt(2) / N, 0, False, None, "fourier", True)
-    d = torch.randn((N, 8), device="cuda")
+    for detrend in (0, None):
+        plan = be.FFTPlan(N, N, nchan, tapers, np.sqrt(2) / N, detrend, False, None, "fourier", True)
+        if reference:
+            assert plan.set_precision(True)
+        am = torch.zeros(nchan, dtype=torch.float32, device="cuda")
+        spec = plan.execute(d, starts, absmax=am)
+        assert plan.tracked_absmax
+        ref = torch.view_as_real(spec).abs().amax(dim=(0, 1, 2, 4))
+        assert bool((am >= ref).all()) and bool((am <= ref * np.sqrt(N)).all()), (detrend, (am / ref).cpu().numpy())
+
+
+def test_plans_without_complex_spectra_say_so(be):
+    """Plans that do not write complex all-taper spectra leave the tensor alone and report it."""
+    d = torch.randn((1024, 8), device="cuda")
     am = torch.zeros(8, dtype=torch.float32, device="cuda")
-    plan.execute(d, torch.zeros(1, device="cuda", dtype=torch.int64), absmax=am)
-    assert not plan.tracked_absmax and float(am.max()) == 0.0
     pow_plan = be.FFTPlan(1024, 1024, 8, O.taper_table("hann", 1024, 1024), 1.0, 0, False, None, "pow", True)
     pow_plan.execute(d, torch.zeros(1, device="cuda", dtype=torch.int64), absmax=am)
-    assert not pow_plan.tracked_absmax
+    assert not pow_plan.tracked_absmax and float(am.max()) == 0.0
