@@ -709,7 +709,7 @@ def main():
         fft_bytes = sum(nb * (N * C * 4 + K * F * C * 8) for _, _, nb in ev_fft)
         # matrix flops the 3-multiplication kernel really issues: 136 sub-tiles x 3 MFMAs of 16x16x4 per 4 rows
         # (every multiple of 16 up to 256 channels: floor(256 / C) frequencies per workgroup, nb (nb + 1) / 2 sub-tiles each)
-        is3m = (C == 256 or not blocked) and not os.environ.get("SPYHIP_CSD_4M")
+        is3m = (C == 256 or not blocked)
         nsub = ((C + 15) // 16) * ((C + 15) // 16 + 1) // 2
         if C > 512:       # 256-channel blocks: Hermitian product per block, a 256-sub-tile rectangle per pair of blocks
             blocks = [min(256, C - 256 * i) for i in range((C + 255) // 256)]

@@ -555,11 +555,11 @@ def csd_kernel_name(nchan, blocked=False):
     import os
     if nchan == 256 and not blocked and not os.environ.get("SPYHIP_CSD_F32"):
         return "spycsd::csdh_kernel"
-    if nchan == 256 and not os.environ.get("SPYHIP_CSD_4M"):
+    if nchan == 256:
         return "spycsd::csd3m_kernel<256, 8, true, false, false>"
-    if nchan <= 512 and not blocked and not os.environ.get("SPYHIP_CSD_4M"):
+    if nchan <= 512 and not blocked:
         return "spycsd::csd3m_kernel<%d, 8, false>" % ((nchan + 15) // 16 * 16)
-    if nchan > 512 and not blocked and not os.environ.get("SPYHIP_CSD_4M"):
+    if nchan > 512 and not blocked:
         return "spycsd::csd3m_kernel<512, 8, false, true> (+ csd3m_kernel<256, 8, false> per 256-channel block)"
     if not blocked and nchan <= 256:
         return "spycsd::csd_accum_kernel<5, 4, %d>" % (1 if nchan == 256 else 2)

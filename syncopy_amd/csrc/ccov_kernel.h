@@ -12,7 +12,8 @@
 //   out[l, a, b] = R_ab(l + q) / (N - l),  a < b          q = 1 for an even number of samples (the reversed
 //                                                         "same" crop starts one sample late), 0 for odd.
 #pragma once
-#include "spy_common.h"
+#include "spy_intrinsics.h"
+#include "../../include/spyhip.h"
 #include "fft2_device.h"
 
 namespace spyfft {

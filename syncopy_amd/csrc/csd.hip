@@ -208,10 +208,8 @@ static int csd_accumulate_impl(spyhip_ctx* ctx, const void* spec_d, int64_t nrow
     }
     // C in (256, 512]: the same path with 512-element rows; the tiles of a frequency are shared by
     // ceil(ntiles / 40) workgroups (512 channels: 4 x 34 tiles), each staging the whole row.
-    // SPYHIP_CSD_4M=1 keeps the 4-multiplication kernels everywhere (A/B measurements, cross-checks).
     // spyhip_csd_set_phase_exact selects them per context (imag / angle outputs, see include/spyhip.h).
-    static const bool env_4m = std::getenv("SPYHIP_CSD_4M") != nullptr;
-    const bool force_4m = env_4m || ctx->csd_phase_exact != 0 || only_4m;
+    const bool force_4m = ctx->csd_phase_exact != 0 || only_4m;
     const bool wide3m = !force_4m && nchan > 256 && spycsd::m3_available(nchan);
     if (!blocked && nchan > 256 && nchan <= 512 && !wide3m) {
         a.fast_nwgf = (a.ntiles + 39) / 40;

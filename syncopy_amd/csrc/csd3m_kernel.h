@@ -8,18 +8,19 @@
 // for the same 8 algorithmic flop per complex MAC.  Reference semantics as csd_kernel.h
 // (connectivity/csd.py:94-102 + the trial sum of shared/computational_routine.py:1022-1032).
 //
-// Three accumulators per output element do not fit one CU (36 x 1024 x 3 floats = 84 % of its whole register file,
-// and matrix accumulators live in the 256 AGPRs of a lane), so ONE frequency is shared by TWO workgroups of 4 waves,
-// ONE wave per SIMD.  The unit of work is the 16 x 16 sub-tile on v_mfma_f32_16x16x4_f32: the lower triangle of the
-// 16 x 16 block matrix has 136 sub-tiles = 8 waves x 17, so every wave carries exactly 51 accumulators (204 AGPRs)
-// and the same matrix work (the 16 diagonal sub-tiles are computed in full: 6 % of the work lands above the
-// diagonal, where nobody reads it).  Every wave's 17 sub-tiles touch 8 of the 16 channel blocks (M3_BLK): 8 LDS
-// fragment reads + <= 13 additions feed 51 MFMAs of 32 cycles - everything that is not a matrix instruction issues
-// in their shadow.  Both workgroups of a frequency stage the whole rows X[r, f, :] (2 KiB each) global -> LDS
-// directly (global_load_lds_dwordx4: no staging registers, no ds_write pass) into three 16-row buffers: iteration c
-// multiplies chunk c while chunk c+2 lands; the second reader of a row is served by the L2 / Infinity Cache or, at
-// worst, by HBM at a rate (2.7 TB/s) the kernel's matrix time covers.  Rows past the end of a ragged last chunk are
-// zero-filled with plain LDS stores.
+// One 512-thread workgroup per frequency, two waves per SIMD.  The unit of work is the 16 x 16 sub-tile on
+// v_mfma_f32_16x16x4_f32: the lower triangle of the 16 x 16 block matrix has 136 sub-tiles = 8 waves x 17, so every
+// wave carries exactly 51 accumulators (204 registers) and the same matrix work (the 16 diagonal sub-tiles are
+// computed in full: 6 % of the work lands above the diagonal, where nobody reads it).  Every wave's 17 sub-tiles touch
+// 8 of the 16 channel blocks (M3_BLK): 8 LDS fragment reads + <= 13 additions feed 51 MFMAs of 32 cycles -
+// everything that is not a matrix instruction issues in their shadow.  The workgroup stages the whole rows
+// X[r, f, :] (2 KiB each) global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass)
+// into three 16-row buffers: iteration c multiplies chunk c while chunk c+2 lands.  Rows past the end of a ragged
+// last chunk are zero-filled with plain LDS stores.
+//
+// Since round 5 the 256-channel, row-major case runs csdh_kernel.h (half-precision matrix cores, split operands); this
+// kernel serves every other channel count, the channel-blocked layout, and the frequencies csdh_kernel declines
+// (CsdArgs::only_flagged).
 //
 // The imaginary part of a diagonal element is P3 - P1 + P2 of rounded sums, i.e. rounding noise instead of the
 // exact zero of X conj(X): csd_finalize_kernel / coh_from_acc_kernel (the readers of the diagonal) set it to zero,
@@ -27,13 +28,9 @@
 #pragma once
 #include <type_traits>
 
-#ifndef SPY_M3_KATTR
-#ifndef SPY_HOST_EMU
-#define SPY_M3_KATTR(WPG) __attribute__((amdgpu_waves_per_eu((WPG) / 4, (WPG) / 4)))
-#else
-#define SPY_M3_KATTR(WPG)
-#endif
-#endif
+#include "spy_intrinsics.h"
+
+#define SPY_M3_KATTR(WPG) SPY_WAVES_PER_EU((WPG) / 4, (WPG) / 4)
 
 namespace spycsd {
 
@@ -46,11 +43,7 @@ __device__ __forceinline__ void m3_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ void m3_sched_fence() {
-#ifndef SPY_HOST_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+__device__ __forceinline__ void m3_sched_fence() { spy_sched_fence(); }
 
 constexpr int M3_CHUNK_BYTES = 32 * 1024;            // per buffer (16 rows of 256 channels or 8 rows of 512), three buffers
 constexpr int M3_LDS_BYTES = 3 * M3_CHUNK_BYTES;
@@ -272,31 +265,14 @@ __host__ __device__ constexpr bool m3_is_col(int g, int i) {
     return false;
 }
 
-#ifndef SPY_HOST_EMU
-// 16 bytes per lane global -> LDS: destination = wave-uniform LDS byte address + 16 * lane.  Issued as inline
-// assembly ON PURPOSE: hipcc would otherwise guard the next ds_read of the loop with s_waitcnt vmcnt(0) and park
-// the matrix pipe for a whole DMA latency once per chunk.  The copies are ordered by hand instead: one
-// s_waitcnt vmcnt(0) before the barrier that ends the iteration they were issued in, two iterations before anybody
-// reads the buffer.  No compiler-generated vector memory access is in flight while these are (the accumulator
-// read-modify-write comes after the loop's last wait), so hipcc's own vmcnt bookkeeping is not disturbed.  M0 (the
-// LDS base of the copy) is saved and restored around the instruction.
-__device__ __forceinline__ void m3_glds16(const void* gsrc, char* lds_wave_base) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(dst)
-                 : "memory");
-}
-#else
-// emulator: the same copy, lane by lane
-inline void m3_glds16(const void* gsrc, char* lds_wave_base) {
-    std::memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16);
-}
-#endif
+// 16 bytes per lane global -> LDS (spy_intrinsics.h: spy_glds16).  The copies are ordered by hand: one spy_wait_vmem()
+// before the barrier that ends the iteration they were issued in, two iterations before anybody reads the buffer.  No
+// compiler-generated vector memory access is in flight while these are (the accumulator read-modify-write comes after
+// the loop's last wait), so hipcc's own vmcnt bookkeeping is not disturbed.
+__device__ __forceinline__ void m3_glds16(const void* gsrc, char* lds_wave_base) { spy_glds16(gsrc, lds_wave_base); }
 
-// G: which 17 sub-tiles; WPG: waves per workgroup (8: one workgroup per frequency, two waves per SIMD; 4: two
-// workgroups per frequency, one wave per SIMD); wave WV of the workgroup stages rows (16 / WPG) WV ... of every chunk
+// G: which 17 sub-tiles; WPG = 8 waves per workgroup (one workgroup per frequency, two waves per SIMD); wave WV of the
+// workgroup stages rows (16 / WPG) WV ... of every chunk
 // EXACT = false: the spectra carry a.C <= CH channels per frequency (any count, odd ones included); the LDS image keeps
 // its CH-channel geometry - every lane fetches the 16 bytes of ITS two LDS elements from wherever they sit in the
 // narrower rows (8-byte aligned sources for odd a.C), lanes of the padding channels a.C ... CH - 1 copy nothing (what
@@ -389,9 +365,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     stage(0, 0);
     if (nchunk > 1) stage(1, 1);
     if (nchunk > 2) stage(2, 2);
-#ifndef SPY_HOST_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    spy_wait_vmem();
     __syncthreads();
 
     // LDS address of this lane's fragments for the current group of four rows: channel (lane & 15) of a block, row
@@ -454,9 +428,7 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
             m3_sched_fence();
             if (st + 1 < KB / 4 || c + 1 < nchunk) load();
         }
-#ifndef SPY_HOST_EMU
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's share of chunk c + 2 has landed
-#endif
+        spy_wait_vmem();                                                // this wave's share of chunk c + 2 has landed
         __syncthreads();
         b0 = b0 == 2 ? 0 : b0 + 1;
     }
@@ -495,9 +467,8 @@ __device__ __forceinline__ void m3_wave(const CsdArgs& a, char* Xb, int f, int l
     });
 }
 
-// WPG = 8: one workgroup of 8 waves per frequency (block b -> frequency item_base / 36 + b);
-// WPG = 4: two workgroups of 4 waves per frequency (block b -> frequency ... + b / 2, sub-tile sets of half b % 2).
-// run-time wave index -> compile-time sub-tile set
+// one workgroup of WPG = 8 waves per frequency (block b -> frequency item_base / 36 + b); run-time wave index ->
+// compile-time sub-tile set
 template <int CH, int WPG, bool EXACT, bool RECT, bool M4, int G0, int G1>
 __device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, int f, int lane) {
     if constexpr (G0 + 1 == G1) {
@@ -513,25 +484,17 @@ __device__ __forceinline__ void m3_dispatch(int g, const CsdArgs& a, char* Xb, i
 // item_base / 36 + b.  272 ... 512: NP workgroups per frequency; block b -> XCD b % 8, slot b / 8, frequency
 // (slot / NP) * 8 + XCD, part slot % NP - all parts of a frequency run on ONE XCD, one after the other in its
 // dispatch order, so the rows they all stage are fetched from HBM once and found in that XCD's L2 afterwards.
-// WPG = 4 (256 channels only): two workgroups of 4 waves per frequency, one wave per SIMD (the measured dead end).
 template <int CH, int WPG, bool EXACT = true, bool RECT = false, bool M4 = false>
 __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdArgs a) {
-    static_assert(CH == 256 || WPG == 8, "the two-workgroup split exists for 256 channels only");
+    static_assert(WPG == 8, "8 waves per workgroup, two per SIMD (one wave per SIMD measured worse and was removed)");
     static_assert(!RECT || !EXACT, "rectangles come with channel sub-ranges");
     constexpr int NP = M3Tab<CH, RECT>::NP;
     SPY_DYN_SMEM(char, Xb);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-#ifndef SPY_HOST_EMU
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#else
-    const int wave = tid >> 6;
-#endif
+    const int wave = spy_wave_index(tid);
     int f, g;
-    if (WPG == 4) {
-        f = (int)(blockIdx.x >> 1);
-        g = 4 * (int)(blockIdx.x & 1) + wave;
-    } else if (NP == 1) {
+    if (NP == 1) {
         f = (int)blockIdx.x;
         // channel-quad-blocked spectra (256 channels): a 128-byte line holds one quad of FOUR consecutive frequencies,
         // so those four workgroups must share an L2: runs of four frequencies per XCD (block b -> XCD b % 8)
@@ -545,7 +508,7 @@ __global__ void __launch_bounds__(64 * WPG) SPY_M3_KATTR(WPG) csd3m_kernel(CsdAr
     f += (int)(a.item_base / M3_TILES_PER_F);
     if ((long long)(f + 1) * M3_TILES_PER_F > a.item_end) return;
     if (CH == 256 && EXACT && a.only_flagged && !a.only_flagged[f]) return;      // (wave-uniform)
-    m3_dispatch<CH, WPG, EXACT, RECT, M4, 0, (WPG == 4 ? 8 : M3Tab<CH, RECT>::NW)>(g, a, Xb, f, lane);
+    m3_dispatch<CH, WPG, EXACT, RECT, M4, 0, M3Tab<CH, RECT>::NW>(g, a, Xb, f, lane);
 }
 
 }  // namespace spycsd

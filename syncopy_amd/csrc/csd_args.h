@@ -1,10 +1,7 @@
 // Argument block, vector types and workgroup size shared by the cross-spectral kernels (csd_kernel.h, csd3m_kernel.h).
 #pragma once
 
-#ifndef SPY_HOST_EMU
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#endif
+#include "spy_intrinsics.h"
 
 namespace spycsd {
 

@@ -29,18 +29,9 @@ __device__ __forceinline__ void tile_of(int tt, int& ti, int& tj) {
     tj = tt - i * (i + 1) / 2;
 }
 
-__device__ __forceinline__ int opaque_i(int v) {
-#ifndef SPY_HOST_EMU
-    asm volatile("" : "+v"(v));
-#endif
-    return v;
-}
+__device__ __forceinline__ int opaque_i(int v) { return spy_opaque(v); }
 
-__device__ __forceinline__ void sched_fence_csd() {
-#ifndef SPY_HOST_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+__device__ __forceinline__ void sched_fence_csd() { spy_sched_fence(); }
 
 constexpr int CSD_PF = 8;    // staged float2 elements per thread and chunk (chunk <= 32 KiB of LDS)
 
@@ -95,11 +86,7 @@ __global__ void __launch_bounds__(CSD_THREADS) csd_accum_kernel(CsdArgs a) {
     constexpr int PER = 4 * (TA + TB);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-#ifndef SPY_HOST_EMU
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile-count tests become s_cbranch, not exec masks
-#else
-    const int wave = tid >> 6;
-#endif
+    const int wave = spy_wave_index(tid);   // scalar: tile-count tests become s_cbranch, not exec masks
     const int l31 = lane & 31, lhi = lane >> 5;
     // waves {0,2,5,7} own TA tiles, {1,3,4,6} own TB: every SIMD carries TA+TB tiles whether the hardware places
     // waves w and w+4 or waves 2s and 2s+1 of a workgroup on the same SIMD

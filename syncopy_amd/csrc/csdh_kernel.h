@@ -62,10 +62,8 @@
 
 namespace spycsd {
 
-#ifndef SPY_HOST_EMU
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#endif
 
 struct CsdhArgs {
     const float2* spec;     // (nrows, F, 256) complex64

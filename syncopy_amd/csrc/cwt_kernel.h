@@ -405,11 +405,7 @@ __global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
 // acc[r, s0+q, c] = (init ? 1 : acc[...]) * spec[r, q, c] ^ expo[q]   (principal branch, 0^e = 0 for e > 0).
 // The modulus goes through a split log2 / exp2 (see below) so that its error does not scale with log|z|; the phase
 // (atan2f, sincosf) is skipped altogether for outputs that only need the modulus.
-#ifdef SPY_HOST_EMU
-#define spy_log2f log2f
-#else
-#define spy_log2f __log2f          // v_log_f32: the argument is a mantissa in [0.5, 1)
-#endif
+#define spy_log2f spy_log2         // v_log_f32 (spy_intrinsics.h): the argument is a mantissa in [0.5, 1)
 constexpr int SLT_MAX_SCALES = 128;
 struct SltArgs {
     float2* acc;

@@ -34,27 +34,12 @@ __device__ __forceinline__ void stg(void* base, unsigned byte_off, T v) {
 }
 // hide a value from loop-invariant code motion: index arithmetic that depends on
 // it is redone per iteration instead of being kept live in dozens of VGPRs
-__device__ __forceinline__ int opaque(int v) {
-#ifndef SPY_HOST_EMU
-    asm volatile("" : "+v"(v));
-#endif
-    return v;
-}
+__device__ __forceinline__ int opaque(int v) { return spy_opaque(v); }
 
 // value of the neighbouring lane (lane ^ 1): one DPP move, no LDS traffic
-__device__ __forceinline__ float lane_swap1(float v) {
-#ifndef SPY_HOST_EMU
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
-#else
-    return __shfl_xor(v, 1);
-#endif
-}
+__device__ __forceinline__ float lane_swap1(float v) { return spy_lane_swap1(v); }
 
-__device__ __forceinline__ void sched_fence() {
-#ifndef SPY_HOST_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+__device__ __forceinline__ void sched_fence() { spy_sched_fence(); }
 
 template <int R>
 __device__ __forceinline__ void dft(float2 (&t)[R]);

@@ -77,10 +77,8 @@ int check_info(spyhip_ctx* ctx, int* info_d, int batch, const char* what) {
 // tiny pivot showed up and the caller must repeat with blocked = false); false: partial pivoting, 16x the traffic
 // `src`: invert src into M (out of place) instead of M in place
 int invert(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d, bool blocked = false, const cd* src = nullptr) {
-    static const bool old_inverse = std::getenv("SPYHIP_INVERSE_OLD") != nullptr;
     // 64-row blocks (half the sweeps over the matrices) where they pad no more than the 32-row blocks would
-    static const bool no_inv64 = std::getenv("SPYHIP_INVERSE_32") != nullptr;
-    if (blocked && n >= 2 * spywil::ZW && (n + 63) / 64 * 64 == (n + 31) / 32 * 32 && !old_inverse && !no_inv64) {
+    if (blocked && n >= 2 * spywil::ZW && (n + 63) / 64 * 64 == (n + 31) / 32 * 32) {
         const size_t lds = (size_t)2 * spywil::ZW * (spywil::ZW + 1) * sizeof(cd);
         SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::zinv64_mfma_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -88,7 +86,7 @@ int invert(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d, bool blocked =
         SPY_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    if (blocked && n >= 2 * spywil::ZM && !old_inverse) {      // matrix-core block Gauss-Jordan
+    if (blocked && n >= 2 * spywil::ZM) {      // matrix-core block Gauss-Jordan
         const int npad = ((n + spywil::ZM - 1) / spywil::ZM) * spywil::ZM;
         const size_t lds = ((size_t)spywil::ZM * (npad + 1) + spywil::ZM * (spywil::ZM + 1)) * sizeof(cd);
         if (lds <= ctx->lds_per_block) {
@@ -131,9 +129,8 @@ int invert_one(spyhip_ctx* ctx, cd* dst, const cd* src, int n, int* inf) {
 }
 
 int cholesky(spyhip_ctx* ctx, cd* M, int n, int batch, int* info_d) {
-    static const bool old_chol = std::getenv("SPYHIP_CHOL_OLD") != nullptr;
     const size_t plds = ((size_t)n * (spywil::CHP + 1) + spywil::CHP * (spywil::CHP + 1)) * sizeof(cd);
-    if (!old_chol && n <= 256 && n >= 2 * spywil::CHP && plds <= ctx->lds_per_block) {      // panels of 32 columns
+    if (n <= 256 && n >= 2 * spywil::CHP && plds <= ctx->lds_per_block) {      // panels of 32 columns
         SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(spywil::zchol_panel_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
         hipLaunchKernelGGL(spywil::zchol_panel_kernel, dim3(batch), dim3(256), plds, ctx->stream, M, n, info_d);
@@ -318,7 +315,7 @@ extern "C" int spyhip_granger(spyhip_ctx* ctx, const void* csd_d, int nfreq, int
     double err = INFINITY;
     bool subset_only = false;            // the last error came from the frequency subset only (a lower bound)
     std::vector<int> hinf(F);
-    static const bool use_plus4 = std::getenv("SPYHIP_PLUS_OLD") == nullptr;
+    constexpr bool use_plus4 = true;
   for (int attempt = 0; attempt < 2 && !converged; ++attempt) {
     // attempt 0 inverts psi with the block Gauss-Jordan kernel; if one of its diagonal blocks was (nearly)
     // singular anywhere, the whole iteration restarts with the partially pivoted kernel

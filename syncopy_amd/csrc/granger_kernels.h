@@ -84,9 +84,6 @@ __global__ void __launch_bounds__(256) zgemm_kernel(const cd* A, const cd* B, cd
 //   Cr += Ar Br ; Cr += (-Ai) Bi ; Ci += Ar Bi ; Ci += Ai Br.
 // The 32 x 32 VALU tile above moves 16 bytes per 16 flop through L2 and stalls at ~28 TFLOP/s; this tile
 // halves the traffic per flop and leaves the multiply-adds to the matrix pipe.
-#ifndef SPY_HOST_EMU
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-#endif
 constexpr int MT = 64;   // output tile
 constexpr int MK = 8;    // k per stage
 // Badd (n x n, or nullptr): op(B) + Badd is multiplied - the skew matrix S of wilson_sf.py:97-98 joins g+ here instead
@@ -98,11 +95,7 @@ constexpr int MK = 8;    // k per stage
 // n = 256.  MODE 2 likewise skips the tiles above the diagonal (|Ref - C| / |Ref| is symmetric for Hermitian Ref, C).
 // MODE 0: plain, 1: with Badd, 2: error check (separate instances: the plain product keeps its 90 registers and
 // three waves per SIMD - with the extra operands in one kernel it dropped to two and ran at half speed)
-#ifndef SPY_HOST_EMU
-#define SPY_ZGEMM_KATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
-#else
-#define SPY_ZGEMM_KATTR
-#endif
+#define SPY_ZGEMM_KATTR SPY_WAVES_PER_EU(3, 3)
 // 64 x 64 output tiles per matrix: all of them, or the lower triangle for the Hermitian modes (2: error check, 3: X X^H)
 __host__ __device__ inline int zgemm_tiles(int n, bool hermitian) {
     const int ntx = (n + 63) / 64;

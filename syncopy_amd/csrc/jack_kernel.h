@@ -6,7 +6,8 @@
 // channel pair): S_t from the trial's K tapers, the replicate, its coherence, d_t = replicate - direct, and the
 // float64 sums of d_t and |d_t|^2 stay in registers; one read-modify-write of the two sum arrays per launch.
 #pragma once
-#include "spy_common.h"
+#include "spy_intrinsics.h"
+#include "../../include/spyhip.h"
 #include "csd_kernel.h"
 
 namespace spycsd {
@@ -21,20 +22,8 @@ struct JackArgs {
     double* sum_d2;       // (F, C, C) float64: += sum_t |d_t|^2
 };
 
-__device__ __forceinline__ float fast_rsqrt(float x) {
-#ifdef SPY_HOST_EMU
-    return 1.0f / sqrtf(x);
-#else
-    return __builtin_amdgcn_rsqf(x);
-#endif
-}
-__device__ __forceinline__ float fast_sqrt(float x) {
-#ifdef SPY_HOST_EMU
-    return sqrtf(x);
-#else
-    return __builtin_amdgcn_sqrtf(x);
-#endif
-}
+__device__ __forceinline__ float fast_rsqrt(float x) { return spy_rsqrt(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return spy_sqrt(x); }
 
 // Workgroup = (frequency, 32 x 32 tile of the lower triangle of the channel square), 256 threads: thread (ti, tq) owns the pairs
 // (i = ti, j = 4 tq .. 4 tq + 3).  Staging as in K7 (ntaper x 64 spectra per trial through LDS, double-buffered).

@@ -60,7 +60,6 @@ int declong64_group(int M);
 int declong64_launch_sub_a(hipStream_t stream, const Long64Args& a, int M, int P, long long nblocks);
 int declong64_launch_sub_b(hipStream_t stream, const Long64Args& a, int M, int P, long long nblocks);
 int declong64_launch_post(hipStream_t stream, const Long64Args& a, int P, int M, int outk, bool mean);
-int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean);
 int f64_any_launch(hipStream_t stream, F64Args a, long long grid, long long chunk, int outk, bool mean);
 int dec_launch_a(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_b(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
@@ -80,8 +79,6 @@ int declong_group(int M);
 int declong_launch_sub_a(hipStream_t stream, const LongArgs& a, int M, int P, long long nblocks);
 int declong_launch_sub_b(hipStream_t stream, const LongArgs& a, int M, int P, long long nblocks);
 int declong_launch_post(hipStream_t stream, const LongArgs& a, int P, int M, int outk, bool mean);
-int pipe_launch(hipStream_t stream, const MtmArgs& a, int log2n, unsigned grid, int outk, bool mean);
-int pipe_max_tapers_demean();
 int mixed_launch(hipStream_t stream, const MtmArgs& a, const MixPlan& g, int threads, size_t lds, unsigned grid, int outk,
                  bool mean);
 }
@@ -95,7 +92,6 @@ struct spyhip_fft_plan {
     int detrend = -1, demean_taper = 0;
     float scale = 1.f;
     bool pow2 = false;
-    bool pipe = false;          // pipelined two-quad kernel (mtmfft_pipe_kernel.h): N = 1024, 2048, 4096
     bool dec = false;           // compile-time radix schedules for decimal lengths (mtmfft_dec_kernel.h)
     bool mixed = false;         // packed mixed-radix engine for 5-smooth lengths (mtmfft_mixed.h)
     spyfft::MixPlan mix{};
@@ -399,47 +395,28 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         // CU) write 64 contiguous bytes per bin row and are 13 % faster; everything else prefers two independent
         // 256-thread workgroups per CU
         if (p->log2n == 12 && output == SPYHIP_OUT_FOURIER && p->keeptapers) p->G = 2;
-        // N = 1024 ... 4096: the pipelined kernel (two quads per workgroup in opposite phases, lane-exchange channel
-        // separation) is an OPT-IN experiment (SPYHIP_FFT_PIPE=1): measured 8.9 vs 7.2 us/trial at c2 - a wave that is
-        // alone on its SIMD while its partner waits on LDS issues one vector instruction per 7+ cycles
-        p->pipe = p->log2n >= 10 && p->log2n <= 12 && std::getenv("SPYHIP_FFT_PIPE") &&
-                  !(p->demean_taper && ntaper > spyfft::pipe_max_tapers_demean()) &&
-                  !(output == SPYHIP_OUT_FOURIER && !p->keeptapers);      // (complex taper mean: 72 accumulator registers)
         if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
         char buf[128];
-        if (p->pipe) std::snprintf(buf, sizeof buf, "mtmfft_pipe_kernel<%d, %s>", p->log2n, mode);
-        else std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
+        std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
                            p->log2n, p->G, mode);
         p->kernel_name = buf;
-    } else if ((((nfft == 400 || nfft == 800 || nfft == 1200 || nfft == 1600 || nfft == 2400 || nfft == 3200 || nfft == 4800 || nfft == 8000) &&
-                 !std::getenv("SPYHIP_NO_DEC20")) ||
+    } else if ((nfft == 400 || nfft == 800 || nfft == 1200 || nfft == 1600 || nfft == 2400 || nfft == 3200 || nfft == 4800 || nfft == 8000 ||
                 nfft == 100 || nfft == 200 || nfft == 500 || nfft == 1000 || nfft == 2000 || nfft == 2500 || nfft == 4000 || nfft == 5000 || nfft == 10000 ||
-                ((nfft == 300 || nfft == 600 || nfft == 1500 || nfft == 3000 || nfft == 6000 || nfft == 7500 || nfft == 768 || nfft == 1536 || nfft == 3072 ||
-                  nfft == 6144) && !std::getenv("SPYHIP_NO_DEC3"))) &&
-               !std::getenv("SPYHIP_NO_DEC") && !std::getenv("SPYHIP_FORCE_GENERIC") &&
-               !std::getenv("SPYHIP_FORCE_LONG") && !std::getenv("SPYHIP_FORCE_MIXED")) {
+                nfft == 300 || nfft == 600 || nfft == 1500 || nfft == 3000 || nfft == 6000 || nfft == 7500 || nfft == 768 || nfft == 1536 || nfft == 3072 ||
+                nfft == 6144) && !std::getenv("SPYHIP_FORCE_GENERIC")) {
         // decimal trial lengths (1 kHz x 0.2 ... 5 s): radix schedules fixed at compile time, 10 values per thread
         p->dec = true;
         if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
         char buf[128];
         std::snprintf(buf, sizeof buf, "mtmfft_dec_kernel<N = %d, %s>", nfft, mode);
         p->kernel_name = buf;
-    } else if (!std::getenv("SPYHIP_NO_MIXED") && !std::getenv("SPYHIP_FORCE_GENERIC") && !std::getenv("SPYHIP_FORCE_LONG") &&
-               // (round 3 sent ONE taper with a Bluestein length M <= 4096 to the chirp-z kernel - 10-20 % faster on
-               // sliding windows - but its two length-M transforms and three pointwise products leave ~4x the float32
-               // error of a direct transform: short Hann windows left the criterion in the seeded sweep, and a 64-point
-               // window went through M = 256.  5-smooth lengths take the mixed-radix engine whatever the taper count;
-               // SPYHIP_PREFER_BLUESTEIN=1 restores the old choice for A/B runs)
-               !(ntaper == 1 && 2 * nfft - 1 <= 4096 && std::getenv("SPYHIP_PREFER_BLUESTEIN") && !std::getenv("SPYHIP_FORCE_MIXED")) &&
+    } else if (!std::getenv("SPYHIP_FORCE_GENERIC") &&
+               // (5-smooth lengths take the mixed-radix engine whatever the taper count: the chirp-z kernel's two length-M
+               // transforms and three pointwise products leave ~4x the float32 error of a direct transform)
                spyfft::mix_schedule(nfft, (nchan + 3) / 4, &p->mix, &p->mix_threads, &p->lds_bytes) &&
                p->lds_bytes <= ctx->lds_per_block) {
         // 5-smooth lengths (2000, 3000, 5000, 500 ...): the packed mixed-radix engine
         p->mixed = true;
-        if (const char* e = std::getenv("SPYHIP_MIX_LAYOUT")) {        // tuning aid: "<log2 quads>,<stage 0|1>"
-            int lg = p->mix.lg, st = p->mix.stage;
-            if (std::sscanf(e, "%d,%d", &lg, &st) == 2 && lg >= 0 && lg <= 4 && (p->mix.th << lg) <= 1024)
-                spyfft::mix_layout(&p->mix, lg, st, &p->mix_threads, &p->lds_bytes);
-        }
         p->G = 1 << p->mix.lg;
         if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
         std::string sched;
@@ -473,7 +450,7 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         char buf[128];
         std::snprintf(buf, sizeof buf, "mtmfft_blue_kernel<%d, %d, %s>", p->log2n, p->G, mode);
         p->kernel_name = buf;
-    } else if (nfft > 10240 && !std::getenv("SPYHIP_FORCE_GENERIC") && !std::getenv("SPYHIP_NO_DECLONG") &&
+    } else if (nfft > 10240 && !std::getenv("SPYHIP_FORCE_GENERIC") &&
                declong_split(nfft, &p->dl_P, &p->dl_M)) {
         // longer than one workgroup's LDS, N = P M with M a scheduled length: decimation in time through HBM
         std::vector<double> ws((size_t)2 * ntaper);
@@ -490,8 +467,7 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         std::snprintf(buf, sizeof buf, "declong<%d x %d, %s>", p->dl_P, p->dl_M, mode);
         p->kernel_name = buf;
     } else if (nfft <= (1 << 19) && !std::getenv("SPYHIP_FORCE_GENERIC") &&
-               !(nfft <= 10240 && [&] { int r[spyfft::GEN_MAXFAC], nf2 = 0; return factorize(nfft, r, &nf2); }() &&
-                 !std::getenv("SPYHIP_FORCE_LONG"))) {
+               !(nfft <= 10240 && [&] { int r[spyfft::GEN_MAXFAC], nf2 = 0; return factorize(nfft, r, &nf2); }())) {
         // (lengths up to 10240 with prime factors <= 13 stay on the mixed-radix LDS kernel below: measured 10-20 %
         // faster than the HBM round trips of this path; everything longer, and awkward lengths, come here)
         // Bluestein with four-step transforms through HBM: M = 2^m >= 2 nfft - 1 (>= 4096), M1 = 2^ceil(m/2), M2 = M / M1
@@ -632,9 +608,8 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
                                         100, 400, 800, 1600, 3200, 8000, 300, 1200, 2400, 4800};
     p->f64_dec = false;
     for (int n : dec64_lengths) p->f64_dec = p->f64_dec || (n == p->nfft);
-    if (std::getenv("SPYHIP_F64_OLD")) p->f64_dec = false;           // A/B runs against the generic kernels
-    p->f64_dl = !p->f64_dec && p->dl_P > 0 && !std::getenv("SPYHIP_NO_DECLONG64") && !std::getenv("SPYHIP_F64_OLD");
-    p->f64_any = !p->f64_dec && !p->f64_dl && !(p->pow2 && p->log2n >= 8 && p->log2n <= 12);
+    p->f64_dl = !p->f64_dec && p->dl_P > 0;
+    p->f64_any = !p->f64_dec && !p->f64_dl;
     if (p->f64_dl && !p->tw64_sub.p) {
         auto table = [](int n) {
             std::vector<double2> t(n);
@@ -660,7 +635,7 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
         int big = 1;
         if (!spywil::plus_plan(p->nfft, &p->f64_plan)) big = 1 << 30;
         else for (int i = 0; i < p->f64_plan.nfac; ++i) big = std::max(big, p->f64_plan.radix[i]);
-        if (big > 61 || std::getenv("SPYHIP_F64_BLUESTEIN")) {
+        if (big > 61) {
             int M = 16;
             while (M < 2 * p->nfft - 1) M <<= 1;
             spywil::plus_plan(M, &p->f64_plan);
@@ -749,7 +724,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
     a.seg_f64 = p->seg_f64 ? 1 : 0;
     a.absmax = (p->absmax && !p->blocked) ? p->absmax : nullptr;
     a.wnorm = p->wnorm;
-    if (a.absmax && !(p->pow2 && !p->pipe && p->log2n <= 13 && !p->precision64)) {
+    if (a.absmax && !(p->pow2 && p->log2n <= 13 && !p->precision64)) {
         // every family but the packed power-of-two kernel (which bounds its spectra from the samples it holds): a pass
         // over the segments ahead of the transform
         const int bt = std::min(256, ((p->nchan + 63) / 64) * 64);
@@ -888,14 +863,13 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             return spyfft::f64_any_launch(p->ctx->stream, fa, grid, p->f64_chunk,
                                           p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), !p->keeptapers);
         }
-        if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
-        return spyfft::f64_launch(p->ctx->stream, fa, p->log2n, (unsigned)grid,
-                                  p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), !p->keeptapers);
+        spy::set_error("fft_exec: no reference-precision kernel for nfft = %d", p->nfft);
+        return -1;
     }
     if (p->pow2) {
         // work items per segment: channel quads (packed kernel) or channel pairs (2^14)
         const bool quad = p->log2n <= 13;
-        const int G = p->pipe ? 2 : p->G;
+        const int G = p->G;
         const int nitem = quad ? (p->nchan + 3) / 4 : npairs;
         a.npg = (nitem + G - 1) / G;
         int S = (quad ? 8 : 16) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;   // workgroups sharing 128-byte rows
@@ -905,9 +879,6 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         const long long grid = ((nclusters + 7) / 8) * S * 8;
         if (grid > 0x7fffffffLL) { spy::set_error("fft_exec: grid too large (%lld blocks)", grid); return -1; }
         const unsigned g = (unsigned)grid;
-        if (p->pipe)
-            return spyfft::pipe_launch(p->ctx->stream, a, p->log2n, g, p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1),
-                                       !p->keeptapers);
         switch (p->log2n) {
             case 8: return launch_quad_mode<8, 16>(p, a, g);
             case 9: return launch_quad_mode<9, 8>(p, a, g);

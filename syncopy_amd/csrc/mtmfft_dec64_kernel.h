@@ -131,11 +131,9 @@ __device__ __forceinline__ void d64_pass(spywil::cd (&v)[C::V], void* lds, int j
             cd wb[4], wa[NA > 1 ? NA : 2];
             if constexpr (C::HOIST) {
                 wb[1] = w1[m];
-#ifndef SPY_HOST_EMU
                 // (the powers are taper-invariant too: without this the compiler hoists all of them out of the taper loop
                 // and spills ~100 registers; only the base twiddle is meant to stay live)
-                asm volatile("" : "+v"(wb[1].x), "+v"(wb[1].y));
-#endif
+                spy_opaque2(wb[1].x, wb[1].y);
             }
             if constexpr (C::HOIST) {
                 wb[2] = cmul(wb[1], wb[1]);
@@ -452,9 +450,7 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
                 // W_N^(r k) = W_N^(r j) (W_N^(r T))^e: two table values per thread, fetched ONCE per workgroup (an L2
                 // round trip between two barriers of every taper otherwise), the rest by multiplication
                 cd w = wdit, step = wdit_step;
-#ifndef SPY_HOST_EMU
-                asm volatile("" : "+v"(w.x), "+v"(w.y));        // (keeps the powers inside the taper loop, see d64_pass)
-#endif
+                spy_opaque2(w.x, w.y);                          // (keeps the powers inside the taper loop, see d64_pass)
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     v[e] = spywil::cmul(v[e], w);

@@ -6,40 +6,6 @@
 
 namespace spyfft {
 
-template <int LOG2N, int OUTK, bool MEAN>
-static int f64_launch_one(hipStream_t stream, const F64Args& a, unsigned grid) {
-    using C = spywil::PCfg<LOG2N>;
-    auto kern = mtmfft_f64_kernel<LOG2N, OUTK, MEAN>;
-    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)C::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T), C::LDS_BYTES, stream, a);
-    SPY_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-template <int LOG2N>
-static int f64_launch_mode(hipStream_t stream, const F64Args& a, unsigned grid, int outk, bool mean) {
-    switch (outk * 2 + (mean ? 1 : 0)) {
-        case 0: return f64_launch_one<LOG2N, 0, false>(stream, a, grid);
-        case 1: return f64_launch_one<LOG2N, 0, true>(stream, a, grid);
-        case 2: return f64_launch_one<LOG2N, 1, false>(stream, a, grid);
-        case 3: return f64_launch_one<LOG2N, 1, true>(stream, a, grid);
-        case 4: return f64_launch_one<LOG2N, 2, false>(stream, a, grid);
-        default: return f64_launch_one<LOG2N, 2, true>(stream, a, grid);
-    }
-}
-
-int f64_launch(hipStream_t stream, const F64Args& a, int log2n, unsigned grid, int outk, bool mean) {
-    switch (log2n) {
-        case 8: return f64_launch_mode<8>(stream, a, grid, outk, mean);
-        case 9: return f64_launch_mode<9>(stream, a, grid, outk, mean);
-        case 10: return f64_launch_mode<10>(stream, a, grid, outk, mean);
-        case 11: return f64_launch_mode<11>(stream, a, grid, outk, mean);
-        case 12: return f64_launch_mode<12>(stream, a, grid, outk, mean);
-        default: spy::set_error("reference-precision FFT: power-of-two lengths 256 ... 4096 only (got 2^%d)", log2n); return -3;
-    }
-}
-
 template <int OUTK, bool MEAN>
 static int f64_any_launch_one(hipStream_t stream, const F64Args& a, unsigned grid) {
     auto kern = mtmfft_f64_any_kernel<OUTK, MEAN>;

@@ -8,7 +8,8 @@
 //     ppc = (|U|^2 - T) / (T (T-1)).
 // A cross spectrum that is exactly zero has arg 0 in the reference (np.angle(0) = 0): u_t = 1.
 #pragma once
-#include "spy_common.h"
+#include "spy_intrinsics.h"
+#include "../../include/spyhip.h"
 
 namespace spyppc {
 

@@ -1,8 +1,6 @@
 // Shared host-side plumbing of libspyhip: context, error reporting, launch checks.
 #pragma once
-#ifndef SPY_HOST_EMU
 #include <hip/hip_runtime.h>
-#endif
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -12,14 +10,10 @@
 
 #include "../../include/spyhip.h"
 
-#ifndef SPY_HOST_EMU
-#define SPY_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) char name##_raw[]; \
-    type* name = reinterpret_cast<type*>(name##_raw)
-#endif
+#include "spy_intrinsics.h"
 
 struct spyhip_ctx {
     int device = 0;
-#ifndef SPY_HOST_EMU
     hipStream_t stream = nullptr;
     void* scratch = nullptr;        // library-owned device scratch (partial sums of split launches), grown on demand
     size_t scratch_bytes = 0;
@@ -32,7 +26,6 @@ struct spyhip_ctx {
     void* k4h_buf = nullptr;        // spyhip_csd_accumulate_split: 256 floats (the library's own range pass) + one flag per frequency
     size_t k4h_bytes = 0;
     int k4h_nf = 0;                 // frequencies the half-precision kernel was launched on in the last call
-#endif
     int csd_phase_exact = 0;        // spyhip_csd_set_phase_exact: 4-multiplication K4 kernels only (csd.hip)
     int granger_iters = 0;          // Wilson iterations of the last spyhip_granger call on this context
     int num_cu = 256;
@@ -43,7 +36,6 @@ namespace spy {
 
 void set_error(const char* fmt, ...);
 
-#ifndef SPY_HOST_EMU
 #define SPY_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \
         hipError_t e__ = (expr);                                                             \
@@ -76,7 +68,6 @@ struct DevBuf {
         if (p) (void)hipFree(p);
     }
 };
-#endif
 
 static inline int ilog2(unsigned v) {
     int l = 0;

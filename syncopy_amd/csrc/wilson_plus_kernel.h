@@ -21,13 +21,7 @@
 #pragma once
 #include "cd_math.h"
 
-#ifndef SPY_PLUS_KATTR
-#ifndef SPY_HOST_EMU
-#define SPY_PLUS_KATTR __attribute__((amdgpu_waves_per_eu(2)))      // two workgroups of 4 waves per CU
-#else
-#define SPY_PLUS_KATTR
-#endif
-#endif
+#define SPY_PLUS_KATTR SPY_MIN_WAVES_PER_EU(2)      // two workgroups of 4 waves per CU
 
 namespace spywil {
 

@@ -12,7 +12,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local BlockCtx* t_ctx = nullptr;
 }  // namespace emu
 
-#include "../../syncopy_amd/csrc/spy_common.h"
+#include "../../include/spyhip.h"
 #include "../../syncopy_amd/csrc/mtmfft_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_generic.h"
 #include "../../syncopy_amd/csrc/csd_kernel.h"
@@ -21,7 +21,6 @@ thread_local BlockCtx* t_ctx = nullptr;
 #include "../../syncopy_amd/csrc/ccov_kernel.h"
 #include "../../syncopy_amd/csrc/jack_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft2_kernel.h"
-#include "../../syncopy_amd/csrc/mtmfft_pipe_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_dec_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_blue_kernel.h"
 #include "../../syncopy_amd/csrc/mtmfft_mixed.h"
@@ -76,20 +75,6 @@ void run_quad_mode(const MtmArgs& a, unsigned grid, int outk, int mean, long onl
         case 3: run_quad<LOG2N, G, 1, true>(a, grid, only_block); break;
         case 4: run_quad<LOG2N, G, 2, false>(a, grid, only_block); break;
         default: run_quad<LOG2N, G, 2, true>(a, grid, only_block); break;
-    }
-}
-
-template <int LOG2N>
-void run_pipe_mode(const MtmArgs& a, unsigned grid, int outk, int mean) {
-    using P = spyfft::CfgP<LOG2N>;
-    auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(P::NTHREADS), P::LDS_BYTES, fn); };
-    switch (outk * 2 + mean) {
-        case 0: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 0, false>(a); }); break;
-        case 1: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 0, true>(a); }); break;
-        case 2: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 1, false>(a); }); break;
-        case 3: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 1, true>(a); }); break;
-        case 4: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 2, false>(a); }); break;
-        default: go([&] { spyfft::mtmfft_pipe_kernel<LOG2N, 2, true>(a); }); break;
     }
 }
 
@@ -152,7 +137,6 @@ static void run_dec_mode(const MtmArgs& a0, int nseg, int nchan, int outk, int m
 
 static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD entry points
 static int g_force_4m = 0;  // SPYHIP_CSD_4M: 256 channels on the 4-multiplication kernel
-static int g_m3_wpg = 8;    // waves per workgroup of the 3-multiplication kernel
 static const float* g_means = nullptr;   // (nseg x nchan) reference-order means for the next FFT call, or none
 
 template <int LOG2N, int G>
@@ -194,7 +178,6 @@ extern "C" {
 
 void emu_set_blocked(int on) { g_blocked = on; }
 void emu_set_force_4m(int on) { g_force_4m = on; }
-void emu_set_m3_wpg(int n) { g_m3_wpg = n; }
 void emu_set_means(const float* m) { g_means = m; }
 
 // spyfft::seq_mean_kernel as spyhip_fft_exec launches it (plan option spyhip_fft_plan_set_reference_mean)
@@ -224,12 +207,10 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     a.out_kind = out_kind; a.out = out;
     a.means = g_means;
     a.blocked = g_blocked;
-    const bool pipe = G >= 100;          // G = 102: the pipelined kernel (two quads per workgroup, mtmfft_pipe_kernel.h)
-    if (pipe) G -= 100;
     const bool quad = log2n <= 13;
     // mtmfft_quad_kernel expects the window times scale / 2 (the plan uploads that table, mtmfft.hip)
     std::vector<float> th;
-    if (quad && !pipe) {
+    if (quad) {
         th.resize((size_t)ntaper * nsig);
         for (size_t i = 0; i < th.size(); ++i) th[i] = (float)((double)tapers[i] * (0.5 * (double)scale));
         a.tapers = th.data();
@@ -243,15 +224,6 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     const unsigned grid = (unsigned)(((nclusters + 7) / 8) * S * 8);
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
     const int mean = keeptapers ? 0 : 1;
-    if (pipe) {
-        if (G != 2) return -1;
-        switch (log2n) {
-            case 10: run_pipe_mode<10>(a, grid, outk, mean); return 0;
-            case 11: run_pipe_mode<11>(a, grid, outk, mean); return 0;
-            case 12: run_pipe_mode<12>(a, grid, outk, mean); return 0;
-            default: return -1;
-        }
-    }
     switch (log2n * 100 + G) {
         case 816: run_quad_mode<8, 16>(a, grid, outk, mean, -1); break;
         case 908: run_quad_mode<9, 8>(a, grid, outk, mean, -1); break;
@@ -568,12 +540,8 @@ int emu_csd_accumulate(const float* spec, long long nrows, int F, int C, float* 
     }
     if (force_tpw == 0 && C == 256 && !g_force_4m) {
         // as csd.hip: 256 channels take the 3-multiplication kernel, one workgroup of 8 waves per frequency
-        // (g_m3_wpg = 4: the variant with two workgroups of 4 waves per frequency)
         a.item_end = (long long)F * spycsd::M3_TILES_PER_F;
-        if (g_m3_wpg == 4)
-            emu::launch(dim3((unsigned)(2 * F)), dim3(256), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 4>(a); });
-        else
-            emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8>(a); });
+        emu::launch(dim3((unsigned)F), dim3(512), spycsd::M3_LDS_BYTES, [&] { spycsd::csd3m_kernel<256, 8>(a); });
         return 8;
     }
     if (force_tpw == 0 && C > 512 && !g_blocked) {

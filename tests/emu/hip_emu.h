@@ -17,7 +17,6 @@
 #include <functional>
 #include <type_traits>
 
-#define SPY_HOST_EMU 1
 #define __global__
 #define __device__
 #define __host__
@@ -70,8 +69,23 @@ static inline void __syncthreads() { pthread_barrier_wait(&emu::t_ctx->bar); }
 // static __shared__ arrays: blocks run one after another, so a plain static is
 // shared by the threads of the running block.
 #define __shared__ static
-// dynamic LDS
+// ---- csrc/spy_intrinsics.h, host version: the kernel headers reach every hardware idiom through these names; defining
+// the header's include guard here keeps the device versions out of the emulator build
+#define SPY_INTRINSICS_H
 #define SPY_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::t_ctx->dyn_smem)
+#define SPY_WAVES_PER_EU(lo, hi)
+#define SPY_MIN_WAVES_PER_EU(n)
+static inline int spy_opaque(int v) { return v; }
+static inline void spy_opaque2(double&, double&) {}
+static inline void spy_sched_fence() {}
+static inline int spy_wave_index(int tid) { return tid >> 6; }
+static inline float spy_rsqrt(float x) { return 1.0f / sqrtf(x); }
+static inline float spy_sqrt(float x) { return sqrtf(x); }
+static inline float spy_log2(float x) { return log2f(x); }
+static inline void spy_wait_vmem() {}
+static inline void spy_glds16(const void* gsrc, char* lds_wave_base) {           // the same copy, lane by lane
+    std::memcpy(lds_wave_base + 16 * (emu::t_threadIdx.x & 63), gsrc, 16);
+}
 
 // ---- wave-level primitives (wave = 64 consecutive threads of the block) ----
 namespace emu {
@@ -97,6 +111,8 @@ static inline T __shfl_xor(T v, int mask) {
     emu::wave_sync();
     return r;
 }
+
+static inline float spy_lane_swap1(float v) { return __shfl_xor(v, 1); }
 
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for r in [0,16)   (cdna_hip_programming.md section 3)
@@ -179,6 +195,13 @@ static inline float atomicAdd(float* p, float v) {
     } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
     return f;
 }
+
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 
 namespace emu {
 // Run `kernel(args...)` for every block of `grid` (sequentially) with `block.x`

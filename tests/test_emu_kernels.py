@@ -202,7 +202,7 @@ def test_csd_mfma_kernel(C, F, R, tpw):
                                    # 4-multiplication kernels, 8-byte aligned copies), even non-multiples of 16
                                    (37, 9, 7), (63, 5, 9), (90, 3, 6), (255, 2, 7), (301, 1, 6), (14, 20, 5)])
 def test_csd_3m_kernel(C, F, R):
-    """csd3m_kernel (3-multiplication complex product, 16 x 16 sub-tiles, two workgroups per frequency, rows global ->
+    """csd3m_kernel (3-multiplication complex product, 16 x 16 sub-tiles, one workgroup per frequency, rows global ->
     LDS by DMA): all 136 sub-tiles land where they belong, ragged last chunks are zero-filled, the accumulation
     continues across launches, and the result agrees with the 4-multiplication kernel to rounding.  The spectra
     carry a 40 dB spread over channels and a strong common component (coherent channels, small imaginary parts) -
@@ -215,16 +215,6 @@ def test_csd_3m_kernel(C, F, R):
     spec = ((rng.normal(size=(R, F, C)) + 1j * rng.normal(size=(R, F, C)) + 2.0 * common) * gain).astype(np.complex64)
     acc = np.zeros((F, C, C), np.complex64)
     assert E.csd_accumulate(spec[:R // 2], acc) == code and E.csd_accumulate(spec[R // 2:], acc) == code
-    if C == 256:                                 # the two-workgroups-per-frequency variant: same sums, same order
-        E.lib().emu_set_m3_wpg(4)
-        try:
-            alt = np.zeros((F, C, C), np.complex64)
-            E.csd_accumulate(spec[:R // 2], alt)
-            E.csd_accumulate(spec[R // 2:], alt)
-        finally:
-            E.lib().emu_set_m3_wpg(8)
-        ii0, jj0 = np.tril_indices(C)
-        assert np.array_equal(alt[:, ii0, jj0], acc[:, ii0, jj0])
     acc4 = np.zeros((F, C, C), np.complex64)
     assert E.csd_accumulate(spec, acc4, force_4m=True) != code
     ref = np.einsum("rfi,rfj->fij", spec.astype(np.complex128), spec.conj().astype(np.complex128))
@@ -558,29 +548,6 @@ def test_offset_channels_match_the_reference_next_to_dc(nsig, nfft, kw):
     plain = E.fft_exec(x, [0], [0], [nsig], nsig, nfft, tap, sc, detrend=0, output="fourier", keeptapers=True, **kw)[0]
     if nsig >= 1000:                         # (short sums happen to round well)
         assert excess(plain[:, :, 1], ref[:, :, 1]) > 1.0
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# K1p: the pipelined two-quad kernel (mtmfft_pipe_kernel.h) - folded column order of the last pass, lane-exchange
-# separation (columns 0 and T/2 through LDS), anti-phased halves, lane-pair 32-byte stores
-@pytest.mark.parametrize("log2n,nchan,K,output,keeptapers,detrend,demean", [
-    (10, 8, 2, "fourier", True, 0, False),      # one wave per half; fast store path with the lane-pair trick
-    (10, 5, 3, "pow", False, 1, False),         # ragged: the second half has one channel; taper mean; linear detrend
-    (10, 3, 1, "abs", True, -1, False),         # second half empty
-    (11, 8, 2, "pow", True, 0, True),           # radix-8 last pass, demean_taper through the LDS tail
-    (11, 12, 2, "fourier", True, -1, False),    # two workgroups per segment
-    (12, 8, 2, "fourier", True, 0, False),      # four waves per half, three radix-16 passes
-    (12, 6, 2, "pow", False, 0, True),
-])
-def test_pipe_kernel_vs_oracle(log2n, nchan, K, output, keeptapers, detrend, demean):
-    n = 1 << log2n
-    _fft_case(n, n, nchan, K, output, keeptapers, detrend, demean_taper=demean, G=102, nseg=2 if log2n < 12 else 1)
-
-
-def test_pipe_kernel_selection_and_padding():
-    # frequency selection, channel selection, zero padding (nsig < nfft) on the general store path
-    _fft_case(700, 1024, 7, 2, "pow", True, 0, G=102, freq_idx=np.array([0, 3, 511, 512, 17]), chan_idx=np.array([6, 0, 3, 3, 1]))
-    _fft_case(1500, 2048, 8, 2, "fourier", True, 1, G=102, freq_idx=np.arange(5, 900, 7))
 
 
 # ---------------------------------------------------------------------------------------------------------------
