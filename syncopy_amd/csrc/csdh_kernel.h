@@ -140,6 +140,84 @@ __device__ __forceinline__ int csdh_exponent(float absmax) {
     return k > 127 ? 127 : k;                                         // (e = 255, Inf / NaN: k = -114, the data decide)
 }
 
+// One sub-tile, 32 rows: X / Y = [plane 0 hi, plane 0 lo, plane 1 hi, plane 1 lo] fragments of the row / column block.
+// Re += P0 P0' + P1 P1'; Im: first group P1 P0', then the accumulator changes sign, then P0 P1' (see the header: with the
+// planes (re, im) in even and (im, re) in odd chunks this is Ai Br - Ar Bi up to the parity of the chunk count).
+__device__ __forceinline__ void csdh_tile(const f16x8 (&X)[4], const f16x8 (&Y)[4], f32x4& re, f32x4& im) {
+    __builtin_amdgcn_s_setprio(1);            // the matrix instructions of a sub-tile ahead of the partner wave's vector work
+    im = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[0], im, 0, 0, 0);
+    im = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[1], im, 0, 0, 0);
+    im = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[3], Y[0], im, 0, 0, 0);
+    re = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[0], re, 0, 0, 0);
+    re = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[1], re, 0, 0, 0);
+    re = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[1], Y[0], re, 0, 0, 0);
+    re = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[2], re, 0, 0, 0);
+    re = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[3], re, 0, 0, 0);
+    re = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[3], Y[2], re, 0, 0, 0);
+    if (!(CSDH_ABL & 32)) im = -im;
+    im = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[2], im, 0, 0, 0);
+    im = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[3], im, 0, 0, 0);
+    im = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[1], Y[2], im, 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// After the last chunk: validity of the frequency, then acc += sub-tile / (2^k_i 2^k_j).  `kexp(channel)` = the scale
+// exponent the operands were split with.
+template <int G, class KEXP>
+__device__ __forceinline__ void csdh_finish(const CsdhArgs& a, f32x4 (&re)[M3Tab<256>::NT], f32x4 (&im)[M3Tab<256>::NT], int nchunk,
+                                            int f, int lane, int* vword, KEXP kexp) {
+    using TAB = M3Tab<256>;
+    constexpr int NT = TAB::NT;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const long long nrows = a.nrows;
+    // ---- the Im accumulators carry the sign (-1)^nchunk relative to (even chunks) Im = Ai Br - Ar Bi ... :
+    // even chunk: planes (re, im): first group = Ai Br (+), then negated, + Ar Bi  ->  -(I + Ai Br - Ar Bi)
+    // odd chunk:  planes (im, re): first group = Ar Bi added to -(I...), negated -> I... - Ar Bi, + Ai Br
+    const float isign = (nchunk & 1) ? -1.f : 1.f;
+
+    // ---- validity of the frequency: the diagonal of the scaled accumulation (waves 6 and 7 own the diagonal sub-tiles)
+    {
+        const float floor2 = (float)nrows * 0.015625f;            // rms^2 >= 2^-6 in scaled units
+        bool bad = false;
+        m3_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (TAB::blk(G, TAB::ta(G, t)) == TAB::blk(G, TAB::tb(G, t))) {
+                // an all-zero diagonal entry is only innocent for a channel that IS zero (a scale of 2^-114 for an
+                // Inf "maximum" would flush a whole channel to zero otherwise)
+                const bool dead = a.absmax[TAB::blk(G, TAB::ta(G, t)) * 16 + l15] == 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * lq + r == l15) {
+                        const float v = re[t][r];
+                        bad = bad || !((v >= floor2 && v < __builtin_inff()) || (v == 0.f && dead));
+                    }
+            }
+        });
+        if (__any(bad) && lane == 0) *vword = 0;
+    }
+    __syncthreads();
+    const bool valid = *vword != 0;
+    if (a.flags && G == 0 && lane == 0) a.flags[f] = valid ? 0 : 1;
+    if (!valid) return;
+
+    // ---- acc += sub-tile / (2^k_i 2^k_j).  Lane l holds column (l & 15) and rows 4 (l >> 4) + r of the 16 x 16 block.
+    m3_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int bi = TAB::blk(G, TAB::ta(G, t)), bj = TAB::blk(G, TAB::tb(G, t));
+        static_assert(bi >= bj, "a sub-tile lies on or below the diagonal");
+        float2* const pb = a.acc + (size_t)f * 65536 + (size_t)(bi * 16 + 4 * lq) * 256 + bj * 16 + l15;
+        const int kj = kexp(bj * 16 + l15);
+        float2 old[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) old[r] = pb[(size_t)r * 256];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = -(kexp(bi * 16 + 4 * lq + r) + kj);
+            pb[(size_t)r * 256] = make_float2(old[r].x + ldexpf(re[t][r], kk), old[r].y + ldexpf(isign * im[t][r], kk));
+        }
+    });
+}
+
 template <int G>
 __device__ __forceinline__ void csdh_wave(const CsdhArgs& a, char* lds, int f, int lane) {
     using TAB = M3Tab<256>;
@@ -295,24 +373,7 @@ __device__ __forceinline__ void csdh_wave(const CsdhArgs& a, char* lds, int f, i
             }
             const f16x8(&X)[4] = A[PL::T.aslot[s]];
             const f16x8(&Y)[4] = PL::T.bslot[s] == 2 ? A[PL::T.aslot[s]] : B[PL::T.bslot[s] & 1];
-            __builtin_amdgcn_s_setprio(1);            // the matrix instructions of a sub-tile ahead of the partner wave's vector work
-            // Im, first group: plane 1 of A x plane 0 of B
-            im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[0], im[t], 0, 0, 0);
-            im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[1], im[t], 0, 0, 0);
-            im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[3], Y[0], im[t], 0, 0, 0);
-            // Re
-            re[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[0], re[t], 0, 0, 0);
-            re[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[1], re[t], 0, 0, 0);
-            re[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[1], Y[0], re[t], 0, 0, 0);
-            re[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[2], re[t], 0, 0, 0);
-            re[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[2], Y[3], re[t], 0, 0, 0);
-            re[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[3], Y[2], re[t], 0, 0, 0);
-            // Im, second group with the opposite sign: plane 0 of A x plane 1 of B
-            if (!(CSDH_ABL & 32)) im[t] = -im[t];
-            im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[2], im[t], 0, 0, 0);
-            im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[0], Y[3], im[t], 0, 0, 0);
-            im[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X[1], Y[2], im[t], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            csdh_tile(X, Y, re[t], im[t]);
             if constexpr (s == S1) {
                 CSDH_STAMP(2);
 #ifdef CSDH_STAMPS
@@ -341,52 +402,7 @@ __device__ __forceinline__ void csdh_wave(const CsdhArgs& a, char* lds, int f, i
         nextp += (size_t)CSDH_KROWS * rowbytes;
     }
 
-    // ---- the Im accumulators carry the sign (-1)^nchunk relative to (even chunks) Im = Ai Br - Ar Bi ... :
-    // even chunk: planes (re, im): first group = Ai Br (+), then negated, + Ar Bi  ->  -(I + Ai Br - Ar Bi)
-    // odd chunk:  planes (im, re): first group = Ar Bi added to -(I...), negated -> I... - Ar Bi, + Ai Br
-    const float isign = (nchunk & 1) ? -1.f : 1.f;
-
-    // ---- validity of the frequency: the diagonal of the scaled accumulation (waves 6 and 7 own the diagonal sub-tiles)
-    {
-        const float floor2 = (float)nrows * 0.015625f;            // rms^2 >= 2^-6 in scaled units
-        bool bad = false;
-        m3_for<0, NT>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            if constexpr (TAB::blk(G, TAB::ta(G, t)) == TAB::blk(G, TAB::tb(G, t))) {
-                // an all-zero diagonal entry is only innocent for a channel that IS zero (a scale of 2^-114 for an
-                // Inf "maximum" would flush a whole channel to zero otherwise)
-                const bool dead = a.absmax[TAB::blk(G, TAB::ta(G, t)) * 16 + l15] == 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * lq + r == l15) {
-                        const float v = re[t][r];
-                        bad = bad || !((v >= floor2 && v < __builtin_inff()) || (v == 0.f && dead));
-                    }
-            }
-        });
-        if (__any(bad) && lane == 0) *vword = 0;
-    }
-    __syncthreads();
-    const bool valid = *vword != 0;
-    if (a.flags && G == 0 && lane == 0) a.flags[f] = valid ? 0 : 1;
-    if (!valid) return;
-
-    // ---- acc += sub-tile / (2^k_i 2^k_j).  Lane l holds column (l & 15) and rows 4 (l >> 4) + r of the 16 x 16 block.
-    m3_for<0, NT>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr int bi = TAB::blk(G, TAB::ta(G, t)), bj = TAB::blk(G, TAB::tb(G, t));
-        static_assert(bi >= bj, "a sub-tile lies on or below the diagonal");
-        float2* const pb = a.acc + (size_t)f * 65536 + (size_t)(bi * 16 + 4 * lq) * 256 + bj * 16 + l15;
-        const int kj = kexp[bj * 16 + l15];
-        float2 old[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) old[r] = pb[(size_t)r * 256];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kk = -(kexp[bi * 16 + 4 * lq + r] + kj);
-            pb[(size_t)r * 256] = make_float2(old[r].x + ldexpf(re[t][r], kk), old[r].y + ldexpf(isign * im[t][r], kk));
-        }
-    });
+    csdh_finish<G>(a, re, im, nchunk, f, lane, vword, [&](int ch) { return kexp[ch]; });
 }
 
 template <int G0, int G1>

@@ -15,6 +15,7 @@
 #include "../include/spyhip.h"
 #include "../syncopy_amd/csrc/csd_kernel.h"
 #include "../syncopy_amd/csrc/csdh_kernel.h"
+#include "csdhp_kernel.h"
 
 __device__ __forceinline__ float hash_unit(unsigned long long i) {
     unsigned long long h = i * 0x9E3779B97F4A7C15ull;
@@ -110,6 +111,42 @@ int main(int argc, char** argv) {
             }
     }
 #endif
+    // the same through the pre-split hand-over (csdhp_kernel.h): planes from csdhp_split_kernel, LDS-DMA, transpose reads
+    float2* accp;
+    uint4* planes;
+    hipMalloc(&accp, (size_t)F * 65536 * 8);
+    hipMemset(accp, 0, (size_t)F * 65536 * 8);
+    hipMalloc(&planes, (size_t)rows * F * 2048);
+    spycsd::csdhp_split_kernel<<<8192, 256>>>((const float4*)spec, rows * F * 64, absmax, planes);
+    spycsd::CsdhArgs ap = a;
+    ap.spec = (const float2*)planes; ap.acc = accp; ap.rs = (long long)F * 256; ap.fs = 256;
+    hipFuncSetAttribute((const void*)spycsd::csdhp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, spycsd::CSDHP_LDS_BYTES);
+    spycsd::csdhp_kernel<<<F, 512, spycsd::CSDHP_LDS_BYTES>>>(ap);
+    hipDeviceSynchronize();
+    printf("csdhp first launch: %s\n", hipGetErrorString(hipGetLastError()));
+    {
+        std::vector<float2> h0(65536), h1(65536);
+        double worst = 0;
+        for (int f : {0, 1, F / 2, F - 1}) {
+            hipMemcpy(h0.data(), acc + (size_t)f * 65536, 65536 * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(h1.data(), accp + (size_t)f * 65536, 65536 * 8, hipMemcpyDeviceToHost);
+            for (int i = 0; i < 256; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    const double n = std::sqrt((double)h0[i * 256 + i].x * h0[j * 256 + j].x);
+                    if (n == 0) continue;
+                    worst = std::max(worst, std::hypot((double)h1[i * 256 + j].x - h0[i * 256 + j].x, (double)h1[i * 256 + j].y - h0[i * 256 + j].y) / n);
+                }
+        }
+        printf("pre-split hand-over vs conversion in the kernel: max |diff| / sqrt(Sii Sjj) = %.3e\n", worst);
+    }
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) spycsd::csdhp_kernel<<<F, 512, spycsd::CSDHP_LDS_BYTES>>>(ap);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("csdhp: rows=%lld F=%d: %.3f ms, %.1f TF algorithmic, %.1f TF fp16 executed   %s\n", rows, F, ms,
+           8.0 * rows * F * 256 * 257 / 2 / ms / 1e9, (double)((rows + 31) / 32) * F * 136 * 12 * 16384.0 / ms / 1e9,
+           hipGetErrorString(hipGetLastError()));
+
     // float32 3M kernel for comparison
     spycsd::CsdArgs b{};
     b.spec = spec; b.nrows = rows; b.F = F; b.C = 256; b.acc = acc3;
