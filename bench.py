@@ -338,8 +338,9 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
     del buf, plan
     # ---- c2 at trial lengths that are not powers of two (1 kHz x 2 / 3 / 5 / 10 / 12 s; BASELINE configs[0] is N = 2000):
     # the compile-time schedules K1d (3000 = 3 x 1000 through the radix-3 decimation, 10000 with split exchanges) and,
-    # beyond one workgroup's LDS, K1L2 (12000 = 6 x 2000 through HBM)
-    for N2 in (2000, 3000, 5000, 10000, 12000):
+    # beyond one workgroup's LDS in quad form, the same schedules on channel PAIRS (CfgD::HALF: 12000 through the 6000-point
+    # schedule, 16384 - configs[3]'s trial length - through the 8192-point one)
+    for N2 in (2000, 3000, 5000, 10000, 12000, 16384):
         T2 = 200
         d2 = synthdata.ar2_uncoupled_fast(C, N2, T2, seed=78)
         tp2 = windows.dpss(N2, 1.0 * N2 / 1000.0, K) * np.sqrt(N2)
@@ -350,7 +351,8 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
         F2 = N2 // 2 + 1
         byt, flop = N2 * C * 4 + F2 * C * 4, K * C * 2.5 * N2 * np.log2(N2)
         bound_us = max(byt / (PEAK_HBM_GBS * 1e9), flop / (PEAK_MFMA_F32_TFLOPS * 1e12)) * 1e6
-        out.append({"name": "c2 shape at N = %d (not a power of two): %d ch x %d samp x %d trials, 7 DPSS tapers, taper mean" % (N2, C, N2, T2),
+        out.append({"name": "c2 shape at N = %d%s: %d ch x %d samp x %d trials, 7 DPSS tapers, taper mean"
+                            % (N2, "" if N2 & (N2 - 1) == 0 else " (not a power of two)", C, N2, T2),
                     "value": T2 / (ms * 1e-3), "unit": "trials/s", "us_per_trial": 1e3 * ms / T2,
                     "channel_samples_per_s": T2 / (ms * 1e-3) * N2 * C, "kernel": plan.kernel_name,
                     "bound": "fft-flop (fp32 vector peak) vs hbm, whichever is larger", "bound_us_per_trial": bound_us,

@@ -74,6 +74,9 @@ int dec_launch_j(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int
 int dec_launch_k(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_l(hipStream_t stream, const MtmArgs& a, int nfft, int nquads, int outk, bool mean);
 int dec_launch_c2(hipStream_t stream, const MtmArgs& a, int nquads);
+int dec_launch_half_a(hipStream_t stream, const MtmArgs& a, int nfft, int npairs, int outk, bool mean);
+int dec_launch_half_b(hipStream_t stream, const MtmArgs& a, int nfft, int npairs, int outk, bool mean);
+int dec_launch_half_c(hipStream_t stream, const MtmArgs& a, int nfft, int npairs, int outk, bool mean);
 // mtmfft_declong_{a,b}.hip: N = P M through HBM (mtmfft_declong.h)
 int declong_group(int M);
 int declong_launch_sub_a(hipStream_t stream, const LongArgs& a, int M, int P, long long nblocks);
@@ -93,6 +96,8 @@ struct spyhip_fft_plan {
     float scale = 1.f;
     bool pow2 = false;
     bool dec = false;           // compile-time radix schedules for decimal lengths (mtmfft_dec_kernel.h)
+    bool half = false;          // ... in HALF form: channel pairs, the real transform through the schedule of nfft / 2 (10240 < nfft <= 20480)
+    spy::DevBuf<float2> twh;    // exp(-2 pi i f / nfft), f <= nfft / 4
     bool mixed = false;         // packed mixed-radix engine for 5-smooth lengths (mtmfft_mixed.h)
     spyfft::MixPlan mix{};
     int mix_threads = 0;
@@ -163,32 +168,6 @@ bool factorize(int n, int* radix, int* nfac) {
     }
     *nfac = k;
     return n == 1;
-}
-
-template <int LOG2N, int G, int OUTK, bool MEAN>
-int launch_pow2(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
-    using C = spyfft::Cfg<LOG2N, G>;
-    auto kern = spyfft::mtmfft_pow2_kernel<LOG2N, G, OUTK, MEAN>;
-    // (per device, cheap: set at every launch)
-    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
-    SPY_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-template <int LOG2N, int G>
-int launch_pow2_mode(const spyhip_fft_plan* p, const MtmArgs& a, unsigned grid) {
-    const bool mean = !p->keeptapers;
-    const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
-    switch (outk * 2 + (mean ? 1 : 0)) {
-        case 0: return launch_pow2<LOG2N, G, 0, false>(p, a, grid);
-        case 1: return launch_pow2<LOG2N, G, 0, true>(p, a, grid);
-        case 2: return launch_pow2<LOG2N, G, 1, false>(p, a, grid);
-        case 3: return launch_pow2<LOG2N, G, 1, true>(p, a, grid);
-        case 4: return launch_pow2<LOG2N, G, 2, false>(p, a, grid);
-        default: return launch_pow2<LOG2N, G, 2, true>(p, a, grid);
-    }
 }
 
 template <int LOG2N, int G, int OUTK, bool MEAN>
@@ -312,6 +291,20 @@ bool declong_split(int nfft, int* P, int* M) {
     return false;
 }
 
+// trial lengths beyond one workgroup's LDS in quad form whose HALF has a compile-time schedule (mtmfft_dec_{m,n}.hip)
+bool half_length(int nfft) {
+    return nfft == 12000 || nfft == 12288 || nfft == 15000 || nfft == 16000 || nfft == 16384 || nfft == 20000;
+}
+
+std::vector<float2> half_step_table(int nfft) {
+    std::vector<float2> t((size_t)nfft / 4 + 1);
+    for (int f = 0; f <= nfft / 4; ++f) {
+        const double ang = -2.0 * PI * (double)f / (double)nfft;
+        t[f] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    return t;
+}
+
 // channel quads interleaved per workgroup of the packed kernel (256 threads up to N = 4096)
 int default_G(int log2n) {
     switch (log2n) {
@@ -395,10 +388,12 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         // CU) write 64 contiguous bytes per bin row and are 13 % faster; everything else prefers two independent
         // 256-thread workgroups per CU
         if (p->log2n == 12 && output == SPYHIP_OUT_FOURIER && p->keeptapers) p->G = 2;
-        if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
+        p->half = p->log2n == 14;          // 2^14: channel pairs through the 8192-point schedule (mtmfft_dec_n.hip)
+        if (p->tw.upload(twiddle_table(p->half ? nfft / 2 : nfft), ctx->stream)) { delete p; return -2; }
+        if (p->half && p->twh.upload(half_step_table(nfft), ctx->stream)) { delete p; return -2; }
         char buf[128];
-        std::snprintf(buf, sizeof buf, "%s<%d, %d, %s>", p->log2n <= 13 ? "mtmfft_quad_kernel" : "mtmfft_pow2_kernel",
-                           p->log2n, p->G, mode);
+        if (p->half) std::snprintf(buf, sizeof buf, "mtmfft_dec_kernel<HALF of N = %d, %s>", nfft, mode);
+        else std::snprintf(buf, sizeof buf, "mtmfft_quad_kernel<%d, %d, %s>", p->log2n, p->G, mode);
         p->kernel_name = buf;
     } else if ((nfft == 400 || nfft == 800 || nfft == 1200 || nfft == 1600 || nfft == 2400 || nfft == 3200 || nfft == 4800 || nfft == 8000 ||
                 nfft == 100 || nfft == 200 || nfft == 500 || nfft == 1000 || nfft == 2000 || nfft == 2500 || nfft == 4000 || nfft == 5000 || nfft == 10000 ||
@@ -406,9 +401,14 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
                 nfft == 6144) && !std::getenv("SPYHIP_FORCE_GENERIC")) {
         // decimal trial lengths (1 kHz x 0.2 ... 5 s): radix schedules fixed at compile time, 10 values per thread
         p->dec = true;
-        if (p->tw.upload(twiddle_table(nfft), ctx->stream)) { delete p; return -2; }
+        // HALF form where it measured faster than the quad form (tools/half_probe.py): 5000 (88 KB of LDS per quad: one
+        // workgroup per CU; pairs 12.8 vs 16.0 us/trial at 256 channels) and 10000 with the taper mean (split exchanges
+        // in quad form: 39.3 vs 43.9, complex 42.6 vs 61.7; with every taper kept the 8-byte stores of a pair cost more)
+        p->half = nfft == 5000 || (nfft == 10000 && !p->keeptapers);
+        if (p->tw.upload(twiddle_table(p->half ? nfft / 2 : nfft), ctx->stream)) { delete p; return -2; }
+        if (p->half && p->twh.upload(half_step_table(nfft), ctx->stream)) { delete p; return -2; }
         char buf[128];
-        std::snprintf(buf, sizeof buf, "mtmfft_dec_kernel<N = %d, %s>", nfft, mode);
+        std::snprintf(buf, sizeof buf, p->half ? "mtmfft_dec_kernel<HALF of N = %d, %s>" : "mtmfft_dec_kernel<N = %d, %s>", nfft, mode);
         p->kernel_name = buf;
     } else if (!std::getenv("SPYHIP_FORCE_GENERIC") &&
                // (5-smooth lengths take the mixed-radix engine whatever the taper count: the chirp-z kernel's two length-M
@@ -466,6 +466,14 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         char buf[128];
         std::snprintf(buf, sizeof buf, "declong<%d x %d, %s>", p->dl_P, p->dl_M, mode);
         p->kernel_name = buf;
+        if (half_length(nfft)) {
+            // ... but up to 20480 samples a channel PAIR still fits one workgroup's LDS: the real transform through the
+            // schedule of nfft / 2 (CfgD::HALF).  The tables above stay for the reference-precision twin (declong64).
+            p->half = true;
+            if (p->tw.upload(twiddle_table(nfft / 2), ctx->stream) || p->twh.upload(half_step_table(nfft), ctx->stream)) { delete p; return -2; }
+            std::snprintf(buf, sizeof buf, "mtmfft_dec_kernel<HALF of N = %d, %s>", nfft, mode);
+            p->kernel_name = buf;
+        }
     } else if (nfft <= (1 << 19) && !std::getenv("SPYHIP_FORCE_GENERIC") &&
                !(nfft <= 10240 && [&] { int r[spyfft::GEN_MAXFAC], nf2 = 0; return factorize(nfft, r, &nf2); }())) {
         // (lengths up to 10240 with prime factors <= 13 stay on the mixed-radix LDS kernel below: measured 10-20 %
@@ -866,13 +874,23 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         spy::set_error("fft_exec: no reference-precision kernel for nfft = %d", p->nfft);
         return -1;
     }
+    if (p->half) {
+        const bool mean = !p->keeptapers;
+        const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+        a.twh = p->twh.p;
+        int rc;
+        if ((rc = spyfft::dec_launch_half_a(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_half_b(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;
+        if ((rc = spyfft::dec_launch_half_c(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;
+        spy::set_error("fft_exec: no half-length schedule for nfft = %d", p->nfft);
+        return -1;
+    }
     if (p->pow2) {
-        // work items per segment: channel quads (packed kernel) or channel pairs (2^14)
-        const bool quad = p->log2n <= 13;
+        // work items per segment: channel quads (2^14 went above: channel pairs through the 8192-point schedule)
         const int G = p->G;
-        const int nitem = quad ? (p->nchan + 3) / 4 : npairs;
+        const int nitem = (p->nchan + 3) / 4;
         a.npg = (nitem + G - 1) / G;
-        int S = (quad ? 8 : 16) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;   // workgroups sharing 128-byte rows
+        int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;   // workgroups sharing 128-byte rows
         a.S = S;
         a.ncl = (a.npg + S - 1) / S;
         const long long nclusters = (long long)nseg * a.ncl;
@@ -886,7 +904,6 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             case 11: return launch_quad_mode<11, 2>(p, a, g);
             case 12: return G == 2 ? launch_quad<12, 2, 2, false>(p, a, g) : launch_quad_mode<12, 1>(p, a, g);
             case 13: return launch_quad_mode<13, 1>(p, a, g);
-            case 14: return launch_pow2_mode<14, 1>(p, a, g);
             default: spy::set_error("no kernel for log2n=%d", p->log2n); return -1;
         }
     }

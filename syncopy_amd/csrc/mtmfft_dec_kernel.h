@@ -33,7 +33,7 @@ __device__ __forceinline__ void dec_dft(C2 (&t)[R]) {
     else static_assert(R == 2, "radix of the compile-time schedules: 2, 4, 5, 8, 10, 16, 20");
 }
 
-template <int V_, int R1_, int R2_, int R3_, int G_, int P_ = 1, bool SPLIT_ = false>
+template <int V_, int R1_, int R2_, int R3_, int G_, int P_ = 1, bool SPLIT_ = false, bool HALF_ = false>
 struct CfgD {
     static constexpr int V = V_, R1 = R1_, R2 = R2_, R3 = R3_, G = G_;
     // P = 3: radix-3 decimation in time in FRONT of the schedule - N = 3 M: three groups of T threads transform the
@@ -44,6 +44,14 @@ struct CfgD {
     // SPLIT: an exchange moves the real parts and then the imaginary parts of the packed values through ONE 8-byte plane
     // (half the LDS, twice the barriers): N = 10000 needs it to fit at all, N = 5000 to hold two workgroups per CU
     static constexpr bool SPLIT = SPLIT_;
+    // HALF: a real transform of 2 N samples through the complex length-N schedule.  A thread set carries channel PAIRS
+    // instead of quads: z[m] = x[2 m] + i x[2 m + 1] (the two channels in the packed halves), and the epilogue turns
+    // Z[f], Z[N - f] into the bins f AND N - f of the length-2N real transform: E = (Z[f] + conj Z[N - f]) / 2,
+    // O = (Z[f] - conj Z[N - f]) / 2i, X[f] = E + W O, X[N - f] = conj(E - W O), W = exp(-2 pi i f / 2N).  Same flops per
+    // channel as the two-channels-per-complex-transform packing, HALF the LDS per workgroup: trials of 10240 < nfft <=
+    // 20480 samples stay in LDS (before: decimation in time through HBM, mtmfft_declong.h: a scratch round trip of
+    // nfft packed values per taper - 16 x the algorithmic traffic at nfft = 12000)
+    static constexpr bool HALF = HALF_;
     static constexpr int M = V * R1 * R2 * R3;               // length of one sub-transform (= N without decimation)
     static constexpr int N = P * M;
     static constexpr int T = M / V;                          // threads per sub-transform
@@ -166,6 +174,8 @@ template <class C, int OUTK, bool MEAN>
 __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(MtmArgs a) {
     constexpr bool CPLX = (OUTK == 2);
     constexpr int V = C::V, N = C::N, T = C::T, TT = C::TT, P = C::P, G = C::G, HV = V / 2;
+    constexpr bool HALF = C::HALF;
+    constexpr int CW = HALF ? 2 : 4;              // channels of a thread set
     SPY_DYN_SMEM(float4, lds);
 
     const int tid = threadIdx.x;
@@ -188,15 +198,15 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
     const int pg = (int)(cidx % a.ncl) * a.S + q;
     if (pg >= a.npg) return;
 
-    const int c0 = 4 * (pg * G + h);
+    const int c0 = CW * (pg * G + h);
     bool has[4];
     unsigned col[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        has[i] = active && c0 + i < a.nchan;
+        has[i] = active && i < CW && c0 + i < a.nchan;
         col[i] = has[i] ? (unsigned)(a.chan_idx ? a.chan_idx[c0 + i] : c0 + i) : 0u;
     }
-    const bool full = has[3];
+    const bool full = has[CW - 1];
     const long long start = a.seg_start[b];
     const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
     const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
@@ -206,7 +216,38 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
 
     // ---- load the segment once: x[e] = sample n = jn0 + TT*e; r = (c0, c1), i = (c2, c3)
     C2 x[V];
-    if (rhi > rlo) {
+    if constexpr (HALF) {
+        // sample pairs (2 m, 2 m + 1), m = jn0 + TT e: the even sample in .r, the odd one in .i, channels (c0, c1) in the halves
+        if (rhi > rlo) {
+            const bool vec2 = (a.chan_idx == nullptr) && full && ((a.ld & 1) == 0) &&
+                              ((reinterpret_cast<size_t>(a.data) & 7) == 0);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int n0 = 2 * (jn0 + TT * e), n1 = n0 + 1;
+                const int nc0 = min(max(n0, rlo), rhi - 1), nc1 = min(max(n1, rlo), rhi - 1);
+                float u0[2], u1[2];
+                if (vec2) {
+                    const float2 t0 = ldg<float2>(seg, (unsigned)nc0 * rowb + col[0] * 4u);
+                    const float2 t1 = ldg<float2>(seg, (unsigned)nc1 * rowb + col[0] * 4u);
+                    u0[0] = t0.x; u0[1] = t0.y; u1[0] = t1.x; u1[1] = t1.y;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float t0 = ldg<float>(seg, (unsigned)nc0 * rowb + col[i] * 4u);
+                        const float t1 = ldg<float>(seg, (unsigned)nc1 * rowb + col[i] * 4u);
+                        u0[i] = has[i] ? t0 : 0.f;
+                        u1[i] = has[i] ? t1 : 0.f;
+                    }
+                }
+                const bool ok0 = (n0 == nc0), ok1 = (n1 == nc1);
+                x[e].r = v2f{ok0 ? u0[0] : 0.f, ok0 ? u0[1] : 0.f};
+                x[e].i = v2f{ok1 ? u1[0] : 0.f, ok1 ? u1[1] : 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) x[e].r = x[e].i = splat(0.f);
+        }
+    } else if (rhi > rlo) {
         const bool vec4 = (a.chan_idx == nullptr) && full && ((a.ld & 3) == 0) &&
                           ((reinterpret_cast<size_t>(a.data) & 15) == 0);
         if (vec4) {
@@ -245,12 +286,48 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
         float f[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = has[i] ? mp[i] : 0.f;
-        const v2f mr = v2f{f[0], f[1]}, mi = v2f{f[2], f[3]};
+        const v2f mr = v2f{f[0], f[1]}, mi = HALF ? mr : v2f{f[2], f[3]};
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const bool in = jn0 + TT * e < a.nsig;
-            x[e].r -= in ? mr : splat(0.f);
-            x[e].i -= in ? mi : splat(0.f);
+            const int n0 = HALF ? 2 * (jn0 + TT * e) : jn0 + TT * e;
+            x[e].r -= n0 < a.nsig ? mr : splat(0.f);
+            x[e].i -= n0 + (HALF ? 1 : 0) < a.nsig ? mi : splat(0.f);
+        }
+    } else if (HALF && a.detrend >= 0) {
+        // (HALF) the float64 sums of the two channels run over the even AND the odd samples
+        const float mid = 0.5f * (float)(a.nsig - 1);
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int n0 = 2 * (jn0 + TT * e), n1 = n0 + 1;
+            const float m0 = (active && n0 < a.nsig) ? 1.f : 0.f, m1 = (active && n1 < a.nsig) ? 1.f : 0.f;
+            s[0] += (double)(m0 * x[e].r[0]);
+            s[1] += (double)(m0 * x[e].r[1]);
+            s[0] += (double)(m1 * x[e].i[0]);
+            s[1] += (double)(m1 * x[e].i[1]);
+            if (a.detrend == 1) {
+                const double d0 = (double)(m0 * ((float)n0 - mid)), d1 = (double)(m1 * ((float)n1 - mid));
+                s[4] += d0 * x[e].r[0];
+                s[5] += d0 * x[e].r[1];
+                s[4] += d1 * x[e].i[0];
+                s[5] += d1 * x[e].i[1];
+            }
+        }
+        block_sum<C::NTHREADS, G, 8>(s, reinterpret_cast<double*>(lds), tid, h);
+        const double inv = 1.0 / a.nsig;
+        const double den = (a.detrend == 1 && a.nsig > 1) ? 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0)) : 0.0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int n0 = 2 * (jn0 + TT * e), n1 = n0 + 1;
+            const double d0 = (double)((float)n0 - mid), d1 = (double)((float)n1 - mid);
+            float t0[2], t1[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                t0[i] = n0 < a.nsig ? (float)(s[i] * inv + s[4 + i] * den * d0) : 0.f;
+                t1[i] = n1 < a.nsig ? (float)(s[i] * inv + s[4 + i] * den * d1) : 0.f;
+            }
+            x[e].r -= v2f{t0[0], t0[1]};
+            x[e].i -= v2f{t1[0], t1[1]};
         }
     } else if (a.detrend >= 0) {
         const float mid = 0.5f * (float)(a.nsig - 1);
@@ -311,7 +388,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
     const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
     constexpr unsigned OSZ = CPLX ? 8u : 4u;   // bytes per output element
     const bool fast = full && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) &&
-                      ((a.nchan & (CPLX ? 1 : 3)) == 0);
+                      ((a.nchan & ((CPLX || HALF) ? 1 : 3)) == 0);
 
     for (int k = 0; k < a.ntaper; ++k) {
         const int je = opaque(j0);
@@ -321,11 +398,16 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
         C2 v[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const unsigned n = (unsigned)(jn + TT * e);
+            const unsigned n = (unsigned)(jn + TT * e) * (HALF ? 2u : 1u);
             const float wl = ldg<float>(w, min(n, nsig_m1) * 4u);
             const float wn = (n <= nsig_m1) ? wl : 0.f;
+            float wo = wn;
+            if constexpr (HALF) {
+                const float wl1 = ldg<float>(w, min(n + 1u, nsig_m1) * 4u);
+                wo = (n + 1u <= nsig_m1) ? wl1 : 0.f;
+            }
             v[e].r = x[e].r * wn;
-            v[e].i = x[e].i * wn;
+            v[e].i = x[e].i * wo;
         }
         if (a.demean_taper) {
             __syncthreads();          // block_sum writes its scratch into the buffer other waves may still be reading
@@ -334,18 +416,18 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
             for (int e = 0; e < V; ++e) {
                 s[0] += v[e].r[0];
                 s[1] += v[e].r[1];
-                s[2] += v[e].i[0];
-                s[3] += v[e].i[1];
+                s[HALF ? 0 : 2] += v[e].i[0];
+                s[HALF ? 1 : 3] += v[e].i[1];
             }
             if (!active) s[0] = s[1] = s[2] = s[3] = 0.0;
             block_sum<C::NTHREADS, G, 4>(s, reinterpret_cast<double*>(lds), tid, h);
             const v2f mr = v2f{(float)(s[0] / a.nsig), (float)(s[1] / a.nsig)};
-            const v2f mi = v2f{(float)(s[2] / a.nsig), (float)(s[3] / a.nsig)};
+            const v2f mi = HALF ? mr : v2f{(float)(s[2] / a.nsig), (float)(s[3] / a.nsig)};
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const bool in = jn + TT * e < a.nsig;
-                v[e].r -= in ? mr : splat(0.f);
-                v[e].i -= in ? mi : splat(0.f);
+                const int n0 = (jn + TT * e) * (HALF ? 2 : 1);
+                v[e].r -= n0 < a.nsig ? mr : splat(0.f);
+                v[e].i -= n0 + (HALF ? 1 : 0) < a.nsig ? mi : splat(0.f);
             }
         }
 
@@ -440,6 +522,14 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
                 xa.i = (z.i - zp.i) * hs;
                 xb.r = (z.i + zp.i) * hs;
                 xb.i = (zp.r - z.r) * hs;
+                if constexpr (HALF) {
+                    // xa = E, xb = O of the pair's real transform: bins f and N - f (f = 0: DC and the Nyquist bin)
+                    const C2 t = cmul_s(xb, ldg<float2>(a.twh, (unsigned)f * 8u));
+                    const C2 d = csub(xa, t);
+                    xa = cadd(xa, t);
+                    xb.r = d.r;
+                    xb.i = -d.i;
+                }
             } else {
                 if (je != 0 || !active) break;
                 f = N / 2;
@@ -447,6 +537,10 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
                 xa.r = zn.r * a.scale;
                 xb.r = zn.i * a.scale;
                 xa.i = xb.i = splat(0.f);
+                if constexpr (HALF) {            // the middle bin is its own partner: X[N / 2] = conj Z[N / 2]
+                    xa.i = -xb.r;
+                    xb.r = splat(0.f);
+                }
             }
             if (MEAN) {
                 if (CPLX) {
@@ -460,6 +554,39 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
                                    convert_real_slow(make_float2(xa.r[1], xa.i[1]), a.out_kind)};
                     ma[e].i += v2f{convert_real_slow(make_float2(xb.r[0], xb.i[0]), a.out_kind),
                                    convert_real_slow(make_float2(xb.r[1], xb.i[1]), a.out_kind)};
+                }
+                continue;
+            }
+            if constexpr (HALF) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && e == HV) break;
+                    const int fb = q ? N - f : f;
+                    const C2 X = q ? xb : xa;
+                    if (fast) {
+                        const unsigned o = ((unsigned)fb * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+                        if (CPLX) {
+                            stg<float4>(slab, o, make_float4(X.r[0], X.i[0], X.r[1], X.i[1]));
+                        } else if (OUTK == 0) {
+                            const v2f pw = X.r * X.r + X.i * X.i;
+                            stg<float2>(slab, o, make_float2(pw[0], pw[1]));
+                        } else {
+                            stg<float2>(slab, o, make_float2(convert_real_slow(make_float2(X.r[0], X.i[0]), a.out_kind),
+                                                             convert_real_slow(make_float2(X.r[1], X.i[1]), a.out_kind)));
+                        }
+                    } else {
+                        const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)fb * 4u) : fb;
+                        if (fi >= 0) {
+                            const float2 Xc[2] = {make_float2(X.r[0], X.i[0]), make_float2(X.r[1], X.i[1])};
+                            const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                if (!has[i]) continue;
+                                if (CPLX) stg<float2>(slab, o + i * OSZ, Xc[i]);
+                                else stg<float>(slab, o + i * OSZ, convert_real<OUTK>(Xc[i], a.out_kind));
+                            }
+                        }
+                    }
                 }
                 continue;
             }
@@ -502,6 +629,33 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
         for (int e = 0; e <= HV; ++e) {
             if (!active || (e == HV && j0 != 0)) break;
             const int f = (e < HV) ? j0 + TT * e : N / 2;
+            if constexpr (HALF) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && e == HV) break;
+                    const int fb = q ? N - f : f;
+                    const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)fb * 4u) : fb;
+                    if (fi < 0) continue;
+                    const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+                    if (CPLX) {
+                        const C2 A = q ? mb[e] : ma[e];
+                        const float2 X[2] = {make_float2(A.r[0] / nt, A.i[0] / nt), make_float2(A.r[1] / nt, A.i[1] / nt)};
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (has[i]) stg<float2>(slab, o + i * OSZ, X[i]);
+                    } else {
+                        const v2f A = q ? ma[e].i : ma[e].r;
+                        if (fast) {
+                            stg<float2>(slab, o, make_float2(A[0] / nt, A[1] / nt));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+                                if (has[i]) stg<float>(slab, o + i * OSZ, A[i] / nt);
+                        }
+                    }
+                }
+                continue;
+            }
             const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
             if (fi < 0) continue;
             const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;

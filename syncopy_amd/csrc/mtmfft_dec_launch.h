@@ -6,10 +6,10 @@
 namespace spyfft {
 
 template <class Cf, int OUTK, bool MEAN>
-int dec_launch_one(hipStream_t stream, MtmArgs a, int nquads) {
+int dec_launch_one(hipStream_t stream, MtmArgs a, int nquads) {        // (Cf::HALF: channel PAIRS)
     constexpr int G = Cf::G;
     a.npg = (nquads + G - 1) / G;
-    int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;     // workgroups sharing 128-byte rows (XCD cluster)
+    int S = (Cf::HALF ? 16 : 8) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;     // workgroups sharing 128-byte rows (XCD cluster)
     a.S = S;
     a.ncl = (a.npg + S - 1) / S;
     const long long nclusters = (long long)a.nseg * a.ncl;

@@ -58,6 +58,8 @@ struct MtmArgs {
     unsigned* absmax;           // nullptr, or nchan bit patterns of non-negative floats raised to a bound of |re|, |im| of every
                                 // complex value written for the channel (spyhip_fft_plan_set_absmax: the range K4h scales by)
     float wnorm;                // max over the tapers of || w * scale ||_2 (the bound is wnorm * ||detrended segment||_2)
+    const float2* twh;          // (CfgD::HALF) exp(-2 pi i f / nfft), f <= nfft / 4: the step from the half-length complex
+                                // transform of (even, odd) samples to the bins of the real transform
 };
 
 // Per-channel mean of a segment exactly as the reference takes it.  scipy.signal.detrend(type="constant") on the
@@ -197,255 +199,6 @@ template <int OUTK>
 __device__ __forceinline__ float convert_real(float2 x, int kind) {
     if (OUTK == 0) return x.x * x.x + x.y * x.y;
     return convert_real_slow(x, kind);
-}
-
-// OUTK: see convert_real; MEAN: average over tapers (keeptapers=False)
-//
-// Register discipline (the kernel must fit 128 VGPRs at 1024 threads):
-//  - addressing = wave-uniform 64-bit base + 32-bit per-lane byte offset (segment
-//    base, taper row, twiddle table, output slab) -> saddr-form global accesses;
-//  - LDS addresses = one lane base + compile-time offsets (fft_device.h);
-//  - inside the taper loop the lane index goes through opaque() so the loop-
-//    invariant address arithmetic is recomputed instead of hoisted into VGPRs;
-//  - loads are branch-free (clamped index + select): the 16 row loads of a
-//    thread are all in flight together.
-template <int LOG2N, int G, int OUTK, bool MEAN>
-__global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmfft_pow2_kernel(MtmArgs a) {
-    using C = Cfg<LOG2N, G>;
-    constexpr bool CPLX = (OUTK == 2);
-    constexpr int N = C::N, T = C::T;
-    SPY_DYN_SMEM(float2, lds);
-
-    const int tid = threadIdx.x;
-    const int h = tid % G, j0 = tid / G;
-
-    // XCD-aware block -> (segment, pair group): the S workgroups that share
-    // 128-byte lines of the (time x channel) rows get ids congruent mod 8
-    // (same XCD / L2) and adjacent in dispatch order.
-    const long long id = blockIdx.x;
-    const int xcd = (int)(id & 7);
-    const long long y = id >> 3;
-    // each XCD walks a contiguous run of clusters (see mtmfft2_kernel.h): the rows of a spectrum meet in one L2
-    const long long nclt = (long long)a.nseg * a.ncl, chunk = (nclt + 7) >> 3;
-    const long long cidx = (long long)xcd * chunk + y / a.S;
-    const int q = (int)(y % a.S);
-    if (cidx >= nclt) return;
-    const int b = (int)(cidx / a.ncl);
-    const int pg = (int)(cidx % a.ncl) * a.S + q;
-    if (pg >= a.npg) return;
-
-    const int c0 = 2 * (pg * G + h), c1 = c0 + 1;
-    const bool has0 = c0 < a.nchan, has1 = c1 < a.nchan;
-    const unsigned col0 = has0 ? (unsigned)(a.chan_idx ? a.chan_idx[c0] : c0) : 0u;
-    const unsigned col1 = has1 ? (unsigned)(a.chan_idx ? a.chan_idx[c1] : c1) : col0;
-    const long long start = a.seg_start[b];
-    // valid sample range [rlo, rhi) relative to the segment start
-    const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
-    const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
-    const int rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
-    const unsigned rowb = (unsigned)a.ld * 4u;        // bytes per row
-    const float* seg = a.data + start * a.ld;         // wave-uniform; only rows in [rlo, rhi) are dereferenced
-
-    // ---- load the segment once: x[e] = sample n = j + T*e of both channels
-    float x0[16], x1[16];
-    if (rhi > rlo) {
-        const bool vec2 = (a.chan_idx == nullptr) && has1 && ((a.ld & 1) == 0) &&
-                          ((reinterpret_cast<size_t>(a.data) & 7) == 0);
-        if (vec2) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = j0 + T * e;
-                const int nc = min(max(n, rlo), rhi - 1);
-                const float2 t = ldg<float2>(seg, (unsigned)nc * rowb + col0 * 4u);
-                x0[e] = (n == nc) ? t.x : 0.f;
-                x1[e] = (n == nc) ? t.y : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = j0 + T * e;
-                const int nc = min(max(n, rlo), rhi - 1);
-                const float u0 = ldg<float>(seg, (unsigned)nc * rowb + col0 * 4u);
-                const float u1 = ldg<float>(seg, (unsigned)nc * rowb + col1 * 4u);
-                x0[e] = (n == nc && has0) ? u0 : 0.f;
-                x1[e] = (n == nc && has1) ? u1 : 0.f;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) x0[e] = x1[e] = 0.f;
-    }
-
-    // ---- polynomial removal over the nsig samples (float64 sums, branch-free; constant: the reference-order means)
-    if (a.detrend == 0 && a.means) {
-        const float* mp = a.means + (size_t)b * a.nchan;
-        const float f0 = has0 ? mp[c0] : 0.f, f1 = has1 ? mp[c1] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const bool in = j0 + T * e < a.nsig;
-            x0[e] -= in ? f0 : 0.f;
-            x1[e] -= in ? f1 : 0.f;
-        }
-    } else if (a.detrend >= 0) {
-        const float mid = 0.5f * (float)(a.nsig - 1);
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int n = j0 + T * e;
-            const float m = (n < a.nsig) ? 1.f : 0.f;
-            s[0] += (double)(m * x0[e]);
-            s[1] += (double)(m * x1[e]);
-            if (a.detrend == 1) {
-                const double dn = (double)(m * ((float)n - mid));   // exact: half-integers < 2^23
-                s[2] += dn * x0[e];
-                s[3] += dn * x1[e];
-            }
-        }
-        block_sum4<LOG2N, G>(s, reinterpret_cast<double*>(lds), tid, h);
-        const double inv = 1.0 / a.nsig;
-        const double m0 = s[0] * inv, m1 = s[1] * inv;
-        if (a.detrend == 1 && a.nsig > 1) {
-            const double den = 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0));
-            const double b0 = s[2] * den, b1 = s[3] * den;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = j0 + T * e;
-                const double dn = (double)((float)n - mid);
-                const float t0 = (float)(m0 + b0 * dn), t1 = (float)(m1 + b1 * dn);
-                x0[e] -= (n < a.nsig) ? t0 : 0.f;
-                x1[e] -= (n < a.nsig) ? t1 : 0.f;
-            }
-        } else {
-            const float f0 = (float)m0, f1 = (float)m1;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bool in = j0 + T * e < a.nsig;
-                x0[e] -= in ? f0 : 0.f;
-                x1[e] -= in ? f1 : 0.f;
-            }
-        }
-    }
-
-    // accumulators for the taper mean (bins e<8 plus the Nyquist bin on j == 0)
-    float2 acc0[MEAN ? 9 : 1], acc1[MEAN ? 9 : 1];
-    if (MEAN) {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) acc0[e] = acc1[e] = make_float2(0.f, 0.f);
-    }
-    const int kout = MEAN ? 1 : a.ntaper;
-    const float hs = 0.5f * a.scale;
-    const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
-    constexpr unsigned OSZ = CPLX ? 8u : 4u;   // bytes per output element
-    // complex outputs of a channel pair are 16 contiguous bytes: aligned when nchan is even
-    const bool pair16 = ((a.nchan & 1) == 0) && ((reinterpret_cast<size_t>(a.out) & 15) == 0);
-
-    for (int k = 0; k < a.ntaper; ++k) {
-        const int j = opaque(j0);
-        float2 v[16];
-        const float* w = a.tapers + (size_t)k * a.nsig;   // wave-uniform
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const unsigned n = (unsigned)(j + T * e);
-            const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, min(n, nsig_m1) * 4u);
-            const float wn = (n <= nsig_m1) ? wl : 0.f;
-            v[e] = make_float2(wn * x0[e], wn * x1[e]);
-        }
-        if (a.demean_taper) {
-            double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s[0] += v[e].x;
-                s[1] += v[e].y;
-            }
-            block_sum4<LOG2N, G>(s, reinterpret_cast<double*>(lds), tid, h);
-            const float m0 = (float)(s[0] / a.nsig), m1 = (float)(s[1] / a.nsig);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bool in = j + T * e < a.nsig;
-                v[e].x -= in ? m0 : 0.f;
-                v[e].y -= in ? m1 : 0.f;
-            }
-        }
-
-        fft_forward<LOG2N, G>(v, lds, j, h, a.tw);
-
-        // ---- separate the two real channels: partner bin N-f lives in the upper half
-        {
-            float2* const wr = lds + C::rbase(j, h);
-#pragma unroll
-            for (int e = 8; e < 16; ++e) wr[e * C::ESTRIDE] = v[e];
-        }
-        __syncthreads();
-        // output slab of (segment b, taper k): wave-uniform base, 32-bit lane offsets
-        char* const slab = reinterpret_cast<char*>(a.out) +
-                           ((size_t)b * kout + (MEAN ? 0 : k)) * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
-        // partner of f = j + T*e is N - f: idx(N - j, h) - e*ESTRIDE (index N = spare slot, unused value)
-        const float2* const pr = lds + C::idx(N - j, h) - 7 * C::ESTRIDE;
-#pragma unroll
-        for (int e = 0; e < 9; ++e) {
-            float2 xa, xb;
-            int f;
-            if (e < 8) {
-                f = j + T * e;
-                const float2 z = v[e];
-                const float2 zl = pr[(7 - e) * C::ESTRIDE];
-                const float2 zp = (f == 0) ? z : zl;
-                xa = make_float2(hs * (z.x + zp.x), hs * (z.y - zp.y));
-                xb = make_float2(hs * (z.y + zp.y), hs * (zp.x - z.x));
-            } else {
-                if (j != 0) break;
-                f = N / 2;
-                xa = make_float2(a.scale * v[8].x, 0.f);
-                xb = make_float2(a.scale * v[8].y, 0.f);
-            }
-            if (MEAN) {
-                if (CPLX) {
-                    acc0[e] = cadd(acc0[e], xa);
-                    acc1[e] = cadd(acc1[e], xb);
-                } else {
-                    acc0[e].x += convert_real<OUTK>(xa, a.out_kind);
-                    acc1[e].x += convert_real<OUTK>(xb, a.out_kind);
-                }
-            } else {
-                const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
-                if (fi >= 0 && !((SPYFFT_ABL & 4) && xa.x != 12345.f)) {
-                    const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
-                    if (CPLX) {
-                        if (has1 && pair16) {
-                            stg<float4>(slab, o, make_float4(xa.x, xa.y, xb.x, xb.y));   // one 16-byte store per bin
-                        } else {
-                            if (has0) stg<float2>(slab, o, xa);
-                            if (has1) stg<float2>(slab, o + OSZ, xb);
-                        }
-                    } else {
-                        if (has0) stg<float>(slab, o, convert_real<OUTK>(xa, a.out_kind));
-                        if (has1) stg<float>(slab, o + OSZ, convert_real<OUTK>(xb, a.out_kind));
-                    }
-                }
-            }
-        }
-        __syncthreads();  // LDS is reused by the next taper
-    }
-
-    if (MEAN) {
-        const float kk = (float)a.ntaper;
-        char* const slab = reinterpret_cast<char*>(a.out) + (size_t)b * (size_t)a.nfsel * (size_t)a.nchan * OSZ;
-#pragma unroll
-        for (int e = 0; e < 9; ++e) {
-            if (e == 8 && j0 != 0) break;
-            const int f = (e < 8) ? j0 + T * e : N / 2;
-            const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
-            if (fi < 0) continue;
-            const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
-            if (CPLX) {
-                if (has0) stg<float2>(slab, o, make_float2(acc0[e].x / kk, acc0[e].y / kk));
-                if (has1) stg<float2>(slab, o + OSZ, make_float2(acc1[e].x / kk, acc1[e].y / kk));
-            } else {
-                if (has0) stg<float>(slab, o, acc0[e].x / kk);
-                if (has1) stg<float>(slab, o + OSZ, acc1[e].x / kk);
-            }
-        }
-    }
 }
 
 }  // namespace spyfft

@@ -176,16 +176,25 @@ def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detren
         assert kind == 2 and keeptapers
         out = np.full((nseg * kout, (nchan + 3) // 4, nfsel, 4), np.nan, dtype=np.complex64)
     if dec is not None:
-        # mtmfft_dec_kernel: the compile-time schedule `dec` (emu_kernels.cpp: emu_mtmfft_dec)
+        # mtmfft_dec_kernel: the compile-time schedule `dec` (emu_kernels.cpp: emu_mtmfft_dec); dec < 0: the HALF form of
+        # nfft = -dec (channel pairs through the schedule of nfft / 2: twiddles of nfft / 2 + the half-step table)
+        half = int(dec) < 0
+        twh = np.ascontiguousarray(twiddles(nfft)[: nfft // 4 + 1]) if half else None
+        lib().emu_set_twh(_p(twh, C.c_float))
         rc = lib().emu_mtmfft_dec(
             C.c_int(int(dec)), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
             _p(ss, C.c_longlong), _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg),
-            C.c_int(nsig), C.c_int(nchan), C.c_int(K), _p(tp, C.c_float), _p(twiddles(nfft), C.c_float),
+            C.c_int(nsig), C.c_int(nchan), C.c_int(K), _p(tp, C.c_float), _p(twiddles(nfft // 2 if half else nfft), C.c_float),
             C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), _p(fpos, C.c_int),
             C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
+        lib().emu_set_twh(None)
         assert rc == 0, f"no emulated decimal kernel {dec}"
         return out
     pow2 = (nfft & (nfft - 1)) == 0 and 256 <= nfft <= 16384 and not force_generic
+    if pow2 and nfft == 16384 and dec is None:
+        # as spyhip_fft_plan_create: 2^14 = channel pairs through the 8192-point schedule (CfgD::HALF)
+        return _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend, demean_taper, freq_idx,
+                         output, keeptapers, chan_idx, G, force_generic, blocked, force_long, no_mixed, mixed_nostage, -16384)
     if pow2:
         log2n = int(np.log2(nfft))
         if G is None:

@@ -41,25 +41,6 @@ using spyfft::MtmArgs;
 namespace {
 
 template <int LOG2N, int G, int OUTK, bool MEAN>
-void run_pow2(const MtmArgs& a, unsigned grid, long only_block) {
-    using C = spyfft::Cfg<LOG2N, G>;
-    emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES,
-                [&] { spyfft::mtmfft_pow2_kernel<LOG2N, G, OUTK, MEAN>(a); }, only_block);
-}
-
-template <int LOG2N, int G>
-void run_pow2_mode(const MtmArgs& a, unsigned grid, int outk, int mean, long only_block) {
-    switch (outk * 2 + mean) {
-        case 0: run_pow2<LOG2N, G, 0, false>(a, grid, only_block); break;
-        case 1: run_pow2<LOG2N, G, 0, true>(a, grid, only_block); break;
-        case 2: run_pow2<LOG2N, G, 1, false>(a, grid, only_block); break;
-        case 3: run_pow2<LOG2N, G, 1, true>(a, grid, only_block); break;
-        case 4: run_pow2<LOG2N, G, 2, false>(a, grid, only_block); break;
-        default: run_pow2<LOG2N, G, 2, true>(a, grid, only_block); break;
-    }
-}
-
-template <int LOG2N, int G, int OUTK, bool MEAN>
 void run_quad(const MtmArgs& a, unsigned grid, long only_block) {
     using C = spyfft::Cfg2<LOG2N, G>;
     emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES,
@@ -117,9 +98,9 @@ template <class Cf>
 static void run_dec_mode(const MtmArgs& a0, int nseg, int nchan, int outk, int mean) {
     MtmArgs a = a0;
     const int G = Cf::G;
-    const int nitem = (nchan + 3) / 4;
+    const int nitem = Cf::HALF ? (nchan + 1) / 2 : (nchan + 3) / 4;      // channel pairs / quads (as mtmfft_dec_launch.h)
     a.npg = (nitem + G - 1) / G;
-    int S = 8 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+    int S = (Cf::HALF ? 16 : 8) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
     a.S = S;
     a.ncl = (a.npg + S - 1) / S;
     const long long nclusters = (long long)nseg * a.ncl;
@@ -138,6 +119,7 @@ static void run_dec_mode(const MtmArgs& a0, int nseg, int nchan, int outk, int m
 static int g_blocked = 0;   // hand-over layout toggle shared by the FFT and CSD entry points
 static int g_force_4m = 0;  // SPYHIP_CSD_4M: 256 channels on the 4-multiplication kernel
 static const float* g_means = nullptr;   // (nseg x nchan) reference-order means for the next FFT call, or none
+static const float* g_twh = nullptr;     // exp(-2 pi i f / nfft), f <= nfft / 4: the table of the HALF-form schedules
 
 template <int LOG2N, int G>
 static void emu_launch_ccov(const spyfft::CcovArgs& a) {
@@ -179,6 +161,7 @@ extern "C" {
 void emu_set_blocked(int on) { g_blocked = on; }
 void emu_set_force_4m(int on) { g_force_4m = on; }
 void emu_set_means(const float* m) { g_means = m; }
+void emu_set_twh(const float* t) { g_twh = t; }
 
 // spyfft::seq_mean_kernel as spyhip_fft_exec launches it (plan option spyhip_fft_plan_set_reference_mean)
 void emu_seq_mean(const float* data, long long ld, const int* chan_idx, const long long* seg_start,
@@ -232,7 +215,6 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
         case 1201: run_quad_mode<12, 1>(a, grid, outk, mean, -1); break;
         case 1202: if (outk != 2 || mean) return -1; run_quad<12, 2, 2, false>(a, grid, -1); break;
         case 1301: run_quad_mode<13, 1>(a, grid, outk, mean, -1); break;
-        case 1401: run_pow2_mode<14, 1>(a, grid, outk, mean, -1); break;
         default: return -1;
     }
     return 0;
@@ -251,9 +233,18 @@ int emu_mtmfft_dec(int id, const float* data, long long ld, const int* chan_idx,
     a.detrend = detrend; a.demean_taper = demean_taper; a.fpos = fpos; a.nfsel = nfsel;
     a.out_kind = out_kind; a.out = out;
     a.means = g_means;
+    a.twh = reinterpret_cast<const float2*>(g_twh);
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
     const int mean = keeptapers ? 0 : 1;
     switch (id) {
+        // HALF form (id = -nfft): channel pairs, the real transform of nfft samples through the schedule of nfft / 2
+        case -2000: run_dec_mode<spyfft::CfgD<10, 10, 10, 1, 2, 1, false, true>>(a, nseg, nchan, outk, mean); break;
+        case -2002: run_dec_mode<spyfft::CfgD<10, 10, 10, 1, 2, 1, true, true>>(a, nseg, nchan, outk, mean); break;     // split exchanges
+        case -1200: run_dec_mode<spyfft::CfgD<10, 10, 2, 1, 4, 3, false, true>>(a, nseg, nchan, outk, mean); break;     // 3 x 200
+        case -5000: run_dec_mode<spyfft::CfgD<10, 10, 5, 5, 1, 1, false, true>>(a, nseg, nchan, outk, mean); break;
+        case -12000: run_dec_mode<spyfft::CfgD<10, 10, 10, 2, 1, 3, false, true>>(a, nseg, nchan, outk, mean); break;
+        case -1024: run_dec_mode<spyfft::CfgD<16, 16, 2, 1, 2, 1, false, true>>(a, nseg, nchan, outk, mean); break;
+        case -16384: run_dec_mode<spyfft::CfgD<16, 16, 16, 2, 1, 1, false, true>>(a, nseg, nchan, outk, mean); break;
         case 1000: run_dec_mode<spyfft::CfgD<10, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;
         case 2000: run_dec_mode<spyfft::CfgD<10, 10, 10, 2, 1>>(a, nseg, nchan, outk, mean); break;
         case 2001: run_dec_mode<spyfft::CfgD<20, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;

@@ -626,6 +626,30 @@ def test_long_trials_through_scratch_memory(P, M, nsig, nchan, K, output, keepta
     assert_parity(out[0], ref[0], what=f"{P} x {M}")
 
 
+@pytest.mark.parametrize("nsig,nfft,nchan,K,output,keeptapers,detrend,demean", [
+    (2000, 2000, 8, 2, "fourier", True, 0, False),     # pairs through 10 x 10 x 10, two pairs per workgroup, fast stores
+    (2000, 2000, 5, 3, "pow", False, 1, True),         # ragged channels, taper mean, line fit over even + odd samples, demean_taper
+    (1999, 2000, 3, 2, "abs", True, 0, False),         # odd sample count: the last pair is half padding
+    (1501, 2000, 4, 2, "fourier", False, -1, False),   # zero padding, complex taper mean
+    (2000, 2002, 6, 2, "fourier", True, 0, False),     # ... with split exchanges (id 2002 = the 1000-point schedule, SPLIT)
+    (1200, 1200, 9, 2, "fourier", True, 0, True),      # 3 x 200: radix-3 decimation in front, four pairs per workgroup
+    (1100, 1200, 4, 3, "pow", False, 1, False),
+    (1024, 1024, 6, 2, "pow", True, 0, False),         # 16 x 16 x 2
+    (5000, 5000, 4, 1, "pow", True, 0, False),         # 10 x 10 x 5 x 5 (the product's choice for nfft = 5000)
+    (12000, 12000, 2, 1, "fourier", True, 0, False),   # 3 x (10 x 10 x 10 x 2): trials beyond a quad's LDS
+])
+def test_dec_kernel_half_form(nsig, nfft, nchan, K, output, keeptapers, detrend, demean):
+    """CfgD::HALF: z[m] = x[2 m] + i x[2 m + 1] through the length-nfft/2 schedule, bins f and nfft/2 - f from Z[f], Z[nfft/2 - f]."""
+    real_nfft = 2000 if nfft == 2002 else nfft
+    _fft_case(nsig, real_nfft, nchan, K, output, keeptapers, detrend, demean_taper=demean, nseg=2 if nfft <= 2002 else 1, dec=-nfft)
+
+
+def test_dec_kernel_half_form_selection():
+    _fft_case(1700, 2000, 6, 2, "pow", True, 0, dec=-2000, nseg=1, freq_idx=np.array([0, 1, 999, 1000, 37, 500, 501, 499]),
+              chan_idx=np.array([5, 0, 2, 2, 1]))
+    _fft_case(1200, 1200, 3, 2, "fourier", False, 0, dec=-1200, nseg=1, freq_idx=np.array([600, 0, 300, 299, 301, 200, 400]))
+
+
 def test_dec_kernel_padding_and_selection():
     _fft_case(1700, 2000, 6, 2, "pow", True, 0, dec=2000, nseg=1, freq_idx=np.array([0, 1, 999, 1000, 37]),
               chan_idx=np.array([5, 0, 2, 2]))

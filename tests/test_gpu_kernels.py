@@ -65,13 +65,18 @@ CASES = [
     (32768, 32768, 3, "dpss", {"NW": 2, "Kmax": 2}, "pow", False, 0, False),           # power of two: plain four-step
     (30000, 30000, 5, "dpss", {"NW": 2, "Kmax": 2}, "abs", True, 0, False),
     (20000, 32768, 2, "hann", {}, "pow", True, None, False),
+    # 10240 < N <= 20480: channel PAIRS through the compile-time schedule of N / 2 (CfgD::HALF, mtmfft_dec_{m,n}.hip);
+    # the reference-precision twins of these lengths stay on N = P M through HBM
+    (12000, 12000, 6, "dpss", {"NW": 3, "Kmax": 3}, "fourier", True, 1, True),        # 3 x 2000 pairs, line fit, demean_taper
+    (12288, 12288, 5, "dpss", {"NW": 2, "Kmax": 2}, "pow", False, 0, False),          # 3 x 2048, odd channel count
+    (15000, 15000, 7, "hann", {}, "abs", True, 0, False),                              # 3 x 2500
+    (14000, 16000, 4, "dpss", {"NW": 2, "Kmax": 2}, "fourier", False, 0, False),      # 8000, zero padding, complex taper mean
+    (20000, 20000, 3, "hann", {}, "pow", True, None, False),                           # 10000: split exchanges
+    (11999, 12000, 3, "dpss", {"NW": 2, "Kmax": 2}, "pow", True, 1, True),             # odd sample count: the last pair is half padding
+    (16001, 16384, 2, "hann", {}, "fourier", True, 0, True),
     # N = P M through HBM (mtmfft_declong.h): scheduled sub-transforms of length M, one radix-P pass, P = 2 ... 8
-    (12000, 12000, 6, "dpss", {"NW": 3, "Kmax": 3}, "fourier", True, 1, True),        # 6 x 2000, line fit, demean_taper
-    (12288, 12288, 5, "dpss", {"NW": 2, "Kmax": 2}, "pow", False, 0, False),          # 3 x 4096
-    (15000, 15000, 7, "hann", {}, "abs", True, 0, False),                              # 3 x 5000
-    (14000, 16000, 4, "dpss", {"NW": 2, "Kmax": 2}, "fourier", False, 0, False),      # 8 x 2000, zero padding
-    (20000, 20000, 3, "hann", {}, "pow", True, None, False),                           # 4 x 5000
     (24000, 24000, 2, "hann", {}, "fourier", True, 0, False),                          # 6 x 4000
+    (30000, 30000, 5, "hann", {}, "pow", False, 1, True),                              # 6 x 5000, line fit, demean_taper
     (50000, 50000, 2, "hann", {}, "pow", True, 0, False),                              # 5 x 10000
     (64000, 64000, 1, "hann", {}, "fourier", True, 0, False),                          # 8 x 8000
     (9000, 20000, 9, "dpss", {"NW": 2, "Kmax": 2}, "pow", False, 1, False),            # ragged quads, mostly padding

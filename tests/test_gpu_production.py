@@ -88,21 +88,23 @@ def test_c3_coherence_256x4096(c3_data):
     assert np.all(np.abs(coh.data[0][:, np.arange(256), np.arange(256)] - 1) < 1e-6)
 
 
-def test_long_trials_256x12000_several_scratch_chunks():
-    """K1L2 (mtmfft_declong.h: 12000 = 6 x 2000 through HBM) at 256 channels x 7 tapers: 86 MB of scratch per trial, so
-    30 trials take two chunks of the 2-GiB scratch - against a float64 rfft of the same tapered trials formed on the device
+@pytest.mark.parametrize("N,T,kernel", [(12000, 30, "HALF of N = 12000"), (24000, 26, "declong<6 x 4000")])
+def test_long_trials_256_channels(N, T, kernel):
+    """Trials beyond a channel quad's LDS at 256 channels x 7 tapers.  12000: channel pairs through the 6000-point schedule
+    (CfgD::HALF).  24000 = 6 x 4000 through HBM (K1L2, mtmfft_declong.h): 172 MB of scratch per trial, so 26 trials take
+    three chunks of the 2-GiB scratch.  Against a float64 rfft of the same tapered trials formed on the device
     (mtmfft.py:96-127; no detrending: the reference-order mean is tests/test_gpu_kernels.py's subject), every 5th trial."""
     torch = pytest.importorskip("torch")
     from scipy.signal import windows
     from syncopy_amd import backend as be
-    C, N, T, K = 256, 12000, 30, 7
+    C, K = 256, 7
     g = torch.Generator(device="cuda").manual_seed(12)
     data = torch.randn((T * N, C), device="cuda", dtype=torch.float32, generator=g)
     tap = windows.dpss(N, 4.0, K) * np.sqrt(N)
     starts = torch.arange(T, device="cuda", dtype=torch.int64) * N
     for output, keeptapers in (("pow", False), ("fourier", True)):
         plan = be.FFTPlan(N, N, C, tap, np.sqrt(2) / N, None, False, None, output, keeptapers)
-        assert "declong<6 x 2000" in plan.kernel_name
+        assert kernel in plan.kernel_name
         got = plan.execute(data, starts)
         w = torch.from_numpy(tap).cuda()                                   # (K, N) float64
         for t in range(0, T, 5):
@@ -113,6 +115,7 @@ def test_long_trials_256x12000_several_scratch_chunks():
                 assert_parity(got[t, 0].cpu().numpy(), ref, what=f"pow trial {t}")
             else:
                 assert_parity(got[t].cpu().numpy(), spec.to(torch.complex64).cpu().numpy(), what=f"fourier trial {t}")
+            del spec, x
         del got, plan
 
 

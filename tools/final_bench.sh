@@ -27,7 +27,7 @@ grep -E "^\"Name\"|spy" "$f" > $O/bench_kernel_stats.csv
 head -6 $O/bench_kernel_stats.csv | cut -c1-170
 cd $R
 hipcc -O2 tools/pmc_harness2.cpp -Iinclude -Lsyncopy_amd -lspyhip -Wl,-rpath,$PWD/syncopy_amd -o /tmp/pmc_harness2 || exit 1
-MODES=${MODES:-"c2 c2f64 n2000 n2000f64 n3000 n3000f64 n5000 n5000f64 n10000 n10000f64 n12000 n12000f64 conv wav"}
+MODES=${MODES:-"c2 c2f64 n2000 n2000f64 n3000 n3000f64 n5000 n5000f64 n10000 n10000f64 n12000 n12000f64 n16384 n16384f64 conv wav"}
 : > $O/secondary_kernel_stats.txt
 : > $O/pmc_secondary.txt
 for m in $MODES; do
