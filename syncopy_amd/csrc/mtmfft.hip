@@ -17,19 +17,8 @@
 namespace spyfft {
 }  // namespace spyfft
 #include "f64_stockham.h"     // PlusPlan + plus_plan (the factor schedule of the any-length reference-precision kernel)
+#include "mtmfft_f64_args.h"  // F64Args (the kernels themselves stay out of this translation unit: they pull in the Wilson kernels)
 namespace spyfft {
-struct F64Args {              // mtmfft_f64_kernel.h (kept out of this translation unit: it pulls in the Wilson kernels)
-    MtmArgs m;
-    const double* tapers64;
-    const double2* tw64;
-    double scale64;
-    spywil::PlusPlan plan;
-    double2* work;
-    long long wg0;
-    int blue_n;
-    const double2* chirp64;
-    const double2* bhat64;
-};
 int dec64_launch_a(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_b(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_c(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
@@ -44,6 +33,8 @@ int dec64_launch_k(hipStream_t stream, const F64Args& a, int nfft, int npairs, i
 int dec64_launch_l(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_m(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
 int dec64_launch_n(hipStream_t stream, const F64Args& a, int nfft, int npairs, int outk, bool mean);
+int dec64_launch_half_a(hipStream_t stream, const F64Args& a, int nfft, int nchan, int outk, bool mean);
+int dec64_launch_half_b(hipStream_t stream, const F64Args& a, int nfft, int nchan, int outk, bool mean);
 struct Long64Args {           // mtmfft_declong64.h (kept out of this translation unit, as F64Args)
     MtmArgs m;
     const double* tapers64;
@@ -126,6 +117,8 @@ struct spyhip_fft_plan {
     bool f64_dec = false;       // ... through the compile-time-schedule kernel (mtmfft_dec64_kernel.h)
     int f64_blue = 0;           // any-length kernel in its Bluestein form: the length M = 2^m >= 2 nfft - 1
     bool f64_dl = false;        // ... N = dl_P x dl_M through HBM (mtmfft_declong64.h)
+    bool f64_half = false;      // ... single channels through the schedule of nfft / 2 (CfgD64::HALF: 10240 < nfft <= 20480)
+    spy::DevBuf<double2> tw64h; // exp(-2 pi i m / (nfft / 2)) for it (tw64 then serves as the half-step table)
     spy::DevBuf<double2> tw64_sub, tw64_P, scratch64;
     size_t scratch64_cap = 0;
     spy::DevBuf<double2> chirp64, bhat64;
@@ -616,8 +609,19 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
                                         100, 400, 800, 1600, 3200, 8000, 300, 1200, 2400, 4800};
     p->f64_dec = false;
     for (int n : dec64_lengths) p->f64_dec = p->f64_dec || (n == p->nfft);
-    p->f64_dl = !p->f64_dec && p->dl_P > 0;
-    p->f64_any = !p->f64_dec && !p->f64_dl;
+    p->f64_half = half_length(p->nfft);
+    if (p->f64_half) p->f64_dec = false;
+    p->f64_dl = !p->f64_dec && !p->f64_half && p->dl_P > 0;
+    p->f64_any = !p->f64_dec && !p->f64_dl && !p->f64_half;
+    if (p->f64_half && !p->tw64h.p) {
+        const int nh = p->nfft / 2;
+        std::vector<double2> t(nh);
+        for (int m = 0; m < nh; ++m) {
+            const double ang = -2.0 * PI * (double)m / (double)nh;
+            t[m] = make_double2(std::cos(ang), std::sin(ang));
+        }
+        if (p->tw64h.upload(t, p->ctx->stream)) return -2;
+    }
     if (p->f64_dl && !p->tw64_sub.p) {
         auto table = [](int n) {
             std::vector<double2> t(n);
@@ -679,7 +683,10 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
     if (!p->precision64) p->fp32_kernel_name = p->kernel_name;
     p->precision64 = true;
     char buf[128];
-    if (p->f64_dl)
+    if (p->f64_half)
+        std::snprintf(buf, sizeof buf, "mtmfft_dec64_kernel<HALF of N = %d, %d, %s>", p->nfft,
+                      p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
+    else if (p->f64_dl)
         std::snprintf(buf, sizeof buf, "declong64_kernel<%d x %d, %d, %s>", p->dl_P, p->dl_M,
                       p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
     else if (p->f64_dec)
@@ -774,6 +781,15 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         fa.scale64 = (double)p->scale;
         const long long grid = (long long)nseg * npairs;
         const int outk64 = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
+        if (p->f64_half) {
+            fa.tw64 = p->tw64h.p;
+            fa.tw64_full = p->tw64.p;
+            int rc;
+            if ((rc = spyfft::dec64_launch_half_a(p->ctx->stream, fa, p->nfft, p->nchan, outk64, !p->keeptapers)) != -100) return rc;
+            if ((rc = spyfft::dec64_launch_half_b(p->ctx->stream, fa, p->nfft, p->nchan, outk64, !p->keeptapers)) != -100) return rc;
+            spy::set_error("fft_exec: no half-length reference-precision schedule for nfft = %d", p->nfft);
+            return -1;
+        }
         if (p->f64_dl) {
             // N = P M through HBM (mtmfft_declong64.h); trend and post-taper mean from the float64 sums of long_stats_kernel.
             // (float64 segments of padded sliding windows, seg_f64, are treated as float32 trials here: the nuance is one

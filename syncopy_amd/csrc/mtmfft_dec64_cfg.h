@@ -34,6 +34,14 @@ using D64_768   = CfgD64<16, 16, 1,  1,  4, false, true, true, 3>;
 using D64_1536  = CfgD64<16, 16, 2,  1,  2, false, true, true, 3>;
 using D64_3072  = CfgD64<16, 16, 4,  1,  1, false, true, true, 3>;
 using D64_6144  = CfgD64<16, 16, 8,  1,  1, false, true, true, 3>;
+// HALF form: single channels, the real transform of 2 N samples through the schedule of N (trials of 12000 ... 20000 samples)
+//                        V   R1  R2  R3  G   SPLIT  XRES  HOIST P  HALF
+using D64H_12000 = CfgD64<10, 10, 10, 2,  1, false, true, true, 3, true>;
+using D64H_12288 = CfgD64<16, 16, 8,  1,  1, false, true, true, 3, true>;
+using D64H_15000 = CfgD64<10, 10, 5,  5,  1, false, true, true, 3, true>;
+using D64H_16000 = CfgD64<20, 20, 20, 1,  1, false, true, true, 1, true>;
+using D64H_16384 = CfgD64<16, 16, 16, 2,  1, false, true, false, 1, true>;
+using D64H_20000 = CfgD64<20, 20, 5,  5,  1, true, true, true, 1, true>;
 // window lengths of sliding-window analyses and the remaining multiples of 100 up to 8000 that factor into the radices
 using D64_100   = CfgD64<10, 10, 1,  1,  16>;
 using D64_400   = CfgD64<20, 20, 1,  1,  8>;      // (10 x 10 x 2 x 2, the float32 choice, measured 2.5 vs 2.2 us/trial here)

@@ -27,7 +27,8 @@
 
 namespace spyfft {
 
-template <int V_, int R1_, int R2_, int R3_, int G_, bool SPLIT_ = false, bool XRES_ = true, bool HOIST_ = true, int P_ = 1>
+template <int V_, int R1_, int R2_, int R3_, int G_, bool SPLIT_ = false, bool XRES_ = true, bool HOIST_ = true, int P_ = 1,
+          bool HALF_ = false>
 struct CfgD64 {
     static constexpr int V = V_, R1 = R1_, R2 = R2_, R3 = R3_, G = G_;
     // P > 1: decimation in time in front of the schedule - N = P M: P groups of T threads transform the sub-sequences
@@ -39,6 +40,10 @@ struct CfgD64 {
     // multiplication (d64_pass); false: every power comes from the table inside the taper loop (N = 8192: the four
     // passes' base twiddles do not fit next to 16 resident values per thread - measured 61.9 vs 53.8 us/trial)
     static constexpr bool HOIST = HOIST_;
+    // HALF (as CfgD::HALF of the float32 kernel): a work item is ONE channel, z[m] = x[2 m] + i x[2 m + 1], and the epilogue
+    // turns Z[f], Z[N - f] into the bins f and N - f of the real transform of 2 N samples - trials of 10240 < nfft <= 20480
+    // samples stay in LDS (before: N = P M through HBM scratch, mtmfft_declong64.h: 40 x the algorithmic traffic at 12000)
+    static constexpr bool HALF = HALF_;
     static constexpr int M = V * R1 * R2 * R3;               // length of one sub-transform (= N without decimation)
     static constexpr int N = P * M;
     static constexpr int T = M / V;                          // threads per sub-transform
@@ -60,6 +65,7 @@ struct CfgD64 {
     static_assert(T % V == 0, "T multiple of V: idx(j + T e) stays affine in e");
     static_assert(NTHREADS <= 1024 && (64 % G) == 0 && (V % 2) == 0, "workgroup shape");
     static_assert(P == 1 || (P == 3 && !SPLIT && XRES), "decimation: radix 3, plain exchanges, resident samples");
+    static_assert(!HALF || (XRES && NTHREADS < 1024 && V <= 20), "HALF form: resident samples, taper mean in registers");
     __device__ static __forceinline__ int idx(int i, int h) { return (i + i / V) * G + h; }
 };
 
@@ -208,9 +214,19 @@ struct D64Src {
     bool some, vec2, has0, has1;
     // the V samples n = j + T e of a thread, branches outside the unrolled loops (straight-line loads: the register
     // allocator copes badly with sixteen diamonds)
-    template <int V, int T>
+    template <int V, int T, bool HALF = false>
     __device__ __forceinline__ void get_all(int j, float (&u0)[V], float (&u1)[V]) const {      // samples j + T e
-        if (some) {
+        if (HALF && some) {
+            // (HALF) u0 = the even, u1 = the odd sample of the pair 2 (j + T e), 2 (j + T e) + 1 of channel col0
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int n0 = 2 * (j + T * e), n1 = n0 + 1;
+                const int nc0 = min(max(n0, rlo), rhi - 1), nc1 = min(max(n1, rlo), rhi - 1);
+                const float t0 = seg[(size_t)nc0 * ld + col0], t1 = seg[(size_t)nc1 * ld + col0];
+                u0[e] = (n0 == nc0 && has0) ? t0 : 0.f;
+                u1[e] = (n1 == nc1 && has0) ? t1 : 0.f;
+            }
+        } else if (some) {
             if (vec2) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
@@ -243,6 +259,8 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
     using spywil::cd;
     constexpr bool CPLX = (OUTK == 2);
     constexpr int V = C::V, N = C::N, T = C::T, TT = C::TT, P = C::P, G = C::G, HV = V / 2;
+    constexpr bool HALF = C::HALF;
+    constexpr int SM = HALF ? 2 : 1;               // sample n of value e: SM (jn + TT e) for the real part, + (HALF ? 1 : 0) for the imaginary
     const MtmArgs& a = fa.m;
     SPY_DYN_SMEM(char, ldsraw);
     void* const lds = ldsraw;
@@ -267,11 +285,12 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
     const int pg = (int)(cidx % a.ncl) * a.S + qs;
     if (pg >= a.npg) return;
 
-    const int c0 = 2 * (pg * G + h);
-    const bool has0 = active && c0 < a.nchan, has1 = active && c0 + 1 < a.nchan;
+    const int c0 = (HALF ? 1 : 2) * (pg * G + h);
+    const int c1 = HALF ? c0 : c0 + 1;            // (HALF: both halves of the complex value belong to channel c0)
+    const bool has0 = active && c0 < a.nchan, has1 = active && c1 < a.nchan;
     D64Src src;
     src.col0 = has0 ? (unsigned)(a.chan_idx ? a.chan_idx[c0] : c0) : 0u;
-    src.col1 = has1 ? (unsigned)(a.chan_idx ? a.chan_idx[c0 + 1] : c0 + 1) : 0u;
+    src.col1 = has1 ? (unsigned)(a.chan_idx ? a.chan_idx[c1] : c1) : 0u;
     src.has0 = has0; src.has1 = has1;
     const long long start = a.seg_start[b];
     const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
@@ -279,12 +298,12 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
     src.rhi = (int)(rh < 0 ? 0 : (rh > a.nsig ? a.nsig : rh));
     src.seg = a.data + start * a.ld;              // only rows in [rlo, rhi) are dereferenced
     src.ld = a.ld;
-    src.vec2 = (a.chan_idx == nullptr) && has1 && ((a.ld & 1) == 0) && ((reinterpret_cast<size_t>(a.data) & 7) == 0);
+    src.vec2 = !HALF && (a.chan_idx == nullptr) && has1 && ((a.ld & 1) == 0) && ((reinterpret_cast<size_t>(a.data) & 7) == 0);
     src.some = src.rhi > src.rlo;
 
     float x0[V], x1[V];           // XRES: resident across the tapers; otherwise refilled per taper
     const bool fit = !(a.detrend == 0 && a.means) && a.detrend >= 0;
-    if (C::XRES || fit) src.template get_all<V, TT>(jn0, x0, x1);
+    if (C::XRES || fit) src.template get_all<V, TT, HALF>(jn0, x0, x1);
 
     // ---- polynomial removal in float32 (scipy.signal.detrend on the float32 trial, compRoutines.py:169-172): the
     // reference-order means (detrend 0) or a float64 fit whose trend is rounded to float32 before it is subtracted;
@@ -294,25 +313,27 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
     double t0c = 0.0, t1c = 0.0, t0s = 0.0, t1s = 0.0; // fitted trend: constant and slope about the centre
     if (a.detrend == 0 && a.means) {
         m0 = has0 ? a.means[(size_t)b * a.nchan + c0] : 0.f;
-        m1 = has1 ? a.means[(size_t)b * a.nchan + c0 + 1] : 0.f;
+        m1 = has1 ? a.means[(size_t)b * a.nchan + c1] : 0.f;
     } else if (fit) {
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         const float lin = a.detrend == 1 ? 1.f : 0.f;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const int n = jn0 + TT * e;
+            const int n = SM * (jn0 + TT * e), n1 = n + (HALF ? 1 : 0);
             const float m = (active && n < a.nsig) ? 1.f : 0.f;           // branch-free masks (exact: 0 or 1)
-            const float u0 = m * x0[e], u1 = m * x1[e];
+            const float mb = (active && n1 < a.nsig) ? 1.f : 0.f;
+            const float u0 = m * x0[e], u1 = mb * x1[e];
             const double dn = (double)(lin * ((float)n - mid));           // exact: half-integers < 2^23
+            const double dn1 = (double)(lin * ((float)n1 - mid));
             s[0] += (double)u0;
-            s[1] += (double)u1;
+            s[HALF ? 0 : 1] += (double)u1;                                // (HALF: one channel, even and odd samples)
             s[2] += dn * u0;
-            s[3] += dn * u1;
+            s[HALF ? 2 : 3] += dn1 * u1;
         }
         block_sum<C::NTHREADS, G, 4>(s, reinterpret_cast<double*>(lds), tid, h);
         const double inv = 1.0 / a.nsig;
         const double den = (a.detrend == 1 && a.nsig > 1) ? 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0)) : 0.0;
-        t0c = s[0] * inv; t1c = s[1] * inv; t0s = s[2] * den; t1s = s[3] * den;
+        t0c = s[0] * inv; t1c = s[HALF ? 0 : 1] * inv; t0s = s[2] * den; t1s = s[HALF ? 2 : 3] * den;
     }
     const bool f64t = fit && a.seg_f64;
     // float32 trend of sample n (what the reference subtracts from the float32 trial); float64 segments: see the taper loop
@@ -320,18 +341,18 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         if (fit && !f64t) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = jn0 + TT * e;
-                const double dn = (double)((float)n - mid);
-                const float q0 = (float)(t0c + t0s * dn), q1 = (float)(t1c + t1s * dn);
+                const int n = SM * (jn0 + TT * e), n1 = n + (HALF ? 1 : 0);
+                const double dn = (double)((float)n - mid), dn1 = (double)((float)n1 - mid);
+                const float q0 = (float)(t0c + t0s * dn), q1 = (float)(t1c + t1s * dn1);
                 x0[e] -= n < a.nsig ? q0 : 0.f;
-                x1[e] -= n < a.nsig ? q1 : 0.f;
+                x1[e] -= n1 < a.nsig ? q1 : 0.f;
             }
         } else if (!fit) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const bool in = jn0 + TT * e < a.nsig;
-                x0[e] -= in ? m0 : 0.f;
-                x1[e] -= in ? m1 : 0.f;
+                const int n = SM * (jn0 + TT * e), n1 = n + (HALF ? 1 : 0);
+                x0[e] -= n < a.nsig ? m0 : 0.f;
+                x1[e] -= n1 < a.nsig ? m1 : 0.f;
             }
         }
     }
@@ -404,17 +425,17 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
             // float64 segments in the reference: the trend is subtracted in float64
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = jn + TT * e;
-                const double wn = tapw(w, (unsigned)n, nsig_m1);
-                const double dn = (double)((float)n - mid);
-                v[e] = make_double2(wn * ((double)x0[e] - (t0c + t0s * dn)), wn * ((double)x1[e] - (t1c + t1s * dn)));
+                const int n = SM * (jn + TT * e), n1 = n + (HALF ? 1 : 0);
+                const double wn = tapw(w, (unsigned)n, nsig_m1), wn1 = HALF ? tapw(w, (unsigned)n1, nsig_m1) : wn;
+                const double dn = (double)((float)n - mid), dn1 = (double)((float)n1 - mid);
+                v[e] = make_double2(wn * ((double)x0[e] - (t0c + t0s * dn)), wn1 * ((double)x1[e] - (t1c + t1s * dn1)));
             }
         } else {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const int n = jn + TT * e;
-                const double wn = tapw(w, (unsigned)n, nsig_m1);
-                v[e] = make_double2(wn * (double)x0[e], wn * (double)x1[e]);     // win *= data_arr (float64)
+                const int n = SM * (jn + TT * e);
+                const double wn = tapw(w, (unsigned)n, nsig_m1), wn1 = HALF ? tapw(w, (unsigned)n + 1u, nsig_m1) : wn;
+                v[e] = make_double2(wn * (double)x0[e], wn1 * (double)x1[e]);     // win *= data_arr (float64)
             }
         }
         if (a.demean_taper) {                                                  // win -= win.mean(axis=0) (float64)
@@ -422,18 +443,17 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 ds[0] += v[e].x;
-                ds[1] += v[e].y;
+                ds[HALF ? 0 : 1] += v[e].y;
             }
             if (!active) ds[0] = ds[1] = 0.0;
             __syncthreads();          // block_sum writes its scratch into the buffer other waves may still be reading
             block_sum<C::NTHREADS, G, 2>(ds, reinterpret_cast<double*>(lds), tid, h);
-            const double dm0 = ds[0] / a.nsig, dm1 = ds[1] / a.nsig;
+            const double dm0 = ds[0] / a.nsig, dm1 = ds[HALF ? 0 : 1] / a.nsig;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                if (jn + TT * e < a.nsig) {
-                    v[e].x -= dm0;
-                    v[e].y -= dm1;
-                }
+                const int n = SM * (jn + TT * e);
+                if (n < a.nsig) v[e].x -= dm0;
+                if (n + (HALF ? 1 : 0) < a.nsig) v[e].y -= dm1;
             }
         }
 
@@ -526,12 +546,18 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
                 }
                 X0 = make_double2(0.5 * (z.x + p.x), 0.5 * (z.y - p.y));
                 X1 = make_double2(0.5 * (z.y + p.y), 0.5 * (p.x - z.x));
+                if constexpr (HALF) {
+                    // X0 = E, X1 = O of the channel's real transform: bins f and N - f (f = 0: DC and the Nyquist bin)
+                    const cd t = spywil::cmul(X1, reinterpret_cast<const cd*>(fa.tw64_full)[f]);
+                    X1 = make_double2(X0.x - t.x, t.y - X0.y);
+                    X0 = make_double2(X0.x + t.x, X0.y + t.y);
+                }
             } else {
                 if (je != 0 || !active) break;
                 f = N / 2;
                 const cd zn = (P == 3) ? d64_dit3_bin<C>(lds, C::M / 2, 1, h) : v[HV];
-                X0 = make_double2(zn.x, 0.0);
-                X1 = make_double2(zn.y, 0.0);
+                X0 = make_double2(zn.x, HALF ? -zn.y : 0.0);        // (HALF: the middle bin is its own partner, X = conj Z)
+                X1 = make_double2(HALF ? 0.0 : zn.y, 0.0);
             }
             // complex64 storage, then the float32 normalisation factor (mtmfft.py:104,117-127)
             const float2 s0 = make_float2(__fmul_rn((float)X0.x, a.scale), __fmul_rn((float)X0.y, a.scale));
@@ -575,6 +601,20 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
                 }
                 continue;
             }
+            if constexpr (HALF) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if ((q == 1 && e == HV) || !has0) break;
+                    const int fb = q ? N - f : f;
+                    const int fi = a.fpos ? a.fpos[fb] : fb;
+                    if (fi < 0) continue;
+                    const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;
+                    const float2 sq = q ? s1 : s0;
+                    if (CPLX) *reinterpret_cast<float2*>(slab + o) = sq;
+                    else *reinterpret_cast<float*>(slab + o) = convert_real<OUTK>(sq, a.out_kind);
+                }
+                continue;
+            }
             if (fast) {
                 const size_t o = ((size_t)f * a.nchan + c0) * OSZ;
                 if (CPLX) *reinterpret_cast<float4*>(slab + o) = make_float4(s0.x, s0.y, s1.x, s1.y);
@@ -603,6 +643,19 @@ __global__ void __launch_bounds__((C::NTHREADS), (C::WPE)) mtmfft_dec64_kernel(F
         for (int e = 0; e <= HV; ++e) {
             if (!active || (e == HV && j0 != 0)) break;
             const int f = e < HV ? j0 + TT * e : N / 2;
+            if constexpr (HALF) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if ((q == 1 && e == HV) || !has0) break;
+                    const int fb = q ? N - f : f;
+                    const int fi = a.fpos ? a.fpos[fb] : fb;
+                    if (fi < 0) continue;
+                    const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;
+                    if constexpr (CPLX) *reinterpret_cast<float2*>(slab + o) = make_float2((q ? macc1[e] : macc0[e]) / nt, (q ? mim1[e] : mim0[e]) / nt);
+                    else *reinterpret_cast<float*>(slab + o) = (q ? macc1[e] : macc0[e]) / nt;
+                }
+                continue;
+            }
             const int fi = a.fpos ? a.fpos[f] : f;
             if (fi < 0) continue;
             const size_t o = ((size_t)fi * a.nchan + c0) * OSZ;

@@ -7,11 +7,11 @@
 namespace spyfft {
 
 template <class Cf, int OUTK, bool MEAN>
-int dec64_launch_one(hipStream_t stream, F64Args fa, int npairs) {
+int dec64_launch_one(hipStream_t stream, F64Args fa, int npairs) {      // (Cf::HALF: single channels)
     constexpr int G = Cf::G;
     MtmArgs& a = fa.m;
     a.npg = (npairs + G - 1) / G;
-    int S = 16 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;    // workgroups sharing 128-byte rows (XCD cluster)
+    int S = (Cf::HALF ? 32 : 16) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;    // workgroups sharing 128-byte rows (XCD cluster)
     a.S = S;
     a.ncl = (a.npg + S - 1) / S;
     const long long nclusters = (long long)a.nseg * a.ncl;

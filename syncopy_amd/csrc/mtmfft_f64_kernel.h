@@ -11,25 +11,9 @@
 #include "f64_stockham.h"
 #include "wilson_plus_kernel.h"
 #include "mtmfft_kernel.h"
+#include "mtmfft_f64_args.h"
 
 namespace spyfft {
-
-struct F64Args {
-    MtmArgs m;
-    const double* tapers64;      // (ntaper x nsig) float64: the reference's windows, not rounded to float32
-    const double2* tw64;         // exp(-2 pi i m / nfft)
-    double scale64;              // unused by the arithmetic (the float32 m.scale multiplies, as in the reference)
-    // any-length variant (mtmfft_f64_any_kernel): factor schedule, two length-nfft work arrays per workgroup, first
-    // work item of this launch
-    spywil::PlusPlan plan;
-    double2* work;
-    long long wg0;
-    // Bluestein form of the any-length kernel (a prime factor above 61): plan.L = M = 2^m >= 2 nfft - 1 and tw64 belongs
-    // to M; chirp64[n] = exp(-i pi n^2 / nfft) (nfft entries), bhat64 = FFT_M of the wrapped conjugate chirp, / M
-    int blue_n;                  // nfft of the Bluestein form, 0 otherwise
-    const double2* chirp64;
-    const double2* bhat64;
-};
 
 // sum of NS doubles over the workgroup (T threads), broadcast; scratch = LDS (free at that point); two barriers
 template <int NS, int T>

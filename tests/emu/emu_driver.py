@@ -89,10 +89,11 @@ def twiddles64(n):
 
 def fft_exec_f64(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend=-1, demean_taper=False,
                  freq_idx=None, output="pow", keeptapers=True, chan_idx=None, reference_mean=False, seg_f64=False,
-                 dec=True, bluestein=False):
+                 dec=True, bluestein=False, emu_id=None):
     """Emulated spyhip_fft_exec of a plan with spyhip_fft_plan_set_precision(plan, 1): `dec` - the compile-time
     schedule of mtmfft_dec64_kernel for this nfft; otherwise the any-length kernel, `bluestein` in its chirp-z form
-    (tables as spyhip_fft_plan_set_precision builds them)."""
+    (tables as spyhip_fft_plan_set_precision builds them).  dec="half": the HALF form (single channels through the
+    schedule of nfft / 2); `emu_id` picks a schedule variant of the emulator that shares its nfft with another (2002)."""
     data = np.ascontiguousarray(data, dtype=np.float32)
     ld = data.shape[1]
     nchan = ld if chan_idx is None else len(chan_idx)
@@ -131,11 +132,12 @@ def fft_exec_f64(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, det
         lib().emu_set_means(_p(means, C.c_float))
     try:
         rc = lib().emu_mtmfft_f64(
-            C.c_int(nfft), C.c_int(M), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int), _p(ss, C.c_longlong),
+            C.c_int(nfft if emu_id is None else emu_id), C.c_int(M), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int), _p(ss, C.c_longlong),
             _p(sl, C.c_longlong), _p(sh, C.c_longlong), C.c_int(nseg), C.c_int(nsig), C.c_int(nchan), C.c_int(K),
             _p(tp, C.c_double), _p(twiddles64(M if bluestein else nfft), C.c_double), _p(chirp, C.c_double),
             _p(bhat, C.c_double), C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), C.c_int(int(seg_f64)),
-            _p(fpos, C.c_int), C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), C.c_int(int(dec and not bluestein)),
+            _p(fpos, C.c_int), C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)),
+            C.c_int(2 if (dec == "half") else int(bool(dec) and not bluestein)),
             out.ctypes.data_as(C.c_void_p))
     finally:
         lib().emu_set_means(None)

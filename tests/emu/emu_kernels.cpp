@@ -889,9 +889,9 @@ template <class Cf>
 static void run_dec64_mode(spyfft::F64Args fa, int nseg, int nchan, int outk, int mean) {
     MtmArgs& a = fa.m;
     const int G = Cf::G;
-    const int npairs = (nchan + 1) / 2;
+    const int npairs = Cf::HALF ? nchan : (nchan + 1) / 2;              // (HALF: single channels, as mtmfft_dec64_launch.h)
     a.npg = (npairs + G - 1) / G;
-    int S = 16 / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
+    int S = (Cf::HALF ? 32 : 16) / G; if (S < 1) S = 1; if (S > a.npg) S = a.npg;
     a.S = S;
     a.ncl = (a.npg + S - 1) / S;
     const long long nclusters = (long long)nseg * a.ncl;
@@ -923,6 +923,25 @@ extern "C" int emu_mtmfft_f64(int nfft, int blue_m, const float* data, long long
     fa.tw64 = reinterpret_cast<const double2*>(tw64);
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
     const int mean = keeptapers ? 0 : 1;
+    if (use_dec == 2) {
+        // HALF form (CfgD64::HALF): single channels through the schedule of nfft / 2; tables as spyhip_fft_plan_set_precision
+        // builds them: tw64 of nfft / 2 for the passes, the length-nfft table for the half step
+        const int rn = nfft == 2002 ? 2000 : nfft;       // (id 2002 = nfft 2000 with split exchanges)
+        std::vector<double2> th((size_t)rn / 2);
+        for (int m = 0; m < rn / 2; ++m) th[m] = reinterpret_cast<const double2*>(tw64)[2 * m];
+        fa.tw64_full = fa.tw64;
+        fa.tw64 = th.data();
+        using spyfft::CfgD64;
+        switch (nfft) {
+            case 2000: run_dec64_mode<CfgD64<10, 10, 10, 1, 2, false, true, true, 1, true>>(fa, nseg, nchan, outk, mean); break;
+            case 2002: run_dec64_mode<CfgD64<10, 10, 10, 1, 2, true, true, true, 1, true>>(fa, nseg, nchan, outk, mean); break;   // split exchanges
+            case 1200: run_dec64_mode<CfgD64<10, 10, 2, 1, 4, false, true, true, 3, true>>(fa, nseg, nchan, outk, mean); break;   // 3 x 200
+            case 1024: run_dec64_mode<CfgD64<16, 16, 2, 1, 2, false, true, false, 1, true>>(fa, nseg, nchan, outk, mean); break;  // powers from the table
+            case 12000: run_dec64_mode<spyfft::D64H_12000>(fa, nseg, nchan, outk, mean); break;
+            default: return -1;
+        }
+        return 0;
+    }
     if (use_dec) {
         switch (nfft) {          // (512 / 2048 / 500 differ from 1024 / 4096 / 1000 in one radix only: left to the GPU tests)
             case 256: run_dec64_mode<spyfft::D64_256>(fa, nseg, nchan, outk, mean); break;

@@ -685,7 +685,7 @@ def test_csd_3m_more_than_512_channels():
 
 # K1r second generation: reference-precision transforms (mtmfft_dec64_kernel.h, mtmfft_f64_kernel.h incl. Bluestein)
 def _f64_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=False, freq_idx=None, chan_idx=None, nseg=1,
-              seed=3, dec=True, bluestein=False, pure_frac=0.99):
+              seed=3, dec=True, bluestein=False, pure_frac=0.99, emu_id=None):
     """Data with 60 dB of dynamic range (a 40 Hz line 1000 x the noise, an offset): the criterion everywhere, and for
     complex output PURE rtol 1e-5 bin by bin on >= 99 % of the bins - which only a float64 transform delivers."""
     rng = np.random.default_rng(seed)
@@ -695,7 +695,8 @@ def _f64_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=Fa
     taper, topt = ("dpss", {"NW": (K + 1) / 2, "Kmax": K}) if K > 1 else ("hann", {})
     tapers = O.taper_table(taper, nsig, nfft, topt)
     out = E.fft_exec_f64(data, ss, ss, ss + nsig, nsig, nfft, tapers, O.spec_scale(nsig, nfft), detrend, demean_taper,
-                         freq_idx, output, keeptapers, chan_idx=chan_idx, reference_mean=True, dec=dec, bluestein=bluestein)
+                         freq_idx, output, keeptapers, chan_idx=chan_idx, reference_mean=True, dec=dec, bluestein=bluestein,
+                         emu_id=emu_id)
     freqs = np.fft.rfftfreq(nfft, 1e-3)
     foi = freqs if freq_idx is None else freqs[freq_idx]
     for b in range(nseg):
@@ -744,6 +745,29 @@ def test_dec64_kernel_options():
     _f64_case(256, 256, 7, 3, "fourier", False, -1, demean_taper=True, nseg=2)    # complex taper mean, demean_taper
     _f64_case(900, 1024, 2, 1, "imag", True, 0, nseg=2)
     _f64_case(4096, 4096, 1, 2, "pow", True, 0)                                   # a single channel: half a pair
+
+
+@pytest.mark.parametrize("nsig,nfft,nchan,K,output,keeptapers,detrend,demean,emu_id", [
+    (2000, 2000, 5, 2, "fourier", True, 0, False, None),     # single channels through 10 x 10 x 10, two per workgroup
+    (2000, 2000, 3, 3, "pow", False, 1, True, None),         # taper mean, line fit over even + odd samples, demean_taper
+    (1999, 2000, 2, 2, "abs", True, 0, False, None),         # odd sample count: the last pair is half padding
+    (1501, 2000, 3, 2, "fourier", False, -1, False, None),   # zero padding, complex taper mean
+    (2000, 2000, 4, 2, "fourier", True, 0, False, 2002),     # split exchanges
+    (1200, 1200, 5, 2, "fourier", True, 0, True, None),      # 3 x 200: radix-3 decimation in front
+    (1100, 1200, 3, 2, "pow", False, 1, False, None),
+    (1024, 1024, 3, 2, "pow", True, 0, False, None),         # powers from the table (no hoisted base twiddles)
+    (12000, 12000, 1, 1, "fourier", True, 0, False, None),   # the product's schedule for nfft = 12000
+])
+def test_dec64_kernel_half_form(nsig, nfft, nchan, K, output, keeptapers, detrend, demean, emu_id):
+    """CfgD64::HALF: one channel = one complex128 transform of (even, odd) samples through the schedule of nfft / 2."""
+    _f64_case(nsig, nfft, nchan, K, output, keeptapers, detrend, demean_taper=demean, nseg=2 if nfft <= 2000 else 1,
+              dec="half", emu_id=emu_id)
+
+
+def test_dec64_kernel_half_form_selection():
+    _f64_case(1700, 2000, 5, 2, "pow", True, 0, dec="half", freq_idx=np.array([0, 1, 999, 1000, 37, 500, 501, 499]),
+              chan_idx=np.array([4, 0, 2, 2]))
+    _f64_case(1200, 1200, 3, 2, "fourier", False, 0, dec="half", freq_idx=np.array([600, 0, 300, 299, 301, 200, 400]))
 
 
 @pytest.mark.parametrize("nfft,nchan,K,bluestein", [(360, 3, 2, False), (1009, 2, 1, True), (134, 3, 2, True),

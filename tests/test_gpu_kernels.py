@@ -558,7 +558,8 @@ def test_reference_precision_resolves_60dB(be):
                                   dict(nsig=3200, nfft=3200, K=3, output="fourier", keeptapers=True, detrend=0, nchan=3),
                                   dict(nsig=4800, nfft=4800, K=2, output="pow", keeptapers=True, detrend=0, nchan=2),
                                   dict(nsig=8000, nfft=8000, K=2, output="fourier", keeptapers=True, detrend=0, nchan=3),
-                                  # beyond one workgroup's LDS: N = P M through HBM (mtmfft_declong64.h)
+                                  # 10240 < N <= 20480: single channels through the schedule of N / 2 (CfgD64::HALF);
+                                  # beyond that N = P M through HBM (mtmfft_declong64.h: 24000, 30000)
                                   dict(nsig=12000, nfft=12000, K=3, output="fourier", keeptapers=True, detrend=0, nchan=5),
                                   dict(nsig=15000, nfft=15000, K=3, output="pow", keeptapers=False, detrend=1, nchan=4),
                                   dict(nsig=14000, nfft=16000, K=2, output="fourier", keeptapers=False, detrend=0, nchan=3,
@@ -567,6 +568,10 @@ def test_reference_precision_resolves_60dB(be):
                                        demean=True),
                                   dict(nsig=12288, nfft=12288, K=2, output="fourier", keeptapers=True, detrend=0, nchan=2),
                                   dict(nsig=24000, nfft=24000, K=2, output="fourier", keeptapers=True, detrend=0, nchan=2),
+                                  dict(nsig=30000, nfft=30000, K=2, output="pow", keeptapers=False, detrend=1, nchan=3),
+                                  dict(nsig=11999, nfft=12000, K=2, output="pow", keeptapers=True, detrend=1, nchan=3, demean=True),
+                                  dict(nsig=16001, nfft=16384, K=2, output="fourier", keeptapers=True, detrend=0, nchan=1),
+                                  dict(nsig=16384, nfft=16384, K=3, output="abs", keeptapers=False, detrend=0, nchan=3),
                                   dict(nsig=50000, nfft=50000, K=1, output="fourier", keeptapers=True, detrend=-1, nchan=1)])
 def test_reference_precision_options(be, case):
     """Every option of the plan through the float64 kernel: padding, detrending modes, demean_taper, taper mean,

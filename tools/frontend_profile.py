@@ -31,3 +31,17 @@ shape = res.data.shape
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+
+# the call alone (result left in HBM): where the host time goes, by own time
+pr = cProfile.Profile()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+pr.enable()
+res = spy.connectivityanalysis(data, method="coh", tapsmofrq=1, polyremoval=0)
+pr.disable()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"profiled call: returned after {1e3 * (t1 - t0):.1f} ms, device idle after {1e3 * (t2 - t0):.1f} ms")
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(40)

@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 hipcc -O2 tools/pmc_harness2.cpp -Iinclude -Lsyncopy_amd -lspyhip -Wl,-rpath,$PWD/syncopy_amd -o /tmp/h2 || exit 1
-for m in ${MODES:-n10000 n5000 c2}; do
- for t in 0 1; do
+for m in ${MODES:-n12000f64 n16384f64}; do
+ for t in 0; do
   rm -rf /tmp/prof_s
   if [ $t = 1 ]; then export SPYHIP_HALF_TRY=1; else unset SPYHIP_HALF_TRY; fi
   ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s --output-format csv -- /tmp/h2 $m > /tmp/h2.log 2>&1 )
