@@ -62,6 +62,8 @@ struct CfgD {
     static constexpr int PLANE = P * PL1;                    // ... per quad
     static constexpr int ESTRIDE = (T + T / V) * G;          // LDS distance of e -> e + 1
     static constexpr size_t LDS_BYTES = (size_t)PLANE * G * (SPLIT ? 8 : 16);
+    // one workgroup per CU (nothing else hides the twiddle reads): base twiddles requested a pass ahead (DecTw)
+    static constexpr bool TWAHEAD = LDS_BYTES > 80 * 1024;
     static_assert(R1 > 1 && V % R1 == 0 && V % R2 == 0 && V % R3 == 0, "every radix divides the values per thread");
     static_assert(T % V == 0, "T multiple of V: idx(j + T e) stays affine in e");
     static_assert(NTHREADS <= 1024 && (64 % G) == 0, "workgroup shape");
@@ -70,11 +72,70 @@ struct CfgD {
     __device__ static __forceinline__ int idx(int i, int h) { return (i + i / V) * G + h; }
 };
 
+// Twiddles of one pass for thread j: butterfly m = j + T m needs w^r, w = tw[k N / (Ns R)], r < R.  As in the power-of-two
+// engine (fft2_device.h: Tw6) only the BASE powers come from the table - w, w^2, w^3 and w^4, w^8, ... - and are requested
+// one pass ahead (DecTw::load sits in front of the previous pass's exchange, whose barriers hide the L2 round trip); the
+// other powers are products w^(4a) w^l.  Measured against R - 1 table reads per butterfly right before its use
+// (tools/dec_probe.hip, reads switched off as the bound): 8192 25.1 (bound 18.4), 4096 8.6 (6.8), 2000 4.9 (4.3) us/trial.
+__device__ __forceinline__ float2 dec_tw_read(const float2* __restrict__ tw, unsigned byte_offset) {
+#if defined(SPYFFT_ABL) && (SPYFFT_ABL & 2)
+    return make_float2(__uint_as_float(byte_offset), 0.5f);      // (tools/dec_probe.hip: the kernel without its table reads)
+#else
+    return ldg<float2>(tw, byte_offset);
+#endif
+}
+
+template <class C, int R, int Ns, bool AHEAD = C::TWAHEAD>
+struct DecTw {
+    static constexpr int MB = C::V / R;
+    static constexpr int NLO = (R - 1 < 3) ? R - 1 : 3;
+    static constexpr int NHI = (R + 3) / 4 - 1;
+    float2 lo[MB][NLO > 0 ? NLO : 1];
+    float2 hi[MB][NHI > 0 ? NHI : 1];
+    __device__ __forceinline__ void load(int j, const float2* __restrict__ tw) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int b = j + C::T * m;
+            const int k = b - (b / Ns) * Ns;
+            const unsigned kb = (unsigned)(k * (C::N / (Ns * R))) * 8u;          // byte offset of tw[k N / (Ns R)]
+#pragma unroll
+            for (int l = 1; l <= NLO; ++l)
+                lo[m][l - 1] = dec_tw_read(tw, kb * (unsigned)l);
+#pragma unroll
+            for (int a = 1; a <= NHI; ++a)
+                hi[m][a - 1] = dec_tw_read(tw, kb * (unsigned)(4 * a));
+        }
+    }
+    __device__ __forceinline__ float2 w(int m, int r) const {        // (r is a compile-time constant once unrolled)
+        const int h = r >> 2, l = r & 3;
+        if (h == 0) return lo[m][l - 1];
+        if (l == 0) return hi[m][h - 1];
+        return cmul(hi[m][h - 1], lo[m][l - 1]);
+    }
+};
+// ... where several workgroups share a CU the other workgroups hide that latency already and the registers of the early
+// request cost occupancy (2000: three -> two workgroups per CU, 4.9 -> 5.3 us/trial): R - 1 table reads at the point of use
+template <class C, int R, int Ns>
+struct DecTw<C, R, Ns, false> {
+    const float2* tw;
+    int j;
+    __device__ __forceinline__ void load(int j_, const float2* __restrict__ tw_) { j = j_; tw = tw_; }
+    __device__ __forceinline__ float2 w(int m, int r) const {
+        const int b = j + C::T * m;
+        const int k = b - (b / Ns) * Ns;
+        const unsigned kb = (unsigned)(k * (C::N / (Ns * R))) * 8u;
+        return dec_tw_read(tw, kb * (unsigned)r);
+    }
+};
+struct DecTwNone {           // the first pass has no twiddles; the last pass has no successor to fetch for
+    __device__ __forceinline__ void load(int, const float2*) {}
+};
+
 // One pass.  In: v[e] = in[j + T e] (pass 0: the tapered samples).  Out: LAST - v[e] = X[j + T e] in registers;
 // otherwise the outputs go through LDS and v[e] = out[j + T e] comes back.
-template <class C, int R, int Ns, bool FIRST, bool LAST>
+template <class C, int R, int Ns, bool FIRST, bool LAST, class TwNow, class TwNext>
 __device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int h, bool active,
-                                         const float2* __restrict__ tw, int region = 0) {
+                                         const float2* __restrict__ tw, const TwNow& now, TwNext& next, int region = 0) {
     constexpr int V = C::V, N = C::N, T = C::T, G = C::G, MB = V / R;      // (tw has N entries: W_M^k = tw[P k])
     int wbase[MB];
 #pragma unroll
@@ -84,10 +145,9 @@ __device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int 
         C2 u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = v[m + MB * r];
-        if (!FIRST) {
-            const unsigned kb = (unsigned)(k * (N / (Ns * R))) * 8u;          // byte offset of tw[k N / (Ns R)]
+        if constexpr (!FIRST) {
 #pragma unroll
-            for (int r = 1; r < R; ++r) u[r] = cmul_s(u[r], ldg<float2>(tw, kb * (unsigned)r));
+            for (int r = 1; r < R; ++r) u[r] = cmul_s(u[r], now.w(m, r));
         }
         dec_dft<R>(u);
 #pragma unroll
@@ -96,6 +156,7 @@ __device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int 
         wbase[m] = region + (FIRST ? (b * (V + 1)) * G + h : (q * (Ns * R + Ns * R / V) + k + k / V) * G + h);
     }
     if (LAST) return;
+    next.load(j, tw);                 // the next pass's base twiddles: in flight across this pass's exchange
     constexpr int WS = FIRST ? G : (Ns + Ns / V) * G;
     const int rb = region + C::idx(j, h);
     if constexpr (!C::SPLIT) {
@@ -145,6 +206,29 @@ __device__ __forceinline__ void dec_pass(C2 (&v)[C::V], float4* lds, int j, int 
             const float2 t = L[rb + e * C::ESTRIDE];
             v[e].r = re[e];
             v[e].i = v2f{t.x, t.y};
+        }
+    }
+}
+
+// The passes of one scheduled transform: radix V from the registers, then R1 (R2, R3); the last one leaves v[e] = Z[j + T e]
+template <class C>
+__device__ __forceinline__ void dec_transform(C2 (&v)[C::V], float4* lds, int j, int h, bool active,
+                                              const float2* __restrict__ tw, int region = 0) {
+    constexpr int V = C::V;
+    DecTwNone none;
+    DecTw<C, C::R1, V> t1;
+    dec_pass<C, V, 1, true, false>(v, lds, j, h, active, tw, none, t1, region);
+    if constexpr (C::NPASS == 2) {
+        dec_pass<C, C::R1, V, false, true>(v, lds, j, h, active, tw, t1, none, region);
+    } else {
+        DecTw<C, C::R2, V * C::R1> t2;
+        dec_pass<C, C::R1, V, false, false>(v, lds, j, h, active, tw, t1, t2, region);
+        if constexpr (C::NPASS == 3) {
+            dec_pass<C, C::R2, V * C::R1, false, true>(v, lds, j, h, active, tw, t2, none, region);
+        } else {
+            DecTw<C, C::R3, V * C::R1 * C::R2> t3;
+            dec_pass<C, C::R2, V * C::R1, false, false>(v, lds, j, h, active, tw, t2, t3, region);
+            dec_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, tw, t3, none, region);
         }
     }
 }
@@ -433,10 +517,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
 
         C2 zpart[C::SPLIT ? HV : 1];      // (SPLIT, P = 3) the partner bins Z[N - f] of this thread's bins
         // ---- the passes: radix V from the registers, then R1 (R2, R3); the last one leaves v[e] = Z[j + T e]
-        dec_pass<C, V, 1, true, false>(v, lds, j, h, active, a.tw, region);
-        dec_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, a.tw, region);
-        if constexpr (C::NPASS >= 3) dec_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, a.tw, region);
-        if constexpr (C::NPASS >= 4) dec_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, a.tw, region);
+        dec_transform<C>(v, lds, j, h, active, a.tw, region);
 
         if constexpr (P == 3) {
             // ---- radix-3 combine of the three sub-transforms: v[e] = F_r[k], k = j + T e  ->  X[k + M r]

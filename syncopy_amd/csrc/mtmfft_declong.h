@@ -109,10 +109,7 @@ __global__ void __launch_bounds__((C::NTHREADS)) declong_sub_kernel(LongArgs a, 
             v[e].i = x[e].i * wn - (in ? di : splat(0.f));
         }
 
-        dec_pass<C, V, 1, true, false>(v, lds, j, h, active, a.tw1);
-        dec_pass<C, C::R1, V, false, C::NPASS == 2>(v, lds, j, h, active, a.tw1);
-        if constexpr (C::NPASS >= 3) dec_pass<C, C::R2, V * C::R1, false, C::NPASS == 3>(v, lds, j, h, active, a.tw1);
-        if constexpr (C::NPASS >= 4) dec_pass<C, C::R3, V * C::R1 * C::R2, false, true>(v, lds, j, h, active, a.tw1);
+        dec_transform<C>(v, lds, j, h, active, a.tw1);
 
         if (valid) {
             const size_t item = ((size_t)bl * a.nquad + q) * m.ntaper + k;

@@ -92,8 +92,9 @@ def test_granger_two_channels():
     for prec in ("auto", "reference"):
         g = got if prec == "auto" else spy.connectivityanalysis(data, method="granger", tapsmofrq=3, precision=prec)
         assert g.info["converged"] and g.info["max rel. err"] < 5e-6
-        np.testing.assert_allclose(g.data, ref.data, atol=2.5e-2)
+        # away from DC: well inside the reference's atol = 1e-2; only the two bins next to DC get the one-iteration bound
         np.testing.assert_allclose(g.data[:, 2:], ref.data[:, 2:], rtol=2e-3, atol=1.5e-3)
+        np.testing.assert_allclose(g.data[:, :2], ref.data[:, :2], atol=2.5e-2)
 
 
 @pytest.mark.parametrize("nsamp", [40, 300])

@@ -5,8 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
-#define SPY_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) char name##_raw[]; \
-    type* name = reinterpret_cast<type*>(name##_raw)
+#include "../syncopy_amd/csrc/spy_intrinsics.h"
 #include "../include/spyhip.h"
 #include "../syncopy_amd/csrc/mtmfft_dec_kernel.h"
 #ifndef DV
