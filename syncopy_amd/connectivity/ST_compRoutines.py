@@ -41,10 +41,13 @@ def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, pol
         if spec.spyhip_blocked:
             backend.csd_accumulate(spec, acc_of_trial(sel[0]), blocked=True)
             continue
+        am = getattr(spec, "spyhip_absmax", None)       # range of the whole batch: a bound for each of its trials too
+        if single_acc:                                  # (one accumulator for every trial: no per-trial bookkeeping)
+            backend.csd_accumulate(spec, acc_of_trial(sel[0]), absmax=am)
+            continue
         groups = {}
         for k, i in enumerate(sel):
             groups.setdefault(id(acc_of_trial(i)), (acc_of_trial(i), []))[1].append(k)
-        am = getattr(spec, "spyhip_absmax", None)       # range of the whole batch: a bound for each of its trials too
         for acc, ks in groups.values():
             if len(ks) == spec.shape[0]:
                 backend.csd_accumulate(spec, acc, absmax=am)

@@ -292,7 +292,8 @@ def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_
     device = dev_data.device
     nchan = dev_data.shape[1] if chan_idx is None else len(chan_idx)
     ci = None if chan_idx is None else torch.tensor(np.asarray(chan_idx), dtype=torch.int32, device=device)
-    lengths = np.array([b - a for a, b in rows])
+    rows_arr = np.asarray(rows, dtype=np.int64).reshape(-1, 2)        # (trials, 2): no per-trial Python work below
+    lengths = rows_arr[:, 1] - rows_arr[:, 0]
     for n in np.unique(lengths):
         which = np.nonzero(lengths == n)[0]
         n = int(n)
@@ -308,8 +309,8 @@ def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_
         for i in range(0, which.size, bmax):
             sel = which[i:i + bmax]
             if upload is not None:
-                upload.wait_rows(max(rows[j][1] for j in sel))
-            starts = torch.tensor([rows[j][0] for j in sel], dtype=torch.int64, device=device)
+                upload.wait_rows(int(rows_arr[sel, 1].max()))
+            starts = torch.from_numpy(np.ascontiguousarray(rows_arr[sel, 0])).to(device)
             # reuse=True: the consumer is done with a batch before it asks for the next one (stream order), so all
             # batches - and all later calls of the same shape - share one device buffer
             buf = backend.handover_buffer(plan.out_shape(len(sel)), device) if reuse and plan.kind == 2 else None
