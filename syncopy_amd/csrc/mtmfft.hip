@@ -68,6 +68,7 @@ int dec_launch_c2(hipStream_t stream, const MtmArgs& a, int nquads);
 int dec_launch_half_a(hipStream_t stream, const MtmArgs& a, int nfft, int npairs, int outk, bool mean);
 int dec_launch_half_b(hipStream_t stream, const MtmArgs& a, int nfft, int npairs, int outk, bool mean);
 int dec_launch_half_c(hipStream_t stream, const MtmArgs& a, int nfft, int npairs, int outk, bool mean);
+int quad_half_launch(hipStream_t stream, const MtmArgs& a, int npairs, int outk, bool mean);
 // mtmfft_declong_{a,b}.hip: N = P M through HBM (mtmfft_declong.h)
 int declong_group(int M);
 int declong_launch_sub_a(hipStream_t stream, const LongArgs& a, int M, int P, long long nblocks);
@@ -344,7 +345,7 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
     std::vector<float> tf((size_t)ntaper * nsig);
     for (size_t i = 0; i < tf.size(); ++i) tf[i] = (float)tapers[i];
     if (p->tapers.upload(tf, ctx->stream)) { delete p; return -2; }
-    if (spy::is_pow2((unsigned)nfft) && nfft >= 256 && nfft <= 8192) {
+    if (spy::is_pow2((unsigned)nfft) && nfft >= 256 && nfft <= 16384) {
         for (size_t i = 0; i < tf.size(); ++i) tf[i] = (float)(tapers[i] * (0.5 * scale));
         if (p->tapers_half.upload(tf, ctx->stream)) { delete p; return -2; }
     }
@@ -385,7 +386,7 @@ extern "C" int spyhip_fft_plan_create(spyhip_ctx* ctx, int nsig, int nfft, int n
         if (p->tw.upload(twiddle_table(p->half ? nfft / 2 : nfft), ctx->stream)) { delete p; return -2; }
         if (p->half && p->twh.upload(half_step_table(nfft), ctx->stream)) { delete p; return -2; }
         char buf[128];
-        if (p->half) std::snprintf(buf, sizeof buf, "mtmfft_dec_kernel<HALF of N = %d, %s>", nfft, mode);
+        if (p->half) std::snprintf(buf, sizeof buf, "mtmfft_quad_kernel<13, 1, %s, HALF of N = %d>", mode, nfft);
         else std::snprintf(buf, sizeof buf, "mtmfft_quad_kernel<%d, %d, %s>", p->log2n, p->G, mode);
         p->kernel_name = buf;
     } else if ((nfft == 400 || nfft == 800 || nfft == 1200 || nfft == 1600 || nfft == 2400 || nfft == 3200 || nfft == 4800 || nfft == 8000 ||
@@ -895,6 +896,13 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
         a.twh = p->twh.p;
         int rc;
+        if (p->nfft == 16384) {
+            // the power-of-two engine in HALF form (53.6 us/trial at 256 channels x 7 tapers; the 8192-point compile-time
+            // schedule on pairs: 59.3)
+            MtmArgs b = a;
+            b.tapers = p->tapers_half.p;          // (the power-of-two kernel expects scale / 2 folded into the window)
+            return spyfft::quad_half_launch(p->ctx->stream, b, npairs, outk, mean);
+        }
         if ((rc = spyfft::dec_launch_half_a(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;
         if ((rc = spyfft::dec_launch_half_b(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;
         if ((rc = spyfft::dec_launch_half_c(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;

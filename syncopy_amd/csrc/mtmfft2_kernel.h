@@ -22,11 +22,16 @@
 namespace spyfft {
 
 // OUTK: 0 = power (inlined), 1 = any other real conversion, 2 = complex; MEAN: average over tapers
-template <int LOG2N, int G, int OUTK, bool MEAN>
+// HALF (2^14 samples, the only power of two beyond a quad's LDS): a thread set carries a channel PAIR, z[m] = x[2 m] +
+// i x[2 m + 1] through the transform of N = nfft / 2, and the epilogue forms the bins f and N - f of the real transform
+// from Z[f], Z[N - f] - exactly CfgD::HALF of mtmfft_dec_kernel.h, on this kernel's radix-16 engine
+template <int LOG2N, int G, int OUTK, bool MEAN, bool HALF = false>
 __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmfft_quad_kernel(MtmArgs a) {
     using C = Cfg2<LOG2N, G>;
     constexpr bool CPLX = (OUTK == 2);
     constexpr int N = C::N, T = C::T;
+    constexpr int CW = HALF ? 2 : 4;              // channels of a thread set
+    constexpr int SM = HALF ? 2 : 1;              // sample index of value e: SM (j + T e) (+ 1 for the imaginary part, HALF)
     SPY_DYN_SMEM(v2f, lds);
     v2f* const lre = lds;
     v2f* const lim = lds + C::PLANE;
@@ -54,15 +59,15 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
     const int pg = (int)(cidx - (unsigned)b * (unsigned)a.ncl) * a.S + q;
     if (pg >= a.npg) return;
 
-    const int c0 = 4 * (pg * G + h);
+    const int c0 = CW * (pg * G + h);
     bool has[4];
     unsigned col[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        has[i] = c0 + i < a.nchan;
+        has[i] = i < CW && c0 + i < a.nchan;
         col[i] = has[i] ? (unsigned)(a.chan_idx ? a.chan_idx[c0 + i] : c0 + i) : 0u;
     }
-    const bool full = has[3];
+    const bool full = has[CW - 1];
     const long long start = a.seg_start[b];
     const long long rl = a.seg_lo[b] - start, rh = a.seg_hi[b] - start;
     const int rlo = (int)(rl < 0 ? 0 : (rl > a.nsig ? a.nsig : rl));
@@ -72,7 +77,38 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
 
     // ---- load the segment once: x[e] = sample n = j + T*e; r = (c0, c1), i = (c2, c3)
     C2 x[16];
-    if (rhi > rlo) {
+    if constexpr (HALF) {
+        // sample pairs (2 m, 2 m + 1), m = j + T e: the even sample in .r, the odd one in .i, channels (c0, c1) in the halves
+        if (rhi > rlo) {
+            const bool vec2 = (a.chan_idx == nullptr) && full && ((a.ld & 1) == 0) &&
+                              ((reinterpret_cast<size_t>(a.data) & 7) == 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n0 = 2 * (j0 + T * e), n1 = n0 + 1;
+                const int nc0 = min(max(n0, rlo), rhi - 1), nc1 = min(max(n1, rlo), rhi - 1);
+                float u0[2], u1[2];
+                if (vec2) {
+                    const float2 t0 = ldg<float2>(seg, (unsigned)nc0 * rowb + col[0] * 4u);
+                    const float2 t1 = ldg<float2>(seg, (unsigned)nc1 * rowb + col[0] * 4u);
+                    u0[0] = t0.x; u0[1] = t0.y; u1[0] = t1.x; u1[1] = t1.y;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float t0 = ldg<float>(seg, (unsigned)nc0 * rowb + col[i] * 4u);
+                        const float t1 = ldg<float>(seg, (unsigned)nc1 * rowb + col[i] * 4u);
+                        u0[i] = has[i] ? t0 : 0.f;
+                        u1[i] = has[i] ? t1 : 0.f;
+                    }
+                }
+                const bool ok0 = (n0 == nc0), ok1 = (n1 == nc1);
+                x[e].r = v2f{ok0 ? u0[0] : 0.f, ok0 ? u0[1] : 0.f};
+                x[e].i = v2f{ok1 ? u1[0] : 0.f, ok1 ? u1[1] : 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e].r = x[e].i = splat(0.f);
+        }
+    } else if (rhi > rlo) {
         const bool vec4 = (a.chan_idx == nullptr) && full && ((a.ld & 3) == 0) &&
                           ((reinterpret_cast<size_t>(a.data) & 15) == 0);
         if (vec4 && rlo == 0 && rhi == N) {
@@ -120,8 +156,8 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         float f[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = has[i] ? mp[i] : 0.f;
-        const v2f mr = v2f{f[0], f[1]}, mi = v2f{f[2], f[3]};
-        if (a.nsig == N) {
+        const v2f mr = v2f{f[0], f[1]}, mi = HALF ? mr : v2f{f[2], f[3]};
+        if (a.nsig == SM * N) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 x[e].r -= mr;
@@ -130,10 +166,46 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const bool in = j0 + T * e < a.nsig;
-                x[e].r -= in ? mr : splat(0.f);
-                x[e].i -= in ? mi : splat(0.f);
+                const int n0 = SM * (j0 + T * e);
+                x[e].r -= n0 < a.nsig ? mr : splat(0.f);
+                x[e].i -= n0 + (HALF ? 1 : 0) < a.nsig ? mi : splat(0.f);
             }
+        }
+    } else if (HALF && a.detrend >= 0) {
+        // (HALF) the float64 sums of the two channels run over the even AND the odd samples
+        const float mid = 0.5f * (float)(a.nsig - 1);
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n0 = 2 * (j0 + T * e), n1 = n0 + 1;
+            const float m0 = (n0 < a.nsig) ? 1.f : 0.f, m1 = (n1 < a.nsig) ? 1.f : 0.f;
+            s[0] += (double)(m0 * x[e].r[0]);
+            s[1] += (double)(m0 * x[e].r[1]);
+            s[0] += (double)(m1 * x[e].i[0]);
+            s[1] += (double)(m1 * x[e].i[1]);
+            if (a.detrend == 1) {
+                const double d0 = (double)(m0 * ((float)n0 - mid)), d1 = (double)(m1 * ((float)n1 - mid));
+                s[4] += d0 * x[e].r[0];
+                s[5] += d0 * x[e].r[1];
+                s[4] += d1 * x[e].i[0];
+                s[5] += d1 * x[e].i[1];
+            }
+        }
+        block_sum<C::NTHREADS, G, 8>(s, reinterpret_cast<double*>(lds), tid, h);
+        const double inv = 1.0 / a.nsig;
+        const double den = (a.detrend == 1 && a.nsig > 1) ? 12.0 / ((double)a.nsig * ((double)a.nsig * a.nsig - 1.0)) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n0 = 2 * (j0 + T * e), n1 = n0 + 1;
+            const double d0 = (double)((float)n0 - mid), d1 = (double)((float)n1 - mid);
+            float t0[2], t1[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                t0[i] = n0 < a.nsig ? (float)(s[i] * inv + s[4 + i] * den * d0) : 0.f;
+                t1[i] = n1 < a.nsig ? (float)(s[i] * inv + s[4 + i] * den * d1) : 0.f;
+            }
+            x[e].r -= v2f{t0[0], t0[1]};
+            x[e].i -= v2f{t1[0], t1[1]};
         }
     } else if (a.detrend >= 0) {
         const float mid = 0.5f * (float)(a.nsig - 1);
@@ -196,18 +268,18 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
     }
     const int kout = MEAN ? 1 : a.ntaper;
     const unsigned nsig_m1 = (unsigned)(a.nsig - 1);
-    const bool wfull = (a.nsig == N);     // uniform: no zero padding behind the window
+    const bool wfull = (a.nsig == SM * N);     // uniform: no zero padding behind the window
     constexpr unsigned OSZ = CPLX ? 8u : 4u;   // bytes per output element
     // straight-line epilogue: all four channels present, every bin kept, 16-byte aligned rows
     const bool fast = full && (a.fpos == nullptr) && ((reinterpret_cast<size_t>(a.out) & 15) == 0) &&
-                      ((a.nchan & (CPLX ? 1 : 3)) == 0);
+                      ((a.nchan & ((CPLX || HALF) ? 1 : 3)) == 0);
 
     // ---- range of the spectra for K4h (spyhip_fft_plan_set_absmax; complex all-taper output only): every bin of channel c
     // obeys |X_c(f)| = |sum_n w[n] x_c[n] e^(...)| <= ||w||_2 ||x_c||_2, so ONE sum of squares of the detrended samples
     // per segment (they are in registers) bounds all tapers and all bins - 32 packed multiply-adds per thread and segment
     // instead of a maximum over every value written.  a.wnorm = max over the tapers of ||w scale||_2 (a per-taper mean
     // removed after the product, demean_taper, only shrinks the norm).
-    if (CPLX && !MEAN && a.absmax != nullptr) {                   // uniform
+    if (CPLX && !MEAN && !HALF && a.absmax != nullptr) {          // uniform (HALF: the host runs seg_range_kernel)
         v2f qr = splat(0.f), qi = splat(0.f);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -228,16 +300,23 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
     }
 
     // taper weights of the first taper; later tapers are prefetched while the previous FFT runs
-    float wn[16];
+    float wn[16], wo[HALF ? 16 : 1];       // (HALF) wo: the weights of the odd samples
     if (wfull) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) wn[e] = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(a.tapers, (unsigned)(j0 + T * e) * 4u);
+        for (int e = 0; e < 16; ++e) {
+            wn[e] = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(a.tapers, (unsigned)(SM * (j0 + T * e)) * 4u);
+            if constexpr (HALF) wo[e] = ldg<float>(a.tapers, (unsigned)(2 * (j0 + T * e) + 1) * 4u);
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const unsigned n = (unsigned)(j0 + T * e);
+            const unsigned n = (unsigned)(SM * (j0 + T * e));
             const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(a.tapers, min(n, nsig_m1) * 4u);
             wn[e] = (n <= nsig_m1) ? wl : 0.f;
+            if constexpr (HALF) {
+                const float wl1 = ldg<float>(a.tapers, min(n + 1u, nsig_m1) * 4u);
+                wo[e] = (n + 1u <= nsig_m1) ? wl1 : 0.f;
+            }
         }
     }
 
@@ -247,19 +326,26 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             v[e].r = x[e].r * wn[e];
-            v[e].i = x[e].i * wn[e];
+            v[e].i = x[e].i * (HALF ? wo[HALF ? e : 0] : wn[e]);
         }
         if (k + 1 < a.ntaper) {
             const float* w = a.tapers + (size_t)(k + 1) * a.nsig;   // wave-uniform
             if (wfull) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) wn[e] = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, (unsigned)(j + T * e) * 4u);
+                for (int e = 0; e < 16; ++e) {
+                    wn[e] = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, (unsigned)(SM * (j + T * e)) * 4u);
+                    if constexpr (HALF) wo[e] = ldg<float>(w, (unsigned)(2 * (j + T * e) + 1) * 4u);
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const unsigned n = (unsigned)(j + T * e);
+                    const unsigned n = (unsigned)(SM * (j + T * e));
                     const float wl = (SPYFFT_ABL & 1) ? a.scale : ldg<float>(w, min(n, nsig_m1) * 4u);
                     wn[e] = (n <= nsig_m1) ? wl : 0.f;
+                    if constexpr (HALF) {
+                        const float wl1 = ldg<float>(w, min(n + 1u, nsig_m1) * 4u);
+                        wo[e] = (n + 1u <= nsig_m1) ? wl1 : 0.f;
+                    }
                 }
             }
         }
@@ -270,17 +356,17 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
             for (int e = 0; e < 16; ++e) {
                 s[0] += v[e].r[0];
                 s[1] += v[e].r[1];
-                s[2] += v[e].i[0];
-                s[3] += v[e].i[1];
+                s[HALF ? 0 : 2] += v[e].i[0];
+                s[HALF ? 1 : 3] += v[e].i[1];
             }
             block_sum<C::NTHREADS, G, 4>(s, reinterpret_cast<double*>(lds), tid, h);
             const v2f mr = v2f{(float)(s[0] / a.nsig), (float)(s[1] / a.nsig)};
-            const v2f mi = v2f{(float)(s[2] / a.nsig), (float)(s[3] / a.nsig)};
+            const v2f mi = HALF ? mr : v2f{(float)(s[2] / a.nsig), (float)(s[3] / a.nsig)};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const bool in = j + T * e < a.nsig;
-                v[e].r -= in ? mr : splat(0.f);
-                v[e].i -= in ? mi : splat(0.f);
+                const int n0 = SM * (j + T * e);
+                v[e].r -= n0 < a.nsig ? mr : splat(0.f);
+                v[e].i -= n0 + (HALF ? 1 : 0) < a.nsig ? mi : splat(0.f);
             }
         }
 
@@ -322,12 +408,24 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                 xa.i = z.i - zp.i;
                 xb.r = z.i + zp.i;
                 xb.i = zp.r - z.r;
+                if constexpr (HALF) {
+                    // xa = E, xb = O of the pair's real transform: bins f and N - f (f = 0: DC and the Nyquist bin)
+                    const C2 t = cmul_s(xb, ldg<float2>(a.twh, (unsigned)f * 8u));
+                    const C2 d = csub(xa, t);
+                    xa = cadd(xa, t);
+                    xb.r = d.r;
+                    xb.i = -d.i;
+                }
             } else {
                 if (j != 0) break;
                 f = N / 2;
                 xa.r = v[8].r * 2.f;
                 xb.r = v[8].i * 2.f;
                 xa.i = xb.i = splat(0.f);
+                if constexpr (HALF) {            // the middle bin is its own partner: X[N / 2] = conj Z[N / 2]
+                    xa.i = -xb.r;
+                    xb.r = splat(0.f);
+                }
             }
             if (MEAN) {
                 if (CPLX) {
@@ -341,6 +439,39 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                                    convert_real_slow(make_float2(xa.r[1], xa.i[1]), a.out_kind)};
                     ma[e].i += v2f{convert_real_slow(make_float2(xb.r[0], xb.i[0]), a.out_kind),
                                    convert_real_slow(make_float2(xb.r[1], xb.i[1]), a.out_kind)};
+                }
+                continue;
+            }
+            if constexpr (HALF) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && e == 8) break;
+                    const int fb = q ? N - f : f;
+                    const C2 X = q ? xb : xa;
+                    if (fast) {
+                        const unsigned o = ((unsigned)fb * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+                        if (CPLX) {
+                            stg<float4>(slab, o, make_float4(X.r[0], X.i[0], X.r[1], X.i[1]));
+                        } else if (OUTK == 0) {
+                            const v2f pw = X.r * X.r + X.i * X.i;
+                            stg<float2>(slab, o, make_float2(pw[0], pw[1]));
+                        } else {
+                            stg<float2>(slab, o, make_float2(convert_real_slow(make_float2(X.r[0], X.i[0]), a.out_kind),
+                                                             convert_real_slow(make_float2(X.r[1], X.i[1]), a.out_kind)));
+                        }
+                    } else {
+                        const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)fb * 4u) : fb;
+                        if (fi >= 0) {
+                            const float2 Xc[2] = {make_float2(X.r[0], X.i[0]), make_float2(X.r[1], X.i[1])};
+                            const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                if (!has[i]) continue;
+                                if (CPLX) stg<float2>(slab, o + i * OSZ, Xc[i]);
+                                else stg<float>(slab, o + i * OSZ, convert_real<OUTK>(Xc[i], a.out_kind));
+                            }
+                        }
+                    }
                 }
                 continue;
             }
@@ -416,10 +547,37 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
         for (int e = 0; e < 9; ++e) {
             if (e == 8 && j0 != 0) break;
             const int f = (e < 8) ? j0 + T * e : N / 2;
+            const float nt = (float)a.ntaper;
+            if constexpr (HALF) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && e == 8) break;
+                    const int fb = q ? N - f : f;
+                    const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)fb * 4u) : fb;
+                    if (fi < 0) continue;
+                    const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
+                    if (CPLX) {
+                        const C2 A = q ? mb[e] : ma[e];
+                        const float2 X[2] = {make_float2(A.r[0] / nt, A.i[0] / nt), make_float2(A.r[1] / nt, A.i[1] / nt)};
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (has[i]) stg<float2>(slab, o + i * OSZ, X[i]);
+                    } else {
+                        const v2f A = q ? ma[e].i : ma[e].r;
+                        if (fast) {
+                            stg<float2>(slab, o, make_float2(A[0] / nt, A[1] / nt));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+                                if (has[i]) stg<float>(slab, o + i * OSZ, A[i] / nt);
+                        }
+                    }
+                }
+                continue;
+            }
             const int fi = a.fpos ? ldg<int>(a.fpos, (unsigned)f * 4u) : f;
             if (fi < 0) continue;
             const unsigned o = ((unsigned)fi * (unsigned)a.nchan + (unsigned)c0) * OSZ;
-            const float nt = (float)a.ntaper;
             if (CPLX) {
                 const float2 X[4] = {make_float2(ma[e].r[0] / nt, ma[e].i[0] / nt), make_float2(ma[e].r[1] / nt, ma[e].i[1] / nt),
                                      make_float2(mb[e].r[0] / nt, mb[e].i[0] / nt), make_float2(mb[e].r[1] / nt, mb[e].i[1] / nt)};

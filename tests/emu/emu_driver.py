@@ -193,17 +193,16 @@ def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detren
         assert rc == 0, f"no emulated decimal kernel {dec}"
         return out
     pow2 = (nfft & (nfft - 1)) == 0 and 256 <= nfft <= 16384 and not force_generic
-    if pow2 and nfft == 16384 and dec is None:
-        # as spyhip_fft_plan_create: 2^14 = channel pairs through the 8192-point schedule (CfgD::HALF)
-        return _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detrend, demean_taper, freq_idx,
-                         output, keeptapers, chan_idx, G, force_generic, blocked, force_long, no_mixed, mixed_nostage, -16384)
     if pow2:
         log2n = int(np.log2(nfft))
         if G is None:
             G = {8: 16, 9: 8, 10: 4, 11: 2, 12: 1, 13: 1, 14: 1}[log2n]
             if log2n == 12 and kind == 2 and keeptapers:
                 G = 2               # as spyhip_fft_plan_create: store-bound complex spectra take two quads per workgroup
-        tw = twiddles(nfft)
+        # 2^14 (as spyhip_fft_plan_create): channel pairs through the 8192-point engine, HALF form of mtmfft_quad_kernel
+        tw = twiddles(nfft // 2 if log2n == 14 else nfft)
+        twh = np.ascontiguousarray(twiddles(nfft)[: nfft // 4 + 1]) if log2n == 14 else None
+        lib().emu_set_twh(_p(twh, C.c_float))
         set_blocked(blocked)
         rc = lib().emu_mtmfft_pow2(
             C.c_int(log2n), C.c_int(G), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
@@ -212,6 +211,7 @@ def _fft_exec(data, seg_start, seg_lo, seg_hi, nsig, nfft, tapers, scale, detren
             C.c_float(scale), C.c_int(detrend), C.c_int(int(demean_taper)), _p(fpos, C.c_int),
             C.c_int(nfsel), C.c_int(kind), C.c_int(int(keeptapers)), out.ctypes.data_as(C.c_void_p))
         set_blocked(False)
+        lib().emu_set_twh(None)
         assert rc == 0, f"no emulated kernel for log2n={log2n} G={G}"
         return out
     if not force_generic and not force_long and not no_mixed:

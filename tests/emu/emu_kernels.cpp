@@ -193,7 +193,7 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     const bool quad = log2n <= 13;
     // mtmfft_quad_kernel expects the window times scale / 2 (the plan uploads that table, mtmfft.hip)
     std::vector<float> th;
-    if (quad) {
+    {
         th.resize((size_t)ntaper * nsig);
         for (size_t i = 0; i < th.size(); ++i) th[i] = (float)((double)tapers[i] * (0.5 * (double)scale));
         a.tapers = th.data();
@@ -207,6 +207,21 @@ int emu_mtmfft_pow2(int log2n, int G, const float* data, long long ld, const int
     const unsigned grid = (unsigned)(((nclusters + 7) / 8) * S * 8);
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
     const int mean = keeptapers ? 0 : 1;
+    if (log2n == 14) {
+        // 2^14: channel pairs through the 8192-point engine (HALF form; `tw` belongs to 8192, the half-step table was set)
+        a.twh = reinterpret_cast<const float2*>(g_twh);
+        using C = spyfft::Cfg2<13, 1>;
+        auto go = [&](auto fn) { emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, fn); };
+        switch (outk * 2 + mean) {
+            case 0: go([&] { spyfft::mtmfft_quad_kernel<13, 1, 0, false, true>(a); }); break;
+            case 1: go([&] { spyfft::mtmfft_quad_kernel<13, 1, 0, true, true>(a); }); break;
+            case 2: go([&] { spyfft::mtmfft_quad_kernel<13, 1, 1, false, true>(a); }); break;
+            case 3: go([&] { spyfft::mtmfft_quad_kernel<13, 1, 1, true, true>(a); }); break;
+            case 4: go([&] { spyfft::mtmfft_quad_kernel<13, 1, 2, false, true>(a); }); break;
+            default: go([&] { spyfft::mtmfft_quad_kernel<13, 1, 2, true, true>(a); }); break;
+        }
+        return 0;
+    }
     switch (log2n * 100 + G) {
         case 816: run_quad_mode<8, 16>(a, grid, outk, mean, -1); break;
         case 908: run_quad_mode<9, 8>(a, grid, outk, mean, -1); break;
@@ -244,7 +259,6 @@ int emu_mtmfft_dec(int id, const float* data, long long ld, const int* chan_idx,
         case -5000: run_dec_mode<spyfft::CfgD<10, 10, 5, 5, 1, 1, false, true>>(a, nseg, nchan, outk, mean); break;
         case -12000: run_dec_mode<spyfft::CfgD<10, 10, 10, 2, 1, 3, false, true>>(a, nseg, nchan, outk, mean); break;
         case -1024: run_dec_mode<spyfft::CfgD<16, 16, 2, 1, 2, 1, false, true>>(a, nseg, nchan, outk, mean); break;
-        case -16384: run_dec_mode<spyfft::CfgD<16, 16, 16, 2, 1, 1, false, true>>(a, nseg, nchan, outk, mean); break;
         case 1000: run_dec_mode<spyfft::CfgD<10, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;
         case 2000: run_dec_mode<spyfft::CfgD<10, 10, 10, 2, 1>>(a, nseg, nchan, outk, mean); break;
         case 2001: run_dec_mode<spyfft::CfgD<20, 10, 10, 1, 2>>(a, nseg, nchan, outk, mean); break;
