@@ -488,6 +488,17 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                 }
                 continue;
             }
+            // (G == 2, complex spectra) the neighbouring row's halves for the 64-byte stores below: fetched by EVERY lane, in
+            // front of the lane-dependent branch (a ragged last quad takes the slow path; its partner two lanes away has
+            // the same quad and goes with it)
+            float4 got2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (CPLX && !MEAN && G == 2 && !HALF) {
+                if (e < 8) {
+                    const bool odd = (j & 1) != 0;
+                    const float4 give = odd ? make_float4(xa.r[0], xa.i[0], xa.r[1], xa.i[1]) : make_float4(xb.r[0], xb.i[0], xb.r[1], xb.i[1]);
+                    got2 = make_float4(spy_lane_swap2(give.x), spy_lane_swap2(give.y), spy_lane_swap2(give.z), spy_lane_swap2(give.w));
+                }
+            }
             if (fast) {
                 const unsigned o = ((unsigned)f * (unsigned)a.nchan + (unsigned)c0) * OSZ;
                 if ((SPYFFT_ABL & 4) && xa.r[0] + xa.r[1] + xa.i[0] + xa.i[1] + xb.r[0] + xb.r[1] + xb.i[0] + xb.i[1] != 12345.f)
@@ -504,6 +515,17 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) SPYFFT_KATTR mtmff
                         const float4 give = odd ? lo : hi;
                         const float4 got = make_float4(lane_swap1(give.x), lane_swap1(give.y), lane_swap1(give.z),
                                                        lane_swap1(give.w));
+                        const unsigned rb = (unsigned)a.nchan * OSZ;     // bytes per bin row
+                        const unsigned oe = odd ? o - rb + 16u : o;      // row of the even lane, this lane's half
+                        stg<float4>(slab, oe, odd ? got : lo);
+                        stg<float4>(slab, oe + rb, odd ? hi : got);
+                    } else if (G == 2 && e < 8) {
+                        // Two quads per workgroup: lanes (j, 0), (j, 1), (j + 1, 0), (j + 1, 1) are neighbours and hold the
+                        // 64 bytes of row j and the 64 bytes of row j + 1.  The same trade two lanes apart (even j hands over
+                        // its upper halves, odd j its lower ones) lets ONE instruction write the whole 64-byte piece of a row:
+                        // 16 line requests per instruction instead of 32
+                        const bool odd = (j & 1) != 0;
+                        const float4 got = got2;
                         const unsigned rb = (unsigned)a.nchan * OSZ;     // bytes per bin row
                         const unsigned oe = odd ? o - rb + 16u : o;      // row of the even lane, this lane's half
                         stg<float4>(slab, oe, odd ? got : lo);

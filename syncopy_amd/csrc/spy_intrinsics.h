@@ -29,6 +29,10 @@ __device__ __forceinline__ int spy_wave_index(int tid) { return __builtin_amdgcn
 __device__ __forceinline__ float spy_lane_swap1(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
 }
+// ... and of the lane two away (lane ^ 2)
+__device__ __forceinline__ float spy_lane_swap2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
+}
 // quarter-rate hardware approximations where 1 ulp is enough
 __device__ __forceinline__ float spy_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float spy_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }

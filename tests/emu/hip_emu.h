@@ -113,6 +113,7 @@ static inline T __shfl_xor(T v, int mask) {
 }
 
 static inline float spy_lane_swap1(float v) { return __shfl_xor(v, 1); }
+static inline float spy_lane_swap2(float v) { return __shfl_xor(v, 2); }
 
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for r in [0,16)   (cdna_hip_programming.md section 3)
