@@ -124,18 +124,41 @@ def test_fft_vs_oracle(be, case):
     assert_parity(got, ref, what=plan.kernel_name)
 
 
-def test_fft_freq_and_channel_selection(be):
+@pytest.mark.parametrize("nsig,nfft", [(1024, 1024), (5000, 5000), (11000, 12000), (16384, 16384), (20000, 20000)])
+def test_fft_freq_and_channel_selection(be, nsig, nfft):
+    """Frequency and channel selections (repeated and reordered channels, an odd count) - also through the pair forms of the
+    long-trial kernels, whose bins f and nfft/2 - f leave one thread together."""
     rng = np.random.default_rng(3)
-    nsig = nfft = 1024
-    data = rng.normal(size=(4 * nsig, 12)).astype(np.float32)
-    fidx = np.array([7, 3, 100, 512, 0, 511], dtype=np.int32)
+    data = rng.normal(size=(3 * nsig + 200, 12)).astype(np.float32)
+    fidx = np.array([7, 3, 100, nfft // 2, 0, nfft // 2 - 1, nfft // 4, nfft // 4 + 1, nfft // 4 - 1], dtype=np.int32)
     cidx = [11, 0, 5, 5, 2]
-    starts = [0, 2048, 100]
+    starts = [0, 2 * nsig, 100]
     for output, keep in (("pow", False), ("fourier", True), ("real", True)):
         got, plan = _run_fft(be, data, nsig, nfft, "dpss", {"NW": 3, "Kmax": 5}, output, keep, 0, False, fidx, cidx,
                              starts)
         ref = _oracle_fft(data, starts, nsig, nfft, "dpss", {"NW": 3, "Kmax": 5}, output, keep, 0, False, fidx, cidx)
         assert_parity(got, ref, what=f"{plan.kernel_name} {output}")
+
+
+def test_fft_zero_extended_segments_of_long_trials(be):
+    """Segments of the pair-form kernels that stick out of [lo, hi) on either side, with an odd first row inside."""
+    rng = np.random.default_rng(6)
+    nsig = nfft = 12000
+    data = rng.normal(size=(30000, 5)).astype(np.float32)
+    starts = np.array([-3001, 0, 20001, 9000], dtype=np.int64)
+    lo = np.array([0, 0, 15000, 9001], dtype=np.int64)
+    hi = np.array([30000, 30000, 30000, 12346], dtype=np.int64)
+    tapers = O.taper_table("hann", nsig, nfft)
+    plan = be.FFTPlan(nsig, nfft, 5, tapers, O.spec_scale(nsig, nfft), None, False, None, "fourier", True)
+    dev = torch.from_numpy(data).cuda()
+    got = plan.execute(dev, torch.from_numpy(starts).cuda(), torch.from_numpy(lo).cuda(), torch.from_numpy(hi).cuda()).cpu().numpy()
+    for b in range(len(starts)):
+        x = np.zeros((nsig, 5), np.float32)
+        a0, a1 = max(starts[b], lo[b]), min(starts[b] + nsig, hi[b])
+        x[a0 - starts[b]:a1 - starts[b]] = data[a0:a1]
+        ref, _ = O.mtmfft_cF(x, foi=np.fft.rfftfreq(nfft, 1e-3), keeptapers=True, polyremoval=None, output="fourier",
+                             method_kwargs=dict(samplerate=1000.0, taper="hann", taper_opt={}, nSamples=nfft, demean_taper=False))
+        assert_parity(got[b], ref[0], what=f"{plan.kernel_name} segment {b}")
 
 
 def test_fft_zero_extended_segments(be):
