@@ -1,6 +1,7 @@
 """Single-trial cross-spectra and cross-covariances on MI355X (signatures of
 syncopy/connectivity/ST_compRoutines.py: cross_spectra_cF:269 / CrossSpectra:427, spectral_dyadic_product_cF:30,
 cross_covariance_cF:466 / CrossCovariance:587)."""
+import weakref
 from hashlib import blake2b
 
 import numpy as np
@@ -247,12 +248,17 @@ class CrossSpectra(ComputationalRoutine):
             # for it: the coherence stage reads the raw lower-triangle accumulator through the fused kernel.
             scale, shape = 1.0 / (K * T), self.outputShape
             state = {"acc": acc, "final": None}
+            out_ref = weakref.ref(out)                     # (the closure lives IN `out`: a strong reference would be a cycle,
+                                                           # and a dropped result would keep its 1 GB of HBM until the cyclic
+                                                           # collector happens to run)
 
             def device_csd():
                 if state["final"] is None:
                     backend.csd_finalize(state["acc"], scale)
                     state["final"] = state["acc"].reshape(shape)
-                    out._acc_raw = None
+                    o = out_ref()
+                    if o is not None:
+                        o._acc_raw = None
                 return state["final"]
 
             out._acc_raw, out._acc_scale = acc, scale

@@ -6,6 +6,7 @@ trial average (AV stage, :677-679).  Parameter handling follows :286-473 and the
 `cross_spectra` helper (:775-872).
 """
 import numbers
+import weakref
 
 import numpy as np
 
@@ -275,7 +276,8 @@ def _jackknife_on_device(data, st, av, st_out, log_dict):
     av.metadata = []
     S, direct, bias, var = st.jackknife_hip(data, av.evaluate_device, fused=getattr(av, "jackknife_accumulate", None))
     st_out._dev = S.reshape(st.outputShape)
-    st_out.set_pending(lambda: backend.to_host(st_out._dev), st.outputShape, np.complex64)
+    st_ref = weakref.ref(st_out)                            # (no cycle through the object's own thunk)
+    st_out.set_pending(lambda: backend.to_host(st_ref()._dev), st.outputShape, np.complex64)
     st.process_metadata(data, st_out)
     out = CrossSpectralData(dimord=st_out.dimord)
     av.initialize(st_out, out._stackingDim, chan_per_worker=None, keeptrials=False)

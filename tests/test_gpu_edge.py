@@ -137,3 +137,36 @@ def test_mtmconvol_first_window_cut_short_at_the_trial_edge(per_trial):
         spy.freqanalysis(data, compute_method="sequential", routine_classes=ORACLE_FREQ, **kw)
     with pytest.raises(ValueError, match="could not broadcast"):
         spy.freqanalysis(data, **({"compute_method": "sequential"} if per_trial else {}), **kw)
+
+
+def test_dropped_results_release_their_device_memory():
+    """A result nobody reads holds its spectra in HBM behind lazy thunks (the trial-averaged CSD: F x C x C complex64).
+    Those thunks must not tie the object into a reference cycle: dropping the result has to release the memory at once,
+    not whenever Python's cyclic collector runs - a loop over recordings would otherwise grow by a CSD per call."""
+    import gc
+    import torch
+    data = _data(512, 64, 12, seed=21)
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        used = []
+        for _ in range(5):
+            r = spy.connectivityanalysis(data, method="coh", taper="hann")
+            torch.cuda.synchronize()
+            del r
+            used.append(torch.cuda.memory_allocated())
+        assert used[-1] <= used[1], used                  # flat after the first calls (plans and buffers are cached once)
+        small = _data(512, 6, 40, seed=22)
+        for d, method, kw in ((data, "csd", {"taper": "hann"}), (small, "granger", {"tapsmofrq": 4})):
+            u0 = None
+            for _ in range(3):
+                r = spy.connectivityanalysis(d, method=method, **kw)
+                torch.cuda.synchronize()
+                del r
+                u = torch.cuda.memory_allocated()
+                u0 = u if u0 is None else u0
+            assert u <= u0, (method, u0, u)
+    finally:
+        if was_enabled:
+            gc.enable()
