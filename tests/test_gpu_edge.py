@@ -167,6 +167,17 @@ def test_dropped_results_release_their_device_memory():
                 u = torch.cuda.memory_allocated()
                 u0 = u if u0 is None else u0
             assert u <= u0, (method, u0, u)
+        for kw in (dict(method="mtmfft", taper="hann", keeptrials=True), dict(method="mtmfft", taper="hann", keeptrials=False),
+                   dict(method="mtmconvol", taper="hann", t_ftimwin=0.128, toi="all", keeptrials=True),
+                   dict(method="wavelet", foi=np.array([20.0, 40.0]), toi="all", keeptrials=False)):
+            u0 = None
+            for _ in range(3):
+                r = spy.freqanalysis(small, output="pow", **kw)
+                torch.cuda.synchronize()
+                del r
+                u = torch.cuda.memory_allocated()
+                u0 = u if u0 is None else u0
+            assert u <= u0, (kw, u0, u)
     finally:
         if was_enabled:
             gc.enable()
