@@ -821,6 +821,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": "float32 transforms (the reference's float64 ones: secondary[0]); the cross-spectral products take "
+                          "each float32 operand as an exact-to-22-bits fp16 (hi, lo) pair on the fp16 matrix cores with float32 "
+                          "accumulation (hi hi' + hi lo' + lo hi'; dropped term <= 2^-22), frequencies whose range a pair cannot "
+                          "hold are redone by the float32 kernel; `selfcheck` = this launch against complex128 under the parity criterion",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: connectivityanalysis method='coh' on AR(2) AnalogData, "
