@@ -467,7 +467,10 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
                                p->output, reinterpret_cast<float*>(p->stage.p));
         }
         const dim3 sg((p->nsig + 63) / 64, p->nscales, accumulate == 2 ? 1 : ns);
+        // real outputs of long trials: tiles of 256 samples x 16 channels (1-KiB reads of the staging rows: 51 -> 46 us/trial at c4)
+        const bool wide = esz == 4 && (p->nsig & 3) == 0 && p->nsig >= 1024;
         if (esz == 8) hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float2>, sg, dim3(256), 0, p->ctx->stream, c);
+        else if (wide) hipLaunchKernelGGL(spyfft::cwt_scatter_wide_kernel, dim3((p->nsig + 255) / 256, sg.y, sg.z), dim3(256), 0, p->ctx->stream, c);
         else hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float>, sg, dim3(256), 0, p->ctx->stream, c);
         SPY_HIP_CHECK(hipGetLastError());
     }

@@ -461,6 +461,37 @@ def test_cwt_trial_sum_mode(be):
     assert_parity(total.cpu().numpy(), ref.cpu().numpy(), what="cwt trial sum")
 
 
+def test_cwt_wide_transposition_tiles(be):
+    """Real outputs of trials of >= 1024 samples leave the staging buffer through 256-sample x 16-channel tiles
+    (cwt_scatter_wide_kernel): ragged in both directions (1500 samples, 21 channels), every accumulation mode and a
+    post-selection of samples, against the oracle."""
+    rng = np.random.default_rng(13)
+    nsig, C, T = 1500, 21, 5
+    x = rng.normal(size=(T * nsig, C)).astype(np.float32)
+    freqs = np.array([12.0, 30.0, 70.0])
+    scales = (1 / freqs) * (6 + np.sqrt(38)) / (4 * np.pi)
+    data = torch.from_numpy(x).cuda()
+    st = torch.arange(T, device="cuda", dtype=torch.int64) * nsig
+    ref = np.stack([O.convert_output(O.cwt(O.detrend(x[t * nsig:(t + 1) * nsig], 0), 1000.0, scales).transpose(1, 0, 2), "pow")
+                    for t in range(T)])
+    plan = be.CWTPlan(nsig, C, scales, 1e-3, 6.0, 0, "pow")
+    each = plan.execute(data, st, st, st + nsig)
+    assert_parity(each.cpu().numpy(), ref, what="wide tiles, per segment")
+    total = torch.zeros(plan.out_shape(1), dtype=torch.float32, device="cuda")
+    plan.execute(data, st[:2].contiguous(), st[:2].contiguous(), (st[:2] + nsig).contiguous(), out=total, accumulate=2)
+    plan.execute(data, st[2:].contiguous(), st[2:].contiguous(), (st[2:] + nsig).contiguous(), out=total, accumulate=2)
+    assert_parity(total.cpu().numpy()[0], ref.astype(np.float64).sum(axis=0).astype(np.float32), what="wide tiles, trial sum")
+    acc = each.clone()
+    plan.execute(data, st, st, st + nsig, out=acc, accumulate=True)
+    assert_parity(acc.cpu().numpy(), 2 * ref, what="wide tiles, out[b] += segment b")
+    keep = np.r_[3:700:7, 1023, 1024, 1499]                      # post-selection: output slot of sample n, or -1
+    tpos = np.full(nsig, -1, dtype=np.int32)
+    tpos[keep] = np.arange(keep.size)
+    sel = be.CWTPlan(nsig, C, scales, 1e-3, 6.0, 0, "pow", tpos=tpos, ntime_out=keep.size)
+    got = sel.execute(data, st, st, st + nsig)
+    assert_parity(got.cpu().numpy(), ref[:, keep], what="wide tiles, selected samples")
+
+
 @pytest.mark.parametrize("output", ["pow", "fourier"])
 def test_cwt_kernels_longer_than_one_block(be, output):
     """Morlet kernels of more than 8191 taps (transform.py:96-103 samples 10 s / dt of them and convolves in full,
