@@ -133,6 +133,8 @@ struct spyhip_fft_plan {
     bool seg_f64 = false;       // the reference holds the segments as float64 arrays (padded sliding windows)
     spy::DevBuf<float> means;
     size_t means_cap = 0;
+    spy::DevBuf<float2> xpair;  // pair-major copy of the segments of a launch (pair forms of trials beyond 10240 samples)
+    size_t xpair_cap = 0;
     std::string kernel_name;
 };
 
@@ -896,6 +898,49 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
         const int outk = p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1);
         a.twh = p->twh.p;
         int rc;
+        if (p->nfft > 10240) {
+            // long trials: a pair workgroup's 8 bytes per row come from a pair-major copy of the segments (pair_stage_kernel)
+            // instead of one L2 request per row and lane; launches of at most 4 GiB of it.  256 ch x 7 tapers incl. the
+            // copy: 12000 51.2 -> 46.4, 16384 49.8 -> 46.6, 20000 102.1 -> 94.9 us/trial (what is left per segment is
+            // what a quad workgroup of the same engine pays as well)
+            const long long xstride = ((long long)p->nsig + 1) & ~1LL;
+            const size_t per_seg = (size_t)npairs * (size_t)xstride;                     // float2 elements
+            const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nseg, (((size_t)4 << 30) / sizeof(float2)) / per_seg));
+            if ((size_t)chunk * per_seg > p->xpair_cap) {
+                if (p->xpair.p) { SPY_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); (void)hipFree(p->xpair.p); p->xpair.p = nullptr; }
+                if (p->xpair.alloc((size_t)chunk * per_seg)) return -2;
+                p->xpair_cap = (size_t)chunk * per_seg;
+            }
+            const size_t oelem = (size_t)(mean ? 1 : p->ntaper) * p->nfsel * p->nchan * (outk == 2 ? 8 : 4);
+            for (int s0 = 0; s0 < nseg; s0 += chunk) {
+                MtmArgs m = a;
+                m.seg_start += s0; m.seg_lo += s0; m.seg_hi += s0;
+                m.nseg = std::min(chunk, nseg - s0);
+                m.out = reinterpret_cast<char*>(a.out) + (size_t)s0 * oelem;
+                if (m.means) m.means += (size_t)s0 * p->nchan;
+                for (int z0 = 0; z0 < m.nseg; z0 += 65535) {
+                    MtmArgs z = m;
+                    z.seg_start += z0; z.seg_lo += z0; z.seg_hi += z0;
+                    const int nz = std::min(65535, m.nseg - z0);
+                    hipLaunchKernelGGL(spyfft::pair_stage_kernel, dim3((unsigned)((xstride + 63) / 64), (p->nchan + 63) / 64, nz), dim3(256), 0,
+                                       p->ctx->stream, z, p->xpair.p + (size_t)z0 * per_seg, xstride, npairs);
+                }
+                SPY_HIP_CHECK(hipGetLastError());
+                m.xpair = p->xpair.p;
+                m.xstride = xstride;
+                m.chan_idx = nullptr;                    // (the copy is in selected-channel order already)
+                if (p->nfft == 16384) {
+                    m.tapers = p->tapers_half.p;
+                    rc = spyfft::quad_half_launch(p->ctx->stream, m, npairs, outk, mean);
+                } else {
+                    rc = spyfft::dec_launch_half_a(p->ctx->stream, m, p->nfft, npairs, outk, mean);
+                    if (rc == -100) rc = spyfft::dec_launch_half_b(p->ctx->stream, m, p->nfft, npairs, outk, mean);
+                    if (rc == -100) { spy::set_error("fft_exec: no half-length schedule for nfft = %d", p->nfft); rc = -1; }
+                }
+                if (rc) return rc;
+            }
+            return 0;
+        }
         if (p->nfft == 16384) {
             // the power-of-two engine in HALF form (53.6 us/trial at 256 channels x 7 tapers; the 8192-point compile-time
             // schedule on pairs: 59.3)

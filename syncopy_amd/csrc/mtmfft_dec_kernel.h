@@ -302,7 +302,18 @@ __global__ void __launch_bounds__((C::NTHREADS)) SPYFFT_KATTR mtmfft_dec_kernel(
     C2 x[V];
     if constexpr (HALF) {
         // sample pairs (2 m, 2 m + 1), m = jn0 + TT e: the even sample in .r, the odd one in .i, channels (c0, c1) in the halves
-        if (rhi > rlo) {
+        if (a.xpair != nullptr) {
+            // ... from the pair-major copy of the segment (pair_stage_kernel): 16 contiguous bytes = both samples
+            const float2* xs = a.xpair + ((size_t)b * ((a.nchan + 1) >> 1) + (size_t)(c0 >> 1)) * (size_t)a.xstride;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const long long n0 = 2LL * (jn0 + TT * e);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (active && n0 < a.xstride) t = *reinterpret_cast<const float4*>(xs + n0);
+                x[e].r = v2f{t.x, t.y};
+                x[e].i = v2f{t.z, t.w};
+            }
+        } else if (rhi > rlo) {
             const bool vec2 = (a.chan_idx == nullptr) && full && ((a.ld & 1) == 0) &&
                               ((reinterpret_cast<size_t>(a.data) & 7) == 0);
 #pragma unroll

@@ -60,6 +60,10 @@ struct MtmArgs {
     float wnorm;                // max over the tapers of || w * scale ||_2 (the bound is wnorm * ||detrended segment||_2)
     const float2* twh;          // (CfgD::HALF) exp(-2 pi i f / nfft), f <= nfft / 4: the step from the half-length complex
                                 // transform of (even, odd) samples to the bins of the real transform
+    const float2* xpair;        // (HALF forms of long trials) nullptr, or the segments of this launch channel-PAIR-major:
+                                // xpair[(b * npair + pair) * xstride + n] = (x_c0[n], x_c1[n]), zeros outside the trial and
+                                // behind nsig (pair_stage_kernel): the 8-byte-per-row gather becomes a stream
+    long long xstride;          // samples per (segment, pair) of xpair (nsig rounded up to even)
 };
 
 // Per-channel mean of a segment exactly as the reference takes it.  scipy.signal.detrend(type="constant") on the
@@ -194,6 +198,36 @@ __device__ __attribute__((noinline)) float convert_real_slow(float2 x, int kind)
         default: return x.x * x.x + x.y * x.y;
     }
 }
+// Segments -> channel-pair-major copy for the pair forms of long trials (MtmArgs::xpair).  A pair workgroup needs 8 bytes of
+// every row; gathered directly that is one 64-byte L2 request per row and lane (19 of the 54 us per trial at 16384 samples
+// x 256 channels).  Here a tile of 64 rows x 64 channels is read along the channels (256 contiguous bytes per row), turned
+// in LDS, and written along the rows: 512 contiguous bytes per pair.  Channel selection and the zero extension outside
+// [seg_lo, seg_hi) happen here, so the transform kernel reads its samples without clamps.
+static __global__ void __launch_bounds__(256) pair_stage_kernel(MtmArgs a, float2* __restrict__ xp, long long xstride, int npair) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const long long start = a.seg_start[b], lo = a.seg_lo[b], hi = a.seg_hi[b];
+    const int c = c0 + lane;
+    const long long col = c < a.nchan ? (a.chan_idx ? a.chan_idx[c] : c) : 0;
+#pragma unroll 4
+    for (int r = w; r < 64; r += 4) {
+        const long long n = r0 + r, row = start + n;
+        float v = 0.f;
+        if (c < a.nchan && n < a.nsig && row >= lo && row < hi) v = a.data[row * a.ld + col];
+        tile[r][lane] = v;
+    }
+    __syncthreads();
+    const long long n = r0 + lane;                       // this lane's row of the tile
+    if (n >= xstride) return;
+#pragma unroll 4
+    for (int q = w; q < 32; q += 4) {                    // 32 pairs of the tile, one per wave and pass
+        const int pair = (c0 >> 1) + q;
+        if (pair >= npair) break;
+        xp[((size_t)b * npair + pair) * (size_t)xstride + n] = make_float2(tile[lane][2 * q], tile[lane][2 * q + 1]);
+    }
+}
+
 // OUTK: 0 = power (the hot path, inlined), 1 = any other real conversion, 2 = complex
 template <int OUTK>
 __device__ __forceinline__ float convert_real(float2 x, int kind) {
