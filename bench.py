@@ -3,19 +3,25 @@
 256 channels x 4096 samples x 1000 trials per GPU, 7 DPSS tapers, full 256x256 CSD).
 
 One "step" = one complete pass of the hot path over the rank's in-HBM trial queue:
-    for every batch of trials:  detrend -> taper -> FFT (complex spectra, all tapers)   [K1]
-                                 acc += X X^H on the fp32 matrix cores                     [K4]
+    reference-order float32 mean of every trial                                            [K0  seq_mean_kernel]
+    detrend -> taper -> FFT (complex spectra, all tapers) + per-channel range              [K1  mtmfft_quad_kernel]
+    acc += X X^H: float32 operands as fp16 (hi, lo) pairs on the half-precision matrix
+        cores, float32 accumulation; frequencies a pair cannot hold redone in float32      [K4h csdh_kernel]
     (N > 1) RCCL all-reduce of the accumulator's packed lower triangle over xGMI           [C1]
     scale + coherence normalisation + Hermitian mirror (one fused pass) -> (F, C, C) float32 [K5]
 Trials shard across ranks with no other exchange (weak scaling: 1000 trials per GPU).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...            (no launcher: this file starts the N ranks itself, or exits 2 if the node
+                                             has fewer than N GPUs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line.  At N = 1 the line also carries `secondary` (the other SURVEY 8(d) numbers: c2
-mtmfft power, c4 sliding-window FFT and Morlet wavelets, c5 Wilson/Granger AV stage - each with its dominant kernel
-and its fraction of the bound it is priced against) and `cpu_baseline` (the reference's CPU path as restated by the
-oracle: one core, and one process per core).
+Rank 0 prints ONE JSON line, kept under 4 KB: headline, `roofline` (K4h), `selfcheck` (the timed launch against
+complex128), at N = 1 also the twins of the headline at the reference's operand precision (`value_f32_products`,
+`value_reference_arithmetic`), a compact `secondary` (c2 mtmfft power, other trial lengths, c4 sliding-window FFT and
+Morlet wavelets, the front-end- and host-copy-inclusive headline, c5 Wilson / Granger) and a compact `cpu_baseline`
+(the oracle on the host cores: BASELINE.md section 4.2).  Everything longer - the full secondary entries with kernel
+names, bounds and counter provenance, notes, the CPU-baseline variants - goes to gpurun_out/bench_detail.json.
 """
 import argparse
 import json
@@ -30,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_MFMA_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16 / FP16 MFMA, dense (2:1 sparsity figures are not a peak)
-PROFILE_ROUND = "r5"            # profiles/<round>_* written by tools/final_bench.sh on the code of this round
+PROFILE_ROUND = "r6"            # profiles/<round>_* written by tools/final_bench.sh on the code of this round
 PEAK_F64_TFLOPS = 78.6          # MI355X_MICROARCH.md: FP64 vector / matrix
 PEAK_HBM_GBS = 8000.0
 # SURVEY 8(d) bound of the headline on one GPU: K4's 3.775e9 algorithmic flops per trial at 157.3 TFLOP/s = 24.0 us
@@ -201,7 +207,7 @@ def pmc_traffic(nrows, nfreq, nchan):
     (bytes or None, provenance): the counters are only reported for the launch shape AND the kernel sources they were
     taken on (first line of the file: shape and `k4_sources_sha`)."""
     sha = k4_sources_sha()
-    for name in (PROFILE_ROUND + "_pmc_headline.txt", "r4_pmc_headline.txt"):
+    for name in (PROFILE_ROUND + "_pmc_headline.txt", "r5_pmc_headline.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -528,12 +534,167 @@ def secondary(torch, be, synthdata, data, N, C, T, refmean=True):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the environment
+    torch.distributed.run would give them) and return the worst exit code.  Rank 0 inherits stdout - its ONE JSON line is
+    this command's line.  Refuses (exit 2) when the node has fewer than N GPUs: a line with another n_gpus than the one
+    asked for is never printed."""
+    import subprocess
+    n = args.gpus
+    if not os.environ.get("SPY_BENCH_LAUNCH_TEST"):
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible: not running\n" % (n, have))
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:           # a rank that died leaves the others in a collective: end them (exact PIDs)
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def launch_test(args):
+    """SPY_BENCH_LAUNCH_TEST=1: the launch / rendezvous / barrier / max-over-ranks plumbing of this file with a gloo process
+    group and NO device work (tests/test_bench_launch.py runs `bench.py --gpus 2` this way on the CPU container).  The line
+    says so in `data` and carries no value."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    seen = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"metric": "launch test", "value": None, "unit": "trials/s", "n_gpus": world, "ranks_seen": int(seen.item()),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(el.item()) / max(args.steps, 1),
+                          "data": "launch-test (no device work)"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def _short(x, digits=4):
+    """Numbers of the compact line: `digits` significant figures."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _short(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, digits) for v in x]
+    return x
+
+
+SECONDARY_KEYS = (("headline under precision", "ref_transforms_k4h"), ("c2 mtmfft power", "c2"), ("c2 under precision", "c2_f64"),
+                  ("c2 shape at N = 2000", "n2000"), ("c2 shape at N = 3000", "n3000"), ("c2 shape at N = 5000", "n5000"),
+                  ("c2 shape at N = 10000", "n10000"), ("c2 shape at N = 12000", "n12000"), ("c2 shape at N = 16384", "n16384"),
+                  ("c4 mtmconvol", "c4_mtmconvol"), ("c4 wavelet", "c4_wavelet"), ("headline through the front end", "front_end"),
+                  ("c5 (BASELINE", "c5_granger_av"))
+
+
+def compact_secondary(entries):
+    """One short record per `secondary` entry for the final line: us/trial (or the entry's own unit), the fraction of the
+    bound it is priced against and counter traffic over algorithmic bytes.  The full entries go to the detail file."""
+    out = {}
+    for e in entries:
+        key = next((k for pre, k in SECONDARY_KEYS if e["name"].startswith(pre)), None)
+        if key is None:
+            continue
+        if key == "front_end":
+            out[key] = _short({"warm": e["value"], "with_host_copy": e["value_with_host_copy"], "back_to_back": e["back_to_back_trials_per_s"],
+                               "pcie_inclusive": e["pcie_inclusive_trials_per_s"], "unit": "trials/s"})
+        elif key == "c5_granger_av":
+            out[key] = _short({"s": e["value"], "iterations": e.get("iterations"), "frac": e.get("frac"), "st_stage_s": e["st_stage_s"]})
+        elif key == "ref_transforms_k4h":
+            out[key] = _short({"trials_per_s": e["value"]})
+        else:
+            rec = {"us_per_trial": e["us_per_trial"], "frac": e.get("frac")}
+            if e.get("traffic_over_algorithmic"):
+                rec["traffic_x"] = e["traffic_over_algorithmic"]
+            if "reference_precision" in e:
+                rec["f64_us_per_trial"] = e["reference_precision"]["us_per_trial"]
+            out[key] = _short(rec, 3)
+    return out
+
+
+DETAIL_FILE = os.path.join("gpurun_out", "bench_detail.json")
+MAX_LINE_BYTES = 4000
+
+
+def emit(line, detail):
+    """The contract's ONE JSON line, under 4 KB so that no capture window cuts it (round 5's 20 KB line reached the driver
+    truncated); everything else (`secondary` in full, notes, CPU-baseline variants, provenance of every counter figure)
+    goes to gpurun_out/bench_detail.json, which travels back with the run."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, DETAIL_FILE), "w") as fh:
+            json.dump(detail, fh, indent=1)
+        line["detail"] = DETAIL_FILE
+    except OSError as exc:
+        line["detail"] = "not written: %s" % exc
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("secondary", "step", "selfcheck_twins"):
+        if len(text) <= MAX_LINE_BYTES:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= MAX_LINE_BYTES, len(text)
+    print(text, flush=True)
+
+
 def main():
     args = parse()
+    if os.environ.get("WORLD_SIZE") is None and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        raise SystemExit(2)
+    if os.environ.get("SPY_BENCH_LAUNCH_TEST"):
+        raise SystemExit(launch_test(args))
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -574,12 +735,14 @@ def main():
     accs = [torch.zeros((F, C, C), dtype=torch.complex64, device="cuda") for _ in range(2 if dist_on else 1)]
     comm_stream = torch.cuda.Stream() if dist_on else None
     done = [None, None]                    # per accumulator: its last collective + coherence pass has finished
-    ev_csd, ev_fft, ev_coll = [], [], []
+    rec_main = {"csd": [], "fft": [], "coll": []}
     nstep = [0]
     # per-channel range of the spectra (largest |re|, |im|), left by the transform kernel for K4h's operand scaling
     absmax = torch.zeros(C, dtype=torch.float32, device="cuda") if (C == 256 and not blocked) else None
 
-    def step(timed, fft_plan=None):
+    def step(rec, fft_plan=None, split=True):
+        """One complete analysis of the rank's T trials.  `rec`: event lists to append this step's K1 / K4 / collective
+        brackets to, or None (untimed).  `split=False`: the cross-spectral products on the float32 matrix instructions."""
         fft_plan = fft_plan or plan
         slot = nstep[0] % len(accs)
         nstep[0] += 1
@@ -593,17 +756,17 @@ def main():
         for b0 in range(0, T, B):
             nb = min(B, T - b0)
             sp = spec[:nb * (K if blocked else 1)]
-            if timed:
+            if rec is not None:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
-            fft_plan.execute(data, starts_all[b0:b0 + nb], out=sp, absmax=absmax)
-            if timed:
+            fft_plan.execute(data, starts_all[b0:b0 + nb], out=sp, absmax=absmax if split else None)
+            if rec is not None:
                 e1.record()
-            be.csd_accumulate(sp, acc, blocked=blocked, absmax=absmax if fft_plan.tracked_absmax else None)
-            if timed:
+            be.csd_accumulate(sp, acc, blocked=blocked, absmax=absmax if (split and fft_plan.tracked_absmax) else None, split=split)
+            if rec is not None:
                 e2.record()
-                ev_fft.append((e0, e1, nb))
-                ev_csd.append((e1, e2, nb))
+                rec["fft"].append((e0, e1, nb))
+                rec["csd"].append((e1, e2, nb))
         if not dist_on:
             # K5 fused: scale + coherency + |.| + Hermitian mirror straight from the raw accumulator
             return be.coh_from_accumulator(acc, 1.0 / (K * T * world), "abs")
@@ -613,13 +776,13 @@ def main():
             comm_stream.wait_event(ready)
             # the accumulator carries its lower triangle only: the product's collective (backend.csd_allreduce_ =
             # spyhip_allreduce_csd: pack -> RCCL all-reduce on the library's communicator -> unpack, 0.54 GB of 1.07)
-            if timed:
+            if rec is not None:
                 c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 c0.record()
             be.csd_allreduce_(acc)
-            if timed:
+            if rec is not None:
                 c1.record()
-                ev_coll.append((c0, c1, F * (C * (C + 1) // 2) * 8))
+                rec["coll"].append((c0, c1, F * (C * (C + 1) // 2) * 8))
             coh = be.coh_from_accumulator(acc, 1.0 / (K * T * world), "abs")
             done[slot] = torch.cuda.Event()
             done[slot].record(comm_stream)
@@ -631,32 +794,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        coh = step(True)
-    fence()
-    el = time.perf_counter() - t0
-    tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
-    if dist_on:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    el = float(tmax.item())
+    fsel = sorted({0, 1, 2, F // 4, F // 2, F - 3, F - 2, F - 1})
 
-    # one more analysis, fenced on both sides: the un-pipelined latency of a single analysis (the timed steps above
-    # overlap the collective / coherence tail of step i with the transforms of step i + 1 when N > 1)
-    fence()
-    t1 = time.perf_counter()
-    coh = step(False)
-    fence()
-    latency = time.perf_counter() - t1
-
-    selfcheck = None
-    if rank == 0 and not blocked and B == T:
-        # parity at the depth that was timed (K * T rows): raw accumulator and coherence of a handful of frequencies
-        # against complex128 products of the spectra of the last step (still in `spec`), criterion of tests/parity.py
-        fsel = sorted({0, 1, 2, F // 4, F // 2, F - 3, F - 2, F - 1})
+    def selfcheck_of(coh, reference_transforms=False):
+        """Parity at the depth that was timed (K * T rows): raw accumulator and coherence of a handful of frequencies
+        against complex128 products of the spectra of the LAST step (still in `spec`), and trial 0's transform against a
+        float64 taper + rfft of the detrended float32 trial (mtmfft.py:96-127); criterion of tests/parity.py.  A
+        collective on every rank (the reference sum needs every rank's spectra); the figures are rank 0's."""
         acc = accs[(nstep[0] - 1) % len(accs)]
         spec3 = spec.reshape(-1, F, C)
         tril = torch.tril(torch.ones(C, C, dtype=torch.bool, device="cuda"))
@@ -673,51 +817,82 @@ def main():
             cref = ref.abs() / torch.outer(d, d)
             tolc = 1e-5 * cref + 1e-6 * cref.max()
             worst_coh = max(worst_coh, float(((coh[f].to(torch.float64) - cref).abs() / tolc).max()))
-        # the transform itself: trial 0, float64 taper + rfft of the detrended float32 trial (mtmfft.py:96-127)
         x0 = data[:N].to(torch.float64)
         x0 = x0 - x0.mean(0, keepdim=True)
         ref = torch.fft.rfft(x0[None] * torch.from_numpy(tapers).cuda()[:, :, None], dim=1) * scale      # (K, F, C)
         got = spec3[:K].to(torch.complex128)
         tol = 1e-5 * ref.abs() + 1e-6 * ref.abs().max()
         worst_fft = float(((got - ref).abs() / tol).max())
-        selfcheck = {"max_err_over_tol": max(worst_csd, worst_coh, worst_fft), "csd": worst_csd, "coherence": worst_coh,
-                     "fft": worst_fft, "rows": int(K * T), "frequencies": fsel,
-                     "criterion": "|a-b| <= 1e-5 |b| + 1e-6 max|b| against complex128 / float64 references of the same inputs"}
-        assert selfcheck["max_err_over_tol"] <= 1.0, selfcheck
-    elif dist_on and not blocked and B == T:
-        for f in sorted({0, 1, 2, F // 4, F // 2, F - 3, F - 2, F - 1}):     # the reference sum needs every rank's spectra
-            x = spec.reshape(-1, F, C)[:, f, :].to(torch.complex128)
-            dist.all_reduce(torch.view_as_real(x.T @ x.conj()))
+        return {"max_err_over_tol": max(worst_csd, worst_coh, worst_fft), "csd": worst_csd, "coherence": worst_coh,
+                "fft": worst_fft, "rows": int(K * T * world)}
 
-    # the same analysis with float64 transforms (precision="reference": what `connectivityanalysis` switches to by itself
-    # when the spectra's dynamic range asks for it) - K1 through mtmfft_dec64_kernel, K4 / K5 unchanged; not `value`
-    ref_prec = None
+    for _ in range(args.warmup):
+        step(None)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        coh = step(rec_main)
+    fence()
+    el = time.perf_counter() - t0
+    tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
+    if dist_on:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+
+    # one more analysis, fenced on both sides: the un-pipelined latency of a single analysis (the timed steps above
+    # overlap the collective / coherence tail of step i with the transforms of step i + 1 when N > 1)
+    fence()
+    t1 = time.perf_counter()
+    coh = step(None)
+    fence()
+    latency = time.perf_counter() - t1
+
+    can_check = not blocked and B == T
+    selfcheck = selfcheck_of(coh) if can_check else None
+    if rank == 0 and selfcheck:
+        assert selfcheck["max_err_over_tol"] <= 1.0, selfcheck
+    fallbacks = be.csd_split_fallbacks() if (C == 256 and not blocked) else None
+
+    # ---- the twins of the headline (N = 1 only; never `value`): the same step with
+    #   (a) the cross-spectral products on the FLOAT32 matrix instructions (csd3m_kernel): float32 operands as the reference's
+    #       complex64 products have them (csd.py:98), float32 transforms;
+    #   (b) float64 taper product + transform rounded to complex64 where mtmfft.py:104-127 rounds, AND float32 products:
+    #       the reference's arithmetic end to end ("reference arithmetic");
+    #   (c) float64 transforms with K4h (what precision="reference" runs by default).
+    twins = {}
     if not blocked and not dist_on:
         plan64 = be.FFTPlan(N, N, C, tapers, scale, detrend=0, demean_taper=False, freq_idx=None, output="fourier",
                             keeptapers=True, reference_mean=refmean)
-        if plan64.set_precision(True):
-            step(False, plan64)
+        has64 = plan64.set_precision(True)
+        ntw = max(2, min(args.steps, 5))
+        for key, fp, split in (("f32_products", plan, False), ("reference_arithmetic", plan64 if has64 else None, False),
+                               ("reference_transforms_k4h", plan64 if has64 else None, True)):
+            if fp is None:
+                continue
+            step(None, fp, split)
             fence()
-            n64 = max(2, min(args.steps, 5))
-            ev64 = len(ev_fft)
-            t64 = time.perf_counter()
-            for _ in range(n64):
-                coh64 = step(True, plan64)
+            rec = {"csd": [], "fft": [], "coll": []}
+            tt = time.perf_counter()
+            for _ in range(ntw):
+                coh_t = step(rec, fp, split)
             fence()
-            el64 = time.perf_counter() - t64
-            fft64 = [a.elapsed_time(b) for a, b, _ in ev_fft[ev64:]]
-            del ev_fft[ev64:], ev_csd[ev64:]
-            ref_prec = {"name": "headline under precision='reference': the same %d trials per step with float64 taper product and "
-                                "transform (complex64 rounding where mtmfft.py:104-127 rounds), K4 / K5 unchanged" % T,
-                        "value": T * n64 / el64, "unit": "trials/s", "ms_per_step": 1e3 * el64 / n64, "steps": n64,
-                        "fft_kernel": plan64.kernel_name, "fft_ms_per_trial": sum(fft64) / (T * n64),
-                        "max_abs_diff_to_float32_coherence": float((coh64 - coh).abs().max())}
+            el_t = time.perf_counter() - tt
+            twins[key] = {"value": T * ntw / el_t, "unit": "trials/s", "ms_per_step": 1e3 * el_t / ntw, "steps": ntw,
+                          "fft_kernel": fp.kernel_name, "csd_kernel": be.csd_kernel_name(C, blocked) if split else "spycsd::csd3m_kernel<256, 8> (float32 operands)",
+                          "fft_ms_per_step": sum(a.elapsed_time(b) for a, b, _ in rec["fft"]) / ntw,
+                          "csd_ms_per_step": sum(a.elapsed_time(b) for a, b, _ in rec["csd"]) / ntw,
+                          "selfcheck": selfcheck_of(coh_t) if can_check else None,
+                          "max_abs_diff_to_headline_coherence": float((coh_t - coh).abs().max())}
+            if rank == 0 and twins[key]["selfcheck"]:
+                assert twins[key]["selfcheck"]["max_err_over_tol"] <= 1.0, (key, twins[key]["selfcheck"])
+            del coh_t
         del plan64
 
     if rank == 0:
         assert bool(torch.isfinite(coh).all()), "non-finite coherence"
         diag = coh[:, torch.arange(C), torch.arange(C)]
         assert float((diag - 1).abs().max()) < 1e-5, "coherence diagonal must be 1"
+        ev_csd, ev_fft, ev_coll = rec_main["csd"], rec_main["fft"], rec_main["coll"]
         csd_ms = [a.elapsed_time(b) for a, b, _ in ev_csd]
         fft_ms = [a.elapsed_time(b) for a, b, _ in ev_fft]
         rows = [nb * K for _, _, nb in ev_csd]
@@ -740,7 +915,6 @@ def main():
             rem = F % ncu
             f_main = F - rem if (F > ncu and 0 < rem and 4 * rem <= ncu) else F
             executed = ((rows[0] + 31) // 32) * f_main * 136 * 12 * 16384.0
-            fallbacks = be.csd_split_fallbacks()
         value = world * T * args.steps / el
         coll = {"executed": bool(dist_on), "backend": "RCCL, library communicator (spyhip_allreduce_csd)" if dist_on else None}
         if ev_coll:
@@ -748,104 +922,116 @@ def main():
         traffic, traffic_prov = pmc_traffic(rows[0], F, C)
         avg_ms = float(np.mean(csd_ms))
         hbm_bytes = rows[0] * F * C * 8 + (2 * F * nsub * 256 * 8 if (is3m or k4h) else 2 * F * (((C + 31) // 32) * ((C + 31) // 32 + 1) // 2) * 1024 * 8)
+        src = (traffic_prov.get("from_profile") or "none") + ((" (" + traffic_prov["refused"] + ")") if traffic_prov.get("refused") else "")
         if k4h:
             ex_tf = executed / (avg_ms * 1e-3) / 1e12
             roofline = {
-                "bound": "mfma",
+                "bound": "mfma", "kernel": "spycsd::csdh_kernel", "achieved": ex_tf, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+                "frac": ex_tf / PEAK_MFMA_F16_TFLOPS, "avg_launch_ms": avg_ms,
+                "executed_mfma_flop_per_launch": executed, "algorithmic_flop_per_launch": flops[0],
+                "algorithmic_TFLOPs": achieved, "fp32_equivalent_frac": achieved / PEAK_MFMA_F32_TFLOPS,
+                "algorithmic_hbm_bytes_per_launch": hbm_bytes, "hbm_GBps": hbm_bytes / (avg_ms * 1e-3) / 1e9,
+                "traffic": traffic, "traffic_source": src, "frequencies_left_to_float32_kernels": fallbacks,
+            }
+            roofline_notes = {
                 "kernel": "spycsd::csdh_kernel (+ its float32 stand-in on flagged frequencies, the row-split <1, 1> tail and its reduction)",
-                # what the half-precision matrix pipe executes: 3 fp16 products per real product, 4 real products per complex one
-                "achieved": ex_tf,
-                "peak": PEAK_MFMA_F16_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": ex_tf / PEAK_MFMA_F16_TFLOPS,
-                "executed_mfma_flop_per_launch": executed,
-                # the same launch in the units of SURVEY 8(d): 8 flop per complex multiply-accumulate on the Hermitian-
-                # minimal triangle, against the float32 matrix peak the survey priced K4 with
-                "algorithmic_TFLOPs": achieved,
-                "flop_per_launch": flops[0],
-                "fp32_equivalent_frac": achieved / PEAK_MFMA_F32_TFLOPS,
-                "fp32_peak": PEAK_MFMA_F32_TFLOPS,
-                "frequencies_left_to_float32_kernels": fallbacks,
                 "note": "achieved = executed fp16 matrix flops per launch / avg_launch_ms: ceil(rows / 32) chunks x frequencies of "
                         "the full rounds x 136 sub-tiles x 12 v_mfma_f32_16x16x32_f16 x 16384 flop (= SQ_INSTS_VALU_MFMA_F16 / "
                         "SQ_INSTS_MFMA x 16384 of profiles/%s_pmc_headline.txt); peak = dense FP16 / BF16 MFMA.  The chip does not "
                         "hold 2.4 GHz under this load: GRBM_GUI_ACTIVE / duration in the same file gives the clock the fraction "
-                        "should also be read against." % PROFILE_ROUND,
+                        "should also be read against.  algorithmic_TFLOPs / fp32_equivalent_frac: the same launch in the units of "
+                        "SURVEY 8(d) (8 flop per complex multiply-accumulate on the Hermitian-minimal triangle) against the float32 "
+                        "matrix peak the survey priced K4 with." % PROFILE_ROUND,
                 "kernel_stats": "profiles/%s_bench_final_kernel_stats.csv (Name = spycsd::csdh_kernel; AverageNs + the tail rows must agree with avg_launch_ms)" % PROFILE_ROUND,
-                "avg_launch_ms": avg_ms,
-                "algorithmic_hbm_bytes_per_launch": hbm_bytes,
-                "hbm_GBps": hbm_bytes / (avg_ms * 1e-3) / 1e9,
-                "hbm_frac": hbm_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_prov,
+                "fp32_peak": PEAK_MFMA_F32_TFLOPS, "hbm_frac": hbm_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic_source": traffic_prov,
             }
         else:
+            ex = ((executed / flops[0]) if executed else 1.0) * achieved
             roofline = {
-                "bound": "mfma",
-                "kernel": be.csd_kernel_name(C, blocked) + " (+ row-split <1, 1> tail and its reduction)",
-                "achieved": achieved,
-                "peak": PEAK_MFMA_F32_TFLOPS,
-                "unit": "TFLOP/s",
-                # frac = what the matrix pipe really does: flops the kernel EXECUTES per launch / duration / peak (<= 1);
-                # algorithmic_frac = SURVEY 8(d)'s credited flops (8 per complex multiply-accumulate on the Hermitian-
-                # minimal triangle) / duration / peak - above frac because the 3-multiplication product executes 3/4 of them
-                "frac": ((executed / flops[0]) if executed else 1.0) * achieved / PEAK_MFMA_F32_TFLOPS,
-                "algorithmic_frac": achieved / PEAK_MFMA_F32_TFLOPS,
-                "flop_per_launch": flops[0],
-                "executed_mfma_flop_per_launch": executed,
-                "executed_TFLOPs": ((executed / flops[0]) if executed else 1.0) * achieved,
-                "note": "achieved = algorithmic flops (8 per complex multiply-accumulate on the Hermitian-minimal triangle, "
-                        "SURVEY 8d) / avg_launch_ms; executed_mfma_flop_per_launch = ceil(rows / 4) x F x sub-tiles x 3 MFMAs x "
-                        "2048 flop; frac = executed / avg_launch_ms / peak",
-                "avg_launch_ms": avg_ms,
-                "algorithmic_hbm_bytes_per_launch": hbm_bytes,
-                "traffic": traffic,
-                "traffic_source": traffic_prov,
+                "bound": "mfma", "kernel": be.csd_kernel_name(C, blocked), "achieved": ex, "peak": PEAK_MFMA_F32_TFLOPS,
+                "unit": "TFLOP/s", "frac": ex / PEAK_MFMA_F32_TFLOPS, "avg_launch_ms": avg_ms,
+                "executed_mfma_flop_per_launch": executed, "algorithmic_flop_per_launch": flops[0],
+                "algorithmic_TFLOPs": achieved, "algorithmic_frac": achieved / PEAK_MFMA_F32_TFLOPS,
+                "algorithmic_hbm_bytes_per_launch": hbm_bytes, "traffic": traffic, "traffic_source": src,
             }
+            roofline_notes = {
+                "note": "achieved = flops the kernel EXECUTES per launch (ceil(rows / 4) x F x sub-tiles x 3 MFMAs x 2048 flop) / "
+                        "avg_launch_ms; algorithmic_* = SURVEY 8(d)'s credited flops (8 per complex multiply-accumulate on the "
+                        "Hermitian-minimal triangle)", "traffic_source": traffic_prov}
+        # the whole step against the bytes SURVEY 8(d) counts for it (input once, accumulator once) and against what the
+        # two-kernel formulation moves (spectra written by K1 and read by K4)
+        step_ms = 1e3 * el / args.steps
+        alg_step = T * N * C * 4 + F * C * C * 8
+        form_step = T * (N * C * 4 + 2 * K * F * C * 8) + 2 * F * C * C * 8
+        step_info = {"fft_ms": sum(fft_ms) / args.steps, "csd_ms": sum(csd_ms) / args.steps,
+                     "fft_stream_GBps": fft_bytes / (sum(fft_ms) * 1e-3) / 1e9,
+                     "algorithmic_GB": alg_step / 1e9, "formulation_GB": form_step / 1e9,
+                     "hbm_frac_of_formulation": form_step / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        if coll.get("pack_allreduce_unpack_ms"):
+            step_info["allreduce_ms"] = coll["pack_allreduce_unpack_ms"]
+            step_info["allreduce_GB"] = coll["bytes"] / 1e9
         line = {
             "metric": "trials/sec for mtmfft+coherence (256 ch x 4096 samples, 7 DPSS tapers, full CSD)",
             "value": value,
             "unit": "trials/s",
-            # whole step against SURVEY 8(d)'s bound of 41.7 k trials/s per GPU (K4 priced at the FLOAT32 matrix peak: the
-            # half-precision formulation of K4 is not bound by it) and against what binds the path now: the 4.19 MB in +
-            # 29.4 MB of spectra written by K1 and read by K4 per trial at the HBM peak
-            "headline_frac": value / (world * HEADLINE_BOUND_TRIALS_PER_S),
-            "headline_hbm_frac": value / (world * PEAK_HBM_GBS * 1e9 / (N * C * 4 + 2 * K * F * C * 8)),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps,
-            "analysis_latency_ms": 1e3 * latency,
-            "selfcheck": selfcheck,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
-            "dtype_note": "float32 transforms (the reference's float64 ones: secondary[0]); the cross-spectral products take "
-                          "each float32 operand as an exact-to-22-bits fp16 (hi, lo) pair on the fp16 matrix cores with float32 "
-                          "accumulation (hi hi' + hi lo' + lo hi'; dropped term <= 2^-22), frequencies whose range a pair cannot "
-                          "hold are redone by the float32 kernel; `selfcheck` = this launch against complex128 under the parity criterion",
+            "dtype": "f32 transforms; CSD operands fp16 hi+lo (22-bit), f32 accumulate" if k4h else "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: connectivityanalysis method='coh' on AR(2) AnalogData, "
-                            f"{C} ch x {N} samp x {T} trials per GPU, tapsmofrq=1 Hz (NW={NW:.3f}, 7 tapers), "
-                            "polyremoval=0, output='abs', inputs resident in HBM",
-                "trials_per_gpu": T, "channels": C, "samples": N, "tapers": K, "freqs": F, "batch": B, "handover_layout": "blocked" if blocked else "standard",
-                "channel_samples_per_s": value * N * C,
-                "fft_kernel": plan.kernel_name + (" (+ seq_mean_kernel pre-pass)" if refmean else ""),
-                "fft_ms_per_trial": sum(fft_ms) / (T * args.steps),
-                "fft_stream_GBps": fft_bytes / (sum(fft_ms) * 1e-3) / 1e9,
-                "csd_ms_per_trial": sum(csd_ms) / (T * args.steps),
-                "collective": coll,
+                "workload": "BASELINE configs[2]: connectivityanalysis method='coh', AR(2) AnalogData, "
+                            f"{C} ch x {N} samp x {T} trials per GPU, tapsmofrq=1 Hz ({K} DPSS tapers), polyremoval=0, "
+                            "output='abs', inputs resident in HBM",
+                "trials_per_gpu": T, "channels": C, "samples": N, "tapers": K, "freqs": F, "batch": B,
+                "fft_kernel": plan.kernel_name + (" + seq_mean_kernel" if refmean else ""),
+                "collective": {"executed": bool(dist_on), "bytes": coll.get("bytes"), "ms": coll.get("pack_allreduce_unpack_ms")},
             },
             "roofline": roofline,
+            "step": step_info,
+            "analysis_latency_ms": 1e3 * latency,
+            "selfcheck": selfcheck,
         }
+        detail = {"line": None, "roofline_notes": roofline_notes, "collective": coll, "twins": twins,
+                  "selfcheck_criterion": "|a-b| <= 1e-5 |b| + 1e-6 max|b| against complex128 / float64 references of the same inputs; frequencies %s" % fsel,
+                  "headline_frac_vs_survey_bound": value / (world * HEADLINE_BOUND_TRIALS_PER_S),
+                  "channel_samples_per_s": value * N * C,
+                  "dtype_note": "float32 transforms (the reference's float64 ones: twins.reference_*); the cross-spectral products take "
+                                "each float32 operand as an exact-to-22-bits fp16 (hi, lo) pair on the fp16 matrix cores with float32 "
+                                "accumulation (hi hi' + hi lo' + lo hi'; dropped term <= 2^-22), frequencies whose range a pair cannot "
+                                "hold are redone by the float32 kernel; `selfcheck` = this launch against complex128 under the parity criterion"}
+        if twins:
+            # the same step at the reference's operand precision, beside `value` (never instead of it)
+            if "f32_products" in twins:
+                line["value_f32_products"] = twins["f32_products"]["value"]
+            if "reference_arithmetic" in twins:
+                line["value_reference_arithmetic"] = twins["reference_arithmetic"]["value"]
+            line["selfcheck_twins"] = {k: (v["selfcheck"] or {}).get("max_err_over_tol") for k, v in twins.items()}
         if world == 1 and not args.no_secondary:
             del spec
-            line["secondary"] = ([ref_prec] if ref_prec else []) + secondary(torch, be, synthdata, data, N, C, T, refmean)
+            sec = secondary(torch, be, synthdata, data, N, C, T, refmean)
+            detail["secondary"] = sec
+            line["secondary"] = compact_secondary(sec)
+            if "reference_transforms_k4h" in twins:
+                line["secondary"]["ref_transforms_k4h"] = {"trials_per_s": twins["reference_transforms_k4h"]["value"]}
+            fe = line["secondary"].get("front_end")
+            if fe:
+                line["value_with_host_copy"] = fe["with_host_copy"]
+                line["value_front_end"] = fe["warm"]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(C, N)
-        print(json.dumps(line), flush=True)
+            cb = cpu_baseline(C, N)
+            detail["cpu_baseline"] = cb
+            line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                    "sample": "1 trial of %d ch x %d samp, cross_spectra_cF as csd.py:94-102, one core" % (C, N),
+                                    "cpu_model": cb["cpu_model"], "best_cpu_trials_per_s": cb["best_cpu_trials_per_s"],
+                                    "best_cpu_cores": cb["best_cpu_cores"]}
+        line = _short(line, 5)
+        detail["line"] = dict(line)
+        emit(line, detail)
     if dist_on:
         torch.cuda.synchronize()
         be.shutdown_library_comm()

@@ -94,16 +94,64 @@ def _host_copy(dst, src):
         f.result()
 
 
+_RESULT_PIN_CAP = 8 << 30       # page-locked bytes results may hold (live arrays + free blocks); beyond: the staged path
+_RESULT_PIN_GRAIN = 64 << 20
+_result_free = {}               # rounded size -> [pinned uint8 tensors]
+_result_bytes = [0]             # page-locked bytes of the pool, live and free
+_result_lock = None
+
+
+def _result_block(nbytes):
+    """A page-locked block for a large result, from the free list or fresh (cudaHostAlloc of 0.5 GB costs ~0.1 s once; the
+    block returns to the list when the array the caller got - and every view of it - is gone).  None when the pool is at
+    its cap."""
+    import threading
+    global _result_lock
+    if _result_lock is None:
+        _result_lock = threading.Lock()
+    size = (nbytes + _RESULT_PIN_GRAIN - 1) // _RESULT_PIN_GRAIN * _RESULT_PIN_GRAIN
+    with _result_lock:
+        lst = _result_free.get(size)
+        if lst:
+            return lst.pop()
+        if _result_bytes[0] + size > _RESULT_PIN_CAP:
+            # free blocks of other sizes are the first to go
+            for k in list(_result_free):
+                while _result_free[k] and _result_bytes[0] + size > _RESULT_PIN_CAP:
+                    _result_free[k].pop()
+                    _result_bytes[0] -= k
+            if _result_bytes[0] + size > _RESULT_PIN_CAP:
+                return None
+        _result_bytes[0] += size
+    return torch.empty(size, dtype=torch.uint8, pin_memory=True)
+
+
+def _result_release(block):
+    with _result_lock:
+        _result_free.setdefault(block.numel(), []).append(block)
+
+
 def to_host(t):
-    """Device tensor -> NumPy array in ordinary pageable memory.  Large results are staged through ONE reusable
-    pinned buffer of 256 MiB per dtype family (pageable D2H copies run at ~6 GB/s, pinned ones at ~57 GB/s on this
-    platform) and copied out chunk by chunk, so a result the user holds on to never keeps page-locked memory
-    alive; small results take the plain path."""
+    """Device tensor -> NumPy array.  Large results land in ONE asynchronous copy in a page-locked block of the result pool
+    (the bus gives ~57 GB/s to pinned memory, ~6 GB/s to pageable memory) and the array handed out IS that block: no
+    second pass through host memory (rounds 2-5 staged through a pinned pair and copied out into pageable memory, 26 GB/s
+    end to end for the 0.54 GB of a 256-channel coherence).  The block goes back to the pool when the array and all its
+    views are garbage; the pool holds at most 8 GiB, beyond which results take the staged path; small results take the
+    plain path."""
     nbytes = t.numel() * t.element_size()
     if not t.is_cuda or nbytes < (8 << 20):
         return t.cpu().numpy()
     t = t.contiguous()
     flat = t.view(-1).view(torch.uint8) if not t.is_complex() else torch.view_as_real(t).view(-1).view(torch.uint8)
+    block = _result_block(nbytes)
+    if block is not None:
+        import weakref
+        block[:nbytes].copy_(flat, non_blocking=True)
+        root = block.numpy()                         # every view handed out keeps `root` alive through .base
+        weakref.finalize(root, _result_release, block)
+        out = root[:nbytes].view(_NP_DTYPE[t.dtype]).reshape(tuple(t.shape))
+        torch.cuda.current_stream(t.device).synchronize()
+        return out
     out = np.empty(t.shape, dtype=_NP_DTYPE[t.dtype])
     dst = out.reshape(-1).view(np.uint8)
     stage = _staging()
@@ -283,6 +331,11 @@ def release_buffers():
     Exposed as `syncopy_amd.release_device_buffers()`."""
     _handover.clear()
     _pin.clear()
+    if _result_lock is not None:
+        with _result_lock:
+            for k, lst in _result_free.items():
+                _result_bytes[0] -= k * len(lst)
+            _result_free.clear()
     for ctx in _contexts.values():
         ctx.lib.spyhip_ctx_trim(ctx.handle)
     if torch.cuda.is_available():
@@ -507,13 +560,14 @@ class csd_phase_exact:
         return False
 
 
-def csd_accumulate(spec, acc, blocked=False, absmax=None):
+def csd_accumulate(spec, acc, blocked=False, absmax=None, split=True):
     """acc[f,i,j] += sum_r spec[r,f,i] conj(spec[r,f,j]) on the lower triangle (MFMA).
     spec: (..., F, C) complex64 (leading dims flattened to rows), or with blocked=True the hand-over layout
     (rows, ceil(C/4), F, 4) of FFTPlan.set_blocked; acc: (F, C, C) complex64.
     256 channels in the standard layout run on the half-precision matrix cores with split operands
     (spyhip_csd_accumulate_split); `absmax`: (256,) float32 bound of |re|, |im| per channel as FFTPlan.execute(...,
-    absmax=) leaves it, or None: the library takes its own pass over the spectra first."""
+    absmax=) leaves it, or None: the library takes its own pass over the spectra first.  `split=False` keeps 256 channels
+    on the float32 matrix instructions (spyhip_csd_accumulate: float32 operands, the reference's operand precision)."""
     assert spec.is_cuda and spec.dtype == torch.complex64 and spec.is_contiguous()
     assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous()
     ctx = context(spec.device)
@@ -528,7 +582,7 @@ def csd_accumulate(spec, acc, blocked=False, absmax=None):
     F, Cn = spec.shape[-2], spec.shape[-1]
     assert tuple(acc.shape) == (F, Cn, Cn), (tuple(acc.shape), (F, Cn, Cn))
     nrows = spec.numel() // (F * Cn)
-    if Cn == 256 and nrows > 0:
+    if Cn == 256 and nrows > 0 and split:
         if absmax is not None:
             assert absmax.is_cuda and absmax.dtype == torch.float32 and absmax.numel() == 256 and absmax.is_contiguous()
         check(ctx.lib.spyhip_csd_accumulate_split(ctx.handle, _ptr(spec), nrows, F, Cn, _ptr(acc), _ptr(absmax)),

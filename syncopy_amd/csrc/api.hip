@@ -48,6 +48,7 @@ extern "C" int spyhip_ctx_destroy(spyhip_ctx* ctx) {
         if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
         if (ctx->arena) (void)hipFree(ctx->arena);
         if (ctx->k4h_buf) (void)hipFree(ctx->k4h_buf);
+        if (ctx->k4h_done) (void)hipEventDestroy(ctx->k4h_done);
     }
     delete ctx;
     return 0;

@@ -121,6 +121,7 @@ extern "C" int spyhip_csd_set_phase_exact(spyhip_ctx* ctx, int on) {
 
 extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
                                      void* acc_d) {
+    if (ctx) ctx->k4h_nf = 0;
     return csd_accumulate_impl(ctx, spec_d, nrows, nfreq, nchan, acc_d, 0);
 }
 
@@ -129,10 +130,14 @@ extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_
 extern "C" int spyhip_csd_accumulate_split(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
                                            void* acc_d, const float* absmax_d) {
     static const bool env_f32 = std::getenv("SPYHIP_CSD_F32") != nullptr;
-    if (!ctx || nchan != 256 || nrows < 1 || env_f32)
+    if (!ctx || nchan != 256 || nrows < 1 || env_f32) {
+        if (ctx) ctx->k4h_nf = 0;           // spyhip_csd_split_fallbacks reports THIS call: nothing went to the half-precision kernel
         return csd_accumulate_impl(ctx, spec_d, nrows, nfreq, nchan, acc_d, 0);
+    }
     if (!spec_d || !acc_d || nfreq < 1) { spy::set_error("csd_accumulate_split: null argument / bad shape"); return -1; }
     SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->k4h_done) SPY_HIP_CHECK(hipEventCreateWithFlags(&ctx->k4h_done, hipEventDisableTiming));
+    else SPY_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->k4h_done, 0));      // the previous call's flag readers are through
     const size_t need = (size_t)nfreq * sizeof(int) + 256 * sizeof(float);
     if (need > ctx->k4h_bytes) {
         if (ctx->k4h_buf) { SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->k4h_buf); ctx->k4h_buf = nullptr; ctx->k4h_bytes = 0; }
@@ -154,6 +159,7 @@ extern "C" int spyhip_csd_accumulate_split(spyhip_ctx* ctx, const void* spec_d, 
     int rc = spycsd::csdh_run(ctx->stream, spec, nrows, nfreq, reinterpret_cast<float2*>(acc_d), absmax_d, flags, f_main,
                               ctx->csd_phase_exact != 0);
     ctx->k4h_nf = f_main;
+    if (!rc) SPY_HIP_CHECK(hipEventRecord(ctx->k4h_done, ctx->stream));         // (behind csdh_kernel and its only_flagged stand-in)
     if (rc || f_main == nfreq) return rc;
     CsdArgs a{};
     a.spec = spec;

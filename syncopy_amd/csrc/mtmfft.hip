@@ -699,13 +699,10 @@ extern "C" int spyhip_fft_plan_set_precision(spyhip_fft_plan* p, int reference) 
         std::snprintf(buf, sizeof buf, "mtmfft_f64_any_kernel<%d, %s> N=%d (Bluestein, M = %d)",
                       p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true",
                       p->nfft, p->f64_blue);
-    else if (p->f64_any)
+    else
         std::snprintf(buf, sizeof buf, "mtmfft_f64_any_kernel<%d, %s> N=%d",
                       p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true",
                       p->nfft);
-    else
-        std::snprintf(buf, sizeof buf, "mtmfft_f64_kernel<%d, %d, %s>", p->log2n,
-                      p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), p->keeptapers ? "false" : "true");
     p->kernel_name = buf;
     return 0;
 }
@@ -864,7 +861,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             spy::set_error("fft_exec: no reference-precision schedule for nfft = %d", p->nfft);
             return -1;
         }
-        if (p->f64_any) {
+        {   // f64_any (spyhip_fft_plan_set_precision: the complement of f64_half / f64_dl / f64_dec)
             // two complex128 work arrays (length nfft, or the Bluestein length M) per workgroup: in LDS while they fit
             // (leaving room for the static reduction scratch), else in global memory, launches of at most 1 GiB of them
             const size_t wlen = p->f64_blue ? (size_t)p->f64_blue : (size_t)p->nfft;
@@ -890,8 +887,6 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             return spyfft::f64_any_launch(p->ctx->stream, fa, grid, p->f64_chunk,
                                           p->output == SPYHIP_OUT_FOURIER ? 2 : (p->output == SPYHIP_OUT_POW ? 0 : 1), !p->keeptapers);
         }
-        spy::set_error("fft_exec: no reference-precision kernel for nfft = %d", p->nfft);
-        return -1;
     }
     if (p->half) {
         const bool mean = !p->keeptapers;
@@ -941,13 +936,7 @@ extern "C" int spyhip_fft_exec(spyhip_fft_plan* p, const float* data_d, int64_t 
             }
             return 0;
         }
-        if (p->nfft == 16384) {
-            // the power-of-two engine in HALF form (53.6 us/trial at 256 channels x 7 tapers; the 8192-point compile-time
-            // schedule on pairs: 59.3)
-            MtmArgs b = a;
-            b.tapers = p->tapers_half.p;          // (the power-of-two kernel expects scale / 2 folded into the window)
-            return spyfft::quad_half_launch(p->ctx->stream, b, npairs, outk, mean);
-        }
+        // (up to 10240 samples: 5000 and 10000 in HALF form, rows gathered straight from the trial queue)
         if ((rc = spyfft::dec_launch_half_a(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;
         if ((rc = spyfft::dec_launch_half_b(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;
         if ((rc = spyfft::dec_launch_half_c(p->ctx->stream, a, p->nfft, npairs, outk, mean)) != -100) return rc;

@@ -26,6 +26,8 @@ struct spyhip_ctx {
     void* k4h_buf = nullptr;        // spyhip_csd_accumulate_split: 256 floats (the library's own range pass) + one flag per frequency
     size_t k4h_bytes = 0;
     int k4h_nf = 0;                 // frequencies the half-precision kernel was launched on in the last call
+    hipEvent_t k4h_done = nullptr;  // recorded behind the last reader of k4h_buf: the next call's stream waits on it, so two
+                                    // calls issued on different streams cannot trade flags (the buffer is per context)
     int csd_phase_exact = 0;        // spyhip_csd_set_phase_exact: 4-multiplication K4 kernels only (csd.hip)
     int granger_iters = 0;          // Wilson iterations of the last spyhip_granger call on this context
     int num_cu = 256;

@@ -150,6 +150,9 @@ def selection_hides_peak(dev_data, rows, chan_idx, nfft, taper, taper_opt, polyr
     return bool(np.sqrt(ratio) > 3.0)
 
 
+_SOFT_FALLBACK = "float32 (no float64 kernel for this length)"
+
+
 def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_taper, freq_idx, output, keeptapers,
              device, blocked=False, whole_trials=True, float32_frames=False):
     """Cached FFTPlan; `blocked` asks for the channel-blocked hand-over layout of the CSD path (the plan's
@@ -165,6 +168,11 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
            float(scale), detrend, bool(demean_taper), fkey, output, bool(keeptapers), str(device), bool(blocked),
            bool(whole_trials), bool(float32_frames), plan_precision())
     plan = _cache_hit(_plan_cache, key)
+    if plan is None and plan_precision() == "reference" and _precision[-1] != "reference":
+        # a soft request that fell back to float32 earlier left its plan under the fall-back key (below)
+        plan = _cache_hit(_plan_cache, key[:-1] + (_SOFT_FALLBACK,))
+        if plan is not None:
+            return plan
     if plan is None:
         tp = taper_table(taper, nsig, nnorm, taper_opt)
         plan = backend.FFTPlan(nsig, nfft, nchan, tp, scale, detrend, demean_taper, freq_idx, output,
@@ -176,8 +184,9 @@ def get_plan(nsig, nfft, nchan, taper, taper_opt, nnorm, scale, detrend, demean_
                     raise PrecisionUnavailable("a transform length up to 2^20 for float64 transforms", varname="precision",
                                                actual=f"nfft = {int(nfft)}")
                 # the soft request ("reference?") falls back to float32: that plan must not sit under the "reference" key,
-                # where a later explicit precision="reference" would take it for a float64 plan
-                key = key[:-1] + ("float32",)
+                # where a later explicit precision="reference" would take it for a float64 plan - nor under "float32",
+                # where it would be found but never looked for by the next soft request (a plan rebuilt per call)
+                key = key[:-1] + (_SOFT_FALLBACK,)
                 if blocked:
                     plan.set_blocked(True)
         elif blocked:
