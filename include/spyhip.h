@@ -344,6 +344,12 @@ int spyhip_cwt_plan_destroy(spyhip_cwt_plan* plan);
  * precision="reference" and the per-trial route, where the copies cost as much).  0 (default): the float32 overlap-save
  * kernels (~5e-7 of a trial's largest coefficient). */
 int spyhip_cwt_plan_set_precision(spyhip_cwt_plan* plan, int reference);
+/* on = 1 (default): scales whose kernel support fits 1024- / 2048-point blocks leave their transform kernel in the output's
+ * own (segment, time, scale, channel) layout (cwt2d_kernel: 16 / 8 channels per workgroup, 64- / 32-byte runs); trial sums
+ * (accumulate = 2) are read-modify-writes of tiles a workgroup owns.  0: every scale through the time-contiguous staging
+ * buffer and the transposition pass (rounds 1-5; kept for A/B measurements and as the cross-check of the direct kernels).
+ * Replaces the (nScales, N, C) array the reference writes once per trial: specest/wavelets/transform.py:88-108. */
+int spyhip_cwt_plan_set_direct(spyhip_cwt_plan* plan, int on);
 /* seg_start_d: row of sample 0 of each pre-selected signal; trial_lo_d/trial_hi_d: rows of the
  * whole trial (detrending range); accumulate: 0 = store, 1 = out_d[b] += result of segment b,
  * 2 = out_d[0] += sum over the nseg segments (trial averaging: one read-modify-write of the output per chunk

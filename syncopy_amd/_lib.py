@@ -43,6 +43,7 @@ SIGNATURES = {
     "spyhip_allreduce": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "spyhip_fft_plan_set_precision": (C.c_int, [vp, C.c_int]),
     "spyhip_cwt_plan_set_precision": (C.c_int, [vp, C.c_int]),
+    "spyhip_cwt_plan_set_direct": (C.c_int, [vp, C.c_int]),
     "spyhip_fft_plan_set_reference_mean": (C.c_int, [vp, C.c_int]),
     "spyhip_fft_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, C.c_double, C.c_int,
                                          C.c_int, c_i32p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),

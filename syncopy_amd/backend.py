@@ -505,6 +505,11 @@ class CWTPlan:
         (spyhip_cwt_plan_set_precision).  Returns False if this plan cannot."""
         return self.ctx.lib.spyhip_cwt_plan_set_precision(self.handle, int(bool(reference))) == 0
 
+    def set_direct(self, on=True):
+        """Scales on short blocks written by their transform kernel in the output layout (default) or, `on=False`, every
+        scale through the staging buffer and the transposition pass (spyhip_cwt_plan_set_direct)."""
+        check(self.ctx.lib.spyhip_cwt_plan_set_direct(self.handle, int(bool(on))), "spyhip_cwt_plan_set_direct")
+
     def out_shape(self, nseg):
         return (nseg, self.ntime_out, self.nscales, self.nchan)
 

@@ -2,6 +2,7 @@
 // overlap-save CWT kernel (spyhip_cwt_plan_create / spyhip_cwt_exec).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 
 #include "spy_common.h"
@@ -16,8 +17,11 @@ using spyfft::CwtArgs;
 struct CwtGroup {
     int log2n = 0, G = 1, V = 0, halo = 0, nblocks = 0, nscales = 0;
     int long_idx = -1, piece = 0;  // long_idx >= 0: piece `piece` of the long_idx-th scale whose kernel exceeds a block
+    bool direct = false;           // 1024- and 2048-point blocks: cwt2d_kernel writes the output layout itself (no staging)
     spy::DevBuf<float2> tw, hspec;
     spy::DevBuf<int> cshift, sidx;
+    spy::DevBuf<int> sidx_stage;   // with direct groups: scale s of this launch -> row of the (compact) staging buffer
+    std::vector<int> scale_ids;    // host copy: the plan's scale index of every scale of this launch
 };
 
 struct spyhip_cwt_plan {
@@ -25,11 +29,18 @@ struct spyhip_cwt_plan {
     int nsig = 0, nchan = 0, nscales = 0, detrend = -1, output = 0, ntime_out = 0;
     std::vector<CwtGroup*> groups;
     bool identity_time = true;
-    spy::DevBuf<int> tpos;
+    spy::DevBuf<int> tpos, tfloor;
     spy::DevBuf<double> trend, trend_part;
     size_t trend_cap = 0;
     spy::DevBuf<char> stage;      // time-contiguous staging of one chunk of segments
+    size_t stage_cap = 0;         // its size in bytes
     int chunk = 0;                // segments per chunk the staging buffer holds
+    bool direct = true;           // spyhip_cwt_plan_set_direct: groups flagged `direct` skip the staging buffer
+    bool direct_ok = true;        // what plan creation decided (slots increasing, 32-bit row offsets)
+    std::vector<int> staged;      // scales that still go through it (blocks of 4096 points and more), in staging-row order
+    spy::DevBuf<int> smap;        // staging row -> scale index (device copy of `staged`)
+    spy::DevBuf<int> lidx_stage;  // long scale -> staging row
+
     std::vector<int> long_scales; // scales whose trimmed kernel has more than CWT_PIECE - 1 taps: run piece by piece
     spy::DevBuf<int> lidx;        // their scale indices on the device
     spy::DevBuf<float2> stage_long;   // (chunk, long scale, channel, time) complex sums of the pieces (real outputs)
@@ -62,10 +73,10 @@ int launch_cwt(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
     return 0;
 }
 
-template <int LOG2N, int G, int OUTK>
+template <int LOG2N, int G, int OUTK, bool PAIRT>
 int launch_cwt2(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
     using C = spyfft::Cfg2<LOG2N, G>;
-    auto kern = spyfft::cwt2_kernel<LOG2N, G, OUTK>;
+    auto kern = spyfft::cwt2_kernel<LOG2N, G, OUTK, PAIRT>;
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
@@ -74,11 +85,36 @@ int launch_cwt2(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
 }
 
 template <int LOG2N, int G>
-int launch_cwt2_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
-    if (p->output == SPYHIP_OUT_FOURIER) return launch_cwt2<LOG2N, G, 2>(p, a, grid);
-    if (p->output == SPYHIP_OUT_POW) return launch_cwt2<LOG2N, G, 0>(p, a, grid);
-    return launch_cwt2<LOG2N, G, 1>(p, a, grid);
+int launch_cwt2_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid, bool pairt = false) {
+    if (pairt) {
+        if (p->output == SPYHIP_OUT_FOURIER) return launch_cwt2<LOG2N, G, 2, true>(p, a, grid);
+        if (p->output == SPYHIP_OUT_POW) return launch_cwt2<LOG2N, G, 0, true>(p, a, grid);
+        return launch_cwt2<LOG2N, G, 1, true>(p, a, grid);
+    }
+    if (p->output == SPYHIP_OUT_FOURIER) return launch_cwt2<LOG2N, G, 2, false>(p, a, grid);
+    if (p->output == SPYHIP_OUT_POW) return launch_cwt2<LOG2N, G, 0, false>(p, a, grid);
+    return launch_cwt2<LOG2N, G, 1, false>(p, a, grid);
 }
+
+template <int LOG2N, int G, int OUTK>
+int launch_cwt2d(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
+    using C = spyfft::Cfg2<LOG2N, G>;
+    auto kern = spyfft::cwt2d_kernel<LOG2N, G, OUTK>;
+    SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, p->ctx->stream, a);
+    SPY_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int LOG2N, int G>
+int launch_cwt2d_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
+    if (p->output == SPYHIP_OUT_FOURIER) return launch_cwt2d<LOG2N, G, 2>(p, a, grid);
+    if (p->output == SPYHIP_OUT_POW) return launch_cwt2d<LOG2N, G, 0>(p, a, grid);
+    return launch_cwt2d<LOG2N, G, 1>(p, a, grid);
+}
+
+constexpr int CWT_DIRECT_G10 = 8, CWT_DIRECT_G11 = 4;     // channel pairs per workgroup of the direct kernels
 
 template <int LOG2N, int G>
 int launch_cwt_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
@@ -233,6 +269,8 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
         // channel PAIRS per workgroup of the packed kernel (<= 2^13); channels per workgroup of the 2^14 kernel
         g->G = g->log2n == 10 ? 4 : (g->log2n == 11 ? 2 : 1);
         g->V = V; g->halo = halo; g->nblocks = (nsig + V - 1) / V; g->nscales = (int)ids.size();
+        g->direct = g->log2n <= 11;
+        g->scale_ids = ids;
         std::vector<float2> tw(NB), hs(ids.size() * (size_t)NB);
         for (int m = 0; m < NB; ++m) {
             const double ang = -2.0 * PI * m / NB;
@@ -287,6 +325,38 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
         }
     }
     if (!p->long_scales.empty() && p->lidx.upload(p->long_scales, ctx->stream)) { delete p; return -2; }
+    // compact staging rows for the scales the direct kernels do not serve
+    {
+        std::vector<int> row(nscales, -1);
+        auto stage_row = [&](int sc) {
+            if (row[sc] < 0) { row[sc] = (int)p->staged.size(); p->staged.push_back(sc); }
+            return row[sc];
+        };
+        std::vector<std::vector<int>> ids(p->groups.size());
+        for (size_t gi = 0; gi < p->groups.size(); ++gi) {
+            CwtGroup* g = p->groups[gi];
+            if (g->direct) continue;
+            if (g->long_idx >= 0) {
+                const int sc = p->long_scales[g->long_idx];
+                // complex outputs: the pieces add up in the scale's own staging row; real ones in the side buffer (row = long index)
+                ids[gi] = {output == SPYHIP_OUT_FOURIER ? stage_row(sc) : g->long_idx};
+                if (output != SPYHIP_OUT_FOURIER) stage_row(sc);
+            }
+        }
+        for (size_t gi = 0; gi < p->groups.size(); ++gi) {
+            CwtGroup* g = p->groups[gi];
+            if (g->direct || g->long_idx >= 0) continue;
+            for (int sc : g->scale_ids) ids[gi].push_back(stage_row(sc));
+        }
+        for (size_t gi = 0; gi < p->groups.size(); ++gi)
+            if (!ids[gi].empty() && p->groups[gi]->sidx_stage.upload(ids[gi], ctx->stream)) { delete p; return -2; }
+        if (!p->staged.empty() && p->smap.upload(p->staged, ctx->stream)) { delete p; return -2; }
+        if (!p->long_scales.empty()) {
+            std::vector<int> lrow;
+            for (int sc : p->long_scales) lrow.push_back(row[sc]);
+            if (p->lidx_stage.upload(lrow, ctx->stream)) { delete p; return -2; }
+        }
+    }
     p->identity_time = (tpos == nullptr);
     p->ntime_out = tpos ? ntime_out : nsig;
     if (tpos) {
@@ -294,7 +364,21 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
         for (int v : tp)
             if (v >= ntime_out) { spy::set_error("cwt_plan_create: tpos entry %d >= ntime_out %d", v, ntime_out); delete p; return -1; }
         if (p->tpos.upload(tp, ctx->stream)) { delete p; return -2; }
+        // the direct kernels address a tile relative to the slot reached before it: slots must increase with the samples
+        std::vector<int> fl(nsig);
+        int last = -1;
+        for (int n = 0; n < nsig; ++n) {
+            if (tp[n] >= 0) {
+                if (tp[n] <= last) p->direct = false;
+                last = tp[n];
+            }
+            fl[n] = std::max(last, 0);
+        }
+        if (p->tfloor.upload(fl, ctx->stream)) { delete p; return -2; }
     }
+    // ... and a block's rows must stay within 32-bit byte offsets
+    if ((double)p->nscales * p->nchan * 8.0 * 2048.0 >= 4294967296.0) p->direct = false;
+    p->direct_ok = p->direct;
     *out = p;
     return 0;
 }
@@ -356,6 +440,7 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
     a.nscales_total = p->nscales;
     a.detrend = p->detrend; a.out_kind = p->output;
     a.tpos = p->identity_time ? nullptr : p->tpos.p;
+    a.tfloor = p->identity_time ? nullptr : p->tfloor.p;
     a.ntime_out = p->ntime_out; a.out = out_d; a.accumulate = accumulate;
     if (p->detrend >= 0) {
         const size_t need = (size_t)nseg * p->nchan * 2;
@@ -379,25 +464,34 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         }
         SPY_HIP_CHECK(hipGetLastError());
     }
-    // staging buffer: as many segments per chunk as fit ~4 GiB (at least one): enough workgroups per launch that
-    // the last partial round of the grid over 256 CUs stays a small fraction
+    // Per-segment outputs (accumulate 0 / 1): scales on 1024- / 2048-point blocks leave their kernel in the output layout
+    // (cwt2d_kernel); the others (and every scale of a plan with spyhip_cwt_plan_set_direct(plan, 0) or float64 precision)
+    // go through the time-contiguous staging buffer.  Trial sums (accumulate 2): every scale staged, the packed kernels
+    // carrying one channel of TWO consecutive segments per thread and storing the sum (cwt_kernel.h, PAIRT) - a staging
+    // row set then holds a pair of segments.  As many row sets per chunk as fit ~4 GiB (at least one).
+    const bool use_direct = p->direct && !p->precision64 && accumulate != 2;
+    bool pairt = accumulate == 2 && !p->precision64;
+    for (const CwtGroup* gr : p->groups) pairt = pairt && gr->log2n <= 13;      // (the 16384-point kernel is not packed)
+    const int nst = use_direct ? (int)p->staged.size() : p->nscales;          // staging rows per row set
     const size_t esz = (p->output == SPYHIP_OUT_FOURIER) ? 8 : 4;
-    const size_t per_seg = (size_t)p->nscales * p->nchan * p->nsig * esz;
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nseg, ((size_t)4 << 30) / std::max<size_t>(per_seg, 1)));
-    if (chunk > p->chunk) {
-        if (p->stage.p) { (void)hipFree(p->stage.p); p->stage.p = nullptr; }
+    const size_t per_seg = (size_t)nst * p->nchan * p->nsig * esz;
+    const int nsets = pairt ? (nseg + 1) / 2 : nseg;
+    int chunk = nst ? (int)std::max<size_t>(1, std::min<size_t>((size_t)nsets, ((size_t)4 << 30) / std::max<size_t>(per_seg, 1)))
+                    : std::min(nseg, 65535);
+    if (per_seg * chunk > p->stage_cap) {
+        if (p->stage.p) { SPY_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); (void)hipFree(p->stage.p); p->stage.p = nullptr; p->stage_cap = 0; }
         if (p->stage.alloc(per_seg * chunk)) return -2;
-        p->chunk = chunk;
+        p->stage_cap = per_seg * chunk;
     }
-    chunk = p->chunk;
     a.stage = p->stage.p;
     const int nlong = (int)p->long_scales.size();
     const bool long_side = nlong > 0 && esz == 4;      // real outputs: the pieces are summed as complex numbers first
     if (long_side && chunk > p->chunk_long) {
-        if (p->stage_long.p) { (void)hipFree(p->stage_long.p); p->stage_long.p = nullptr; }
+        if (p->stage_long.p) { SPY_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); (void)hipFree(p->stage_long.p); p->stage_long.p = nullptr; }
         if (p->stage_long.alloc((size_t)chunk * nlong * p->nchan * p->nsig)) return -2;
         p->chunk_long = chunk;
     }
+    if (pairt) chunk *= 2;                             // from here on: segments per chunk
     for (int s0 = 0; s0 < nseg; s0 += chunk) {
         const int ns = std::min(chunk, nseg - s0);
         CwtArgs c = a;
@@ -432,41 +526,59 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
                 if (rc) return rc;
             }
         }
-        for (const CwtGroup* gr : p->groups) {           // one launch per block length
+        for (size_t gi = 0; gi < p->groups.size(); ++gi) {           // one launch per block length
+            const CwtGroup* gr = p->groups[gi];
             if (p->precision64) break;
             CwtArgs k = c;
             k.nscales = gr->nscales;
             k.sidx = gr->sidx.p;
             k.tw = gr->tw.p; k.hspec = gr->hspec.p; k.cshift = gr->cshift.p;
             k.V = gr->V; k.halo = gr->halo; k.nblocks = gr->nblocks;
+            if (use_direct && gr->direct) {
+                // (G = 4 / 2 - the staged kernels' workgroup shape, 32- / 16-byte runs - measured 284 against 236 us/trial at c4)
+                const int G = gr->log2n == 10 ? CWT_DIRECT_G10 : CWT_DIRECT_G11;
+                const long long ngrp = ((p->nchan + 1) / 2 + G - 1) / G;
+                const long long grid = (long long)ns * ngrp * gr->nblocks;
+                if (grid > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
+                int rc = gr->log2n == 10 ? launch_cwt2d_out<10, CWT_DIRECT_G10>(p, k, (unsigned)grid)
+                                         : launch_cwt2d_out<11, CWT_DIRECT_G11>(p, k, (unsigned)grid);
+                if (rc) return rc;
+                continue;
+            }
+            if (use_direct) { k.sidx = gr->sidx_stage.p; k.nscales_total = nst; }     // compact staging rows
             if (gr->long_idx >= 0) {
                 k.stage_add = gr->piece > 0;
-                if (long_side) { k.stage = p->stage_long.p; k.nscales_total = nlong; }
+                if (long_side) { k.stage = p->stage_long.p; k.nscales_total = nlong; k.sidx = gr->sidx.p; }
             }
-            const long long nunit = gr->log2n <= 13 ? (p->nchan + 1) / 2 : p->nchan;   // channel pairs / channels
+            // work units per row set: channel pairs of a segment; (PAIRT) channels of a segment pair; channels (2^14 blocks)
+            const long long nunit = pairt ? p->nchan : (gr->log2n <= 13 ? (p->nchan + 1) / 2 : p->nchan);
             const long long ngrp = (nunit + gr->G - 1) / gr->G;
-            const long long grid = (long long)ns * ngrp * gr->nblocks;
+            const long long grid = (long long)(pairt ? (ns + 1) / 2 : ns) * ngrp * gr->nblocks;
             if (grid > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
             const unsigned g = (unsigned)grid;
             int rc;
             switch (gr->log2n) {
-                case 10: rc = launch_cwt2_out<10, 4>(p, k, g); break;
-                case 11: rc = launch_cwt2_out<11, 2>(p, k, g); break;
-                case 12: rc = launch_cwt2_out<12, 1>(p, k, g); break;
-                case 13: rc = launch_cwt2_out<13, 1>(p, k, g); break;
+                case 10: rc = launch_cwt2_out<10, 4>(p, k, g, pairt); break;
+                case 11: rc = launch_cwt2_out<11, 2>(p, k, g, pairt); break;
+                case 12: rc = launch_cwt2_out<12, 1>(p, k, g, pairt); break;
+                case 13: rc = launch_cwt2_out<13, 1>(p, k, g, pairt); break;
                 case 14: rc = gr->long_idx >= 0 ? launch_cwt<14, 1, 2>(p, k, g) : launch_cwt_out<14, 1>(p, k, g); break;
                 default: spy::set_error("cwt_exec: unsupported block length 2^%d", gr->log2n); return -1;
             }
             if (rc) return rc;
         }
+        if (nst == 0) continue;                       // every scale left its kernel in the output layout
         if (long_side && !p->precision64) {
             const long long tot = (long long)ns * nlong * p->nchan * p->nsig;
             if ((tot + 255) / 256 > 0x7fffffffLL) { spy::set_error("cwt_exec: grid too large"); return -1; }
             hipLaunchKernelGGL(spyfft::cwt_long_convert_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                               p->ctx->stream, p->stage_long.p, p->lidx.p, nlong, ns, p->nscales, p->nchan, p->nsig,
-                               p->output, reinterpret_cast<float*>(p->stage.p));
+                               p->ctx->stream, p->stage_long.p, use_direct ? p->lidx_stage.p : p->lidx.p, nlong, ns, nst, p->nchan,
+                               p->nsig, p->output, reinterpret_cast<float*>(p->stage.p));
         }
-        const dim3 sg((p->nsig + 63) / 64, p->nscales, accumulate == 2 ? 1 : ns);
+        if (pairt) c.nseg = (ns + 1) / 2;             // scatter kernels: row sets to add up ...
+        c.nscales = nst;                              // ... staging rows per row set ...
+        if (use_direct) { c.smap = p->smap.p; c.nscales_out = p->nscales; }     // ... and where they go in the output
+        const dim3 sg((p->nsig + 63) / 64, nst, accumulate == 2 ? 1 : ns);
         // real outputs of long trials: tiles of 256 samples x 16 channels (1-KiB reads of the staging rows: 51 -> 46 us/trial at c4)
         const bool wide = esz == 4 && (p->nsig & 3) == 0 && p->nsig >= 1024;
         if (esz == 8) hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float2>, sg, dim3(256), 0, p->ctx->stream, c);
@@ -474,6 +586,13 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         else hipLaunchKernelGGL(spyfft::cwt_scatter_kernel<float>, sg, dim3(256), 0, p->ctx->stream, c);
         SPY_HIP_CHECK(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" int spyhip_cwt_plan_set_direct(spyhip_cwt_plan* p, int on) {
+    if (!p) { spy::set_error("cwt_plan_set_direct: null plan"); return -1; }
+    if (on && !p->direct_ok) return -3;          // (slots not increasing / rows beyond 32-bit offsets: staging only)
+    p->direct = on != 0;
     return 0;
 }
 

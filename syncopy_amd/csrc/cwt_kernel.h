@@ -36,6 +36,7 @@ struct CwtArgs {
     const double* trend;          // (nseg x nchan x 2): mean, slope about the trial centre
     int out_kind;
     const int* tpos;              // nsig: output slot of sample n, or -1; nullptr = identity
+    const int* tfloor;            // nsig: the largest slot among the samples 0 ... n (0 if none) - direct kernels' tile reference
     int ntime_out;
     void* out;                    // (nseg, ntime_out, nscales, nchan)
     int accumulate;
@@ -45,6 +46,8 @@ struct CwtArgs {
     const int* sidx;              // scale s of this launch -> scale index of the plan (nullptr = identity): scales
     int nscales_total;            // are grouped by the block length their kernel support needs (0 = nscales)
     int stage_add;                // 1: add to the staging values (later pieces of a kernel longer than one block)
+    const int* smap;              // scatter kernels: staging row s of a segment -> scale index of the output (nullptr = identity)
+    int nscales_out;              // scatter kernels: scales of the output (0 = nscales: every scale is staged)
 };
 
 // per (segment, channel): mean and least-squares slope over the trial rows [lo, hi), in two
@@ -234,7 +237,11 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) cwt_kernel(CwtArgs 
 // Packed variant (block lengths up to 8192): one thread carries TWO channels in the halves of packed fp32
 // registers (fft2_device.h) - both share the kernel spectrum H_s, so the spectral multiply and every butterfly
 // of the forward and the nscales inverse transforms run on v_pk_* instructions for two channels at once.
-template <int LOG2N, int G, int OUTK>
+// PAIRT (trial sums, accumulate == 2): the two halves carry the SAME channel of two consecutive segments instead, and
+// what leaves the thread is the sum of their converted values - half the staging rows to write, half for the
+// transposition pass to read and add (the staging round trip is what the trial average costs: 420 -> 210 MB per trial at
+// 128 channels x 16384 samples x 25 scales).  Staging row set bp holds segments 2 bp and 2 bp + 1.
+template <int LOG2N, int G, int OUTK, bool PAIRT = false>
 __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArgs a) {
     using C = Cfg2<LOG2N, G>;
     constexpr int N = C::N, T = C::T;
@@ -242,30 +249,35 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArg
     SPY_DYN_SMEM(v2f, lds);
     const int tid = threadIdx.x;
     const int h = tid % G, j = tid / G;
-    const int npair = (a.nchan + 1) / 2;
-    const int ngrp = (npair + G - 1) / G;
+    const int nunit = PAIRT ? a.nchan : (a.nchan + 1) / 2;
+    const int ngrp = (nunit + G - 1) / G;
     long long id = blockIdx.x;
     const int blk = (int)(id % a.nblocks);
     id /= a.nblocks;
     const int cg = (int)(id % ngrp);
-    const int b = (int)(id / ngrp);
-    const int c0 = 2 * (cg * G + h);
-    const bool has[2] = {c0 < a.nchan, c0 + 1 < a.nchan};
-    long long col[2];
+    const int b = (int)(id / ngrp);                 // segment, or (PAIRT) pair of segments
+    const int c0 = PAIRT ? cg * G + h : 2 * (cg * G + h);
+    const int bs[2] = {PAIRT ? 2 * b : b, PAIRT ? 2 * b + 1 : b};
+    const bool has[2] = {c0 < a.nchan, PAIRT ? (c0 < a.nchan && bs[1] < a.nseg) : (c0 + 1 < a.nchan)};
+    long long col[2], start[2], tlo[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) col[i] = has[i] ? (a.chan_idx ? a.chan_idx[c0 + i] : c0 + i) : 0;
-    const long long start = a.seg_start[b], tlo = a.trial_lo[b];
+    for (int i = 0; i < 2; ++i) {
+        const int c = PAIRT ? c0 : c0 + i;
+        col[i] = has[i] ? (a.chan_idx ? a.chan_idx[c] : c) : 0;
+        start[i] = has[i] ? a.seg_start[bs[i]] : 0;
+        tlo[i] = has[i] ? a.trial_lo[bs[i]] : 0;
+    }
     const int o0 = blk * a.V;
 
-    double mean[2] = {0.0, 0.0}, slope[2] = {0.0, 0.0}, mid = 0.0;
+    double mean[2] = {0.0, 0.0}, slope[2] = {0.0, 0.0}, mid[2] = {0.0, 0.0};
     if (a.detrend >= 0) {
-        mid = 0.5 * (double)(a.trial_hi[b] - tlo - 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (has[i]) {
-                const double* t = a.trend + ((size_t)b * a.nchan + c0 + i) * 2;
+                const double* t = a.trend + ((size_t)bs[i] * a.nchan + (PAIRT ? c0 : c0 + i)) * 2;
                 mean[i] = t[0];
                 slope[i] = t[1];
+                mid[i] = 0.5 * (double)(a.trial_hi[bs[i]] - tlo[i] - 1);
             }
     }
 
@@ -276,12 +288,12 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArg
         const int u = o0 - a.halo + j + T * e;
         float x[2] = {0.f, 0.f};
         if (u >= 0 && u < a.nsig) {
-            const long long row = start + u;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 if (has[i]) {
+                    const long long row = start[i] + u;
                     x[i] = a.data[row * a.ld + col[i]];
-                    if (a.detrend >= 0) x[i] -= (float)(mean[i] + slope[i] * ((double)(row - tlo) - mid));
+                    if (a.detrend >= 0) x[i] -= (float)(mean[i] + slope[i] * ((double)(row - tlo[i]) - mid[i]));
                 }
         }
         v[e].r = v2f{x[0], x[1]};
@@ -305,12 +317,142 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArg
         for (int e = 0; e < 16; ++e) {
             const int n = j + T * e - sh + o0;
             if (n < o0 || n >= nend) continue;
+            if (PAIRT) {
+                if (!has[0]) continue;
+                if (CPLX) {
+                    reinterpret_cast<float2*>(a.stage)[rowo + n] = make_float2(v[e].r[0] + v[e].r[1], v[e].i[0] + v[e].i[1]);   // (the absent half is 0)
+                } else {
+                    float y = convert_real<OUTK>(make_float2(v[e].r[0], v[e].i[0]), a.out_kind);
+                    if (has[1]) y += convert_real<OUTK>(make_float2(v[e].r[1], v[e].i[1]), a.out_kind);
+                    reinterpret_cast<float*>(a.stage)[rowo + n] = y;
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (!has[i]) continue;
                 const float2 y = make_float2(v[e].r[i], v[e].i[i]);
                 if (CPLX) reinterpret_cast<float2*>(a.stage)[rowo + (size_t)i * a.nsig + n] = y;
                 else reinterpret_cast<float*>(a.stage)[rowo + (size_t)i * a.nsig + n] = convert_real<OUTK>(y, a.out_kind);
+            }
+        }
+    }
+}
+
+// Direct variant (round 6): the results leave the workgroup in the output's own layout (segment, slot(time), scale,
+// channel) - no staging buffer, no transposition pass - for per-segment outputs (accumulate 0 / 1: keeptrials).  A
+// workgroup carries G = 8 (1024-point blocks) or 4 (2048) channel PAIRS, the pair index fastest across lanes: the 2 G
+// channels of one time sample are 8 G contiguous bytes (64 / 32), one store instruction of a wave writes 64 / G such runs.
+// c4 wavelet, keeptrials: 293 -> 245 us/trial.  Trial sums stay on the staged kernels (PAIRT above): summing in the
+// output layout is a read-modify-write per trial whose latency the two waves of a SIMD do not hide (measured with the
+// workgroup owning its tile and walking the segments: 309 us/trial against 215 staged).
+template <int LOG2N, int G, int OUTK>
+__global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2d_kernel(CwtArgs a) {
+    using C = Cfg2<LOG2N, G>;
+    constexpr int N = C::N, T = C::T;
+    constexpr bool CPLX = (OUTK == 2);
+    constexpr unsigned ESZ = CPLX ? 8u : 4u;
+    SPY_DYN_SMEM(v2f, lds);
+    const int tid = threadIdx.x;
+    const int h = tid % G, j = tid / G;
+    const int npair = (a.nchan + 1) / 2;
+    const int ngrp = (npair + G - 1) / G;
+    long long id = blockIdx.x;
+    const int blk = (int)(id % a.nblocks);
+    id /= a.nblocks;
+    const int cg = (int)(id % ngrp);
+    const int b = (int)(id / ngrp);
+    const int c0 = 2 * (cg * G + h);
+    const bool has[2] = {c0 < a.nchan, c0 + 1 < a.nchan};
+    const bool vec = has[1] && !(a.nchan & 1);      // both channels, 8-byte aligned pairs
+    long long col[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) col[i] = has[i] ? (a.chan_idx ? a.chan_idx[c0 + i] : c0 + i) : 0;
+    const long long start = a.seg_start[b], tlo = a.trial_lo[b];
+    const int o0 = blk * a.V;
+    const int nend = min(o0 + a.V, a.nsig);
+    const int nsc = a.nscales_total ? a.nscales_total : a.nscales;
+
+    double mean[2] = {0.0, 0.0}, slope[2] = {0.0, 0.0}, mid = 0.0;
+    if (a.detrend >= 0) {
+        mid = 0.5 * (double)(a.trial_hi[b] - tlo - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (has[i]) {
+                const double* t = a.trend + ((size_t)b * a.nchan + c0 + i) * 2;
+                mean[i] = t[0];
+                slope[i] = t[1];
+            }
+    }
+    C2 v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int u = o0 - a.halo + j + T * e;
+        float x[2] = {0.f, 0.f};
+        if (u >= 0 && u < a.nsig) {
+            const long long row = start + u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (has[i]) {
+                    x[i] = a.data[row * a.ld + col[i]];
+                    if (a.detrend >= 0) x[i] -= (float)(mean[i] + slope[i] * ((double)(row - tlo) - mid));
+                }
+        }
+        v[e].r = v2f{x[0], x[1]};
+        v[e].i = splat(0.f);
+    }
+    fft2_forward<LOG2N, G>(v, lds, j, h, a.tw);
+    C2 Z[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Z[e] = v[e];
+
+    // Stores: a wave-uniform base (segment, reference slot of the tile, scale) + a 32-bit byte offset per value (the
+    // host admits a plan to this kernel only if a block's rows span less than 4 GiB): no 64-bit address per value
+    const unsigned rowb = (unsigned)nsc * (unsigned)a.nchan * ESZ;        // bytes from one time slot to the next
+    const unsigned cb = (unsigned)c0 * ESZ;
+    const int sref = a.tpos ? a.tfloor[o0] : o0;    // a slot at or below every slot of the tile (tpos is increasing)
+    char* const tile = reinterpret_cast<char*>(a.out) + ((size_t)(a.seg0 + b) * a.ntime_out + sref) * (size_t)rowb;
+    for (int s = 0; s < a.nscales; ++s) {
+        const float2* H = a.hspec + (size_t)s * N;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = cmul_s(Z[e], ldg<float2>(H, (unsigned)(j + T * e) * 8u));
+        fft2_inverse<LOG2N, G>(v, lds, j, h, a.tw);
+        const int sh = a.cshift[s];
+        char* const sb = tile + (size_t)(a.sidx ? a.sidx[s] : s) * a.nchan * ESZ;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = j + T * e - sh + o0;
+            if (!has[0] || n < o0 || n >= nend) continue;
+            const int slot = a.tpos ? ldg<int>(a.tpos, (unsigned)n * 4u) : n;
+            if (slot < 0) continue;
+            const unsigned off = (unsigned)(slot - sref) * rowb + cb;
+            if (CPLX) {
+                float4 y = make_float4(v[e].r[0], v[e].i[0], v[e].r[1], v[e].i[1]);
+                if (vec) {
+                    if (a.accumulate) { const float4 q = ldg<float4>(sb, off); y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w; }
+                    stg<float4>(sb, off, y);
+                } else {
+                    if (a.accumulate) { const float2 q = ldg<float2>(sb, off); y.x += q.x; y.y += q.y; }
+                    stg<float2>(sb, off, make_float2(y.x, y.y));
+                    if (has[1]) {
+                        if (a.accumulate) { const float2 q = ldg<float2>(sb, off + 8u); y.z += q.x; y.w += q.y; }
+                        stg<float2>(sb, off + 8u, make_float2(y.z, y.w));
+                    }
+                }
+            } else {
+                float2 y = make_float2(convert_real<OUTK>(make_float2(v[e].r[0], v[e].i[0]), a.out_kind),
+                                       has[1] ? convert_real<OUTK>(make_float2(v[e].r[1], v[e].i[1]), a.out_kind) : 0.f);
+                if (vec) {
+                    if (a.accumulate) { const float2 q = ldg<float2>(sb, off); y.x += q.x; y.y += q.y; }
+                    stg<float2>(sb, off, y);
+                } else {
+                    if (a.accumulate) y.x += ldg<float>(sb, off);
+                    stg<float>(sb, off, y.x);
+                    if (has[1]) {
+                        if (a.accumulate) y.y += ldg<float>(sb, off + 4u);
+                        stg<float>(sb, off + 4u, y.y);
+                    }
+                }
             }
         }
     }
@@ -347,6 +489,7 @@ __global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
     const V* const st0 = reinterpret_cast<const V*>(a.stage) + (size_t)s * a.nchan * (size_t)a.nsig;
     V* const out = reinterpret_cast<V*>(a.out);
     const int oseg = sum_segs ? 0 : a.seg0 + bl0;
+    const int nso = a.nscales_out ? a.nscales_out : a.nscales, so = a.smap ? a.smap[s] : s;   // staging row -> output scale
     const int n = n0 + tx;
     for (int c0 = 0; c0 < a.nchan; c0 += 64) {
         if (c0) __syncthreads();
@@ -389,7 +532,7 @@ __global__ void __launch_bounds__(256) cwt_scatter_kernel(CwtArgs a) {
             if (m >= a.nsig || c >= a.nchan) continue;
             const int slot = a.tpos ? a.tpos[m] : m;
             if (slot < 0) continue;
-            V* const o = out + (((size_t)oseg * a.ntime_out + slot) * a.nscales + s) * a.nchan + c;
+            V* const o = out + (((size_t)oseg * a.ntime_out + slot) * nso + so) * a.nchan + c;
             V val = tile[tx][r];
             if (a.accumulate) {
                 const V old = *o;
@@ -417,6 +560,7 @@ __global__ void __launch_bounds__(256) cwt_scatter_wide_kernel(CwtArgs a) {
     const float* const st0 = reinterpret_cast<const float*>(a.stage) + (size_t)s * a.nchan * (size_t)a.nsig;
     float* const out = reinterpret_cast<float*>(a.out);
     const int oseg = sum_segs ? 0 : a.seg0 + bl0;
+    const int nso = a.nscales_out ? a.nscales_out : a.nscales, so = a.smap ? a.smap[s] : s;   // staging row -> output scale
     const int nq = n0 + 4 * lane;
     const int cc = threadIdx.x & 15, mm = threadIdx.x >> 4;        // output side: 16 channels x 16 samples per pass
     for (int c0 = 0; c0 < a.nchan; c0 += TC) {
@@ -441,7 +585,7 @@ __global__ void __launch_bounds__(256) cwt_scatter_wide_kernel(CwtArgs a) {
             if (m >= a.nsig || c >= a.nchan) continue;
             const int slot = a.tpos ? a.tpos[m] : m;
             if (slot < 0) continue;
-            float* const o = out + (((size_t)oseg * a.ntime_out + slot) * a.nscales + s) * a.nchan + c;
+            float* const o = out + (((size_t)oseg * a.ntime_out + slot) * nso + so) * a.nchan + c;
             float val = tile[cc * LD + m0];
             if (a.accumulate) val = *o + val;
             *o = val;

@@ -492,6 +492,67 @@ def test_cwt_wide_transposition_tiles(be):
     assert_parity(got.cpu().numpy(), ref[:, keep], what="wide tiles, selected samples")
 
 
+@pytest.mark.parametrize("output", ["pow", "abs", "fourier"])
+@pytest.mark.parametrize("C", [21, 32, 1])
+def test_cwt_direct_kernels_equal_the_staged_path(be, output, C):
+    """cwt2d_kernel (1024- / 2048-point blocks written in the output layout by the transform kernel) against the same plan
+    with every scale through the staging buffer and the transposition pass (set_direct(False)): the same arithmetic per
+    value up to the compiler's contraction choices (agreement to 2e-6, five times tighter than the parity criterion); trial
+    sums differ in summation order as well.  Scales
+    on every block length at once (70 Hz: 1024, 30: 2048, 8: 4096 - staged in either mode), odd channel counts (the
+    padded pair and the unaligned scalar stores), a post-selection of samples."""
+    rng = np.random.default_rng(17)
+    nsig, T = 3000, 5
+    x = rng.normal(size=(T * nsig, C)).astype(np.float32) + 3.0
+    freqs = np.array([8.0, 30.0, 45.0, 70.0, 95.0])
+    scales = (1 / freqs) * (6 + np.sqrt(38)) / (4 * np.pi)
+    data = torch.from_numpy(x).cuda()
+    st = torch.arange(T, device="cuda", dtype=torch.int64) * nsig
+    keep = np.r_[0:5, 3:2900:7, 1023, 1024, 2047, 2048, 2999]
+    keep = np.unique(keep)
+    tpos = np.full(nsig, -1, dtype=np.int32)
+    tpos[keep] = np.arange(keep.size)
+    for kw in ({}, {"tpos": tpos, "ntime_out": keep.size}):
+        direct = be.CWTPlan(nsig, C, scales, 1e-3, 6.0, 0, output, **kw)
+        staged = be.CWTPlan(nsig, C, scales, 1e-3, 6.0, 0, output, **kw)
+        staged.set_direct(False)
+        a = direct.execute(data, st, st, st + nsig)
+        b = staged.execute(data, st, st, st + nsig)
+        # (two instantiations of the same engine: the compiler contracts multiply-adds differently, so not bit for bit)
+        assert_parity(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol_rel=2e-7, what=f"direct vs staged, {output}, {C} ch, tpos={bool(kw)}")
+        a2, b2 = a.clone(), b.clone()
+        direct.execute(data, st, st, st + nsig, out=a2, accumulate=True)
+        staged.execute(data, st, st, st + nsig, out=b2, accumulate=True)
+        assert_parity(a2.cpu().numpy(), b2.cpu().numpy(), rtol=2e-6, atol_rel=2e-7, what="direct vs staged, out[b] += segment b")
+        assert_parity(a2.cpu().numpy(), 2 * a.cpu().numpy(), rtol=1e-6, atol_rel=1e-7, what="direct, out[b] += segment b")
+        ta = torch.zeros(direct.out_shape(1), dtype=a.dtype, device="cuda")
+        tb = torch.zeros(direct.out_shape(1), dtype=a.dtype, device="cuda")
+        for lo, hi in ((0, 2), (2, 5)):
+            direct.execute(data, st[lo:hi].contiguous(), st[lo:hi].contiguous(), (st[lo:hi] + nsig).contiguous(), out=ta, accumulate=2)
+            staged.execute(data, st[lo:hi].contiguous(), st[lo:hi].contiguous(), (st[lo:hi] + nsig).contiguous(), out=tb, accumulate=2)
+        ref = (a.to(torch.complex128) if a.is_complex() else a.double()).sum(dim=0, keepdim=True)
+        assert_parity(ta.cpu().numpy(), ref.cpu().numpy().astype(ta.cpu().numpy().dtype), what="direct trial sum")
+        assert_parity(tb.cpu().numpy(), ref.cpu().numpy().astype(tb.cpu().numpy().dtype), what="staged trial sum")
+
+
+def test_cwt_direct_trial_sum_many_trials(be):
+    """Trial sums with more trials than split owners: 128 channels x 4000 samples x 37 trials, every scale on the direct
+    kernels (no staging buffer at all), in two calls; against the float64 sum of the per-trial outputs."""
+    rng = np.random.default_rng(19)
+    nsig, C, T = 4000, 128, 37
+    data = torch.from_numpy(rng.normal(size=(T * nsig, C)).astype(np.float32)).cuda()
+    scales = (1 / np.array([24.0, 40.0, 64.0, 100.0])) * (6 + np.sqrt(38)) / (4 * np.pi)
+    plan = be.CWTPlan(nsig, C, scales, 1e-3, 6.0, 0, "pow")
+    st = torch.arange(T, device="cuda", dtype=torch.int64) * nsig
+    total = torch.zeros(plan.out_shape(1), dtype=torch.float32, device="cuda")
+    ref = torch.zeros(plan.out_shape(1), dtype=torch.float64, device="cuda")
+    for lo, hi in ((0, 30), (30, 37)):
+        s = st[lo:hi].contiguous()
+        plan.execute(data, s, s, s + nsig, out=total, accumulate=2)
+        ref += plan.execute(data, s, s, s + nsig).double().sum(dim=0, keepdim=True)
+    assert_parity(total.cpu().numpy(), ref.float().cpu().numpy(), what="direct trial sum, 37 trials")
+
+
 @pytest.mark.parametrize("output", ["pow", "fourier"])
 def test_cwt_kernels_longer_than_one_block(be, output):
     """Morlet kernels of more than 8191 taps (transform.py:96-103 samples 10 s / dt of them and convolves in full,
