@@ -298,6 +298,25 @@ def _cwt_precision(plan):
                                       actual=f"nsig = {plan.nsig}")
 
 
+def _wavelet_params(method_kwargs):
+    """(w0, family, order) of the transform.  Two spellings of `method_kwargs`: this package's front end passes plain
+    numbers ("w0", "family", "order"); the reference's freqanalysis passes the wavelet function OBJECT it built
+    (freqanalysis.py:893-897: {"samplerate", "scales", "wavelet"}; classes Morlet(w0) / Paul(m) / DOG(m) and Ricker, Marr,
+    Mexican_hat = DOG(2): specest/wavelets/wavelets.py:13-363) - read by class name and attribute, so that wavelet_cF is a
+    drop-in under the reference's own WaveletTransform."""
+    wav = method_kwargs.get("wavelet")
+    if wav is None or isinstance(wav, str):
+        return float(method_kwargs.get("w0", 6.0)), method_kwargs.get("family"), method_kwargs.get("order")
+    names = [c.__name__ for c in type(wav).__mro__]
+    if "Paul" in names:
+        return 6.0, "Paul", int(wav.m)
+    if "DOG" in names:
+        return 6.0, "DOG", int(wav.m)
+    if "Morlet" in names:
+        return float(wav.w0), None, None
+    raise ValueError("unknown wavelet function %r" % type(wav).__name__)
+
+
 def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwargs, sum_trials=False):
     """Wavelet spectra of trials `rows` (absolute [start, stop)) with per-trial pre/post-selections.
     Returns a list of (nTime, 1, nScales, C) device tensors - or, with `sum_trials`, their sum as ONE such
@@ -307,8 +326,7 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
     ci = None if chans is None else torch.tensor(np.asarray(chans), dtype=torch.int32, device=device)
     scales = np.asarray(method_kwargs["scales"], dtype=np.float64)
     dt = 1.0 / method_kwargs["samplerate"]
-    w0 = float(method_kwargs.get("w0", 6.0))
-    family, order = method_kwargs.get("family"), method_kwargs.get("order")
+    w0, family, order = _wavelet_params(method_kwargs)
     results = [None] * len(rows)
     groups = {}
     for k, ((a, b), ps, qs) in enumerate(zip(rows, pre, post)):
@@ -344,7 +362,7 @@ def _wavelet_device(dev, rows, pre, post, chans, polyremoval, output, method_kwa
     return results
 
 
-def wavelet_cF(trl_dat, preselect, postselect, toi=None, timeAxis=0, polyremoval=None, output="pow", noCompute=False,
+def wavelet_cF(trl_dat, preselect, postselect, toi=None, timeAxis=0, polyremoval=0, output="pow", noCompute=False,
                chunkShape=None, method_kwargs=None):
     """Morlet wavelet transform of one trial; returns (nTime, 1, nScales, nChannel)."""
     dat = trl_dat.T if timeAxis != 0 else trl_dat
