@@ -290,7 +290,7 @@ class CrossSpectra(ComputationalRoutine):
         mine = rows[lo:hi][:sample]
         looks = getattr(data, "_looks", None)
         key = (tuple(mine), None if chans is None else tuple(int(c) for c in chans), cfg["nSamples"], str(cfg["taper"]),
-               repr(sorted((cfg["taper_opt"] or {}).items())), bool(cfg["demean_taper"]), pr, freq_idx.tobytes())
+               repr(sorted((cfg["taper_opt"] or {}).items())), bool(cfg["demean_taper"]), pr, freq_idx.tobytes(), T)
         if looks is not None and key in looks:
             ratio, K = looks[key]
         else:
@@ -299,8 +299,8 @@ class CrossSpectra(ComputationalRoutine):
                 for _, spec in hs.run_mtmfft_batches(dev, mine, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"],
                                                      cfg["demean_taper"], False, pr, None, "pow", True, reuse=True,
                                                      upload=upload):
-                    ratio = max(ratio, hs.dynamic_range(spec, kept=freq_idx))        # whole axis: see hs.dynamic_range
                     K = spec.shape[1]
+                    ratio = max(ratio, hs.dynamic_range(spec, kept=freq_idx, few_products=T * K <= 16))   # whole axis: see hs.dynamic_range
             if looks is not None:
                 looks[key] = (ratio, K)
         ratio = parallel.allreduce_max(ratio)

@@ -97,13 +97,17 @@ def plan_precision():
     return "reference" if _precision[-1] in ("reference", "reference?") else "float32"
 
 
-def dynamic_range(spec, kept=None):
+def dynamic_range(spec, kept=None, few_products=False):
     """How far the weakest part of a channel's KEPT spectrum sits below its mean power, judged on tapered spectra
     (B, K, F, C) complex64 of a few trials over the WHOLE frequency axis: max over channels of mean_f P / q_2%(P[kept])
     with P = the trial- and taper-averaged power (`spec`: the power spectra of every taper, or complex spectra).  The mean runs over every bin - an offset nobody removed or a line
     outside the kept band raises the float32 transform's error in the kept bins just the same; the two kept bins next
     to DC are left out of the quantile (they belong to the detrending).  A low percentile, not the minimum: one empty
-    bin (a notch, the Nyquist bin of an even filter) is not what the spectrum is like."""
+    bin (a notch, the Nyquist bin of an even filter) is not what the spectrum is like.
+    `few_products`: the caller averages so few (trial, taper) products (<= 16) that nothing averages the float32 error of ONE
+    weak bin away - then the weakest kept bin counts, the bins next to DC included (a coherence of 0.003 at the DC bin of
+    four demeaned Hann-tapered trials sat at 1.13 x the criterion, tests/test_gpu_fuzz.py family 500000 seed 284; float64
+    transforms of a handful of trials cost nothing)."""
     from .. import backend
     if spec.is_complex():
         spec = spec.abs().square()
@@ -114,11 +118,12 @@ def dynamic_range(spec, kept=None):
     num = p.mean(axis=0)
     if kept is not None:
         kept = np.asarray(kept)
-        kept = kept[kept >= 2] if (kept >= 2).sum() >= 4 else kept
+        if not few_products:
+            kept = kept[kept >= 2] if (kept >= 2).sum() >= 4 else kept
         p = p[kept]
-    elif p.shape[0] >= 6:
+    elif p.shape[0] >= 6 and not few_products:
         p = p[2:]
-    q = np.maximum(np.quantile(p, 0.02, axis=0), 1e-38)
+    q = np.maximum(p.min(axis=0) if few_products else np.quantile(p, 0.02, axis=0), 1e-38)
     return float((num / q).max())
 
 

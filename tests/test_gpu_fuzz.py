@@ -66,19 +66,38 @@ def _detrend_frames_exact(frames, kind):
     return sps.detrend(np.asarray(frames, dtype=np.float64), type=kind).astype(frames.dtype)
 
 
-def _check(got, ref, exact, what, atol_rel=ATOL_REL):
+def _modulus_scale(fn, data, classes, kw):
+    """Largest MODULUS behind an output that is a projection of a complex quantity (real / imag): the absolute floor of the
+    criterion refers to that scale, not to the largest projection (tests/test_gpu_depth.py: IMAG_ATOL).  Three samples minus
+    their regression line under a Hann window leave ONE non-zero sample: every cross spectrum is real, the reference's
+    'imag' output is rounding residue of 0 (1e-8) of coherencies of modulus 1, and the real part of the one kept bin of
+    such a trial's 4-point transform is residue of a spectrum of modulus 0.4 (families 500000 / 900000: seeds 23, 668,
+    1624).  The oracle's own complex result gives the scale."""
+    if kw.get("output") not in ("real", "imag"):
+        return None
+    full = dict(kw, output="complex" if kw.get("method") == "coh" else "fourier")
+    if full["output"] == "fourier" and kw.get("method") == "mtmfft":
+        full.update(keeptapers=True, keeptrials=True)
+    try:
+        return float(np.abs(np.asarray(fn(data, **full, compute_method="sequential", routine_classes=classes).data)).max())
+    except Exception:                                 # noqa: BLE001 - no scale, the plain criterion
+        return None
+
+
+def _check(got, ref, exact, what, atol_rel=ATOL_REL, scale=None):
     """The shared criterion, widened element by element by twice the reference's OWN detrending noise where there is
     any: scipy.signal.detrend(type="linear") fits a float32 trial with a float32 least-squares solve, which leaves a
     coherent ramp of ~1e-7 of a channel's offset in the data - the bins next to DC of such a channel (and every
     normalised quantity formed there) are made of it.  The kernels fit in float64; `exact` is the oracle with a float64
     fit, |ref - exact| is therefore the reference's rounding, not ours."""
     if getattr(got, "per_trial_route", None) is not None:
-        _check(got.per_trial_route, ref, exact, what + " [per-trial route]", atol_rel)
+        _check(got.per_trial_route, ref, exact, what + " [per-trial route]", atol_rel, scale)
     a, b = np.asarray(got.data), np.asarray(ref.data)
     if np.abs(b).max() < 1e-12:          # (three samples minus their own regression line: the reference result IS rounding
         assert np.abs(a).max() < 1e-6, what     # residue of zero - nothing to compare but the magnitude)
         return
-    tol = RTOL * np.abs(b) + atol_rel * np.abs(b).max()
+    # `scale`: the largest modulus of the complex quantity a real / imag output is a projection of (_modulus_scale)
+    tol = RTOL * np.abs(b) + atol_rel * max(float(np.abs(b).max()), scale or 0.0)
     err = np.abs(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64) - b)
     if exact is not None:
         if "polyremoval': 1" in what or "polyremoval=1" in what:
@@ -164,7 +183,8 @@ def test_mtmfft_random_options(seed):
         kw["foilim"] = [float(rng.uniform(0, 100)), float(rng.uniform(150, 500))]
     got, ref, exact = _run_both(spy.freqanalysis, data, ORACLE_FREQ, kw)
     if got is not None:
-        _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {data.data.shape[1]}")
+        _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {data.data.shape[1]}",
+               scale=_modulus_scale(spy.freqanalysis, data, ORACLE_FREQ, kw))
 
 
 @pytest.mark.parametrize("seed", range(24 * SCALE))
@@ -202,7 +222,8 @@ def test_connectivity_random_options(seed):
             for arr in (got.data, ref.data) + ((exact.data,) if exact is not None else ()):
                 idx = np.arange(arr.shape[-1])
                 arr[..., idx, idx] = 0
-        _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {data.data.shape[1]}", atol_rel=floor)
+        _check(got, ref, exact, f"seed {seed}: {kw} lengths {lengths} ch {data.data.shape[1]}", atol_rel=floor,
+               scale=_modulus_scale(spy.connectivityanalysis, data, ORACLE_CONN, kw))
 
 
 @pytest.mark.parametrize("seed", range(16 * SCALE))
@@ -398,7 +419,14 @@ def test_granger_random_networks(seed):
         assert not got.info["converged"]       # say so (wilson_sf.py:197-254) and neither result means anything
         return
     assert got.info["converged"]
-    np.testing.assert_allclose(got.data, ref.data, atol=0.1, err_msg=f"seed {seed} {kw}")
+    # The DC bin is not compared: method="granger" demeans every TAPERED trial (demean_taper, connectivity_analysis.py:864),
+    # so X_k(0) = 0 and S(0) = 0 in exact arithmetic - what either side factorises there is the rounding residue
+    # of its own transform (1e-9 of the spectrum in the reference's float64 FFT rounded to complex64, 1e-8 in float32
+    # kernels), and ln(S_ii / (S_ii - ...)) of a residue matrix is a different number on each side, up to ~0.15 (family
+    # 500000, seed 94: 0.152 against 0.050 for one pair, the oracle run on to rtol / 100 keeps its 0.050 - it is not the
+    # stopping point).  Finite and of that size is all that can be said.
+    assert np.isfinite(got.data).all() and np.abs(got.data[:, 0]).max() < 1.0 and np.abs(ref.data[:, 0]).max() < 1.0
+    np.testing.assert_allclose(got.data[:, 1:], ref.data[:, 1:], atol=0.1, err_msg=f"seed {seed} {kw}")
     np.testing.assert_allclose(got.data[:, 2:], ref.data[:, 2:], rtol=2e-3, atol=1e-2, err_msg=f"seed {seed} {kw}")
 
 
