@@ -418,8 +418,10 @@ class FFTPlan:
     def execute(self, data, seg_start, seg_lo=None, seg_hi=None, chan_idx=None, out=None, absmax=None):
         """data: (rows, ld) float32 cuda tensor; seg_*: int64 cuda tensors of equal length.
         `absmax`: (nchan,) float32 cuda tensor that every call RAISES to the largest |re|, |im| written per channel - the
-        range csd_accumulate(..., absmax=) scales by (spyhip_fft_plan_set_absmax); `self.tracked_absmax` says whether
-        this plan's kernel delivered it (False: the tensor is untouched, pass absmax=None to csd_accumulate)."""
+        range csd_accumulate(..., absmax=) scales by (spyhip_fft_plan_set_absmax); the returned tensor's
+        `spyhip_absmax_tracked` says whether this plan's kernel delivered it (False: `absmax` is untouched, pass
+        absmax=None to csd_accumulate).  `self.tracked_absmax` repeats the answer of the LAST call for single-threaded
+        callers; the tensor attribute is the one that stays right when a cached plan serves several threads."""
         assert data.is_cuda and data.dtype == torch.float32 and data.dim() == 2 and data.is_contiguous()
         dev = data.device
         nseg = int(seg_start.numel())
@@ -439,10 +441,11 @@ class FFTPlan:
             assert out.is_cuda and out.is_contiguous() and out.dtype == self.out_dtype
             assert tuple(out.shape) == self.out_shape(nseg), (tuple(out.shape), self.out_shape(nseg))
         self.ctx.bind_stream()
-        self.tracked_absmax = False
+        tracked = False
         if absmax is not None:
             assert absmax.is_cuda and absmax.dtype == torch.float32 and absmax.numel() == self.nchan and absmax.is_contiguous()
-            self.tracked_absmax = self.ctx.lib.spyhip_fft_plan_set_absmax(self.handle, _ptr(absmax)) == 0
+            tracked = self.ctx.lib.spyhip_fft_plan_set_absmax(self.handle, _ptr(absmax)) == 0      # (-3: not tracked)
+        self.tracked_absmax = tracked
         try:
             check(self.ctx.lib.spyhip_fft_exec(self.handle, _ptr(data), int(data.shape[1]), _ptr(chan_idx),
                                                _ptr(seg_start), _ptr(seg_lo), _ptr(seg_hi), nseg, _ptr(out)),
@@ -450,6 +453,7 @@ class FFTPlan:
         finally:
             if self.tracked_absmax:
                 self.ctx.lib.spyhip_fft_plan_set_absmax(self.handle, None)
+        out.spyhip_absmax_tracked = self.tracked_absmax
         return out
 
     def __del__(self):

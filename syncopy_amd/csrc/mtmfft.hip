@@ -585,9 +585,8 @@ extern "C" int spyhip_fft_plan_set_absmax(spyhip_fft_plan* p, float* absmax_d) {
     // the packed power-of-two kernel (mtmfft2_kernel.h) bounds its spectra from the samples it holds; every other family
     // (other lengths, float64 transforms) gets a pass over the segments ahead of the transform (seg_range_kernel)
     const bool ok = !p->blocked && p->output == SPYHIP_OUT_FOURIER && p->keeptapers;
-    if (!ok) {
+    if (!ok) {                 // a documented answer ("not tracked"), not a failure: the error string stays as it is
         p->absmax = nullptr;
-        spy::set_error("fft_plan_set_absmax: this plan's kernel does not deliver the range of its spectra");
         return -3;
     }
     p->absmax = reinterpret_cast<unsigned*>(absmax_d);

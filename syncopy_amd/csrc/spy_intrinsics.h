@@ -2,6 +2,10 @@
 // kernel attribute or a compiler vector type goes through one of the names below, so that the kernel sources themselves
 // are plain C++: the host-side kernel emulator of the test suite (tests/emu/) defines SPY_INTRINSICS_H and its own
 // versions of the same names before it includes a kernel header, and nothing in csrc/ knows about it.
+// ONE EXCEPTION, stated rather than hidden: csdh_kernel.h (K4h) uses v_mfma_f32_16x16x32_f16, v_fma_mix inline assembly,
+// s_setprio, sched_barrier and readfirstlane directly - its instruction stream IS the kernel - and is
+// therefore not built by the emulator: K4h is covered on the GPU only (tests/test_gpu_k4h.py, test_gpu_depth.py, the smoke
+// test, bench.py's selfcheck); its float32 stand-in csd3m_kernel is emulated.
 #ifndef SPY_INTRINSICS_H
 #define SPY_INTRINSICS_H
 #include <hip/hip_runtime.h>

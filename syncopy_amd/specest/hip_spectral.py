@@ -336,5 +336,5 @@ def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_
             spec = plan.execute(dev_data, starts, chan_idx=ci, out=buf, absmax=am)
             spec.spyhip_blocked = plan.blocked
             spec.spyhip_ntaper = plan.kout
-            spec.spyhip_absmax = am if plan.tracked_absmax else None
+            spec.spyhip_absmax = am if getattr(spec, "spyhip_absmax_tracked", plan.tracked_absmax) else None
             yield sel, spec
