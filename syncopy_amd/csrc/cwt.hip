@@ -30,6 +30,8 @@ struct spyhip_cwt_plan {
     std::vector<CwtGroup*> groups;
     bool identity_time = true;
     spy::DevBuf<int> tpos, tfloor;
+    spy::DevBuf<float> xt;        // channel-major copy of the chunk's pre-selected signals (cwt_stage_input_kernel)
+    size_t xt_cap = 0;
     spy::DevBuf<double> trend, trend_part;
     size_t trend_cap = 0;
     spy::DevBuf<char> stage;      // time-contiguous staging of one chunk of segments
@@ -492,6 +494,16 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         p->chunk_long = chunk;
     }
     if (pairt) chunk *= 2;                             // from here on: segments per chunk
+    // channel-major copy of the chunk's signals for the float32 kernels (several channels per row: a gather otherwise)
+    const bool use_xt = !p->precision64 && p->nchan > 1;
+    if (use_xt) {
+        const size_t need = (size_t)std::min(chunk, nseg) * p->nchan * p->nsig;
+        if (need > p->xt_cap) {
+            if (p->xt.p) { SPY_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); (void)hipFree(p->xt.p); p->xt.p = nullptr; p->xt_cap = 0; }
+            if (p->xt.alloc(need)) return -2;
+            p->xt_cap = need;
+        }
+    }
     for (int s0 = 0; s0 < nseg; s0 += chunk) {
         const int ns = std::min(chunk, nseg - s0);
         CwtArgs c = a;
@@ -502,6 +514,12 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
         if (a.trend) c.trend = a.trend + (size_t)s0 * p->nchan * 2;
         c.nseg = ns;
         if (p->nscales > 65535 || ns > 65535) { spy::set_error("cwt_exec: grid too large"); return -1; }
+        if (use_xt) {
+            hipLaunchKernelGGL(spyfft::cwt_stage_input_kernel, dim3((p->nsig + 63) / 64, (p->nchan + 63) / 64, ns), dim3(256), 0,
+                               p->ctx->stream, c, p->xt.p);
+            SPY_HIP_CHECK(hipGetLastError());
+            c.xt = p->xt.p;
+        }
         if (p->precision64) {
             // float64 convolutions, one workgroup per (segment, channel), three length-L work arrays each: launches of
             // at most ~2 GiB of them

@@ -46,6 +46,10 @@ struct CwtArgs {
     const int* sidx;              // scale s of this launch -> scale index of the plan (nullptr = identity): scales
     int nscales_total;            // are grouped by the block length their kernel support needs (0 = nscales)
     int stage_add;                // 1: add to the staging values (later pieces of a kernel longer than one block)
+    const float* xt;              // nullptr, or the pre-selected signals of this launch's segments channel-major and
+                                  // time-contiguous: xt[(b * nchan + c) * nsig + n] (cwt_stage_input_kernel) - a transform
+                                  // workgroup needs 4 ... 32 bytes of every 4 nchan-byte row of the trial; from the copy its
+                                  // lanes read consecutive samples (c4 wavelet: 430 MB of fetches per trial for 46 MB of input)
     const int* smap;              // scatter kernels: staging row s of a segment -> scale index of the output (nullptr = identity)
     int nscales_out;              // scatter kernels: scales of the output (0 = nscales: every scale is staged)
 };
@@ -162,6 +166,30 @@ __global__ void __launch_bounds__(64) cwt_mean_np_kernel(CwtArgs a, double* tren
     o[1] = 0.0;
 }
 
+// The pre-selected signals of a chunk of segments, turned channel-major (CwtArgs::xt): tiles of 64 samples x 64 channels
+// read along the channels (256 contiguous bytes per row of the trial), turned in LDS, written along time.  One pass over
+// the input (8.4 MB read + written per trial at 128 channels x 16384 samples) instead of a gather by every block group.
+__global__ void __launch_bounds__(256) cwt_stage_input_kernel(CwtArgs a, float* xt) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const long long start = a.seg_start[b];
+    const int c = c0 + tx;
+    const long long col = c < a.nchan ? (a.chan_idx ? a.chan_idx[c] : c) : 0;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int n = n0 + r;
+        if (n < a.nsig && c < a.nchan) tile[r][tx] = a.data[(start + n) * a.ld + col];
+    }
+    __syncthreads();
+    const int n = n0 + tx;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int cc = c0 + r;
+        if (n < a.nsig && cc < a.nchan) xt[((size_t)b * a.nchan + cc) * (size_t)a.nsig + n] = tile[tx][r];
+    }
+}
+
 template <int LOG2N, int G, int OUTK>
 __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) cwt_kernel(CwtArgs a) {
     using C = Cfg<LOG2N, G>;
@@ -198,7 +226,7 @@ __global__ void __launch_bounds__((Cfg<LOG2N, G>::NTHREADS)) cwt_kernel(CwtArgs 
         float x = 0.f;
         if (has && u >= 0 && u < a.nsig) {
             const long long row = start + u;
-            x = a.data[row * a.ld + col];
+            x = a.xt ? a.xt[((size_t)b * a.nchan + c) * (size_t)a.nsig + u] : a.data[row * a.ld + col];
             if (a.detrend >= 0) x -= (float)(mean + slope * ((double)(row - tlo) - mid));
         }
         v[e] = make_float2(x, 0.f);
@@ -292,7 +320,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2_kernel(CwtArg
             for (int i = 0; i < 2; ++i)
                 if (has[i]) {
                     const long long row = start[i] + u;
-                    x[i] = a.data[row * a.ld + col[i]];
+                    x[i] = a.xt ? a.xt[((size_t)bs[i] * a.nchan + (PAIRT ? c0 : c0 + i)) * (size_t)a.nsig + u] : a.data[row * a.ld + col[i]];
                     if (a.detrend >= 0) x[i] -= (float)(mean[i] + slope[i] * ((double)(row - tlo[i]) - mid[i]));
                 }
         }
@@ -394,7 +422,7 @@ __global__ void __launch_bounds__((Cfg2<LOG2N, G>::NTHREADS)) cwt2d_kernel(CwtAr
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 if (has[i]) {
-                    x[i] = a.data[row * a.ld + col[i]];
+                    x[i] = a.xt ? a.xt[((size_t)b * a.nchan + c0 + i) * (size_t)a.nsig + u] : a.data[row * a.ld + col[i]];
                     if (a.detrend >= 0) x[i] -= (float)(mean[i] + slope[i] * ((double)(row - tlo) - mid));
                 }
         }
