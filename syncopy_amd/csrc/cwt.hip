@@ -28,6 +28,10 @@ struct spyhip_cwt_plan {
     spyhip_ctx* ctx = nullptr;
     int nsig = 0, nchan = 0, nscales = 0, detrend = -1, output = 0, ntime_out = 0;
     std::vector<CwtGroup*> groups;
+    // trial sums (accumulate = 2) take longer blocks (build_groups): their own groups for the scales a block holds, built
+    // at the first such call, followed by the (shared) piece groups of the long scales
+    std::vector<CwtGroup*> groups_sum, groups_sum_owned;
+    bool groups_sum_built = false;
     bool identity_time = true;
     spy::DevBuf<int> tpos, tfloor;
     spy::DevBuf<float> xt;        // channel-major copy of the chunk's pre-selected signals (cwt_stage_input_kernel)
@@ -57,7 +61,10 @@ struct spyhip_cwt_plan {
     spy::DevBuf<double2> tw64, hspec64, work64;
     spy::DevBuf<int> centre64;
     long long chunk64 = 0;
-    ~spyhip_cwt_plan() { for (auto* g : groups) delete g; }
+    ~spyhip_cwt_plan() {
+        for (auto* g : groups) delete g;
+        for (auto* g : groups_sum_owned) delete g;
+    }
 };
 
 namespace {
@@ -125,6 +132,70 @@ int launch_cwt_out(spyhip_cwt_plan* p, const CwtArgs& a, unsigned grid) {
     return launch_cwt<LOG2N, G, 1>(p, a, grid);
 }
 }  // namespace
+
+// Groups of scales by the block length their (trimmed) kernel support needs: >= 4x the kernel (>= 75 % of a block is
+// output) while that stays on the packed engine (<= 8192), else >= 2x, up to the 16384-point engine - and never below
+// `nbmin`.  Which minimum pays depends on where the results go (measured at 128 ch x 16384 samples x 25 scales 4 ... 100 Hz,
+// us/trial: trial sums 169 / 162 / 146 / 189 at 1024 / 2048 / 4096 / 8192 - longer blocks waste less on the halo and the
+// staged kernels take them; per-trial outputs 245 / 250 / 265: the direct kernels exist for 1024 and 2048 points only).
+// Built from the sampled kernels the plan keeps (ker_re / ker_im / ker_c); appends to `out`.
+static int build_groups(spyhip_cwt_plan* p, int nbmin, std::vector<CwtGroup*>& out) {
+    spyhip_ctx* ctx = p->ctx;
+    const int nscales = p->nscales, nsig = p->nsig;
+    std::vector<int> need(nscales);
+    for (int s = 0; s < nscales; ++s) {
+        const int Lt = (int)p->ker_re[s].size();
+        int NB = nbmin;
+        while (NB < 4 * (Lt + 1) && NB < 8192) NB <<= 1;
+        while (NB < 2 * (Lt + 1) && NB < 16384) NB <<= 1;
+        need[s] = 2 * (Lt + 1) > 16384 ? 0 : NB;    // (0: cut into pieces, spyhip_cwt_plan::long_scales)
+    }
+    for (int NB = 1024; NB <= 16384; NB <<= 1) {
+        std::vector<int> ids;
+        for (int s = 0; s < nscales; ++s)
+            if (need[s] == NB) ids.push_back(s);
+        if (ids.empty()) continue;
+        int halo = 0, right = 0, lmax = 1;
+        for (int s : ids) {
+            const int Lt = (int)p->ker_re[s].size();
+            lmax = std::max(lmax, Lt);
+            halo = std::max(halo, Lt - 1 - p->ker_c[s]);              // reach to the left: L-1-c
+            right = std::max(right, p->ker_c[s]);
+        }
+        const int V = NB - halo - right;
+        if (V < 1) {
+            spy::set_error("cwt_plan_create: kernel support of %d taps exceeds the %d-point block FFT "
+                           "(scale too large for this signal length)", lmax, NB);
+            return -3;
+        }
+        auto* g = new CwtGroup();
+        out.push_back(g);
+        g->log2n = spy::ilog2((unsigned)NB);
+        // channel PAIRS per workgroup of the packed kernel (<= 2^13); channels per workgroup of the 2^14 kernel
+        g->G = g->log2n == 10 ? 4 : (g->log2n == 11 ? 2 : 1);
+        g->V = V; g->halo = halo; g->nblocks = (nsig + V - 1) / V; g->nscales = (int)ids.size();
+        g->direct = g->log2n <= 11;
+        g->scale_ids = ids;
+        std::vector<float2> tw(NB), hs(ids.size() * (size_t)NB);
+        for (int m = 0; m < NB; ++m) {
+            const double ang = -2.0 * PI * m / NB;
+            tw[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+        std::vector<int> cshift(ids.size());
+        for (size_t q = 0; q < ids.size(); ++q) {
+            const int sc = ids[q];
+            std::vector<double> re(NB, 0.0), im(NB, 0.0);
+            for (size_t m = 0; m < p->ker_re[sc].size(); ++m) { re[m] = p->ker_re[sc][m]; im[m] = p->ker_im[sc][m]; }
+            spy::fft_host(re, im);
+            for (int k = 0; k < NB; ++k) hs[q * NB + k] = make_float2((float)(re[k] / NB), (float)(im[k] / NB));
+            cshift[q] = halo + p->ker_c[sc];
+        }
+        if (g->tw.upload(tw, ctx->stream) || g->hspec.upload(hs, ctx->stream) || g->cshift.upload(cshift, ctx->stream) ||
+            g->sidx.upload(ids, ctx->stream))
+            return -2;
+    }
+    return 0;
+}
 
 // family 0: Morlet(w0 = p0) as Morlet.time / cwt_time sample it; family 1: the superlet formulation MorletSL with
 // p0 = c_i cycles inside the Gaussian envelope of p1 = k_sd standard deviations (specest/superlet.py:268-363);
@@ -231,68 +302,10 @@ static int cwt_plan_create_impl(spyhip_ctx* ctx, int nsig, int nchan, int nscale
         p->ker_im.push_back(kers[s].im);
         p->ker_c.push_back(kers[s].c);
     }
-    // block length per scale, within what the LDS FFTs support
-    std::vector<int> need(nscales);
-    for (int s = 0; s < nscales; ++s) {
-        const int Lt = (int)kers[s].re.size();
-        // >= 4x the kernel (>= 75 % of a block is output) while that stays on the packed engine (<= 8192),
-        // else >= 2x, up to the 16384-point engine
-        int NB = 1024;
-        while (NB < 4 * (Lt + 1) && NB < 8192) NB <<= 1;
-        while (NB < 2 * (Lt + 1) && NB < 16384) NB <<= 1;
-        need[s] = NB;
-        if (2 * (Lt + 1) > 16384) {                 // longer than one block can serve: cut into pieces (below)
-            need[s] = 0;
-            p->long_scales.push_back(s);
-        }
-    }
-    for (int NB = 1024; NB <= 16384; NB <<= 1) {
-        std::vector<int> ids;
-        for (int s = 0; s < nscales; ++s)
-            if (need[s] == NB) ids.push_back(s);
-        if (ids.empty()) continue;
-        int halo = 0, right = 0, lmax = 1;
-        for (int s : ids) {
-            const int Lt = (int)kers[s].re.size();
-            lmax = std::max(lmax, Lt);
-            halo = std::max(halo, Lt - 1 - kers[s].c);               // reach to the left: L-1-c
-            right = std::max(right, kers[s].c);
-        }
-        const int V = NB - halo - right;
-        if (V < 1) {
-            spy::set_error("cwt_plan_create: kernel support of %d taps exceeds the %d-point block FFT "
-                           "(scale too large for this signal length)", lmax, NB);
-            delete p;
-            return -3;
-        }
-        auto* g = new CwtGroup();
-        p->groups.push_back(g);
-        g->log2n = spy::ilog2((unsigned)NB);
-        // channel PAIRS per workgroup of the packed kernel (<= 2^13); channels per workgroup of the 2^14 kernel
-        g->G = g->log2n == 10 ? 4 : (g->log2n == 11 ? 2 : 1);
-        g->V = V; g->halo = halo; g->nblocks = (nsig + V - 1) / V; g->nscales = (int)ids.size();
-        g->direct = g->log2n <= 11;
-        g->scale_ids = ids;
-        std::vector<float2> tw(NB), hs(ids.size() * (size_t)NB);
-        for (int m = 0; m < NB; ++m) {
-            const double ang = -2.0 * PI * m / NB;
-            tw[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-        }
-        std::vector<int> cshift(ids.size());
-        for (size_t q = 0; q < ids.size(); ++q) {
-            const int sc = ids[q];
-            std::vector<double> re(NB, 0.0), im(NB, 0.0);
-            for (size_t m = 0; m < kers[sc].re.size(); ++m) { re[m] = kers[sc].re[m]; im[m] = kers[sc].im[m]; }
-            spy::fft_host(re, im);
-            for (int k = 0; k < NB; ++k) hs[q * NB + k] = make_float2((float)(re[k] / NB), (float)(im[k] / NB));
-            cshift[q] = halo + kers[sc].c;
-        }
-        if (g->tw.upload(tw, ctx->stream) || g->hspec.upload(hs, ctx->stream) || g->cshift.upload(cshift, ctx->stream) ||
-            g->sidx.upload(ids, ctx->stream)) {
-            delete p;
-            return -2;
-        }
-    }
+    // block length per scale and the groups of scales that share one (build_groups); scales whose kernel no block holds
+    for (int s = 0; s < nscales; ++s)
+        if (2 * ((int)kers[s].re.size() + 1) > 16384) p->long_scales.push_back(s);
+    if (int rc = build_groups(p, 1024, p->groups)) { delete p; return rc; }
     // ---- kernels longer than a block: h = sum_p h_p (pieces of CWT_PIECE taps), y = sum_p h_p * x.  Piece p is an
     // overlap-save convolution of its own: taps [p PL, p PL + Lp), centre c_p = c - p PL (may be negative or beyond the
     // piece), input window from o0 - halo_p with halo_p = Lp - 1 - c_p, output n of block o0 at q = n - o0 + Lp - 1.
@@ -473,7 +486,19 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
     // row set then holds a pair of segments.  As many row sets per chunk as fit ~4 GiB (at least one).
     const bool use_direct = p->direct && !p->precision64 && accumulate != 2;
     bool pairt = accumulate == 2 && !p->precision64;
-    for (const CwtGroup* gr : p->groups) pairt = pairt && gr->log2n <= 13;      // (the 16384-point kernel is not packed)
+    const std::vector<CwtGroup*>* groups = &p->groups;
+    if (pairt && p->nsig >= 4096) {                  // trial sums of long signals: blocks of at least 4096 points
+        if (!p->groups_sum_built) {
+            if (int rc = build_groups(p, 4096, p->groups_sum_owned)) return rc;
+            p->groups_sum = p->groups_sum_owned;
+            for (CwtGroup* gr : p->groups)
+                if (gr->long_idx >= 0) p->groups_sum.push_back(gr);
+            p->groups_sum_built = true;
+        }
+        groups = &p->groups_sum;
+    }
+    for (const CwtGroup* gr : *groups) pairt = pairt && gr->log2n <= 13;       // (the 16384-point kernel is not packed)
+    if (!pairt) groups = &p->groups;
     const int nst = use_direct ? (int)p->staged.size() : p->nscales;          // staging rows per row set
     const size_t esz = (p->output == SPYHIP_OUT_FOURIER) ? 8 : 4;
     const size_t per_seg = (size_t)nst * p->nchan * p->nsig * esz;
@@ -544,8 +569,8 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
                 if (rc) return rc;
             }
         }
-        for (size_t gi = 0; gi < p->groups.size(); ++gi) {           // one launch per block length
-            const CwtGroup* gr = p->groups[gi];
+        for (size_t gi = 0; gi < groups->size(); ++gi) {              // one launch per block length
+            const CwtGroup* gr = (*groups)[gi];
             if (p->precision64) break;
             CwtArgs k = c;
             k.nscales = gr->nscales;

@@ -535,11 +535,13 @@ def test_cwt_direct_kernels_equal_the_staged_path(be, output, C):
         assert_parity(tb.cpu().numpy(), ref.cpu().numpy().astype(tb.cpu().numpy().dtype), what="staged trial sum")
 
 
-def test_cwt_direct_trial_sum_many_trials(be):
-    """Trial sums with more trials than split owners: 128 channels x 4000 samples x 37 trials, every scale on the direct
-    kernels (no staging buffer at all), in two calls; against the float64 sum of the per-trial outputs."""
+def test_cwt_trial_sums_long_signals_own_block_groups(be):
+    """Trial sums of signals of 4096 samples and more run on their own block groups (at least 4096 points per block,
+    spyhip_cwt_exec: build_groups) with one channel of TWO trials per packed thread: 128 channels x 4500 samples x 37
+    trials (an odd count: the last pair is half empty) in two calls, against the float64 sum of the per-trial outputs,
+    which come from the 1024- / 2048-point direct kernels."""
     rng = np.random.default_rng(19)
-    nsig, C, T = 4000, 128, 37
+    nsig, C, T = 4500, 128, 37
     data = torch.from_numpy(rng.normal(size=(T * nsig, C)).astype(np.float32)).cuda()
     scales = (1 / np.array([24.0, 40.0, 64.0, 100.0])) * (6 + np.sqrt(38)) / (4 * np.pi)
     plan = be.CWTPlan(nsig, C, scales, 1e-3, 6.0, 0, "pow")
