@@ -62,8 +62,17 @@ def _detrend_exact(x, polyremoval):
 
 
 def _detrend_frames_exact(frames, kind):
-    """O.detrend_frames with the fit in float64 (the frames of a `toi`-array mtmconvol are float32 in the reference)."""
-    return sps.detrend(np.asarray(frames, dtype=np.float64), type=kind).astype(frames.dtype)
+    """O.detrend_frames with the FIT in float64 and everything else as scipy.signal.detrend does it on the float32 frames
+    of a `toi`-array mtmconvol (stft.py:101-132): the trend is rounded to the frames' dtype and subtracted in it
+    (signaltools.py: `newdata - A @ coef`) - with channels riding on offsets of 20 standard deviations that rounding is
+    1.9e-6 per sample, the same on both sides, and not part of what the float64 fit changes (family 1700000, seed 187:
+    the Nyquist bin of 32-sample windows sat at 1.11 x while the float64-rounded variant of this helper was 1.8 x away
+    from BOTH sides)."""
+    f64 = np.asarray(frames, dtype=np.float64)
+    trend = f64 - sps.detrend(f64, type=kind)
+    if frames.dtype == np.float32:
+        return frames - trend.astype(np.float32)
+    return (f64 - trend).astype(frames.dtype)
 
 
 def _modulus_scale(fn, data, classes, kw):

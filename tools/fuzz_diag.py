@@ -12,11 +12,11 @@ fn = {"mtmfft": T.test_mtmfft_random_options, "conn": T.test_connectivity_random
       "tf": T.test_timefrequency_random_options, "sel": T.test_mtmfft_selections_and_window_options,
       "welch": T.test_welch_and_superlet_random_options, "toi": T.test_timefrequency_toi_foi_offsets,
       "consel": T.test_connectivity_selections_and_spectral_input, "corr": T.test_corr_and_jackknife_random_options}[kind]
-def report(got, ref, exact, what="", atol_rel=parity.ATOL_REL, rtol=parity.RTOL):
+def report(got, ref, exact, what="", atol_rel=parity.ATOL_REL, rtol=parity.RTOL, scale=None):
     if getattr(got, "per_trial_route", None) is not None:
-        report(got.per_trial_route, ref, exact, what + " [per-trial route]", atol_rel, rtol)
+        report(got.per_trial_route, ref, exact, what + " [per-trial route]", atol_rel, rtol, scale)
     a = np.asarray(got.data); b = np.asarray(ref.data)
-    tol = rtol * np.abs(b) + atol_rel * np.abs(b).max()
+    tol = rtol * np.abs(b) + atol_rel * max(float(np.abs(b).max()), scale or 0.0)
     if exact is not None:
         base = tol.copy()
         e0 = np.abs(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64) - b)
