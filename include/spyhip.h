@@ -215,6 +215,15 @@ int spyhip_csd_set_phase_exact(spyhip_ctx* ctx, int on);
  * spyhip_csd_accumulate.  Same reference lines (connectivity/csd.py:94-102). */
 int spyhip_csd_accumulate_split(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
                                 void* acc_d, const float* absmax_d);
+/* The same update for the frequencies [f0, f0 + nf) only (spec_d and acc_d still point at frequency 0; nchan = 256 and
+ * absmax_d are required): a caller that launches range by range can normalise and ship the results of range r while range
+ * r + 1 is being accumulated - the coherence pipeline of the front end hides three quarters of its 0.54 GB host copy this
+ * way.  The ranges of one accumulation may come in any order but must not overlap; together they equal one full call; a
+ * range that reaches into the last partial round of workgroups (nfreq % CUs frequencies at the end) must end at nfreq.
+ * Reference lines: connectivity/csd.py:94-102 (products), shared/computational_routine.py:1022-1036 (a result the caller
+ * can read). */
+int spyhip_csd_accumulate_split_range(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                                      void* acc_d, const float* absmax_d, int f0, int nf);
 /* number of frequencies the last spyhip_csd_accumulate_split call of this context handed to the float32 kernels
  * (synchronises the stream; for tests and benchmarks) */
 int spyhip_csd_split_fallbacks(spyhip_ctx* ctx, int* count);

@@ -184,7 +184,7 @@ def serve():
         spec.spyhip_blocked, spec.spyhip_ntaper, spec.spyhip_absmax = False, spec.shape[1], None
         yield np.arange(len(rows)), spec
 
-    def csd_accumulate(spec, acc, blocked=False, absmax=None, split=True):
+    def csd_accumulate(spec, acc, blocked=False, absmax=None, **kw):
         s = spec.reshape(-1, spec.shape[-2], spec.shape[-1])
         acc += torch.einsum("rfi,rfj->fij", s, s.conj())
         return acc

@@ -54,6 +54,7 @@ SIGNATURES = {
     "spyhip_csd_accumulate": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "spyhip_csd_set_phase_exact": (C.c_int, [vp, C.c_int]),
     "spyhip_csd_accumulate_split": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
+    "spyhip_csd_accumulate_split_range": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int]),
     "spyhip_csd_split_fallbacks": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "spyhip_fft_plan_set_absmax": (C.c_int, [vp, vp]),
     "spyhip_csd_accumulate_blocked": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),

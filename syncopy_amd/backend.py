@@ -99,6 +99,7 @@ _RESULT_PIN_GRAIN = 64 << 20
 _result_free = {}               # rounded size -> [pinned uint8 tensors]
 _result_bytes = [0]             # page-locked bytes of the pool, live and free
 _result_lock = None
+_result_zombies = []            # (copy-finished event, block) of HostLandings dropped unread while their copy was under way
 
 
 def _result_block(nbytes):
@@ -111,6 +112,10 @@ def _result_block(nbytes):
         _result_lock = threading.Lock()
     size = (nbytes + _RESULT_PIN_GRAIN - 1) // _RESULT_PIN_GRAIN * _RESULT_PIN_GRAIN
     with _result_lock:
+        # blocks of landings nobody read, whose copy has finished meanwhile
+        for item in [z for z in _result_zombies if z[0].query()]:
+            _result_zombies.remove(item)
+            _result_free.setdefault(item[1].numel(), []).append(item[1])
         lst = _result_free.get(size)
         if lst:
             return lst.pop()
@@ -336,6 +341,10 @@ def release_buffers():
             for k, lst in _result_free.items():
                 _result_bytes[0] -= k * len(lst)
             _result_free.clear()
+            for ev, blk in _result_zombies:
+                ev.synchronize()
+                _result_bytes[0] -= blk.numel()
+            del _result_zombies[:]
     for ctx in _contexts.values():
         ctx.lib.spyhip_ctx_trim(ctx.handle)
     if torch.cuda.is_available():
@@ -569,14 +578,16 @@ class csd_phase_exact:
         return False
 
 
-def csd_accumulate(spec, acc, blocked=False, absmax=None, split=True):
+def csd_accumulate(spec, acc, blocked=False, absmax=None, split=True, ranges=None):
     """acc[f,i,j] += sum_r spec[r,f,i] conj(spec[r,f,j]) on the lower triangle (MFMA).
     spec: (..., F, C) complex64 (leading dims flattened to rows), or with blocked=True the hand-over layout
     (rows, ceil(C/4), F, 4) of FFTPlan.set_blocked; acc: (F, C, C) complex64.
     256 channels in the standard layout run on the half-precision matrix cores with split operands
     (spyhip_csd_accumulate_split); `absmax`: (256,) float32 bound of |re|, |im| per channel as FFTPlan.execute(...,
     absmax=) leaves it, or None: the library takes its own pass over the spectra first.  `split=False` keeps 256 channels
-    on the float32 matrix instructions (spyhip_csd_accumulate: float32 operands, the reference's operand precision)."""
+    on the float32 matrix instructions (spyhip_csd_accumulate: float32 operands, the reference's operand precision).
+    `ranges` = [(f0, f1), ...] (frequency_ranges): the K4h update launched range by range, `acc.spyhip_range_events` =
+    [(f0, f1, event)] of THIS call for coh_pipeline (None after a call in one piece)."""
     assert spec.is_cuda and spec.dtype == torch.complex64 and spec.is_contiguous()
     assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous()
     ctx = context(spec.device)
@@ -594,11 +605,107 @@ def csd_accumulate(spec, acc, blocked=False, absmax=None, split=True):
     if Cn == 256 and nrows > 0 and split:
         if absmax is not None:
             assert absmax.is_cuda and absmax.dtype == torch.float32 and absmax.numel() == 256 and absmax.is_contiguous()
+        if ranges and absmax is not None and not os.environ.get("SPYHIP_CSD_F32"):
+            # frequency range by frequency range, an event behind each: whoever turns the accumulator into a result can
+            # start on range r while range r + 1 is still being accumulated (coh_pipeline)
+            stream = torch.cuda.current_stream(spec.device)
+            events = []
+            for f0, f1 in ranges:
+                check(ctx.lib.spyhip_csd_accumulate_split_range(ctx.handle, _ptr(spec), nrows, F, Cn, _ptr(acc), _ptr(absmax),
+                                                                int(f0), int(f1 - f0)), "spyhip_csd_accumulate_split_range")
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                events.append((int(f0), int(f1), ev))
+            acc.spyhip_range_events = events
+            return acc
+        acc.spyhip_range_events = None
         check(ctx.lib.spyhip_csd_accumulate_split(ctx.handle, _ptr(spec), nrows, F, Cn, _ptr(acc), _ptr(absmax)),
               "spyhip_csd_accumulate_split")
         return acc
     check(ctx.lib.spyhip_csd_accumulate(ctx.handle, _ptr(spec), nrows, F, Cn, _ptr(acc)), "spyhip_csd_accumulate")
     return acc
+
+
+class HostLanding:
+    """A page-locked block of the result pool that an asynchronous device-to-host copy is filling.  `array()` waits for
+    the copy and hands the block out as a NumPy array (it returns to the pool when the array and its views are garbage);
+    a landing nobody reads gives its block back when it dies - once the copy has finished (until then the block waits in
+    `_result_zombies`), so that the next user of the block is not overwritten by it."""
+
+    def __init__(self, block, nbytes, shape, np_dtype):
+        self.block, self.nbytes, self.shape, self.np_dtype, self.done = block, nbytes, tuple(shape), np_dtype, None
+
+    def tensor(self, torch_dtype):
+        return self.block[:self.nbytes].view(torch_dtype).reshape(self.shape)
+
+    def array(self):
+        import weakref
+        self.done.synchronize()
+        block, self.block = self.block, None
+        root = block.numpy()
+        weakref.finalize(root, _result_release, block)
+        return root[:self.nbytes].view(self.np_dtype).reshape(self.shape)
+
+    def __del__(self):
+        try:
+            if self.block is not None:
+                if self.done is not None and not self.done.query():
+                    with _result_lock:               # still being written: parked until the copy is through
+                        _result_zombies.append((self.done, self.block))
+                else:
+                    _result_release(self.block)
+        except Exception:
+            pass
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def coh_pipeline(acc, scale, output, events):
+    """The coherence result of an accumulator whose last update came range by range (csd_accumulate(ranges=)): on a side
+    stream, for every range as soon as its event has passed, the fused normalisation (coh_from_accumulator) and the
+    asynchronous copy of that range into a page-locked landing block - under the matrix products of the next range.  The
+    0.54 GB of a 256-channel coherence then cost the caller the copy of the LAST range (~2.5 ms) instead of 9.5 ms behind
+    the kernels.  Returns (device result (F, C, C), HostLanding or None when the result pool is full).  The caller's stream
+    waits for the normalisation, not for the copies."""
+    F, Cn, _ = acc.shape
+    kind = OUTPUT_KIND[output]
+    odt = torch.complex64 if kind == 2 else torch.float32
+    res = torch.empty((F, Cn, Cn), dtype=odt, device=acc.device)
+    nbytes = res.numel() * res.element_size()
+    block = _result_block(nbytes)
+    landing = HostLanding(block, nbytes, (F, Cn, Cn), _NP_DTYPE[odt]) if block is not None else None
+    host = landing.tensor(odt) if landing is not None else None
+    main, side = torch.cuda.current_stream(acc.device), _side_stream(acc.device)
+    acc.record_stream(side)
+    res.record_stream(side)
+    normalised = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        last = len(events) - 1
+        for k, (f0, f1, ev) in enumerate(events):
+            side.wait_event(ev)
+            coh_from_accumulator(acc[f0:f1], scale, output, out=res[f0:f1])
+            if k == last:
+                normalised.record(side)
+            if host is not None:
+                # in pieces of ~16 MB: the small host-to-device copies of the NEXT analysis (segment tables) queue behind
+                # whatever piece is on the bus, not behind a whole range
+                step = max(1, (16 << 20) // (Cn * Cn * res.element_size()))
+                for g0 in range(f0, f1, step):
+                    g1 = min(f1, g0 + step)
+                    host[g0:g1].copy_(res[g0:g1], non_blocking=True)
+        if landing is not None:
+            landing.done = torch.cuda.Event()
+            landing.done.record(side)
+    main.wait_event(normalised)
+    return res, landing
 
 
 def csd_split_fallbacks(device=None):
@@ -755,13 +862,30 @@ def coh_normalize(csd, output="abs"):
     return out
 
 
-def coh_from_accumulator(acc, scale, output="abs"):
+def frequency_ranges(nfreq, device=None, parts=4):
+    """[(f0, f1)] cutting `nfreq` frequencies into `parts` runs of whole rounds of workgroups (one K4h workgroup per
+    frequency and CU), the remainder with the last; None when there are fewer than two rounds per part."""
+    ncu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    rounds = nfreq // ncu
+    if rounds < 2 * parts:
+        return None
+    per = rounds // parts
+    edges = [k * per * ncu for k in range(parts)] + [nfreq]
+    return [(edges[k], edges[k + 1]) for k in range(parts)]
+
+
+def coh_from_accumulator(acc, scale, output="abs", out=None):
     """Coherence straight from the RAW lower-triangle accumulator of csd_accumulate (scale = 1/(tapers*trials)):
-    csd_finalize + coh_normalize fused, bit-identical, a third of the traffic.  acc is left untouched."""
+    csd_finalize + coh_normalize fused, bit-identical, a third of the traffic.  acc is left untouched.  Every frequency
+    is on its own: `acc[f0:f1]` with `out=res[f0:f1]` does a range."""
     assert acc.is_cuda and acc.dtype == torch.complex64 and acc.is_contiguous() and acc.dim() == 3
     F, Cn, _ = acc.shape
     kind = OUTPUT_KIND[output]
-    out = torch.empty((F, Cn, Cn), dtype=torch.complex64 if kind == 2 else torch.float32, device=acc.device)
+    odt = torch.complex64 if kind == 2 else torch.float32
+    if out is None:
+        out = torch.empty((F, Cn, Cn), dtype=odt, device=acc.device)
+    else:
+        assert out.is_cuda and out.is_contiguous() and out.dtype == odt and tuple(out.shape) == (F, Cn, Cn)
     ctx = context(acc.device)
     ctx.bind_stream()
     check(ctx.lib.spyhip_coh_from_accumulator(ctx.handle, _ptr(acc), F, Cn, float(scale), kind, _ptr(out)),

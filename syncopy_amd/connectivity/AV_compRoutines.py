@@ -79,6 +79,19 @@ class NormalizeCrossSpectra(_AverageRoutine):
 
     def compute_hip(self, data, out):
         raw = getattr(data, "_acc_raw", None)
+        events = getattr(raw, "spyhip_range_events", None) if raw is not None else None
+        if events:
+            # the ST stage's last update came frequency range by frequency range: normalise and ship each range to a
+            # page-locked landing block while the next is still being accumulated (backend.coh_pipeline) - reading
+            # `.data` then waits for the copy of the last range only (compute_sequential hands over a result the caller
+            # can read, computational_routine.py:1022-1036)
+            res, landing = backend.coh_pipeline(raw, data._acc_scale, self.cfg["output"], events)
+            res = res.unsqueeze(0)
+            out._dev = res
+            shape = tuple(res.shape)
+            out.set_pending((lambda: landing.array().reshape(shape)) if landing is not None else (lambda: backend.to_host(res)),
+                            shape, np.complex64 if res.is_complex() else np.float32)
+            return
         if raw is not None:
             # straight from the ST stage's raw accumulator: scale + normalise + convert + mirror in one pass
             res = backend.coh_from_accumulator(raw, data._acc_scale, self.cfg["output"]).unsqueeze(0)

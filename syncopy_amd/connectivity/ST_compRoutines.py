@@ -30,7 +30,7 @@ def _freq_selection(nSamples, samplerate, foi):
 
 
 def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, polyremoval, freq_idx, acc_of_trial,
-                 single_acc=False, upload=None):
+                 single_acc=False, upload=None, ranges=None):
     """Accumulate sum_k X_k X_k^H of every trial in `rows` into `acc_of_trial(i)` (device (F,C,C) c64).
     `single_acc`: every trial lands in the same accumulator, so the spectra may take the channel-blocked
     hand-over layout between the FFT and the CSD kernel (coalesced stores, identical results)."""
@@ -44,7 +44,7 @@ def _csd_of_rows(dev, rows, chans, nSamples, taper, taper_opt, demean_taper, pol
             continue
         am = getattr(spec, "spyhip_absmax", None)       # range of the whole batch: a bound for each of its trials too
         if single_acc:                                  # (one accumulator for every trial: no per-trial bookkeeping)
-            backend.csd_accumulate(spec, acc_of_trial(sel[0]), absmax=am)
+            backend.csd_accumulate(spec, acc_of_trial(sel[0]), absmax=am, ranges=ranges)
             continue
         groups = {}
         for k, i in enumerate(sel):
@@ -231,8 +231,13 @@ class CrossSpectra(ComputationalRoutine):
         else:
             acc = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
             getter = lambda i: acc                         # noqa: E731
+        # one rank, a result of 64 MB and more, 256 channels: the cross-spectral update goes frequency range by frequency
+        # range so that the AV stage can normalise and ship range r under the products of range r + 1 (backend.coh_pipeline)
+        ranges = None
+        if not self.keeptrials and C == 256 and not parallel.collective_active() and F * C * C * 4 >= (64 << 20):
+            ranges = backend.frequency_ranges(F, dev.device)
         K = _csd_of_rows(dev, rows, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"], cfg["demean_taper"], pr,
-                         freq_idx, getter, single_acc=not self.keeptrials, upload=upload) if rows else 1
+                         freq_idx, getter, single_acc=not self.keeptrials, upload=upload, ranges=ranges) if rows else 1
         data.device_data()                                  # (an upload in flight ends here at the latest)
         K = int(cfg["taper_opt"].get("Kmax", K)) if cfg["taper_opt"] else K
         self.metadata = [{"freqs_hash": _freqs_hash(freqs)}] * T

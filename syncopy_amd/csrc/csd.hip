@@ -126,22 +126,26 @@ extern "C" int spyhip_csd_accumulate(spyhip_ctx* ctx, const void* spec_d, int64_
 }
 
 // K4h (csdh_kernel.h): 256 channels on the half-precision matrix cores with split float32 operands.  The frequencies
-// beyond the last full round of workgroups go to the re-cut float32 tail like on the other paths.
-extern "C" int spyhip_csd_accumulate_split(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
-                                           void* acc_d, const float* absmax_d) {
+// beyond the last full round of workgroups go to the re-cut float32 tail like on the other paths.  [f0, f0 + nf): the
+// frequencies of this call - a caller that wants the results of a range while the next is still being accumulated (the
+// coherence pipeline: normalisation and host copy of range r under the products of range r + 1) launches range by range.
+static int csd_accumulate_split_range(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan, void* acc_d,
+                                      const float* absmax_d, int f0, int nf) {
     static const bool env_f32 = std::getenv("SPYHIP_CSD_F32") != nullptr;
-    if (!ctx || nchan != 256 || nrows < 1 || env_f32) {
-        if (ctx) ctx->k4h_nf = 0;           // spyhip_csd_split_fallbacks reports THIS call: nothing went to the half-precision kernel
-        return csd_accumulate_impl(ctx, spec_d, nrows, nfreq, nchan, acc_d, 0);
+    if (!spec_d || !acc_d || nfreq < 1 || f0 < 0 || nf < 0 || f0 + nf > nfreq) {
+        spy::set_error("csd_accumulate_split: null argument / bad shape");
+        return -1;
     }
-    if (!spec_d || !acc_d || nfreq < 1) { spy::set_error("csd_accumulate_split: null argument / bad shape"); return -1; }
+    if (nf == 0) return 0;
     SPY_HIP_CHECK(hipSetDevice(ctx->device));
+    (void)env_f32;
     if (!ctx->k4h_done) SPY_HIP_CHECK(hipEventCreateWithFlags(&ctx->k4h_done, hipEventDisableTiming));
     else SPY_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->k4h_done, 0));      // the previous call's flag readers are through
     const size_t need = (size_t)nfreq * sizeof(int) + 256 * sizeof(float);
     if (need > ctx->k4h_bytes) {
         if (ctx->k4h_buf) { SPY_HIP_CHECK(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->k4h_buf); ctx->k4h_buf = nullptr; ctx->k4h_bytes = 0; }
         SPY_HIP_CHECK(hipMalloc(&ctx->k4h_buf, need));
+        SPY_HIP_CHECK(hipMemsetAsync(ctx->k4h_buf, 0, need, ctx->stream));      // (ranges not launched yet read as "not flagged")
         ctx->k4h_bytes = need;
     }
     float* const own_max = reinterpret_cast<float*>(ctx->k4h_buf);
@@ -156,18 +160,45 @@ extern "C" int spyhip_csd_accumulate_split(spyhip_ctx* ctx, const void* spec_d, 
     const long long rem = nfreq % ctx->num_cu;
     int f_main = nfreq;
     if (nfreq > ctx->num_cu && rem > 0 && rem * 4 <= ctx->num_cu) f_main = nfreq - (int)rem;
-    int rc = spycsd::csdh_run(ctx->stream, spec, nrows, nfreq, reinterpret_cast<float2*>(acc_d), absmax_d, flags, f_main,
+    const int f1 = f0 + nf, h1 = std::min(f1, f_main);
+    if (f1 > f_main && f1 != nfreq) {          // the re-cut float32 tail [f_main, nfreq) goes in one piece
+        spy::set_error("csd_accumulate_split_range: a range beyond frequency %d must end at nfreq = %d", f_main, nfreq);
+        return -1;
+    }
+    int rc = 0;
+    if (h1 > f0)
+        rc = spycsd::csdh_run(ctx->stream, spec, nrows, nfreq, reinterpret_cast<float2*>(acc_d), absmax_d, flags, f0, h1 - f0,
                               ctx->csd_phase_exact != 0);
     ctx->k4h_nf = f_main;
     if (!rc) SPY_HIP_CHECK(hipEventRecord(ctx->k4h_done, ctx->stream));         // (behind csdh_kernel and its only_flagged stand-in)
-    if (rc || f_main == nfreq) return rc;
+    if (rc || f1 <= f_main) return rc;
     CsdArgs a{};
     a.spec = spec;
     a.nrows = nrows; a.F = nfreq; a.C = 256;
     a.acc = reinterpret_cast<float2*>(acc_d);
     a.nt = 8; a.ntiles = 36; a.nitems = (long long)nfreq * 36; a.cpad = 256;
     a.fast_per = 36;
-    return launch_tail(ctx, a, (long long)f_main * 36, nrows, nfreq, 256);
+    return launch_tail(ctx, a, (long long)std::max(f0, f_main) * 36, nrows, nfreq, 256);
+}
+
+extern "C" int spyhip_csd_accumulate_split(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                                           void* acc_d, const float* absmax_d) {
+    static const bool env_f32 = std::getenv("SPYHIP_CSD_F32") != nullptr;
+    if (!ctx || nchan != 256 || nrows < 1 || env_f32) {
+        if (ctx) ctx->k4h_nf = 0;           // spyhip_csd_split_fallbacks reports THIS call: nothing went to the half-precision kernel
+        return csd_accumulate_impl(ctx, spec_d, nrows, nfreq, nchan, acc_d, 0);
+    }
+    return csd_accumulate_split_range(ctx, spec_d, nrows, nfreq, nchan, acc_d, absmax_d, 0, nfreq);
+}
+
+extern "C" int spyhip_csd_accumulate_split_range(spyhip_ctx* ctx, const void* spec_d, int64_t nrows, int nfreq, int nchan,
+                                                 void* acc_d, const float* absmax_d, int f0, int nf) {
+    static const bool env_f32 = std::getenv("SPYHIP_CSD_F32") != nullptr;
+    if (!ctx || nchan != 256 || nrows < 1 || env_f32 || !absmax_d) {
+        spy::set_error("csd_accumulate_split_range: 256 channels, at least one row and the range of the spectra (absmax_d) are required");
+        return -1;
+    }
+    return csd_accumulate_split_range(ctx, spec_d, nrows, nfreq, nchan, acc_d, absmax_d, f0, nf);
 }
 
 extern "C" int spyhip_csd_split_fallbacks(spyhip_ctx* ctx, int* count) {

@@ -7,12 +7,12 @@
 
 namespace spycsd {
 
-int csdh_run(hipStream_t stream, const float2* spec, long long nrows, int F, float2* acc, const float* absmax, int* flags, int nf,
-             bool phase_exact) {
+int csdh_run(hipStream_t stream, const float2* spec, long long nrows, int F, float2* acc, const float* absmax, int* flags, int f0,
+             int nf, bool phase_exact) {
     if (nf <= 0 || nrows <= 0) return 0;
     if (nrows > 0x7fffffffLL) { spy::set_error("csd_accumulate: more than 2^31 - 1 rows in one call"); return -1; }
     CsdhArgs a{};
-    a.spec = spec; a.nrows = nrows; a.F = F; a.acc = acc; a.absmax = absmax; a.flags = flags; a.f0 = 0; a.nf = nf;
+    a.spec = spec; a.nrows = nrows; a.F = F; a.acc = acc; a.absmax = absmax; a.flags = flags; a.f0 = f0; a.nf = nf;
     a.rs = (long long)F * 256; a.fs = 256;
     SPY_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(csdh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       CSDH_LDS_BYTES));
@@ -22,7 +22,7 @@ int csdh_run(hipStream_t stream, const float2* spec, long long nrows, int F, flo
     CsdArgs b{};
     b.spec = spec; b.nrows = nrows; b.F = F; b.C = 256; b.acc = acc;
     b.nt = 8; b.ntiles = M3_TILES_PER_F; b.nitems = (long long)F * M3_TILES_PER_F; b.cpad = 256;
-    b.item_base = 0; b.item_end = (long long)nf * M3_TILES_PER_F;
+    b.item_base = (long long)f0 * M3_TILES_PER_F; b.item_end = (long long)(f0 + nf) * M3_TILES_PER_F;
     b.only_flagged = flags;
     if (phase_exact) {
         auto k = csd3m_kernel<256, 8, true, false, true>;

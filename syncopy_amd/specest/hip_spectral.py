@@ -22,6 +22,23 @@ def _bounded_put(cache, key, value):
     cache[key] = value
 
 
+_rows_cache = {}
+
+
+def _device_rows(host_rows, device):
+    """Segment start rows (int64) on the device.  Repeated analyses of one recording ask for the same tables: a small
+    cache saves the host-to-device copy - which otherwise queues behind whatever the copy engine is busy with (the result
+    of the previous analysis on its way to the host)."""
+    if host_rows.nbytes > (1 << 20):
+        return torch.from_numpy(host_rows).to(device)
+    key = (str(device), host_rows.tobytes())
+    t = _cache_hit(_rows_cache, key)
+    if t is None:
+        t = torch.from_numpy(host_rows).to(device)
+        _bounded_put(_rows_cache, key, t)
+    return t
+
+
 def _cache_hit(cache, key):
     """Look up `key`; a hit moves the entry to the most-recent end."""
     value = cache.get(key)
@@ -324,7 +341,7 @@ def run_mtmfft_batches(dev_data, rows, chan_idx, nfft, taper, taper_opt, demean_
             sel = which[i:i + bmax]
             if upload is not None:
                 upload.wait_rows(int(rows_arr[sel, 1].max()))
-            starts = torch.from_numpy(np.ascontiguousarray(rows_arr[sel, 0])).to(device)
+            starts = _device_rows(np.ascontiguousarray(rows_arr[sel, 0]), device)
             # reuse=True: the consumer is done with a batch before it asks for the next one (stream order), so all
             # batches - and all later calls of the same shape - share one device buffer
             buf = backend.handover_buffer(plan.out_shape(len(sel)), device) if reuse and plan.kind == 2 else None

@@ -63,7 +63,7 @@ def _patch():
         spec.spyhip_ntaper = spec.shape[1]
         yield np.arange(len(rows)), spec
 
-    def csd_accumulate(spec, acc, blocked=False, absmax=None):
+    def csd_accumulate(spec, acc, blocked=False, absmax=None, **kw):
         s = spec.reshape(-1, spec.shape[-2], spec.shape[-1])
         acc += torch.einsum("rfi,rfj->fij", s, s.conj())
         return acc

@@ -208,3 +208,66 @@ def test_plans_without_complex_spectra_say_so(be):
     pow_plan = be.FFTPlan(1024, 1024, 8, O.taper_table("hann", 1024, 1024), 1.0, 0, False, None, "pow", True)
     pow_plan.execute(d, torch.zeros(1, device="cuda", dtype=torch.int64), absmax=am)
     assert not pow_plan.tracked_absmax and float(am.max()) == 0.0
+
+
+def test_ranges_equal_one_piece_and_pipeline_result():
+    """The cross-spectral update launched frequency range by frequency range (spyhip_csd_accumulate_split_range) is the same
+    update - bit for bit, flagged frequencies and the re-cut float32 tail included - and the pipelined coherence
+    (normalisation and host copy of range r under the products of range r + 1, backend.coh_pipeline) lands the same array
+    on the host as the fused kernel followed by a plain copy."""
+    import torch
+    from syncopy_amd import backend as be
+    be.require_gpu()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    R, F, C = 500, 2049, 256
+    x = torch.randn((R, F, C, 2), generator=g, device="cuda", dtype=torch.float32)
+    x[:, 700, 5] *= 1e7                       # a line 140 dB above one channel's floor in range 1: left to the float32 kernel
+    x[:, 1800, 9] *= 1e7                      # ... and one in range 3
+    spec = torch.view_as_complex(x)
+    am = torch.view_as_real(spec).abs().amax(dim=(0, 1, 3)).contiguous()
+    ranges = be.frequency_ranges(F)
+    assert ranges == [(0, 512), (512, 1024), (1024, 1536), (1536, 2049)]
+    one = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    be.csd_accumulate(spec, one, absmax=am)
+    flagged_one = be.csd_split_fallbacks()
+    assert one.spyhip_range_events is None
+    parts = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    be.csd_accumulate(spec, parts, absmax=am, ranges=ranges)
+    assert be.csd_split_fallbacks() == flagged_one >= 2
+    assert torch.equal(torch.view_as_real(one), torch.view_as_real(parts))
+    # in any order
+    rev = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
+    be.csd_accumulate(spec, rev, absmax=am, ranges=ranges[::-1])
+    assert torch.equal(torch.view_as_real(one), torch.view_as_real(rev))
+    for output in ("abs", "complex"):
+        ref = be.to_host(be.coh_from_accumulator(one, 1.0 / R, output))
+        res, landing = be.coh_pipeline(parts, 1.0 / R, output, parts.spyhip_range_events)
+        assert landing is not None
+        got = landing.array()
+        assert got.shape == ref.shape and got.dtype == ref.dtype and np.array_equal(got, ref, equal_nan=True)
+        assert np.array_equal(res.cpu().numpy(), ref, equal_nan=True)
+        del got, landing                      # the block goes back to the pool ...
+    res, landing = be.coh_pipeline(parts, 1.0 / R, "abs", parts.spyhip_range_events)
+    del landing                               # ... also when nobody reads it
+    torch.cuda.synchronize()
+
+
+def test_front_end_coherence_through_the_pipeline():
+    """spy.connectivityanalysis(method='coh') on 256 channels x 4096 samples (2049 frequencies: four ranges): the pipelined
+    result against the same analysis with the pipeline switched off (a process group of one rank keeps the update in one
+    piece) - the same kernels on the same data, so equal bit for bit - and `.data` readable twice."""
+    import torch
+    import syncopy_amd as spy
+    from syncopy_amd import backend as be
+    data = spy.synthdata.ar2_network(AdjMat=np.zeros((256, 256)), nSamples=4096, nTrials=12, seed=3)
+    got = spy.connectivityanalysis(data, method="coh", tapsmofrq=1)
+    a = np.array(got.data)
+    assert a.shape == (1, 2049, 256, 256) and np.isfinite(a).all() and np.allclose(a[0, :, np.arange(256), np.arange(256)], 1, atol=1e-5)
+    assert np.array_equal(a, np.array(got.data))
+    keep = be.frequency_ranges
+    be.frequency_ranges = lambda *args, **kw: None
+    try:
+        plain = spy.connectivityanalysis(data, method="coh", tapsmofrq=1)
+    finally:
+        be.frequency_ranges = keep
+    assert np.array_equal(a, np.array(plain.data))
