@@ -862,12 +862,14 @@ def coh_normalize(csd, output="abs"):
     return out
 
 
-def frequency_ranges(nfreq, device=None, parts=4):
-    """[(f0, f1)] cutting `nfreq` frequencies into `parts` runs of whole rounds of workgroups (one K4h workgroup per
-    frequency and CU), the remainder with the last; None when there are fewer than two rounds per part."""
+def frequency_ranges(nfreq, device=None, parts=8):
+    """[(f0, f1)] cutting `nfreq` frequencies into (at most) `parts` runs of whole rounds of workgroups (one K4h workgroup
+    per frequency and CU), the remainder with the last; None below two rounds.  256 channels x 2049 frequencies, result
+    read on the host: 27.8 / 25.3 / 24.0 ms per call with 2 / 4 / 8 ranges (32.0 in one piece)."""
     ncu = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
     rounds = nfreq // ncu
-    if rounds < 2 * parts:
+    parts = min(parts, rounds)
+    if parts < 2:
         return None
     per = rounds // parts
     edges = [k * per * ncu for k in range(parts)] + [nfreq]

@@ -221,12 +221,12 @@ def test_ranges_equal_one_piece_and_pipeline_result():
     g = torch.Generator(device="cuda").manual_seed(21)
     R, F, C = 500, 2049, 256
     x = torch.randn((R, F, C, 2), generator=g, device="cuda", dtype=torch.float32)
-    x[:, 700, 5] *= 1e7                       # a line 140 dB above one channel's floor in range 1: left to the float32 kernel
-    x[:, 1800, 9] *= 1e7                      # ... and one in range 3
+    x[:, 700, 5] *= 1e7                       # a line 140 dB above one channel's floor in range 2: left to the float32 kernel
+    x[:, 1800, 9] *= 1e7                      # ... and one in the last range
     spec = torch.view_as_complex(x)
     am = torch.view_as_real(spec).abs().amax(dim=(0, 1, 3)).contiguous()
     ranges = be.frequency_ranges(F)
-    assert ranges == [(0, 512), (512, 1024), (1024, 1536), (1536, 2049)]
+    assert ranges == [(256 * k, 256 * (k + 1) if k < 7 else 2049) for k in range(8)]
     one = torch.zeros((F, C, C), dtype=torch.complex64, device="cuda")
     be.csd_accumulate(spec, one, absmax=am)
     flagged_one = be.csd_split_fallbacks()
@@ -253,7 +253,7 @@ def test_ranges_equal_one_piece_and_pipeline_result():
 
 
 def test_front_end_coherence_through_the_pipeline():
-    """spy.connectivityanalysis(method='coh') on 256 channels x 4096 samples (2049 frequencies: four ranges): the pipelined
+    """spy.connectivityanalysis(method='coh') on 256 channels x 4096 samples (2049 frequencies: eight ranges): the pipelined
     result against the same analysis with the pipeline switched off (a process group of one rank keeps the update in one
     piece) - the same kernels on the same data, so equal bit for bit - and `.data` readable twice."""
     import torch
