@@ -489,7 +489,11 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
     const std::vector<CwtGroup*>* groups = &p->groups;
     if (pairt && p->nsig >= 4096) {                  // trial sums of long signals: blocks of at least 4096 points
         if (!p->groups_sum_built) {
-            if (int rc = build_groups(p, 4096, p->groups_sum_owned)) return rc;
+            if (int rc = build_groups(p, 4096, p->groups_sum_owned)) {
+                for (auto* g : p->groups_sum_owned) delete g;
+                p->groups_sum_owned.clear();
+                return rc;
+            }
             p->groups_sum = p->groups_sum_owned;
             for (CwtGroup* gr : p->groups)
                 if (gr->long_idx >= 0) p->groups_sum.push_back(gr);
@@ -634,7 +638,11 @@ extern "C" int spyhip_cwt_exec(spyhip_cwt_plan* p, const float* data_d, int64_t 
 
 extern "C" int spyhip_cwt_plan_set_direct(spyhip_cwt_plan* p, int on) {
     if (!p) { spy::set_error("cwt_plan_set_direct: null plan"); return -1; }
-    if (on && !p->direct_ok) return -3;          // (slots not increasing / rows beyond 32-bit offsets: staging only)
+    if (on && !p->direct_ok) {                   // (slots not increasing / rows beyond 32-bit offsets: staging only)
+        spy::set_error("cwt_plan_set_direct: this plan's outputs cannot be written by the transform kernels (time slots not "
+                       "increasing with the samples, or rows beyond 32-bit offsets)");
+        return -3;
+    }
     p->direct = on != 0;
     return 0;
 }

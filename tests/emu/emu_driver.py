@@ -454,7 +454,7 @@ def coh_normalize(csd, output="abs"):
     return out
 
 
-def cwt_plan_tables(nsig, scales, dt, w0):
+def cwt_plan_tables(nsig, scales, dt, w0, nbmin=1024):
     """NumPy mirror of the plan construction in syncopy_amd/csrc/cwt.hip."""
     kers, halo, right = [], 0, 0
     for sc in scales:
@@ -470,7 +470,7 @@ def cwt_plan_tables(nsig, scales, dt, w0):
         kers.append((h, c - m0))
         halo = max(halo, h.size - 1 - (c - m0))
         right = max(right, c - m0)
-    NB = 1024
+    NB = nbmin
     while NB < 2 * (halo + right + 1) and NB < 16384:
         NB *= 2
     V = NB - halo - right
@@ -486,26 +486,31 @@ def cwt_plan_tables(nsig, scales, dt, w0):
 
 
 def cwt_exec(data, seg_start, trial_lo, trial_hi, nsig, scales, dt, w0=6.0, detrend=-1, output="pow", tpos=None,
-             ntime_out=None, chan_idx=None):
+             ntime_out=None, chan_idx=None, accumulate=0, mode=0, nbmin=1024):
+    """`mode` as cwt.hip combines the kernel variants: bit 0 trial sums on pairs of segments (accumulate=2), bit 1 the direct
+    kernels (1024- / 2048-point blocks, accumulate 0 / 1), bit 2 the channel-major input copy; `nbmin`: the shortest
+    block (build_groups)."""
     data = np.ascontiguousarray(data, dtype=np.float32)
     ld = data.shape[1]
     nchan = ld if chan_idx is None else len(chan_idx)
     ci = None if chan_idx is None else np.ascontiguousarray(chan_idx, dtype=np.int32)
     ss, tl, th = (np.ascontiguousarray(a, dtype=np.int64) for a in (seg_start, trial_lo, trial_hi))
-    NB, V, halo, cshift, hspec = cwt_plan_tables(nsig, scales, dt, w0)
+    NB, V, halo, cshift, hspec = cwt_plan_tables(nsig, scales, dt, w0, nbmin)
     log2n = int(np.log2(NB))
     G = {10: 4, 11: 2}.get(log2n, 1)      # channel pairs per workgroup (packed kernel), 2^14: channels
+    if mode & 2:
+        G = {10: 8, 11: 4}[log2n]         # the direct kernels' workgroups
     tw = twiddles(NB)
     kind = OUT_KINDS[output]
     tp = None if tpos is None else np.ascontiguousarray(tpos, dtype=np.int32)
     nto = nsig if tpos is None else int(ntime_out)
-    out = np.zeros((len(ss), nto, len(scales), nchan), dtype=np.complex64 if kind == 2 else np.float32)
+    out = np.zeros((1 if accumulate == 2 else len(ss), nto, len(scales), nchan), dtype=np.complex64 if kind == 2 else np.float32)
     rc = lib().emu_cwt(C.c_int(log2n), C.c_int(G), _p(data, C.c_float), C.c_longlong(ld), _p(ci, C.c_int),
                        _p(ss, C.c_longlong), _p(tl, C.c_longlong), _p(th, C.c_longlong), C.c_int(len(ss)),
                        C.c_int(nsig), C.c_int(nchan), C.c_int(len(scales)), _p(tw, C.c_float),
                        hspec.ctypes.data_as(C.POINTER(C.c_float)), _p(cshift, C.c_int), C.c_int(V), C.c_int(halo),
                        C.c_int((nsig + V - 1) // V), C.c_int(detrend), C.c_int(kind), _p(tp, C.c_int), C.c_int(nto),
-                       out.ctypes.data_as(C.c_void_p), C.c_int(0))
+                       out.ctypes.data_as(C.c_void_p), C.c_int(accumulate), C.c_int(mode))
     assert rc == 0
     return out
 

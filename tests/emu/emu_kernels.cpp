@@ -732,7 +732,10 @@ int emu_ccov(const float* acc, const float* tw, int nfft, int nchan, int nsample
 int emu_cwt(int log2n, int G, const float* data, long long ld, const int* chan_idx, const long long* seg_start,
             const long long* trial_lo, const long long* trial_hi, int nseg, int nsig, int nchan, int nscales,
             const float* tw, const float* hspec, const int* cshift, int V, int halo, int nblocks, int detrend,
-            int out_kind, const int* tpos, int ntime_out, void* out, int accumulate) {
+            int out_kind, const int* tpos, int ntime_out, void* out, int accumulate, int mode) {
+    // mode bit 0: trial sums on PAIRS of segments (cwt2_kernel<..., PAIRT>; accumulate = 2); bit 1: the direct kernels
+    // (cwt2d_kernel, 1024- / 2048-point blocks with 8 / 4 channel pairs per workgroup; accumulate 0 / 1); bit 2: the
+    // channel-major input copy (cwt_stage_input_kernel) - as cwt.hip combines them
     spyfft::CwtArgs a{};
     a.data = data; a.ld = ld; a.chan_idx = chan_idx; a.seg_start = seg_start; a.trial_lo = trial_lo; a.trial_hi = trial_hi;
     a.nseg = nseg; a.nsig = nsig; a.nchan = nchan; a.nscales = nscales;
@@ -750,14 +753,60 @@ int emu_cwt(int log2n, int G, const float* data, long long ld, const int* chan_i
         emu::launch(dim3((unsigned)(((size_t)nseg * nchan + 255) / 256)), dim3(256), 0,
                     [&] { spyfft::cwt_trend_final_kernel(a, part.data(), trend.data()); });
     }
-    const int nunit = log2n <= 13 ? (nchan + 1) / 2 : nchan;      // packed kernel: channel pairs
-    const unsigned grid = (unsigned)nseg * (unsigned)((nunit + G - 1) / G) * (unsigned)nblocks;
+    const bool pairt = (mode & 1) != 0, direct = (mode & 2) != 0;
+    std::vector<float> xt;
+    if (mode & 4) {
+        xt.assign((size_t)nseg * nchan * nsig, 0.f);
+        emu::launch(dim3((nsig + 63) / 64, (nchan + 63) / 64, nseg), dim3(256), 0, [&] { spyfft::cwt_stage_input_kernel(a, xt.data()); });
+        a.xt = xt.data();
+    }
     const int outk = out_kind == SPYHIP_OUT_FOURIER ? 2 : (out_kind == SPYHIP_OUT_POW ? 0 : 1);
+    if (direct) {
+        std::vector<int> fl(nsig, 0);
+        if (tpos) {
+            int last = -1;
+            for (int n = 0; n < nsig; ++n) { if (tpos[n] >= 0) last = tpos[n]; fl[n] = last > 0 ? last : 0; }
+            a.tfloor = fl.data();
+        }
+        const unsigned dgrid = (unsigned)nseg * (unsigned)(((nchan + 1) / 2 + G - 1) / G) * (unsigned)nblocks;
+#define CWT2D_CASE(L, GG) \
+        if (log2n == L && G == GG) { \
+            using C = spyfft::Cfg2<L, GG>; \
+            if (outk == 2) emu::launch(dim3(dgrid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2d_kernel<L, GG, 2>(a); }); \
+            else if (outk == 0) emu::launch(dim3(dgrid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2d_kernel<L, GG, 0>(a); }); \
+            else emu::launch(dim3(dgrid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2d_kernel<L, GG, 1>(a); }); \
+            return 0; \
+        }
+        CWT2D_CASE(10, 8) CWT2D_CASE(11, 4)
+#undef CWT2D_CASE
+        return -1;
+    }
+    const int nsets = pairt ? (nseg + 1) / 2 : nseg;              // staging row sets
+    const int nunit = pairt ? nchan : (log2n <= 13 ? (nchan + 1) / 2 : nchan);      // packed kernel: channel pairs / (PAIRT) channels
+    const unsigned grid = (unsigned)nsets * (unsigned)((nunit + G - 1) / G) * (unsigned)nblocks;
     // one chunk holding every segment (cwt.hip sizes chunks by memory; the kernels are the same)
-    std::vector<float> stage((size_t)nseg * nscales * nchan * nsig * (outk == 2 ? 2 : 1), 0.f);
+    std::vector<float> stage((size_t)nsets * nscales * nchan * nsig * (outk == 2 ? 2 : 1), 0.f);
     a.stage = stage.data();
     a.seg0 = 0;
     const dim3 sgrid((nsig + 63) / 64, nscales, accumulate == 2 ? 1 : nseg);
+    if (pairt) {
+        if (accumulate != 2 || log2n > 13) return -1;
+        spyfft::CwtArgs sc = a;
+        sc.nseg = nsets;                                           // the transposition pass adds row SETS
+#define CWT2P_CASE(L, GG) \
+        if (log2n == L && G == GG) { \
+            using C = spyfft::Cfg2<L, GG>; \
+            if (outk == 2) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2_kernel<L, GG, 2, true>(a); }); \
+            else if (outk == 0) emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2_kernel<L, GG, 0, true>(a); }); \
+            else emu::launch(dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, [&] { spyfft::cwt2_kernel<L, GG, 1, true>(a); }); \
+            if (outk == 2) emu::launch(sgrid, dim3(256), 0, [&] { spyfft::cwt_scatter_kernel<float2>(sc); }); \
+            else emu::launch(sgrid, dim3(256), 0, [&] { spyfft::cwt_scatter_kernel<float>(sc); }); \
+            return 0; \
+        }
+        CWT2P_CASE(10, 4) CWT2P_CASE(11, 2) CWT2P_CASE(12, 1) CWT2P_CASE(13, 1)
+#undef CWT2P_CASE
+        return -1;
+    }
 #define CWT_CASE(L, GG) \
     if (log2n == L && G == GG) { \
         using C = spyfft::Cfg<L, GG>; \

@@ -314,6 +314,48 @@ def test_cwt_kernel(nsig, scales, detrend, output):
     assert_parity(out, ref, what="cwt")
 
 
+@pytest.mark.parametrize("output", ["pow", "fourier"])
+@pytest.mark.parametrize("nbmin,nchan", [(1024, 3), (2048, 4)])
+def test_cwt_direct_kernels(output, nbmin, nchan):
+    """cwt2d_kernel (round 6): the transform kernel writes the (time, scale, channel) layout itself - 1024- and 2048-point
+    blocks, an odd channel count (padded pair, scalar stores), plain and accumulating (out[b] += segment b) calls, a
+    post-selection of samples, the channel-major input copy in front of it."""
+    rng = np.random.default_rng(nbmin + nchan)
+    nsig, T = 1400, 2
+    data = rng.normal(size=(T * nsig + 30, nchan)).astype("f4") + 1.5
+    ss = np.array([10, nsig + 20])
+    lo, hi = ss.copy(), ss + nsig
+    scales = np.array([0.012, 0.004])
+    ref = np.stack([O.convert_output(O.cwt(O.detrend(np.array(data[a:a + nsig]), 0), 1000.0, scales).transpose(1, 0, 2), output)
+                    for a in ss])
+    for mode in (2, 2 | 4):
+        out = E.cwt_exec(data, ss, lo, hi, nsig, scales, 1e-3, 6.0, 0, output, mode=mode, nbmin=nbmin)
+        assert_parity(out, ref, what=f"direct cwt, mode {mode}")
+    keep = np.r_[0:3, 5:1300:9, 1023, 1024, 1399]
+    tpos = np.full(nsig, -1, dtype=np.int32)
+    tpos[keep] = np.arange(keep.size)
+    sel = E.cwt_exec(data, ss, lo, hi, nsig, scales, 1e-3, 6.0, 0, output, tpos=tpos, ntime_out=keep.size, mode=2 | 4, nbmin=nbmin)
+    assert_parity(sel, ref[:, keep], what="direct cwt, selected samples")
+
+
+@pytest.mark.parametrize("output", ["pow", "fourier"])
+@pytest.mark.parametrize("T", [4, 5])
+def test_cwt_trial_sums_on_pairs_of_trials(output, T):
+    """cwt2_kernel<..., PAIRT> (round 6): one channel of TWO consecutive trials in the packed halves, their sum staged;
+    an odd trial count leaves the last pair half empty; with and without the channel-major input copy; 2048-point
+    blocks as the trial-sum policy of cwt.hip picks longer ones."""
+    rng = np.random.default_rng(T)
+    nsig, nchan = 900, 3
+    data = rng.normal(size=(T * nsig, nchan)).astype("f4") - 0.7
+    ss = np.arange(T) * nsig
+    scales = np.array([0.015, 0.005])
+    ref = sum(O.convert_output(O.cwt(O.detrend(np.array(data[a:a + nsig]), 0), 1000.0, scales).transpose(1, 0, 2).astype(np.complex128), output)
+              for a in ss)[None]
+    for mode, nbmin in ((1, 1024), (1 | 4, 1024), (1 | 4, 2048)):
+        out = E.cwt_exec(data, ss, ss, ss + nsig, nsig, scales, 1e-3, 6.0, 0, output, accumulate=2, mode=mode, nbmin=nbmin)
+        assert_parity(out, ref.astype(out.dtype), what=f"pair sums, mode {mode}, blocks >= {nbmin}")
+
+
 @pytest.mark.parametrize("n", [32, 37, 70])
 def test_blocked_inverse(n):
     """Block Gauss-Jordan inverse (16 x 16 diagonal blocks): ragged sizes, identity padding, tiny-pivot flag."""
