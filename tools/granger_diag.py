@@ -4,10 +4,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-import torch
 import syncopy_amd as spy
-from syncopy_amd import backend as be
-from oracle import spy_oracle as O
 from oracle_routines import ORACLE_CONN
 
 seed = int(sys.argv[1])
