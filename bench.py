@@ -917,7 +917,10 @@ def main():
             f_main = F - rem if (F > ncu and 0 < rem and 4 * rem <= ncu) else F
             executed = ((rows[0] + 31) // 32) * f_main * 136 * 12 * 16384.0
         value = world * T * args.steps / el
-        coll = {"executed": bool(dist_on), "backend": "RCCL, library communicator (spyhip_allreduce_csd)" if dist_on else None}
+        coll = {"executed": bool(dist_on), "backend": None}
+        if dist_on:
+            coll["backend"] = ("RCCL through torch.distributed (the library's communicator could not be created on every rank)"
+                               if getattr(be, "_lib_comm_failed", None) else "RCCL, library communicator (spyhip_allreduce_csd)")
         if ev_coll:
             coll.update({"bytes": ev_coll[0][2], "pack_allreduce_unpack_ms": float(np.mean([a.elapsed_time(b) for a, b, _ in ev_coll]))})
         traffic, traffic_prov = pmc_traffic(rows[0], F, C)

@@ -744,6 +744,7 @@ def csd_kernel_name(nchan, blocked=False):
 
 
 _lib_comm = {}          # device index -> identity of the process group the library's RCCL communicator was built under
+_lib_comm_failed = {}   # device index -> True once the communicator could not be created on every rank (torch route from then on)
 
 
 def _group_identity():
@@ -764,7 +765,7 @@ def _library_comm(ctx):
     ident = _group_identity()
     have = _lib_comm.get(ctx.device)
     if have == ident:
-        return
+        return True
     if have is not None:
         check(ctx.lib.spyhip_comm_destroy(ctx.handle), "spyhip_comm_destroy")
         _lib_comm.pop(ctx.device, None)
@@ -777,8 +778,26 @@ def _library_comm(ctx):
     uid = uid.cuda(ctx.device)
     dist.broadcast(uid, src=0)
     raw = (C.c_ubyte * 128).from_buffer_copy(uid.cpu().numpy().tobytes())
-    check(ctx.lib.spyhip_comm_init(ctx.handle, raw, rank, size), "spyhip_comm_init")
+    ok, err = 1, None
+    try:
+        check(ctx.lib.spyhip_comm_init(ctx.handle, raw, rank, size), "spyhip_comm_init")
+    except SpyHipError as exc:                   # (librccl not found, an initialisation error on this rank ...)
+        ok, err = 0, exc
+    # every rank must take the same route from here on: one that failed while the others joined would leave them waiting
+    # in the first collective - the (working) process group carries the verdict
+    flag = torch.tensor([ok], dtype=torch.int32, device=uid.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if ok:
+            ctx.lib.spyhip_comm_destroy(ctx.handle)
+        _lib_comm_failed[ctx.device] = True
+        if rank == 0:
+            import sys
+            sys.stderr.write("syncopy_amd: the library's RCCL communicator could not be created on every rank (%s); sums over "
+                             "ranks go through torch.distributed instead\n" % (err if err is not None else "another rank failed"))
+        return False
     _lib_comm[ctx.device] = ident
+    return True
 
 
 def shutdown_library_comm():
@@ -812,8 +831,8 @@ def csd_allreduce_(acc):
     ctx = context(acc.device)
     ctx.bind_stream()
     import torch.distributed as dist
-    if dist.get_backend() == "nccl" and not os.environ.get("SPY_TORCH_COLLECTIVE"):
-        _library_comm(ctx)
+    if (dist.get_backend() == "nccl" and not os.environ.get("SPY_TORCH_COLLECTIVE") and not _lib_comm_failed.get(ctx.device)
+            and _library_comm(ctx)):
         ctx.bind_stream()
         check(ctx.lib.spyhip_allreduce_csd(ctx.handle, _ptr(acc), F, Cn), "spyhip_allreduce_csd")
         return acc

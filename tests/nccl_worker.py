@@ -59,6 +59,22 @@ def main(out_path):
         res["library_allreduce_bit_exact"] = np.array(torch.equal(
             torch.view_as_real(acc2[:, ii, jj].contiguous()), torch.view_as_real(acc[:, ii, jj].contiguous())))
         res["library_comm_up"] = np.array(bool(be._lib_comm))
+        # the communicator cannot be created (here: its init entry point made to fail on this rank): every rank learns it
+        # through the process group, nobody waits in a collective the others never enter, and the sum takes the
+        # torch.distributed route with the same bits
+        be.shutdown_library_comm()
+        ctx = be.context()
+        real_init = ctx.lib.spyhip_comm_init
+        ctx.lib.spyhip_comm_init = lambda *a: -1
+        try:
+            acc3 = before.clone()
+            be.csd_allreduce_(acc3)
+        finally:
+            ctx.lib.spyhip_comm_init = real_init
+        res["fallback_allreduce_bit_exact"] = np.array(torch.equal(
+            torch.view_as_real(acc3[:, ii, jj].contiguous()), torch.view_as_real(acc[:, ii, jj].contiguous())))
+        res["fallback_taken"] = np.array(bool(be._lib_comm_failed) and not be._lib_comm)
+        be._lib_comm_failed.clear()                  # (the analyses below use the library's communicator again)
         if os.environ.get("SPY_NCCL_C5"):
             # BASELINE configs[4] through the front end, trial-sharded over the ranks of this group: every rank holds
             # the recording, transforms its contiguous shard of the trials, ONE all-reduce of the packed CSD triangle,

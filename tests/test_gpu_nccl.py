@@ -47,6 +47,7 @@ def test_front_ends_under_nccl_group(tmp_path):
     z = np.load(out)
     assert int(z["world"]) == n and bool(z["pack_allreduce_unpack_bit_exact"])
     assert bool(z["library_comm_up"]) and bool(z["library_allreduce_bit_exact"])
+    assert bool(z["fallback_taken"]) and bool(z["fallback_allreduce_bit_exact"])     # a communicator that cannot be created
     # every rank staged the rows of its own trial shard and nothing else: disjoint spans in rank order, together the
     # recording; the bytes over PCIe add up to ONE copy of it (not one per rank)
     st = z["staged_rows_and_bytes_per_rank"]
