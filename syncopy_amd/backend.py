@@ -98,7 +98,8 @@ _RESULT_PIN_CAP = 8 << 30       # page-locked bytes results may hold (live array
 _RESULT_PIN_GRAIN = 64 << 20
 _result_free = {}               # rounded size -> [pinned uint8 tensors]
 _result_bytes = [0]             # page-locked bytes of the pool, live and free
-_result_lock = None
+import threading as _threading_mod
+_result_lock = _threading_mod.Lock()
 _result_zombies = []            # (copy-finished event, block) of HostLandings dropped unread while their copy was under way
 
 
@@ -106,10 +107,6 @@ def _result_block(nbytes):
     """A page-locked block for a large result, from the free list or fresh (cudaHostAlloc of 0.5 GB costs ~0.1 s once; the
     block returns to the list when the array the caller got - and every view of it - is gone).  None when the pool is at
     its cap."""
-    import threading
-    global _result_lock
-    if _result_lock is None:
-        _result_lock = threading.Lock()
     size = (nbytes + _RESULT_PIN_GRAIN - 1) // _RESULT_PIN_GRAIN * _RESULT_PIN_GRAIN
     with _result_lock:
         # blocks of landings nobody read, whose copy has finished meanwhile
@@ -134,6 +131,37 @@ def _result_block(nbytes):
 def _result_release(block):
     with _result_lock:
         _result_free.setdefault(block.numel(), []).append(block)
+
+
+_prewarm_threads = []
+
+
+def prewarm_landing(nbytes):
+    """Make sure the result pool holds a free page-locked block for a result of `nbytes` - in a background thread: the
+    first analysis of a process page-locks 0.54 GB for its coherence result (~8 ms), which this moves under the upload
+    and the transforms instead of in front of the first host copy.  No-op when a free block of that size exists."""
+    import threading
+    size = (nbytes + _RESULT_PIN_GRAIN - 1) // _RESULT_PIN_GRAIN * _RESULT_PIN_GRAIN
+    with _result_lock:
+        if _result_free.get(size):
+            return
+    dev = torch.cuda.current_device()
+
+    def work():
+        torch.cuda.set_device(dev)
+        block = _result_block(nbytes)
+        if block is not None:
+            _result_release(block)
+
+    th = threading.Thread(target=work, name="spyhip-prewarm", daemon=True)
+    th.start()
+    _prewarm_threads[:] = [t for t in _prewarm_threads if t.is_alive()] + [th]
+
+
+def _prewarm_join():
+    for th in _prewarm_threads:
+        th.join()
+    del _prewarm_threads[:]
 
 
 def to_host(t):
@@ -336,7 +364,8 @@ def release_buffers():
     Exposed as `syncopy_amd.release_device_buffers()`."""
     _handover.clear()
     _pin.clear()
-    if _result_lock is not None:
+    _prewarm_join()
+    if True:
         with _result_lock:
             for k, lst in _result_free.items():
                 _result_bytes[0] -= k * len(lst)
@@ -605,7 +634,9 @@ def csd_accumulate(spec, acc, blocked=False, absmax=None, split=True, ranges=Non
     if Cn == 256 and nrows > 0 and split:
         if absmax is not None:
             assert absmax.is_cuda and absmax.dtype == torch.float32 and absmax.numel() == 256 and absmax.is_contiguous()
-        if ranges and absmax is not None and not os.environ.get("SPYHIP_CSD_F32"):
+        if ranges and absmax is not None and nrows >= 1024 and not os.environ.get("SPYHIP_CSD_F32"):
+            # (small batches - a recording consumed chunk by chunk behind its upload - stay in one piece: eight launches of
+            # a few hundred rows each cost more than the pipeline gives a call that waits for the bus anyway)
             # frequency range by frequency range, an event behind each: whoever turns the accumulator into a result can
             # start on range r while range r + 1 is still being accumulated (coh_pipeline)
             stream = torch.cuda.current_stream(spec.device)
@@ -683,6 +714,7 @@ def coh_pipeline(acc, scale, output, events):
     odt = torch.complex64 if kind == 2 else torch.float32
     res = torch.empty((F, Cn, Cn), dtype=odt, device=acc.device)
     nbytes = res.numel() * res.element_size()
+    _prewarm_join()
     block = _result_block(nbytes)
     landing = HostLanding(block, nbytes, (F, Cn, Cn), _NP_DTYPE[odt]) if block is not None else None
     host = landing.tensor(odt) if landing is not None else None

@@ -236,6 +236,8 @@ class CrossSpectra(ComputationalRoutine):
         ranges = None
         if not self.keeptrials and C == 256 and not parallel.collective_active() and F * C * C * 4 >= (64 << 20):
             ranges = backend.frequency_ranges(F, dev.device)
+            if ranges:
+                backend.prewarm_landing(F * C * C * 4)       # (the float32 coherence outputs; complex ones find no block and allocate)
         K = _csd_of_rows(dev, rows, chans, cfg["nSamples"], cfg["taper"], cfg["taper_opt"], cfg["demean_taper"], pr,
                          freq_idx, getter, single_acc=not self.keeptrials, upload=upload, ranges=ranges) if rows else 1
         data.device_data()                                  # (an upload in flight ends here at the latest)

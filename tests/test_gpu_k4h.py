@@ -219,7 +219,7 @@ def test_ranges_equal_one_piece_and_pipeline_result():
     from syncopy_amd import backend as be
     be.require_gpu()
     g = torch.Generator(device="cuda").manual_seed(21)
-    R, F, C = 500, 2049, 256
+    R, F, C = 1024, 2049, 256                 # (batches below 1024 rows stay in one piece: backend.csd_accumulate)
     x = torch.randn((R, F, C, 2), generator=g, device="cuda", dtype=torch.float32)
     x[:, 700, 5] *= 1e7                       # a line 140 dB above one channel's floor in range 2: left to the float32 kernel
     x[:, 1800, 9] *= 1e7                      # ... and one in the last range
@@ -259,8 +259,18 @@ def test_front_end_coherence_through_the_pipeline():
     import torch
     import syncopy_amd as spy
     from syncopy_amd import backend as be
-    data = spy.synthdata.ar2_network(AdjMat=np.zeros((256, 256)), nSamples=4096, nTrials=12, seed=3)
-    got = spy.connectivityanalysis(data, method="coh", tapsmofrq=1)
+    T, N, C = 160, 4096, 256                  # 1120 rows of spectra: above the 1024 from which the update goes by ranges
+    x = spy.synthdata.ar2_uncoupled_fast(C, N, T, seed=3).cpu().numpy()
+    trl = np.stack([np.arange(T) * N, np.arange(1, T + 1) * N, np.zeros(T)], axis=1)
+    data = spy.AnalogData(x, samplerate=1000.0, trialdefinition=trl)
+    seen = []
+    keep_pipe = be.coh_pipeline
+    be.coh_pipeline = lambda *a, **k: (seen.append(1), keep_pipe(*a, **k))[1]
+    try:
+        got = spy.connectivityanalysis(data, method="coh", tapsmofrq=1)
+    finally:
+        be.coh_pipeline = keep_pipe
+    assert seen, "the pipelined path did not run"
     a = np.array(got.data)
     assert a.shape == (1, 2049, 256, 256) and np.isfinite(a).all() and np.allclose(a[0, :, np.arange(256), np.arange(256)], 1, atol=1e-5)
     assert np.array_equal(a, np.array(got.data))
