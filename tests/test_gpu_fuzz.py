@@ -427,16 +427,86 @@ def test_granger_random_networks(seed):
     if ref.info["reg. factor"] == -1:          # no regularisation brings the condition number under cond_max: both sides
         assert not got.info["converged"]       # say so (wilson_sf.py:197-254) and neither result means anything
         return
+    if not ref.info["converged"]:              # the error test never passes within nIter = 100 on either side (a regularised
+        assert not got.info["converged"]       # matrix whose DC bin is all regularisation: family 0, seed 274): both say so
+        return
     assert got.info["converged"]
     # The DC bin is not compared: method="granger" demeans every TAPERED trial (demean_taper, connectivity_analysis.py:864),
     # so X_k(0) = 0 and S(0) = 0 in exact arithmetic - what either side factorises there is the rounding residue
     # of its own transform (1e-9 of the spectrum in the reference's float64 FFT rounded to complex64, 1e-8 in float32
     # kernels), and ln(S_ii / (S_ii - ...)) of a residue matrix is a different number on each side, up to ~0.15 (family
     # 500000, seed 94: 0.152 against 0.050 for one pair, the oracle run on to rtol / 100 keeps its 0.050 - it is not the
-    # stopping point).  Finite and of that size is all that can be said.
-    assert np.isfinite(got.data).all() and np.abs(got.data[:, 0]).max() < 1.0 and np.abs(ref.data[:, 0]).max() < 1.0
-    np.testing.assert_allclose(got.data[:, 1:], ref.data[:, 1:], atol=0.1, err_msg=f"seed {seed} {kw}")
-    np.testing.assert_allclose(got.data[:, 2:], ref.data[:, 2:], rtol=2e-3, atol=1e-2, err_msg=f"seed {seed} {kw}")
+    # stopping point).  Finite is all that can be said (family 0, seed 274: above 1 on one side).
+    assert np.isfinite(got.data).all()
+    # End to end the two sides may differ by more than the fixed tolerances without either stage being off: the Wilson
+    # factorisation couples all frequencies, S(0) is a zero matrix made of each side's own rounding residue, and the
+    # estimate at the bins next to DC moves with it (family 3300000, seed 261: 0.1015 against 0.0891 at 6 Hz for cross-
+    # spectral matrices that agree to 0.035 of the criterion; the product's AV kernels on the ORACLE's matrix give the
+    # oracle's 0.08911, the oracle's factorisation run to 1e-13 as well).  So the stages are held to parity one by one -
+    #   ST: the product's cross-spectral matrix against the oracle's under the shared criterion;
+    #   AV: the product's Granger kernels against the oracle's factorisation ON THE SAME (the product's) matrix;
+    # - and the end-to-end difference to what the reference's OWN estimate moves by when it is handed the product's
+    # matrix instead of its own (`moved`), on top of the fixed tolerances.
+    csd_got = _product_granger_csd(data, kw)
+    csd_ref = _oracle_granger_csd(data, kw)
+    _assert = np.testing.assert_allclose
+    tolc = RTOL * np.abs(csd_ref) + ATOL_REL * np.abs(csd_ref).max()
+    assert (np.abs(csd_got - csd_ref) <= tolc).all(), f"seed {seed} {kw}: ST stage {float((np.abs(csd_got - csd_ref) / tolc).max()):.3g}"
+    on_got, _ = O.granger_cF(csd_got[None])
+    on_ref, _ = O.granger_cF(csd_ref[None])
+    # (both loops stop at the first error below rtol = 5e-6 and may leave one iteration apart: the bin next to DC, where the
+    # factorisation converges last, is held to 0.1, the others to the reference's own acceptance tolerance, atol 1e-2,
+    # tests/test_connectivity.py:149)
+    _assert(got.data[:, 1:], on_got[:, 1:], atol=0.1, err_msg=f"seed {seed} {kw}: AV stage on the same matrix")
+    _assert(got.data[:, 2:], on_got[:, 2:], rtol=2e-3, atol=1e-2, err_msg=f"seed {seed} {kw}: AV stage on the same matrix")
+    moved = np.abs(on_got - on_ref)
+    err = np.abs(np.asarray(got.data, dtype=np.float64) - np.asarray(ref.data, dtype=np.float64))
+    assert (err[:, 1:] <= 0.1 + 2 * moved[:, 1:]).all(), f"seed {seed} {kw}"
+    tol = 2e-3 * np.abs(ref.data) + 1e-2 + 2 * moved
+    assert (err[:, 2:] <= tol[:, 2:]).all(), f"seed {seed} {kw}: {float((err - tol)[:, 2:].max()):.3g} over"
+
+
+def _granger_st_options(data, kw):
+    """nSamples, taper options of the ST stage of method='granger' as connectivityanalysis derives them
+    (connectivity_analysis.py:540-575: process_padding, process_taper on the mean trial length)."""
+    from syncopy_amd.shared.input_processors import process_padding, process_taper
+    fs = float(data.samplerate)
+    lens = np.diff(data.trialdefinition[:, :2]).squeeze(axis=1)
+    nS = process_padding(kw.get("pad", "maxperlen"), lens, fs)
+    freqs = np.fft.rfftfreq(nS, 1 / fs)
+    taper, topt = process_taper("hann", None, kw["tapsmofrq"], None, keeptapers=False, foimax=freqs.max(), samplerate=fs,
+                                nSamples=lens.mean(), output="pow")
+    return int(nS), taper, topt, fs
+
+
+def _product_granger_csd(data, kw):
+    """The product's trial-averaged cross-spectral matrix as its batched route forms it for method='granger'
+    (demean_taper, polyremoval=0): transforms, K4, scale + mirror - (F, C, C) complex64 on the host."""
+    import torch
+    from syncopy_amd import backend as be
+    from syncopy_amd.specest import hip_spectral as hs
+    from syncopy_amd.datatype import device_rows
+    nS, taper, topt, _ = _granger_st_options(data, kw)
+    dev, rows = data.device_data(), device_rows(data)
+    C = dev.shape[1]
+    acc = torch.zeros((nS // 2 + 1, C, C), dtype=torch.complex64, device=dev.device)
+    K = 1
+    for _, spec in hs.run_mtmfft_batches(dev, rows, None, nS, taper, topt, True, False, 0, None, "fourier", True, reuse=True):
+        be.csd_accumulate(spec, acc)
+        K = spec.shape[1]
+    be.csd_finalize(acc, 1.0 / (K * len(rows)))
+    return acc.cpu().numpy()
+
+
+def _oracle_granger_csd(data, kw):
+    """The same matrix in the reference's arithmetic: cross_spectra_cF per trial, complex64 sequential trial sum."""
+    nS, taper, topt, fs = _granger_st_options(data, kw)
+    acc = None
+    for t in data.trials:
+        r, _ = O.cross_spectra_cF(np.array(t), samplerate=fs, nSamples=nS, foi=None, taper=taper, taper_opt=topt, demean_taper=True,
+                                  polyremoval=0)
+        acc = r if acc is None else acc.__iadd__(r)
+    return (acc / np.float32(len(data.trials)))[0].astype(np.complex64)
 
 
 @pytest.mark.parametrize("seed", range(16 * SCALE))

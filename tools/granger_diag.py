@@ -31,3 +31,64 @@ for f in (0, 1, 2, 3, 10):
 csd = spy.connectivityanalysis(data, method="csd", tapsmofrq=kw["tapsmofrq"], pad=kw.get("pad", "maxperlen"), compute_method="sequential",
                                routine_classes=ORACLE_CONN)
 print("csd (not demean_taper) shape", csd.data.shape)
+
+# ---- the same cross-spectral matrix through both factorisations: is it the input or the iteration?
+import torch
+from oracle import spy_oracle as O
+from syncopy_amd import backend as be
+fs = float(data.samplerate)
+trials = [np.asarray(t) for t in data.trials]
+N = trials[0].shape[0]
+NW = kw["tapsmofrq"] * N / fs
+topt = {"NW": NW, "Kmax": max(int(2 * NW - 1), 1)}
+acc = None
+for t in trials:
+    r, _ = O.cross_spectra_cF(t.copy(), samplerate=fs, nSamples=N, foi=None, taper="dpss", taper_opt=topt, demean_taper=True, polyremoval=0)
+    acc = r.astype(np.complex64) if acc is None else acc + r
+csd_ref = (acc / np.float32(len(trials))).astype(np.complex64)          # (1, F, C, C)
+G_or, meta = O.granger_cF(csd_ref)
+G_or_tight, meta_t = O.granger_cF(csd_ref, rtol=5e-9, nIter=300)
+sym = (0.5 * (csd_ref[0].astype(np.complex128) + csd_ref[0].astype(np.complex128).conj().transpose(0, 2, 1)))[None]
+G_or_sym, meta_s = O.granger_cF(sym, rtol=1e-13, nIter=300)
+Gk, info = be.granger(torch.from_numpy(np.ascontiguousarray(csd_ref[0])).cuda())
+Gk_t, info_t = be.granger(torch.from_numpy(np.ascontiguousarray(csd_ref[0])).cuda(), rtol=1e-13, niter=300)
+Gk, Gk_t = Gk.cpu().numpy(), Gk_t.cpu().numpy()
+print("oracle on its csd: err", float(meta["max rel. err--float"]), "| tight:", float(meta_t["max rel. err--float"]), "| symmetrised, complex128:",
+      float(meta_s["max rel. err--float"]), "| kernels on the oracle's csd:", info, "| kernels tight:", info_t)
+i = np.unravel_index(np.argmax(np.abs(got.data[0, 2:] - ref.data[0, 2:])), got.data[0, 2:].shape)
+f, a, b = i[0] + 2, i[1], i[2]
+print("worst element beyond the two bins next to DC: f=%d pair (%d, %d): front end kernels %.5f, front end oracle %.5f" % (f, a, b, got.data[0, f, a, b], ref.data[0, f, a, b]))
+print("  same csd (the oracle's): oracle %.5f | oracle to 5e-9 %.5f | oracle on the symmetrised complex128 matrix to 1e-13 %.5f | kernels %.5f | kernels to 1e-13 %.5f"
+      % (G_or[0, f, a, b], G_or_tight[0, f, a, b], G_or_sym[0, f, a, b], Gk[f, a, b], Gk_t[f, a, b]))
+
+# ---- the product's own cross-spectral matrix (demean_taper as method="granger" sets it) against the oracle's
+from syncopy_amd.specest import hip_spectral as hs
+from syncopy_amd.datatype import device_rows
+dev = data.device_data()
+rows = device_rows(data)
+C = dev.shape[1]
+F = N // 2 + 1
+for prec in ("float32", "reference"):
+    acc_d = torch.zeros((F, C, C), dtype=torch.complex64, device=dev.device)
+    K = 1
+    with hs.precision(prec):
+        for sel, spec in hs.run_mtmfft_batches(dev, rows, None, N, "dpss", topt, True, False, 0, None, "fourier", True, reuse=True):
+            be.csd_accumulate(spec, acc_d)
+            K = spec.shape[1]
+    be.csd_finalize(acc_d, 1.0 / (K * len(rows)))
+    mine = acc_d.cpu().numpy()
+    refc = csd_ref[0]
+    tol = 1e-5 * np.abs(refc) + 1e-6 * np.abs(refc).max()
+    r = np.abs(mine - refc) / tol
+    print(prec, "transforms: csd err/tol max %.3g at %s; per frequency (first 6 bins): %s; |csd| there: %s"
+          % (r.max(), np.unravel_index(r.argmax(), r.shape), np.round(r.reshape(F, -1).max(axis=1)[:6], 3), np.abs(refc).reshape(F, -1).max(axis=1)[:6]))
+    Gm, _ = be.granger(acc_d)
+    print("   granger of it at the worst element: %.5f" % float(Gm[f, a, b]))
+
+# ---- the product's ST stage with the ORACLE's AV stage on its result (routine_classes): isolates the AV kernels
+try:
+    mixed = spy.connectivityanalysis(data, **kw, routine_classes={"granger": ORACLE_CONN["granger"]})
+    print("product ST + oracle AV at the worst element: %.5f (product end to end %.5f, oracle end to end %.5f); max |product - mixed| over f >= 1: %.3g"
+          % (mixed.data[0, f, a, b], got.data[0, f, a, b], ref.data[0, f, a, b], float(np.abs(got.data[0, 1:] - mixed.data[0, 1:]).max())))
+except Exception as exc:
+    import traceback; traceback.print_exc()
