@@ -427,9 +427,11 @@ def test_granger_random_networks(seed):
     if ref.info["reg. factor"] == -1:          # no regularisation brings the condition number under cond_max: both sides
         assert not got.info["converged"]       # say so (wilson_sf.py:197-254) and neither result means anything
         return
-    if not ref.info["converged"]:              # the error test never passes within nIter = 100 on either side (a regularised
-        assert not got.info["converged"]       # matrix whose DC bin is all regularisation: family 0, seed 274): both say so
-        return
+    if not ref.info["converged"] and not got.info["converged"]:
+        return                                 # the error test passes on neither side within nIter = 100 (a regularised matrix
+                                               # whose DC bin is all regularisation: family 0, seed 274) and both say so
+    # (the ORACLE's loop alone failing to report convergence is common - its error stalls just above rtol on a complex64
+    # matrix that is Hermitian only to rounding, about a quarter of these networks - and its estimate is compared as it is)
     assert got.info["converged"]
     # The DC bin is not compared: method="granger" demeans every TAPERED trial (demean_taper, connectivity_analysis.py:864),
     # so X_k(0) = 0 and S(0) = 0 in exact arithmetic - what either side factorises there is the rounding residue
